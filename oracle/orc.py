@@ -1,0 +1,303 @@
+"""ctypes binding of the CPU ORACLE (oracle/liborc.so) and of the compiled reference harness
+(oracle/_ref/libpcr_ref.so).  TEST INFRASTRUCTURE ONLY: importable from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg — never from the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORC = None
+_REF = None
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_corr", C.c_float), ("max_iter", C.c_uint64), ("eps", C.c_float)]
+
+
+class IcpStats(C.Structure):
+    _fields_ = [("iters_run", C.c_uint64), ("converged", C.c_int), ("empty_pairs", C.c_int),
+                ("last_pairs", C.c_uint64), ("last_loss", C.c_float)]
+
+
+def build(ref: bool = True) -> None:
+    """Compile liborc.so and, when /root/reference is present, _ref/libpcr_ref.so."""
+    subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
+    if ref and os.path.isdir("/root/reference"):
+        subprocess.run(["make", "-C", _HERE, "ref"], check=True, capture_output=True)
+
+
+def lib():
+    global _ORC
+    if _ORC is None:
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        L = C.CDLL(path)
+        sz = C.c_size_t
+        L.orc_d2_f32.restype = C.c_float
+        L.orc_d2_f32.argtypes = [C.c_float] * 6
+        L.orc_nn1_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, u32p, f32p]
+        L.orc_nn1_tiecount_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, u32p]
+        L.orc_knn_f64.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_int, i32p, f64p]
+        L.orc_radius_f64.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_double, i64p, C.c_void_p, C.c_void_p]
+        L.orc_radius_f32.argtypes = [f32p, sz, C.c_int, f32p, sz, C.c_float, i64p, C.c_void_p, C.c_void_p]
+        L.orc_transform_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p]
+        L.orc_kabsch_accumulate.restype = C.c_int64
+        L.orc_kabsch_accumulate.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, u32p, f32p, C.c_float, f64p]
+        L.orc_svd3.argtypes = [f64p, f64p, f64p, f64p]
+        L.orc_kabsch_solve.restype = C.c_int
+        L.orc_kabsch_solve.argtypes = [f64p, f32p, f32p]
+        L.orc_mat4_mul_f32.argtypes = [f32p, f32p, f32p]
+        L.orc_icp_p2p_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, f32p,
+                                      C.POINTER(IcpParams), f32p, C.POINTER(IcpStats), C.c_void_p, C.c_void_p]
+        L.orc_plane_count_f32pts.argtypes = [f32p, f32p, f32p, sz, f64p, sz, C.c_double, i64p]
+        L.orc_plane_count_f64pts.argtypes = [f64p, f64p, f64p, sz, f64p, sz, C.c_double, i64p]
+        L.orc_plane_mask_f32pts.argtypes = [f32p, f32p, f32p, sz, f64p, C.c_double, u8p]
+        L.orc_plane_from_3pts.argtypes = [f64p, f64p]
+        L.orc_hw2_knn_add.argtypes = [f64p, i32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                      C.c_double, C.c_int]
+        L.orc_nano_knn_add.argtypes = [f32p, u64p, sz, C.POINTER(sz), C.c_float, sz]
+        _ORC = L
+    return _ORC
+
+
+def ref_path() -> str:
+    return os.path.join(_HERE, "_ref", "libpcr_ref.so")
+
+
+def have_ref() -> bool:
+    return os.path.exists(ref_path())
+
+
+def ref():
+    """The REFERENCE's own code (hw2 kd-tree/octree, vendored nanoflann) behind a C harness."""
+    global _REF
+    if _REF is None:
+        L = C.CDLL(ref_path())
+        sz = C.c_size_t
+        dp = C.POINTER(C.c_double)
+        L.ref_nano_nn1_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, C.c_int, C.c_int,
+                                       u32p, f32p, dp, dp]
+        L.ref_nano_knn_f64.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_int, C.c_int, u64p, f64p]
+        L.ref_hw2_kd_knn.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_int, C.c_int, i32p, f64p,
+                                     C.c_void_p, dp, dp]
+        L.ref_hw2_kd_radius.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_double, C.c_int, i64p,
+                                        C.c_void_p, C.c_void_p]
+        L.ref_hw2_oct_knn.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_int, C.c_int, C.c_double, i32p, f64p]
+        L.ref_hw2_read_binary.restype = C.c_int64
+        L.ref_hw2_read_binary.argtypes = [C.c_char_p, f64p, sz]
+        _REF = L
+    return _REF
+
+
+# ----------------------------------------------------------------------------- numpy-level helpers
+def _soa(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[0] == 3
+    return a[0].copy(), a[1].copy(), a[2].copy()
+
+
+def nn1_f32(tgt_soa, src_soa):
+    """Brute-force canonical 1-NN. tgt/src: (3, n) f32. Returns (idx u32, d2 f32)."""
+    tx, ty, tz = _soa(tgt_soa)
+    sx, sy, sz = _soa(src_soa)
+    idx = np.empty(sx.size, np.uint32)
+    d2 = np.empty(sx.size, np.float32)
+    lib().orc_nn1_f32(tx, ty, tz, tx.size, sx, sy, sz, sx.size, idx, d2)
+    return idx, d2
+
+
+def nn1_tiecount_f32(tgt_soa, src_soa):
+    tx, ty, tz = _soa(tgt_soa)
+    sx, sy, sz = _soa(src_soa)
+    cnt = np.empty(sx.size, np.uint32)
+    lib().orc_nn1_tiecount_f32(tx, ty, tz, tx.size, sx, sy, sz, sx.size, cnt)
+    return cnt
+
+
+def knn_f64(db, q, k):
+    db = np.ascontiguousarray(db, np.float64)
+    q = np.ascontiguousarray(q, np.float64)
+    m, dim = q.shape
+    idx = np.empty((m, k), np.int32)
+    dist = np.empty((m, k), np.float64)
+    lib().orc_knn_f64(db, db.shape[0], dim, q, m, k, idx, dist)
+    return idx, dist
+
+
+def radius_f64(db, q, r):
+    db = np.ascontiguousarray(db, np.float64)
+    q = np.ascontiguousarray(q, np.float64)
+    m, dim = q.shape
+    row = np.empty(m + 1, np.int64)
+    lib().orc_radius_f64(db, db.shape[0], dim, q, m, r, row, None, None)
+    idx = np.empty(max(1, int(row[-1])), np.int32)
+    dist = np.empty(max(1, int(row[-1])), np.float64)
+    lib().orc_radius_f64(db, db.shape[0], dim, q, m, r, row, idx.ctypes.data, dist.ctypes.data)
+    return row, idx[: row[-1]], dist[: row[-1]]
+
+
+def radius_f32(db, q, r):
+    db = np.ascontiguousarray(db, np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    m, dim = q.shape
+    row = np.empty(m + 1, np.int64)
+    lib().orc_radius_f32(db, db.shape[0], dim, q, m, r, row, None, None)
+    idx = np.empty(max(1, int(row[-1])), np.int32)
+    dist = np.empty(max(1, int(row[-1])), np.float32)
+    lib().orc_radius_f32(db, db.shape[0], dim, q, m, r, row, idx.ctypes.data, dist.ctypes.data)
+    return row, idx[: row[-1]], dist[: row[-1]]
+
+
+def transform_f32(soa, R, t):
+    x, y, z = _soa(soa)
+    lib().orc_transform_f32(x, y, z, x.size, np.ascontiguousarray(R, np.float32).reshape(9),
+                            np.ascontiguousarray(t, np.float32).reshape(3))
+    return np.stack([x, y, z])
+
+
+def kabsch_accumulate(src_soa, tgt_soa, idx, d2, max_corr):
+    sx, sy, sz = _soa(src_soa)
+    tx, ty, tz = _soa(tgt_soa)
+    sums = np.zeros(16, np.float64)
+    last = lib().orc_kabsch_accumulate(sx, sy, sz, sx.size, tx, ty, tz,
+                                       np.ascontiguousarray(idx, np.uint32),
+                                       np.ascontiguousarray(d2, np.float32), max_corr, sums)
+    return sums, int(last)
+
+
+def kabsch_solve(sums):
+    R = np.zeros(9, np.float32)
+    t = np.zeros(3, np.float32)
+    rc = lib().orc_kabsch_solve(np.ascontiguousarray(sums, np.float64), R, t)
+    return rc, R.reshape(3, 3), t
+
+
+def svd3(A):
+    U = np.zeros(9); S = np.zeros(3); V = np.zeros(9)
+    lib().orc_svd3(np.ascontiguousarray(A, np.float64).reshape(9), U, S, V)
+    return U.reshape(3, 3), S, V.reshape(3, 3)
+
+
+def icp_p2p_f32(src_soa, tgt_soa, init_T=None, max_corr=1.0, max_iter=20, eps=1e-8, trace=False):
+    sx, sy, sz = _soa(src_soa)
+    tx, ty, tz = _soa(tgt_soa)
+    T0 = np.eye(4, dtype=np.float32) if init_T is None else np.ascontiguousarray(init_T, np.float32)
+    prm = IcpParams(max_corr, max_iter, eps)
+    st = IcpStats()
+    out = np.zeros(16, np.float32)
+    per_T = np.zeros((max_iter, 16), np.float32) if trace else None
+    per_n = np.zeros(max_iter, np.uint64) if trace else None
+    lib().orc_icp_p2p_f32(sx, sy, sz, sx.size, tx, ty, tz, tx.size, T0.reshape(16), C.byref(prm), out,
+                          C.byref(st), per_T.ctypes.data if trace else None,
+                          per_n.ctypes.data if trace else None)
+    stats = dict(iters_run=int(st.iters_run), converged=int(st.converged), empty_pairs=int(st.empty_pairs),
+                 last_pairs=int(st.last_pairs), last_loss=float(st.last_loss))
+    if trace:
+        return out.reshape(4, 4), stats, per_T.reshape(max_iter, 4, 4), per_n
+    return out.reshape(4, 4), stats
+
+
+def plane_count(soa, planes4, thr):
+    planes4 = np.ascontiguousarray(planes4, np.float64).reshape(-1, 4)
+    counts = np.zeros(planes4.shape[0], np.int64)
+    a = np.asarray(soa)
+    if a.dtype == np.float64:
+        x, y, z = (np.ascontiguousarray(a[i]) for i in range(3))
+        lib().orc_plane_count_f64pts(x, y, z, x.size, planes4, planes4.shape[0], thr, counts)
+    else:
+        x, y, z = _soa(a)
+        lib().orc_plane_count_f32pts(x, y, z, x.size, planes4, planes4.shape[0], thr, counts)
+    return counts
+
+
+def plane_mask(soa, plane4, thr):
+    x, y, z = _soa(soa)
+    mask = np.zeros(x.size, np.uint8)
+    lib().orc_plane_mask_f32pts(x, y, z, x.size, np.ascontiguousarray(plane4, np.float64).reshape(4), thr, mask)
+    return mask
+
+
+def plane_from_3pts(p):
+    out = np.zeros(4)
+    lib().orc_plane_from_3pts(np.ascontiguousarray(p, np.float64).reshape(9), out)
+    return out
+
+
+# ----------------------------------------------------------------------------- reference harness
+def ref_nano_nn1_f32(tgt_soa, src_soa, leaf=2, threads=1):
+    """vendored nanoflann, f32, as ICPpoint2point instantiates it. Returns (idx, d2, build_ms, query_ms)."""
+    tx, ty, tz = _soa(tgt_soa)
+    sx, sy, sz = _soa(src_soa)
+    idx = np.empty(sx.size, np.uint32)
+    d2 = np.empty(sx.size, np.float32)
+    b = C.c_double(); q = C.c_double()
+    ref().ref_nano_nn1_f32(tx, ty, tz, tx.size, sx, sy, sz, sx.size, leaf, threads, idx, d2,
+                           C.byref(b), C.byref(q))
+    return idx, d2, b.value, q.value
+
+
+def ref_nano_knn_f64(db, q, k, leaf=10):
+    db = np.ascontiguousarray(db, np.float64)
+    q = np.ascontiguousarray(q, np.float64)
+    m, dim = q.shape
+    idx = np.empty((m, k), np.uint64)
+    d2 = np.empty((m, k), np.float64)
+    ref().ref_nano_knn_f64(db, db.shape[0], dim, q, m, k, leaf, idx, d2)
+    return idx, d2
+
+
+def ref_hw2_kd_knn(db, q, k, leaf=1, want_cmp=False):
+    db = np.ascontiguousarray(db, np.float64)
+    q = np.ascontiguousarray(q, np.float64)
+    m, dim = q.shape
+    idx = np.empty((m, k), np.int32)
+    dist = np.empty((m, k), np.float64)
+    cmp = np.zeros(m, np.int32)
+    b = C.c_double(); t = C.c_double()
+    ref().ref_hw2_kd_knn(db, db.shape[0], dim, q, m, k, leaf, idx, dist, cmp.ctypes.data,
+                         C.byref(b), C.byref(t))
+    if want_cmp:
+        return idx, dist, cmp, b.value, t.value
+    return idx, dist
+
+
+def ref_hw2_kd_radius(db, q, r, leaf=1):
+    db = np.ascontiguousarray(db, np.float64)
+    q = np.ascontiguousarray(q, np.float64)
+    m, dim = q.shape
+    row = np.empty(m + 1, np.int64)
+    ref().ref_hw2_kd_radius(db, db.shape[0], dim, q, m, r, leaf, row, None, None)
+    idx = np.empty(max(1, int(row[-1])), np.int32)
+    dist = np.empty(max(1, int(row[-1])), np.float64)
+    ref().ref_hw2_kd_radius(db, db.shape[0], dim, q, m, r, leaf, row, idx.ctypes.data, dist.ctypes.data)
+    return row, idx[: row[-1]], dist[: row[-1]]
+
+
+def ref_hw2_oct_knn(db, q, k, leaf=32, min_extent=0.0001):
+    db = np.ascontiguousarray(db, np.float64)
+    q = np.ascontiguousarray(q, np.float64)
+    m, dim = q.shape
+    idx = np.empty((m, k), np.int32)
+    dist = np.empty((m, k), np.float64)
+    ref().ref_hw2_oct_knn(db, db.shape[0], dim, q, m, k, leaf, min_extent, idx, dist)
+    return idx, dist
+
+
+def ref_hw2_read_binary(path, cap=200000):
+    out = np.zeros((cap, 3), np.float64)
+    n = ref().ref_hw2_read_binary(path.encode(), out, cap)
+    return out[: min(n, cap)], int(n)

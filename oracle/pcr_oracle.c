@@ -1,0 +1,470 @@
+/*
+ * pcr_oracle.c — CPU ORACLE (test infrastructure, NOT the product).  See pcr_oracle.h.
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/Makefile).
+ * -ffp-contract=off matters: one fused multiply-add changes d2 in the last bit and flips
+ * near-tie winners.
+ */
+#include "pcr_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ A1 */
+/* nanoflann.hpp:403-406: result = 0; for d in 0..2: diff = a[d] - pt(b,d); result += diff*diff */
+float orc_d2_f32(float qx, float qy, float qz, float tx, float ty, float tz)
+{
+    float result = 0.0f;
+    float d0 = qx - tx; result += d0 * d0;
+    float d1 = qy - ty; result += d1 * d1;
+    float d2 = qz - tz; result += d2 * d2;
+    return result;
+}
+
+/* ------------------------------------------------------------------ A6 (search) */
+void orc_nn1_f32(const float* tx, const float* ty, const float* tz, size_t nt,
+                 const float* sx, const float* sy, const float* sz, size_t ns,
+                 uint32_t* idx, float* d2)
+{
+    for (size_t i = 0; i < ns; i++) {
+        /* nanoflann.hpp:163 worst = FLT_MAX; :1360 accept iff dist < worst; :184 strict > on insert.
+         * Ascending j + strict < gives "min d2, lowest index on ties". */
+        float best = FLT_MAX;
+        uint32_t bi = UINT32_MAX;
+        const float qx = sx[i], qy = sy[i], qz = sz[i];
+        for (size_t j = 0; j < nt; j++) {
+            float d = orc_d2_f32(qx, qy, qz, tx[j], ty[j], tz[j]);
+            if (d < best) { best = d; bi = (uint32_t)j; }
+        }
+        idx[i] = bi;
+        d2[i] = (bi == UINT32_MAX) ? INFINITY : best;
+    }
+}
+
+void orc_nn1_tiecount_f32(const float* tx, const float* ty, const float* tz, size_t nt,
+                          const float* sx, const float* sy, const float* sz, size_t ns,
+                          uint32_t* tie_count)
+{
+    for (size_t i = 0; i < ns; i++) {
+        float best = FLT_MAX;
+        uint32_t cnt = 0;
+        for (size_t j = 0; j < nt; j++) {
+            float d = orc_d2_f32(sx[i], sy[i], sz[i], tx[j], ty[j], tz[j]);
+            if (d < best) { best = d; cnt = 1; }
+            else if (d == best) cnt++;
+        }
+        tie_count[i] = cnt;
+    }
+}
+
+/* ------------------------------------------------------------------ A2 */
+double orc_dist_f64(const double* t, const double* q, int dim)
+{
+    /* kdtree.hpp:341-346: diff = 0; diff += pow(db[idx][i] - query[i], 2); diff = sqrt(diff).
+     * glibc pow(x, 2) == x*x exactly (correctly rounded square). */
+    double diff = 0.0;
+    for (int i = 0; i < dim; i++) {
+        double e = t[i] - q[i];
+        diff += e * e;
+    }
+    return sqrt(diff);
+}
+
+/* canonical (distance, index) insertion: ascending distance, ties by ascending index */
+static void canon_insert(double* dist, int32_t* idx, int k, int* count, double d, int32_t i)
+{
+    int n = *count;
+    if (n == k) {
+        /* full: reject unless strictly better than the last in canonical order */
+        if (!(d < dist[k - 1] || (d == dist[k - 1] && i < idx[k - 1]))) return;
+        n = k - 1;
+    }
+    int pos = n;
+    while (pos > 0 && (dist[pos - 1] > d || (dist[pos - 1] == d && idx[pos - 1] > i))) {
+        dist[pos] = dist[pos - 1];
+        idx[pos] = idx[pos - 1];
+        pos--;
+    }
+    dist[pos] = d;
+    idx[pos] = i;
+    *count = n + 1;
+}
+
+void orc_knn_f64(const double* db, size_t n, int dim, const double* q, size_t m, int k,
+                 int32_t* idx, double* dist)
+{
+    for (size_t qi = 0; qi < m; qi++) {
+        double* dd = dist + qi * (size_t)k;
+        int32_t* ii = idx + qi * (size_t)k;
+        int count = 0;
+        for (int s = 0; s < k; s++) { dd[s] = 1e10; ii[s] = 0; }   /* resultSet.hpp:35-42 */
+        for (size_t j = 0; j < n; j++) {
+            double d = orc_dist_f64(db + j * (size_t)dim, q + qi * (size_t)dim, dim);
+            if (d > 1e10) continue;                                   /* resultSet.hpp:69 with worst=1e10 */
+            canon_insert(dd, ii, k, &count, d, (int32_t)j);
+        }
+        for (int s = count; s < k; s++) { dd[s] = 1e10; ii[s] = 0; }
+    }
+}
+
+/* ------------------------------------------------------------------ A11 */
+void orc_radius_f64(const double* db, size_t n, int dim, const double* q, size_t m, double r,
+                    int64_t* row_ptr, int32_t* idx, double* dist)
+{
+    int64_t w = 0;
+    for (size_t qi = 0; qi < m; qi++) {
+        row_ptr[qi] = w;
+        for (size_t j = 0; j < n; j++) {
+            double d = orc_dist_f64(db + j * (size_t)dim, q + qi * (size_t)dim, dim);
+            if (d <= r) {                                             /* resultSet.hpp:133 */
+                if (idx) idx[w] = (int32_t)j;
+                if (dist) dist[w] = d;
+                w++;
+            }
+        }
+    }
+    row_ptr[m] = w;
+}
+
+void orc_radius_f32(const float* db, size_t n, int dim, const float* q, size_t m, float r,
+                    int64_t* row_ptr, int32_t* idx, float* dist)
+{
+    /* Homework7/hw7/src/kdtree.cpp: same loop with ElemType float (include/kdtree.hpp:13) */
+    int64_t w = 0;
+    for (size_t qi = 0; qi < m; qi++) {
+        row_ptr[qi] = w;
+        for (size_t j = 0; j < n; j++) {
+            float diff = 0.0f;
+            for (int c = 0; c < dim; c++) {
+                float e = db[j * (size_t)dim + c] - q[qi * (size_t)dim + c];
+                diff += e * e;
+            }
+            diff = sqrtf(diff);
+            if (diff <= r) {
+                if (idx) idx[w] = (int32_t)j;
+                if (dist) dist[w] = diff;
+                w++;
+            }
+        }
+    }
+    row_ptr[m] = w;
+}
+
+/* ------------------------------------------------------------------ A4 */
+void orc_hw2_knn_add(double* dist, int* index, int capacity, int* count, double* worst,
+                     double d, int i)
+{
+    /* resultSet.hpp:65-91 */
+    if (d > *worst) return;
+    if (*count < capacity) (*count)++;
+    int pos = *count - 1;
+    while (pos > 0) {
+        if (dist[pos - 1] > d) {
+            dist[pos] = dist[pos - 1];
+            index[pos] = index[pos - 1];
+            pos--;
+        } else break;
+    }
+    dist[pos] = d;
+    index[pos] = i;
+    *worst = dist[capacity - 1];
+}
+
+/* ------------------------------------------------------------------ A3 */
+void orc_nano_knn_add(float* dists, size_t* indices, size_t capacity, size_t* count,
+                      float d, size_t index)
+{
+    /* leaf gate nanoflann.hpp:1360 (worst re-read here; nanoflann caches it per leaf :1354,
+     * which only delays the rejection of candidates the insertion loop would drop anyway) */
+    if (!(d < dists[capacity - 1])) return;
+    size_t i;
+    for (i = *count; i > 0; --i) {                                   /* :182-192 */
+        if (dists[i - 1] > d) {
+            if (i < capacity) { dists[i] = dists[i - 1]; indices[i] = indices[i - 1]; }
+        } else break;
+    }
+    if (i < capacity) { dists[i] = d; indices[i] = index; }
+    if (*count < capacity) (*count)++;
+}
+
+/* ------------------------------------------------------------------ A8 */
+void orc_transform_f32(float* x, float* y, float* z, size_t n, const float R[9], const float t[3])
+{
+    /* registration.cpp:173 `point = R * point + t` — Eigen evaluates the 3x3 * 3x1 product as a
+     * lazy coefficient-wise inner product, left to right, then adds t. */
+    for (size_t i = 0; i < n; i++) {
+        float px = x[i], py = y[i], pz = z[i];
+        float nx = ((R[0] * px + R[1] * py) + R[2] * pz) + t[0];
+        float ny = ((R[3] * px + R[4] * py) + R[5] * pz) + t[1];
+        float nz = ((R[6] * px + R[7] * py) + R[8] * pz) + t[2];
+        x[i] = nx; y[i] = ny; z[i] = nz;
+    }
+}
+
+/* ------------------------------------------------------------------ A7 */
+int64_t orc_kabsch_accumulate(const float* sx, const float* sy, const float* sz, size_t ns,
+                              const float* tx, const float* ty, const float* tz,
+                              const uint32_t* idx, const float* d2, float max_corr,
+                              double sums[16])
+{
+    for (int k = 0; k < 16; k++) sums[k] = 0.0;
+    int64_t last = -1;
+    for (size_t i = 0; i < ns; i++) {
+        if (!(d2[i] < max_corr)) continue;                            /* registration.cpp:936 */
+        uint32_t j = idx[i];
+        double p[3] = { sx[i], sy[i], sz[i] };
+        double q[3] = { tx[j], ty[j], tz[j] };
+        for (int c = 0; c < 3; c++) { sums[c] += p[c]; sums[3 + c] += q[c]; }
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) sums[6 + 3 * r + c] += q[r] * p[c];
+        sums[15] += 1.0;
+        last = (int64_t)i;
+    }
+    return last;
+}
+
+static void mat3_mul(const double A[9], const double B[9], double C[9])
+{
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+
+static double det3(const double M[9])
+{
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6])
+         + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+void orc_svd3(const double A[9], double U[9], double S[3], double V[9])
+{
+    /* One-sided (Hestenes) Jacobi: rotate column pairs of W = A*V until mutually orthogonal. */
+    double W[9], Vm[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    memcpy(W, A, sizeof W);
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < 2; p++) {
+            for (int q = p + 1; q < 3; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int r = 0; r < 3; r++) {
+                    alpha += W[3 * r + p] * W[3 * r + p];
+                    beta += W[3 * r + q] * W[3 * r + q];
+                    gamma += W[3 * r + p] * W[3 * r + q];
+                }
+                if (gamma == 0.0) continue;
+                double lim = sqrt(alpha * beta);
+                if (fabs(gamma) <= DBL_EPSILON * lim) continue;
+                off = fmax(off, fabs(gamma) / (lim > 0 ? lim : 1.0));
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+                for (int r = 0; r < 3; r++) {
+                    double wp = W[3 * r + p], wq = W[3 * r + q];
+                    W[3 * r + p] = c * wp - s * wq;
+                    W[3 * r + q] = s * wp + c * wq;
+                    double vp = Vm[3 * r + p], vq = Vm[3 * r + q];
+                    Vm[3 * r + p] = c * vp - s * vq;
+                    Vm[3 * r + q] = s * vp + c * vq;
+                }
+            }
+        }
+        if (off == 0.0) break;
+    }
+    double sv[3];
+    for (int c = 0; c < 3; c++)
+        sv[c] = sqrt(W[c] * W[c] + W[3 + c] * W[3 + c] + W[6 + c] * W[6 + c]);
+    /* sort descending (Eigen::JacobiSVD convention) */
+    int ord[3] = { 0, 1, 2 };
+    for (int a = 0; a < 2; a++)
+        for (int b = a + 1; b < 3; b++)
+            if (sv[ord[b]] > sv[ord[a]]) { int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+    double smax = sv[ord[0]];
+    for (int c = 0; c < 3; c++) {
+        int o = ord[c];
+        S[c] = sv[o];
+        for (int r = 0; r < 3; r++) V[3 * r + c] = Vm[3 * r + o];
+        if (sv[o] > 0.0 && sv[o] > smax * DBL_EPSILON * 8.0) {
+            for (int r = 0; r < 3; r++) U[3 * r + c] = W[3 * r + o] / sv[o];
+        } else {
+            for (int r = 0; r < 3; r++) U[3 * r + c] = 0.0;   /* completed below */
+        }
+    }
+    /* complete U for (numerically) rank-deficient A: keep it orthonormal */
+    int defined[3];
+    for (int c = 0; c < 3; c++)
+        defined[c] = (U[c] != 0.0 || U[3 + c] != 0.0 || U[6 + c] != 0.0);
+    if (!defined[0]) {             /* A == 0 */
+        double I[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+        memcpy(U, I, sizeof I);
+        return;
+    }
+    if (!defined[1]) {
+        /* any unit vector orthogonal to u0 */
+        double u0[3] = { U[0], U[3], U[6] };
+        int k = 0;
+        if (fabs(u0[1]) < fabs(u0[k])) k = 1;
+        if (fabs(u0[2]) < fabs(u0[k])) k = 2;
+        double e[3] = { 0, 0, 0 };
+        e[k] = 1.0;
+        double dot = u0[k];
+        double v[3] = { e[0] - dot * u0[0], e[1] - dot * u0[1], e[2] - dot * u0[2] };
+        double nv = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        U[1] = v[0] / nv; U[4] = v[1] / nv; U[7] = v[2] / nv;
+        defined[1] = 1;
+    }
+    if (!defined[2]) {
+        /* u2 = u0 x u1 */
+        U[2] = U[3] * U[7] - U[6] * U[4];
+        U[5] = U[6] * U[1] - U[0] * U[7];
+        U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+}
+
+int orc_kabsch_solve(const double sums[16], float R[9], float t[3])
+{
+    double M = sums[15];
+    if (!(M > 0.0)) return -1;
+    double pbar[3], qbar[3];
+    for (int c = 0; c < 3; c++) { pbar[c] = sums[c] / M; qbar[c] = sums[3 + c] / M; }   /* :979-980 */
+    double H[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            H[3 * r + c] = sums[6 + 3 * r + c] - M * qbar[r] * pbar[c];                   /* :982-985 */
+    double U[9], S[3], V[9], Vt[9], Rd[9];
+    orc_svd3(H, U, S, V);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Vt[3 * r + c] = V[3 * c + r];
+    mat3_mul(U, Vt, Rd);                                                                 /* :988 */
+    double det = det3(Rd);
+    if (det < 0) {                                                                       /* :990-996 */
+        double Ut[9], VB[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ut[3 * r + c] = U[3 * c + r];
+        for (int r = 0; r < 3; r++) {
+            VB[3 * r] = V[3 * r]; VB[3 * r + 1] = V[3 * r + 1]; VB[3 * r + 2] = V[3 * r + 2] * det;
+        }
+        mat3_mul(VB, Ut, Rd);                                                            /* V*B*U^T (sic) */
+    }
+    for (int k = 0; k < 9; k++) R[k] = (float)Rd[k];
+    for (int r = 0; r < 3; r++) {                                                        /* :998 */
+        double Rp = ((double)R[3 * r] * pbar[0] + (double)R[3 * r + 1] * pbar[1]) + (double)R[3 * r + 2] * pbar[2];
+        t[r] = (float)(qbar[r] - Rp);
+    }
+    return 0;
+}
+
+void orc_mat4_mul_f32(const float A[16], const float B[16], float out[16])
+{
+    float tmp[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            float acc = A[4 * r] * B[c];
+            acc = acc + A[4 * r + 1] * B[4 + c];
+            acc = acc + A[4 * r + 2] * B[8 + c];
+            acc = acc + A[4 * r + 3] * B[12 + c];
+            tmp[4 * r + c] = acc;
+        }
+    memcpy(out, tmp, sizeof tmp);
+}
+
+/* ------------------------------------------------------------------ A9 */
+void orc_icp_p2p_f32(const float* sx, const float* sy, const float* sz, size_t ns,
+                     const float* tx, const float* ty, const float* tz, size_t nt,
+                     const float init_T[16], const orc_icp_params* prm,
+                     float out_T[16], orc_icp_stats* stats,
+                     float* per_iter_T, uint64_t* per_iter_pairs)
+{
+    float* px = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+    float* py = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+    float* pz = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+    uint32_t* idx = (uint32_t*)malloc(sizeof(uint32_t) * (ns ? ns : 1));
+    float* d2 = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+    memcpy(px, sx, sizeof(float) * ns);
+    memcpy(py, sy, sizeof(float) * ns);
+    memcpy(pz, sz, sizeof(float) * ns);
+
+    float R0[9] = { init_T[0], init_T[1], init_T[2], init_T[4], init_T[5], init_T[6],
+                    init_T[8], init_T[9], init_T[10] };
+    float t0[3] = { init_T[3], init_T[7], init_T[11] };
+    orc_transform_f32(px, py, pz, ns, R0, t0);                        /* :872-874 */
+
+    float T_total[16] = { R0[0], R0[1], R0[2], t0[0], R0[3], R0[4], R0[5], t0[1],
+                          R0[6], R0[7], R0[8], t0[2], 0, 0, 0, 1 };   /* :910-913 */
+    orc_icp_stats st;
+    memset(&st, 0, sizeof st);
+    float last_loss = 0.0f;                                           /* :915 */
+    uint64_t unchanged = 0;                                           /* :916 */
+    for (uint64_t iter = 0; iter < prm->max_iter; iter++) {           /* :917 */
+        orc_nn1_f32(tx, ty, tz, nt, px, py, pz, ns, idx, d2);         /* :925-934 */
+        double sums[16];
+        int64_t last = orc_kabsch_accumulate(px, py, pz, ns, tx, ty, tz, idx, d2,
+                                             prm->max_corr, sums);   /* :936-940, :964-985 */
+        float loss = 0.0f;
+        if (last >= 0) loss = d2[last] * d2[last];                    /* :939 (overwritten, not summed) */
+        st.last_pairs = (uint64_t)sums[15];
+        st.last_loss = loss;
+        if (per_iter_pairs) per_iter_pairs[iter] = st.last_pairs;
+        if (fabsf(last_loss - loss) < prm->eps) unchanged++;          /* :948-951 (never reset) */
+        if (unchanged > 15) { st.converged = 1; break; }              /* :954-958 */
+        last_loss = loss;                                             /* :961 */
+        float Rd[9], td[3];
+        if (orc_kabsch_solve(sums, Rd, td) != 0) { st.empty_pairs = 1; break; }
+        float T_delta[16] = { Rd[0], Rd[1], Rd[2], td[0], Rd[3], Rd[4], Rd[5], td[1],
+                              Rd[6], Rd[7], Rd[8], td[2], 0, 0, 0, 1 };
+        if (per_iter_T) memcpy(per_iter_T + 16 * iter, T_delta, sizeof T_delta);
+        orc_mat4_mul_f32(T_delta, T_total, T_total);                  /* :1000-1002 */
+        orc_transform_f32(px, py, pz, ns, Rd, td);                    /* :1003 */
+        st.iters_run++;
+    }
+    memcpy(out_T, T_total, sizeof T_total);                           /* :1008-1009 */
+    if (stats) *stats = st;
+    free(px); free(py); free(pz); free(idx); free(d2);
+}
+
+/* ------------------------------------------------------------------ A10 */
+static inline double plane_dist(double x, double y, double z, const double* p)
+{
+    /* np.c_[X, 1].dot(params): row . params, k = 0..3 in order, f64 */
+    return fabs(((x * p[0] + y * p[1]) + z * p[2]) + 1.0 * p[3]);
+}
+
+void orc_plane_count_f32pts(const float* x, const float* y, const float* z, size_t n,
+                            const double* planes4, size_t n_planes, double thr, int64_t* counts)
+{
+    for (size_t h = 0; h < n_planes; h++) {
+        int64_t c = 0;
+        for (size_t i = 0; i < n; i++)
+            c += plane_dist((double)x[i], (double)y[i], (double)z[i], planes4 + 4 * h) < thr;
+        counts[h] = c;
+    }
+}
+
+void orc_plane_count_f64pts(const double* x, const double* y, const double* z, size_t n,
+                            const double* planes4, size_t n_planes, double thr, int64_t* counts)
+{
+    for (size_t h = 0; h < n_planes; h++) {
+        int64_t c = 0;
+        for (size_t i = 0; i < n; i++)
+            c += plane_dist(x[i], y[i], z[i], planes4 + 4 * h) < thr;
+        counts[h] = c;
+    }
+}
+
+void orc_plane_mask_f32pts(const float* x, const float* y, const float* z, size_t n,
+                           const double plane4[4], double thr, uint8_t* mask)
+{
+    for (size_t i = 0; i < n; i++)
+        mask[i] = plane_dist((double)x[i], (double)y[i], (double)z[i], plane4) < thr;
+}
+
+void orc_plane_from_3pts(const double p[9], double params[4])
+{
+    /* ground_detection_ransac.py:158-169 */
+    double v1[3] = { p[3] - p[0], p[4] - p[1], p[5] - p[2] };
+    double v2[3] = { p[6] - p[0], p[7] - p[1], p[8] - p[2] };
+    double a = (v1[1] * v2[2]) - (v1[2] * v2[1]);
+    double b = (v1[2] * v2[0]) - (v1[0] * v2[2]);
+    double c = (v1[0] * v2[1]) - (v1[1] * v2[0]);
+    double d = -(a * p[0] + b * p[1] + c * p[2]);
+    double n = sqrt(a * a + b * b + c * c);
+    params[0] = a / n; params[1] = b / n; params[2] = c / n; params[3] = d / n;
+}

@@ -1,0 +1,143 @@
+/*
+ * pcr_oracle.h — CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A plain-C restatement of the reference's algorithm for the k-NN correspondence +
+ * ICP + plane-inlier hot path.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product path (libpcr_hip.so) never links, loads or calls it.
+ *
+ * Pinning status:
+ *   - A1/A3/A6 (f32 squared distance, nanoflann result set, 1-NN argmin): PINNED against
+ *     the vendored nanoflann 1.3.2 compiled from /root/reference (oracle/_ref) and the
+ *     fixtures generated from it (tests/golden/gen_golden.py).
+ *   - A2/A4/A11 (f64 sqrt distance, hw2 result sets, k-NN, radius-NN): PINNED against the
+ *     hw2 headers compiled from /root/reference and the known-answer vector of
+ *     Homework2/hw2/result_cpp.txt:11-33.
+ *   - A10 (plane-inlier count): PINNED against the numpy expression of
+ *     Homework4/ground_detection_ransac.py:138-139 evaluated by tests/golden/gen_golden.py.
+ *   - A7/A9 (Kabsch via Eigen JacobiSVD, ICP loop): hw9 needs PCL+Eigen, which are absent ->
+ *     the reference cannot be built here and holds no golden for this step:
+ *     **parity unpinned** at the Eigen boundary; this file restates registration.cpp:862-1011
+ *     line by line with f64 accumulation.
+ *
+ * All citations are relative to /root/reference/.
+ */
+#ifndef PCR_ORACLE_H
+#define PCR_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- A1: nanoflann L2_Adaptor::evalMetric, dim 3 (Homework9/hw9/include/nanoflann.hpp:403-406) */
+float orc_d2_f32(float qx, float qy, float qz, float tx, float ty, float tz);
+
+/* ---- A6 search part: brute-force 1-NN, A1 arithmetic, canonical tie rule
+ * (min d2, then lowest target index).  Acceptance follows nanoflann:
+ * a candidate is accepted only if d2 < FLT_MAX (nanoflann.hpp:163,1360); a query with no
+ * acceptable candidate gets idx = UINT32_MAX, d2 = +inf.  SoA inputs. */
+void orc_nn1_f32(const float* tx, const float* ty, const float* tz, size_t nt,
+                 const float* sx, const float* sy, const float* sz, size_t ns,
+                 uint32_t* idx, float* d2);
+/* size of the tie set {j : d2_j == d2_min} per query (test helper for the tie-set rule). */
+void orc_nn1_tiecount_f32(const float* tx, const float* ty, const float* tz, size_t nt,
+                          const float* sx, const float* sy, const float* sz, size_t ns,
+                          uint32_t* tie_count);
+
+/* ---- A2: hw2 leaf distance (Homework2/hw2/include/kdtree.hpp:341-346):
+ * d = sqrt(((0 + (t0-q0)^2) + (t1-q1)^2) + (t2-q2)^2) in f64. */
+double orc_dist_f64(const double* t, const double* q, int dim);
+
+/* ---- A2+A4: brute-force k-NN over an n x dim AoS f64 database for m queries, canonical order
+ * (distance ascending, then index ascending).  Slots beyond n are (1e10, 0) like the
+ * pre-filled hw2 result set (resultSet.hpp:35-42).  idx: m*k int32, dist: m*k f64. */
+void orc_knn_f64(const double* db, size_t n, int dim, const double* q, size_t m, int k,
+                 int32_t* idx, double* dist);
+
+/* ---- A11: radius search, membership d <= r (inclusive, resultSet.hpp:133), CSR output in
+ * ascending index order.  Call with idx==NULL to get row_ptr only (row_ptr has m+1 entries). */
+void orc_radius_f64(const double* db, size_t n, int dim, const double* q, size_t m, double r,
+                    int64_t* row_ptr, int32_t* idx, double* dist);
+/* float variant used by Homework7/hw7/src/kdtree.cpp (ElemType float): d = sqrtf(sum) in f32 */
+void orc_radius_f32(const float* db, size_t n, int dim, const float* q, size_t m, float r,
+                    int64_t* row_ptr, int32_t* idx, float* dist);
+
+/* ---- A4: hw2 KNNResultSet::addPoint restated on caller arrays (resultSet.hpp:65-91).
+ * dist/index arrays have `capacity` slots pre-filled (1e10, 0); *count and *worst are state. */
+void orc_hw2_knn_add(double* dist, int* index, int capacity, int* count, double* worst,
+                     double d, int i);
+/* ---- A3: nanoflann KNNResultSet::addPoint (nanoflann.hpp:175-202) incl. the leaf gate
+ * `dist < worstDist` (:1360). dists[capacity-1] must be initialised to FLT_MAX (:163). */
+void orc_nano_knn_add(float* dists, size_t* indices, size_t capacity, size_t* count,
+                      float d, size_t i);
+
+/* ---- A8: transformCloudInplace (Homework9/hw9/src/registration.cpp:165-178), f32, unfused,
+ * row-wise ((R_i0*x + R_i1*y) + R_i2*z) + t_i.  R row-major 3x3. SoA in place. */
+void orc_transform_f32(float* x, float* y, float* z, size_t n, const float R[9], const float t[3]);
+
+/* ---- A7 accumulation: f64 sums over kept pairs (d2 < max_corr, registration.cpp:936):
+ * sums[0..2] = sum p (source), [3..5] = sum q (target), [6..14] = sum q_r * p_c (row-major 3x3,
+ * rows = target, cols = source, registration.cpp:985), [15] = count.
+ * Also returns the index of the last kept source (for `loss`, :939) or -1. */
+int64_t orc_kabsch_accumulate(const float* sx, const float* sy, const float* sz, size_t ns,
+                              const float* tx, const float* ty, const float* tz,
+                              const uint32_t* idx, const float* d2, float max_corr,
+                              double sums[16]);
+
+/* 3x3 SVD (f64, one-sided Jacobi, singular values sorted descending like Eigen::JacobiSVD).
+ * A row-major; A = U diag(S) V^T. */
+void orc_svd3(const double A[9], double U[9], double S[3], double V[9]);
+
+/* ---- A7 solve: from the 16 sums to (R_delta, t_delta) as f32, registration.cpp:979-998 incl. the
+ * det<0 branch `R = V*B*U^T` (:990-996, sic).  Returns 0, or -1 when count == 0. */
+int orc_kabsch_solve(const double sums[16], float R[9], float t[3]);
+
+/* 4x4 f32 compose T_out = A * B, row-major, sequential k, unfused (registration.cpp:1002). */
+void orc_mat4_mul_f32(const float A[16], const float B[16], float out[16]);
+
+typedef struct {
+    float max_corr;      /* m_ICP_max_corres_dist, compared against the SQUARED distance (:936) */
+    uint64_t max_iter;   /* m_ICP_max_iter */
+    float eps;           /* m_ICP_loss_epsilon */
+} orc_icp_params;
+
+typedef struct {
+    uint64_t iters_run;       /* iterations whose update was applied */
+    int converged;            /* 1 if the `unchanged_count > 15` break fired (:954) */
+    int empty_pairs;          /* 1 if an iteration kept no pair (reference would divide by zero) */
+    uint64_t last_pairs;      /* kept pairs in the last executed NN pass */
+    float last_loss;
+} orc_icp_stats;
+
+/* ---- A9: ICPpoint2point (registration.cpp:862-1011, Appendix of SURVEY.md).  src is copied,
+ * init_T (row-major 4x4, [R t; 0 1]) applied, then the loop.  out_T row-major 4x4.
+ * If per_iter_T != NULL it receives max_iter * 16 floats: [R_delta t_delta; 0 1] of each
+ * executed iteration; per_iter_pairs (optional) the kept-pair count of each NN pass. */
+void orc_icp_p2p_f32(const float* sx, const float* sy, const float* sz, size_t ns,
+                     const float* tx, const float* ty, const float* tz, size_t nt,
+                     const float init_T[16], const orc_icp_params* prm,
+                     float out_T[16], orc_icp_stats* stats,
+                     float* per_iter_T, uint64_t* per_iter_pairs);
+
+/* ---- A10: plane-inlier count (Homework4/ground_detection_ransac.py:138-139,152-153):
+ * dist_i = |((x_i*a + y_i*b) + z_i*c) + 1.0*d| in f64 on f32-or-f64 points (np.c_ promotes to f64;
+ * numpy's dot of an N x 4 f64 matrix with a 4-vector sums k = 0..3 sequentially for each row).
+ * counts[h] = #{i : dist_i < thr}.  xyz is SoA. */
+void orc_plane_count_f32pts(const float* x, const float* y, const float* z, size_t n,
+                            const double* planes4, size_t n_planes, double thr, int64_t* counts);
+void orc_plane_count_f64pts(const double* x, const double* y, const double* z, size_t n,
+                            const double* planes4, size_t n_planes, double thr, int64_t* counts);
+/* final mask (:152-153): mask[i] = dist_i < thr for ONE plane. */
+void orc_plane_mask_f32pts(const float* x, const float* y, const float* z, size_t n,
+                           const double plane4[4], double thr, uint8_t* mask);
+
+/* ---- estimate_plane_params (ground_detection_ransac.py:158-169) in f64. p: 3 points x 3, row-major. */
+void orc_plane_from_3pts(const double p[9], double params[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCR_ORACLE_H */

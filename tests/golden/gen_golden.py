@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference and oracle/_ref/libpcr_ref.so, i.e. the
+reference's hw2 headers + vendored nanoflann compiled from where they lie — `make -C oracle ref`).
+The fixtures (data: inputs + expected outputs) are committed; the reference never travels.
+
+    python tests/golden/gen_golden.py
+
+Fixtures:
+  F1 kat_kitti_q5.npz        known-answer test of Homework2/hw2/result_cpp.txt:11-33 (query = point #5,
+                             k = 8, leaf 32, radius 1.66, first 100 000 points of 000000.bin) + the points
+  F2 nn1_nanoflann_*.npz     1-NN idx + d2 (f32) from vendored nanoflann, leaf 2 (ICP's configuration)
+  F3 knn_hw2_*.npz           k-NN idx + dist (f64) from the hw2 kd-tree, k in {1, 8}, + octree cross-check
+  F4 radius_hw2_*.npz        radius sets from the hw2 kd-tree, r in {0.5, 1.0} (stored sorted by index)
+  F5 plane_hw4.npz           Homework4 plane-inlier counts + masks (numpy expression of
+                             ground_detection_ransac.py:138-139,152-153; params from the reference's own
+                             estimate_plane_params, :158-169, executed from its source)
+  F6 icp_selfgolden.npz      ICP trace from the repo's own f64 restatement (SELF-GOLDEN: hw9 cannot be
+                             built here — PCL/Eigen absent — so this pins regression, not reference parity)
+"""
+import ast
+import hashlib
+import importlib
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import orc  # noqa: E402
+
+synth = importlib.import_module("hands-on-point-cloud-processing_amd.synth")
+OUT = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **kw)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB  " + ", ".join(f"{k}{getattr(v, 'shape', '')}" for k, v in kw.items()))
+
+
+def read_kitti_bin(path):
+    a = np.fromfile(path, dtype=np.float32).reshape(-1, 4)
+    return a[:, :3].copy()
+
+
+# ------------------------------------------------------------------ F1
+def f1():
+    pts, n_read = orc.ref_hw2_read_binary(f"{REF}/Homework2/hw2/000000.bin")
+    raw = read_kitti_bin(f"{REF}/Homework2/hw2/000000.bin")
+    assert n_read == raw.shape[0] + 1, (n_read, raw.shape)          # readBinary's EOF duplicate (test.hpp:24)
+    assert np.array_equal(pts[-1], pts[-2])
+    db32 = raw[:100000]
+    db = db32.astype(np.float64)
+    q = db[5:6]
+    idx, dist, cmp, _, _ = orc.ref_hw2_kd_knn(db, q, 8, leaf=32, want_cmp=True)
+    # published answer, result_cpp.txt:13-20
+    assert idx[0].tolist() == [5, 1972, 6, 1971, 1970, 3946, 8, 3945] and int(cmp[0]) == 49
+    row, ridx, rdist = orc.ref_hw2_kd_radius(db, q, 1.66, leaf=32)
+    oidx, odist = orc.ref_hw2_oct_knn(db, q, 8, leaf=32)
+    assert np.array_equal(oidx, idx)
+    save("kat_kitti_q5.npz", db_f32=db32, query_index=np.int64(5), k=np.int64(8), knn_idx=idx[0], knn_dist=dist[0],
+         comparison_count=np.int64(cmp[0]), radius=np.float64(1.66), radius_idx_visit_order=ridx,
+         radius_dist_visit_order=rdist, n_points_readBinary=np.int64(n_read), n_points_file=np.int64(raw.shape[0]))
+
+
+# ------------------------------------------------------------------ F2 / F3 / F4
+def perturbed_copy(p32):
+    """KITTI-subset pair: the scan vs its own 1 deg / 0.3 m perturbed copy (BASELINE.md §2 protocol)."""
+    a = math.radians(1.0)
+    R = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]])
+    q = (R @ p32.T.astype(np.float64)).T + np.array([0.3, 0.0, 0.0])
+    return q.astype(np.float32)
+
+
+def f2_f3_f4():
+    raw = read_kitti_bin(f"{REF}/Homework2/hw2/000000.bin")
+    cases = {}
+    for n in (1000, 4096):
+        src, tgt = synth.kitti_like_pair(n)
+        cases[f"synth{n}"] = (src, tgt)
+    sub = raw[:: raw.shape[0] // 4096][:4096]
+    cases["kitti4096"] = (np.ascontiguousarray(perturbed_copy(sub).T), np.ascontiguousarray(sub.T))
+    # lattice data (test.hpp:142 semantics) -> exact ties and duplicates
+    lat_t = synth.lattice_cloud(1000, 3, 10.0, seed=101, levels=12).astype(np.float32)
+    lat_s = synth.lattice_cloud(1000, 3, 10.0, seed=202, levels=12).astype(np.float32)
+    cases["lattice1000"] = (np.ascontiguousarray(lat_s.T), np.ascontiguousarray(lat_t.T))
+    for name, (src, tgt) in cases.items():
+        idx, d2, _, _ = orc.ref_nano_nn1_f32(tgt, src, leaf=2)
+        save(f"nn1_nanoflann_{name}.npz", src=src, tgt=tgt, idx=idx, d2=d2, leaf=np.int64(2))
+
+    # hw2 f64: queries = second cloud, db = first (duplicate-free inputs: hw2's build recurses forever on
+    # duplicates with multiplicity > leaf_size, kdtree.hpp:237-243 — SURVEY.md §7.2)
+    for name in ("synth1000", "kitti4096"):
+        src, tgt = cases[name]
+        db = np.unique(tgt.T.astype(np.float64), axis=0)
+        rng_order = np.argsort(synth.splitmix64(77, np.arange(db.shape[0], dtype=np.uint64)), kind="stable")
+        db = np.ascontiguousarray(db[rng_order])
+        q = np.ascontiguousarray(src.T.astype(np.float64))[:512]
+        out = {"db": db, "q": q}
+        for k in (1, 8):
+            idx, dist = orc.ref_hw2_kd_knn(db, q, k, leaf=1)
+            oidx, odist = orc.ref_hw2_oct_knn(db, q, k, leaf=1)
+            assert np.array_equal(odist, dist)
+            nidx, nd2 = orc.ref_nano_knn_f64(db, q, k, leaf=10)
+            out[f"idx_k{k}"] = idx
+            out[f"dist_k{k}"] = dist
+            out[f"nano_idx_k{k}"] = nidx
+            out[f"nano_d2_k{k}"] = nd2
+        save(f"knn_hw2_{name}.npz", **out)
+        out = {"db": db, "q": q}
+        for r in (0.5, 1.0):
+            row, ridx, rdist = orc.ref_hw2_kd_radius(db, q, r, leaf=1)
+            # canonical order = ascending index inside each row (the reference emits visit order)
+            sidx = ridx.copy(); sdist = rdist.copy()
+            for i in range(q.shape[0]):
+                o = np.argsort(ridx[row[i]:row[i + 1]], kind="stable")
+                sidx[row[i]:row[i + 1]] = ridx[row[i]:row[i + 1]][o]
+                sdist[row[i]:row[i + 1]] = rdist[row[i]:row[i + 1]][o]
+            tag = str(r).replace(".", "p")
+            out[f"row_r{tag}"] = row
+            out[f"idx_r{tag}"] = sidx
+            out[f"dist_r{tag}"] = sdist
+        save(f"radius_hw2_{name}.npz", **out)
+
+    # lattice k-NN on duplicate-free lattice db (ties in distance remain) — k = 8 tie groups.
+    # leaf 32 (the KAT's leaf size): with leaf 1 the reference's own build never terminates on this input —
+    # KDTreeBuildFastMedian sends every point with value <= median left (kdtree.hpp:237-243), so a node like
+    # {(1,2,2),(2,1,2),(2,2,1)} (median == max on every axis) recurses until the stack overflows, even
+    # without duplicates (observed: SIGSEGV at 70 points of this very cloud).
+    db = np.unique(synth.lattice_cloud(1200, 3, 10.0, seed=303, levels=16), axis=0)
+    q = synth.lattice_cloud(256, 3, 10.0, seed=404, levels=16)
+    out = {"db": db, "q": q}
+    for k in (1, 8):
+        idx, dist = orc.ref_hw2_kd_knn(db, q, k, leaf=32)
+        nidx, nd2 = orc.ref_nano_knn_f64(db, q, k, leaf=10)
+        out[f"idx_k{k}"] = idx; out[f"dist_k{k}"] = dist
+        out[f"nano_idx_k{k}"] = nidx; out[f"nano_d2_k{k}"] = nd2
+    save("knn_hw2_lattice.npz", **out)
+
+
+# ------------------------------------------------------------------ F5
+def load_reference_function(pyfile, fname):
+    """Execute ONE function definition of a reference .py file (no module import: the module imports
+    open3d/bottleneck/mylib, which are absent; the function itself is pure numpy/math)."""
+    tree = ast.parse(open(pyfile).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == fname][0]
+    ns = {"np": np, "math": math}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), pyfile, "exec"), ns)
+    return ns[fname]
+
+
+def f5():
+    pyfile = f"{REF}/Homework4/ground_detection_ransac.py"
+    estimate_plane_params = load_reference_function(pyfile, "estimate_plane_params")
+    raw = read_kitti_bin(f"{REF}/Homework4/test/000111.bin")            # read_velodyne_bin (:23-34): N x 3 f32
+    pts = np.ascontiguousarray(raw[:: raw.shape[0] // 8192][:8192])
+    thr = 0.15                                                           # ransac_on_segments default (:54)
+    ground = np.where(np.abs(pts[:, 2] + 1.73) < 0.4)[0]
+    c = np.arange(16 * 3, dtype=np.uint64)
+    pick = (synth.splitmix64(555, c) % np.uint64(ground.size)).astype(np.int64).reshape(16, 3)
+    params = np.zeros((16, 4), np.float64)
+    counts = np.zeros(16, np.int64)
+    masks = np.zeros((16, pts.shape[0]), np.uint8)
+    for h in range(16):
+        sel = pts[ground[pick[h]]].astype(np.float64)   # f64 rows -> f64 params (numpy-1.18 behaviour)
+        p = estimate_plane_params(sel)
+        assert p.dtype == np.float64
+        params[h] = p
+        # ground_detection_ransac.py:138-139
+        dists = np.fabs(np.c_[pts, np.ones((pts.shape[0], 1))].dot(p))
+        counts[h] = np.sum([dists < thr])
+        masks[h] = dists < thr                                            # :152-153 (same expression on all points)
+    # a fixed horizontal hypothesis through the sensor-height ground
+    save("plane_hw4.npz", pts_f32=pts, params=params, thr=np.float64(thr), counts=counts,
+         masks=np.packbits(masks, axis=1), picked=ground[pick])
+
+
+# ------------------------------------------------------------------ F6
+def f6():
+    src, tgt = synth.kitti_like_pair(4096)
+    T, st, per_T, per_n = orc.icp_p2p_f32(src, tgt, max_corr=1.0, max_iter=20, eps=1e-8, trace=True)
+    save("icp_selfgolden.npz", src=src, tgt=tgt, T=T, per_iter_T=per_T, per_iter_pairs=per_n,
+         iters_run=np.int64(st["iters_run"]), converged=np.int64(st["converged"]),
+         last_loss=np.float32(st["last_loss"]))
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "reference not present"
+    orc.build(ref=True)
+    f1(); f2_f3_f4(); f5(); f6()
