@@ -1,0 +1,76 @@
+"""Build libpcr_hip.so (hand-written gfx950 kernels + the C ABI of include/pcr.h) IN-TREE with hipcc.
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the resulting .so
+travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libpcr_hip.so")
+OBJ = os.path.join(HERE, "build")
+
+SOURCES = ["api.cpp", "numerics.cpp", "icp.cpp", "comm.cpp", "nn1_brute.hip", "kabsch.hip", "plane.hip",
+           "search_f64.hip"]
+
+# -ffp-contract=off: the distance arithmetic contract is UNFUSED (nanoflann.hpp:403-406 / kdtree.hpp:341-346);
+#   one fma changes d2 in the last bit and flips near-tie winners.
+# -fno-slp-vectorize: keeps the inner loop on plain v_sub/v_mul/v_add_f32; the SLP vectoriser otherwise packs
+#   pairs into v_pk_mul_f32 / v_pk_add_f32, which issue at half rate on gfx950 and need extra v_mov to form
+#   register pairs (measured: profiles/).
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(a: str, b: str) -> bool:
+    return os.path.exists(a) and os.path.getmtime(a) >= os.path.getmtime(b)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    headers = [os.path.join(CSRC, "pcr_internal.hpp"), os.path.join(ROOT, "include", "pcr.h"), __file__]
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s + ".o")
+        if force or not _newer(obj, src) or any(not _newer(obj, h) for h in headers):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [cc, *FLAGS, "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(compile_one, jobs))
+    objs = [os.path.join(OBJ, s + ".o") for s in SOURCES]
+    if jobs or not os.path.exists(OUT):
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,379 @@
+// api.cpp — context, cloud management and the thin extern "C" entry points of libpcr_hip.so.
+#include "pcr_internal.hpp"
+
+#include <cmath>
+#include <limits>
+#include <new>
+
+namespace pcr {
+
+int fail(pcr_ctx* ctx, int code, const char* what, hipError_t e)
+{
+    if (ctx) {
+        ctx->err = what ? what : "";
+        if (e != hipSuccess) {
+            ctx->err += ": ";
+            ctx->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+int ensure_keys(pcr_ctx* ctx, size_t n)
+{
+    if (n <= ctx->keys_cap) return PCR_OK;
+    if (ctx->keys) PCR_HIP(ctx, hipFree(ctx->keys));
+    ctx->keys = nullptr;
+    ctx->keys_cap = 0;
+    size_t cap = padded(n);
+    PCR_HIP(ctx, hipMalloc((void**)&ctx->keys, cap * sizeof(unsigned long long)));
+    ctx->keys_cap = cap;
+    return PCR_OK;
+}
+
+int ensure_scratch(pcr_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_cap) return PCR_OK;
+    if (ctx->scratch) PCR_HIP(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_cap = 0;
+    size_t cap = (bytes + (1 << 20)) & ~((size_t)(1 << 20) - 1);
+    PCR_HIP(ctx, hipMalloc(&ctx->scratch, cap));
+    ctx->scratch_cap = cap;
+    return PCR_OK;
+}
+
+int ensure_stage(pcr_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->host_stage_cap) return PCR_OK;
+    if (ctx->host_stage) PCR_HIP(ctx, hipHostFree(ctx->host_stage));
+    ctx->host_stage = nullptr;
+    ctx->host_stage_cap = 0;
+    size_t cap = (bytes + (1 << 20)) & ~((size_t)(1 << 20) - 1);
+    PCR_HIP(ctx, hipHostMalloc(&ctx->host_stage, cap, hipHostMallocDefault));
+    ctx->host_stage_cap = cap;
+    return PCR_OK;
+}
+
+int64_t tune_get(const pcr_ctx* ctx, const char* key, int64_t dflt)
+{
+    auto it = ctx->tune.find(key);
+    return (it == ctx->tune.end() || it->second == 0) ? dflt : it->second;
+}
+
+ProfScope::ProfScope(pcr_ctx* c, const char* n) : ctx(c), name(n)
+{
+    if (!ctx->prof_on) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    hipEventRecord(a, ctx->stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (!a || !b) return;
+    hipEventRecord(b, ctx->stream);
+    ctx->prof[name].pending.emplace_back(a, b);
+}
+
+void prof_flush(pcr_ctx* ctx)
+{
+    for (auto& kv : ctx->prof) {
+        for (auto& ev : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                kv.second.launches++;
+                kv.second.total_ms += ms;
+            }
+            hipEventDestroy(ev.first);
+            hipEventDestroy(ev.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+static int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out)
+{
+    pcr_cloud* c = new (std::nothrow) pcr_cloud();
+    if (!c) return fail(ctx, PCR_ERR_NOMEM, "cloud alloc");
+    c->n = n;
+    c->cap = padded(n);
+    hipError_t e = hipMalloc((void**)&c->base, 3 * c->cap * sizeof(float));
+    if (e != hipSuccess) { delete c; return fail(ctx, PCR_ERR_HIP, "hipMalloc(cloud)", e); }
+    *out = c;
+    return PCR_OK;
+}
+
+}  // namespace pcr
+
+using namespace pcr;
+
+extern "C" {
+
+const char* pcr_version(void) { return "pcr-mi355x 0.1 (gfx950)"; }
+
+int pcr_ctx_create(int device, pcr_ctx** out)
+{
+    if (!out) return PCR_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return PCR_ERR_HIP;
+    pcr_ctx* ctx = new (std::nothrow) pcr_ctx();
+    if (!ctx) return PCR_ERR_NOMEM;
+    ctx->device = device;
+#define CK(call)                                          \
+    do {                                                  \
+        hipError_t e__ = (call);                          \
+        if (e__ != hipSuccess) {                          \
+            fprintf(stderr, "pcr_ctx_create: %s: %s\n", #call, hipGetErrorString(e__)); \
+            delete ctx;                                   \
+            return PCR_ERR_HIP;                           \
+        }                                                 \
+    } while (0)
+    CK(hipSetDevice(device));
+    CK(hipGetDeviceProperties(&ctx->prop, device));
+    CK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CK(hipMalloc((void**)&ctx->partials, 1024 * 17 * sizeof(double)));
+    ctx->partials_cap = 1024 * 17;
+    CK(hipMalloc((void**)&ctx->dev_out, 64 * sizeof(double)));
+    CK(hipHostMalloc((void**)&ctx->host_out, 64 * sizeof(double), hipHostMallocDefault));
+#undef CK
+    *out = ctx;
+    return PCR_OK;
+}
+
+int pcr_ctx_destroy(pcr_ctx* ctx)
+{
+    if (!ctx) return PCR_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    prof_flush(ctx);
+    pcr_comm_destroy(ctx);
+    if (ctx->keys) hipFree(ctx->keys);
+    if (ctx->partials) hipFree(ctx->partials);
+    if (ctx->dev_out) hipFree(ctx->dev_out);
+    if (ctx->host_out) hipHostFree(ctx->host_out);
+    if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->host_stage) hipHostFree(ctx->host_stage);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PCR_OK;
+}
+
+int pcr_ctx_sync(pcr_ctx* ctx)
+{
+    if (!ctx) return PCR_ERR_ARG;
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+const char* pcr_ctx_last_error(const pcr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int pcr_ctx_device_info(const pcr_ctx* ctx, char* arch, size_t arch_cap, int* n_cu, uint64_t* hbm_bytes)
+{
+    if (!ctx) return PCR_ERR_ARG;
+    if (arch && arch_cap) {
+        strncpy(arch, ctx->prop.gcnArchName, arch_cap - 1);
+        arch[arch_cap - 1] = 0;
+    }
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = ctx->prop.totalGlobalMem;
+    return PCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- clouds
+int pcr_cloud_create(pcr_ctx* ctx, const float* host_xyz, size_t n, int layout, pcr_cloud** out)
+{
+    if (!ctx || !out || (n && !host_xyz) || layout < PCR_SOA || layout > PCR_AOS4) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_create");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    pcr_cloud* c = nullptr;
+    int rc = cloud_alloc(ctx, n, &c);
+    if (rc) return rc;
+    // stage as padded SoA: x padding = +inf, y/z padding = 0
+    rc = ensure_stage(ctx, 3 * c->cap * sizeof(float));
+    if (rc) { pcr_cloud_destroy(ctx, c); return rc; }
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer may still be in flight
+    float* st = (float*)ctx->host_stage;
+    float* sx = st, *sy = st + c->cap, *sz = st + 2 * c->cap;
+    if (layout == PCR_SOA) {
+        memcpy(sx, host_xyz, n * sizeof(float));
+        memcpy(sy, host_xyz + n, n * sizeof(float));
+        memcpy(sz, host_xyz + 2 * n, n * sizeof(float));
+    } else {
+        const size_t stride = layout == PCR_AOS3 ? 3 : 4;
+        for (size_t i = 0; i < n; i++) {
+            sx[i] = host_xyz[i * stride];
+            sy[i] = host_xyz[i * stride + 1];
+            sz[i] = host_xyz[i * stride + 2];
+        }
+    }
+    for (size_t i = n; i < c->cap; i++) { sx[i] = std::numeric_limits<float>::infinity(); sy[i] = 0.f; sz[i] = 0.f; }
+    hipError_t e = hipMemcpyAsync(c->base, st, 3 * c->cap * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { pcr_cloud_destroy(ctx, c); return fail(ctx, PCR_ERR_HIP, "cloud upload", e); }
+    *out = c;
+    return PCR_OK;
+}
+
+int pcr_cloud_clone(pcr_ctx* ctx, const pcr_cloud* src, pcr_cloud** out)
+{
+    if (!ctx || !src || !out) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_clone");
+    pcr_cloud* c = nullptr;
+    int rc = cloud_alloc(ctx, src->n, &c);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(c->base, src->base, 3 * c->cap * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) { pcr_cloud_destroy(ctx, c); return fail(ctx, PCR_ERR_HIP, "cloud clone", e); }
+    *out = c;
+    return PCR_OK;
+}
+
+int pcr_cloud_assign(pcr_ctx* ctx, pcr_cloud* dst, const pcr_cloud* src)
+{
+    if (!ctx || !dst || !src || dst->n != src->n) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_assign");
+    PCR_HIP(ctx, hipMemcpyAsync(dst->base, src->base, 3 * src->cap * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    return PCR_OK;
+}
+
+int pcr_cloud_read(pcr_ctx* ctx, const pcr_cloud* c, float* host_xyz, int layout)
+{
+    if (!ctx || !c || (c->n && !host_xyz) || layout < PCR_SOA || layout > PCR_AOS4) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_read");
+    const size_t n = c->n;
+    if (n == 0) return PCR_OK;
+    int rc = ensure_stage(ctx, 3 * c->cap * sizeof(float));
+    if (rc) return rc;
+    float* st = (float*)ctx->host_stage;
+    PCR_HIP(ctx, hipMemcpyAsync(st, c->base, 3 * c->cap * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const float* sx = st, *sy = st + c->cap, *sz = st + 2 * c->cap;
+    if (layout == PCR_SOA) {
+        memcpy(host_xyz, sx, n * sizeof(float));
+        memcpy(host_xyz + n, sy, n * sizeof(float));
+        memcpy(host_xyz + 2 * n, sz, n * sizeof(float));
+    } else {
+        const size_t stride = layout == PCR_AOS3 ? 3 : 4;
+        for (size_t i = 0; i < n; i++) {
+            host_xyz[i * stride] = sx[i];
+            host_xyz[i * stride + 1] = sy[i];
+            host_xyz[i * stride + 2] = sz[i];
+        }
+    }
+    return PCR_OK;
+}
+
+size_t pcr_cloud_size(const pcr_cloud* c) { return c ? c->n : 0; }
+
+int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
+{
+    if (!c) return PCR_OK;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (c->base) hipFree(c->base);
+    delete c;
+    return PCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- 1-NN
+int pcr_nn1_f32_async(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
+{
+    if (!ctx || !tgt || !src) return fail(ctx, PCR_ERR_ARG, "pcr_nn1_f32_async");
+    return launch_nn1_brute(ctx, tgt, src);
+}
+
+int pcr_nn1_fetch(pcr_ctx* ctx, size_t n, uint32_t* idx, float* d2)
+{
+    if (!ctx || n != ctx->keys_n || (n && (!idx || !d2))) return fail(ctx, PCR_ERR_ARG, "pcr_nn1_fetch");
+    if (n == 0) return PCR_OK;
+    int rc = ensure_scratch(ctx, n * 8);
+    if (rc) return rc;
+    uint32_t* idx_dev = (uint32_t*)ctx->scratch;
+    float* d2_dev = (float*)((char*)ctx->scratch + n * 4);
+    rc = nn1_unpack(ctx, n, idx_dev, d2_dev);
+    if (rc) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(idx, idx_dev, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipMemcpyAsync(d2, d2_dev, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+int pcr_nn1_f32(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t* idx, float* d2)
+{
+    int rc = pcr_nn1_f32_async(ctx, tgt, src);
+    if (rc) return rc;
+    return pcr_nn1_fetch(ctx, src->n, idx, d2);
+}
+
+// ---------------------------------------------------------------------------------------------- A8 / A7
+int pcr_transform_f32(pcr_ctx* ctx, pcr_cloud* cloud, const float T[16])
+{
+    if (!ctx || !cloud || !T) return fail(ctx, PCR_ERR_ARG, "pcr_transform_f32");
+    const float R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
+    const float t[3] = { T[3], T[7], T[11] };
+    return launch_transform(ctx, cloud, R, t);
+}
+
+int pcr_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr, double sums[16],
+                    int64_t* last_kept, float* last_d2)
+{
+    if (!ctx || !tgt || !src || !sums) return fail(ctx, PCR_ERR_ARG, "pcr_kabsch_sums");
+    if (src->n == 0) {
+        for (int k = 0; k < 16; k++) sums[k] = 0.0;
+        if (last_kept) *last_kept = -1;
+        if (last_d2) *last_d2 = 0.f;
+        return PCR_OK;
+    }
+    int rc = launch_kabsch_sums(ctx, tgt, src, max_corr);
+    if (rc) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(ctx->host_out, ctx->dev_out, 18 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(sums, ctx->host_out, 16 * sizeof(double));
+    if (last_kept) *last_kept = (int64_t)ctx->host_out[16];
+    if (last_d2) *last_d2 = (float)ctx->host_out[17];
+    return PCR_OK;
+}
+
+int pcr_kabsch_solve(const double sums[16], float R[9], float t[3])
+{
+    if (!sums || !R || !t) return PCR_ERR_ARG;
+    return kabsch_solve(sums, R, t);
+}
+
+// ---------------------------------------------------------------------------------------------- profiling / tuning
+int pcr_prof_reset(pcr_ctx* ctx)
+{
+    if (!ctx) return PCR_ERR_ARG;
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_flush(ctx);
+    ctx->prof.clear();
+    return PCR_OK;
+}
+
+int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* total_ms)
+{
+    if (!ctx || !kernel) return PCR_ERR_ARG;
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_flush(ctx);
+    auto it = ctx->prof.find(kernel);
+    if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.total_ms;
+    return PCR_OK;
+}
+
+int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value)
+{
+    if (!ctx || !key) return PCR_ERR_ARG;
+    if (!strcmp(key, "prof")) { ctx->prof_on = value != 0; return PCR_OK; }
+    ctx->tune[key] = value;
+    return PCR_OK;
+}
+
+void pcr_shard_range(size_t n, int nranks, int rank, size_t* begin, size_t* end)
+{
+    if (nranks < 1) nranks = 1;
+    if (rank < 0) rank = 0;
+    if (rank >= nranks) rank = nranks - 1;
+    const size_t base = n / (size_t)nranks, rem = n % (size_t)nranks;
+    const size_t b = (size_t)rank * base + ((size_t)rank < rem ? (size_t)rank : rem);
+    const size_t e = b + base + ((size_t)rank < rem ? 1 : 0);
+    if (begin) *begin = b;
+    if (end) *end = e;
+}
+
+}  // extern "C"

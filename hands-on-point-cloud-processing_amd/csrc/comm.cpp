@@ -1,0 +1,143 @@
+// comm.cpp — the one collective of the path: all-reduce(sum) of <= 64 f64 per ICP iteration.
+// Transport 1: RCCL over xGMI (one process per GPU).  librccl is bound with dlopen at first use so that a
+// single-GPU process never loads it and so that, inside a PyTorch process, the already loaded
+// librccl.so.1 (same SONAME) is shared instead of a second copy.
+// Transport 2: a host callback (caller's own process group; used by the gloo CPU tests).
+// The message is 128-192 B: pure latency (one ring/tree hop chain), nowhere near the 7 x ~153 GB/s xGMI
+// link bound — see DESIGN.md §multi-GPU.
+#include "pcr_internal.hpp"
+
+#include <dlfcn.h>
+
+namespace pcr {
+
+namespace {
+
+struct UniqueId {
+    char internal[PCR_COMM_ID_BYTES];
+};
+
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+
+Rccl& rccl()
+{
+    static Rccl r;
+    if (r.handle || !r.err.empty()) return r;
+    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char* n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) { r.err = std::string("dlopen(librccl): ") + dlerror(); return r; }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) {
+        r.err = "librccl: missing symbols";
+        r.handle = nullptr;
+    }
+    return r;
+}
+
+constexpr int kNcclFloat64 = 8;   // rccl.h: ncclFloat64 = 8
+constexpr int kNcclSum = 0;       // rccl.h: ncclSum = 0
+
+}  // namespace
+
+int comm_allreduce_f64(pcr_ctx* ctx, double* host_buf, double* dev_buf, int n)
+{
+    Comm& c = ctx->comm;
+    if (c.nranks <= 1) return PCR_OK;
+    if (c.cb) {
+        int rc = c.cb(c.cb_user, host_buf, n);
+        if (rc != 0) return fail(ctx, PCR_ERR_COMM, "allreduce callback failed");
+        return PCR_OK;
+    }
+    if (c.rccl) {
+        Rccl& r = rccl();
+        PCR_HIP(ctx, hipMemcpyAsync(dev_buf, host_buf, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        int rc = r.AllReduce(dev_buf, dev_buf, (size_t)n, kNcclFloat64, kNcclSum, c.rccl, ctx->stream);
+        if (rc != 0) {
+            ctx->err = std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
+            return PCR_ERR_COMM;
+        }
+        PCR_HIP(ctx, hipMemcpyAsync(host_buf, dev_buf, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return PCR_OK;
+    }
+    return fail(ctx, PCR_ERR_STATE, "nranks > 1 but no transport attached");
+}
+
+}  // namespace pcr
+
+using namespace pcr;
+
+extern "C" {
+
+int pcr_comm_unique_id(char id[PCR_COMM_ID_BYTES])
+{
+    if (!id) return PCR_ERR_ARG;
+    Rccl& r = rccl();
+    if (!r.handle) { fprintf(stderr, "pcr_comm_unique_id: %s\n", r.err.c_str()); return PCR_ERR_COMM; }
+    UniqueId u;
+    memset(&u, 0, sizeof u);
+    int rc = r.GetUniqueId(&u);
+    if (rc != 0) return PCR_ERR_COMM;
+    memcpy(id, u.internal, PCR_COMM_ID_BYTES);
+    return PCR_OK;
+}
+
+int pcr_comm_init_rccl(pcr_ctx* ctx, int nranks, int rank, const char id[PCR_COMM_ID_BYTES])
+{
+    if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_rccl");
+    pcr_comm_destroy(ctx);
+    Rccl& r = rccl();
+    if (!r.handle) return fail(ctx, PCR_ERR_COMM, r.err.c_str());
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    UniqueId u;
+    memcpy(u.internal, id, PCR_COMM_ID_BYTES);
+    void* comm = nullptr;
+    int rc = r.CommInitRank(&comm, nranks, u, rank);
+    if (rc != 0) {
+        ctx->err = std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
+        return PCR_ERR_COMM;
+    }
+    ctx->comm.nranks = nranks;
+    ctx->comm.rank = rank;
+    ctx->comm.rccl = comm;
+    return PCR_OK;
+}
+
+int pcr_comm_init_callback(pcr_ctx* ctx, int nranks, int rank, pcr_allreduce_fn fn, void* user)
+{
+    if (!ctx || !fn || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_callback");
+    pcr_comm_destroy(ctx);
+    ctx->comm.nranks = nranks;
+    ctx->comm.rank = rank;
+    ctx->comm.cb = fn;
+    ctx->comm.cb_user = user;
+    return PCR_OK;
+}
+
+int pcr_comm_destroy(pcr_ctx* ctx)
+{
+    if (!ctx) return PCR_ERR_ARG;
+    if (ctx->comm.rccl) {
+        Rccl& r = rccl();
+        if (r.handle) r.CommDestroy(ctx->comm.rccl);
+    }
+    ctx->comm = Comm();
+    return PCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// pcr_internal.hpp — shared host-side declarations of libpcr_hip.so (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pcr.h"
+
+namespace pcr {
+
+// Every cloud is allocated with its length rounded up to PAD points; x of the padding is +inf so that a
+// padded target can never win a nearest-neighbour comparison (d2 = +inf is not < FLT_MAX).
+constexpr size_t PAD = 1024;
+
+inline size_t padded(size_t n) { return ((n + PAD - 1) / PAD) * PAD + PAD; }   // always >= 1 full pad block
+
+struct ProfEntry {
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct Comm {
+    int nranks = 1;
+    int rank = 0;
+    void* rccl = nullptr;          // ncclComm_t
+    pcr_allreduce_fn cb = nullptr;
+    void* cb_user = nullptr;
+};
+
+}  // namespace pcr
+
+struct pcr_cloud {
+    size_t n = 0;
+    size_t cap = 0;     // padded length of each of x, y, z
+    float* base = nullptr;   // device; x = base, y = base + cap, z = base + 2*cap
+    float* x() const { return base; }
+    float* y() const { return base + cap; }
+    float* z() const { return base + 2 * cap; }
+};
+
+struct pcr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+    // workspace
+    unsigned long long* keys = nullptr;   // (d2_bits << 32 | idx) per query of the last nn1 pass
+    size_t keys_cap = 0;
+    size_t keys_n = 0;
+    double* partials = nullptr;           // block partial sums of the Kabsch pass
+    size_t partials_cap = 0;
+    double* dev_out = nullptr;            // 32 doubles: reduced sums + bookkeeping
+    double* host_out = nullptr;           // pinned mirror
+    void* scratch = nullptr;              // generic device scratch
+    size_t scratch_cap = 0;
+    void* host_stage = nullptr;           // pinned staging for uploads / downloads
+    size_t host_stage_cap = 0;
+    pcr::Comm comm;
+    std::map<std::string, pcr::ProfEntry> prof;
+    bool prof_on = true;
+    std::map<std::string, int64_t> tune;
+};
+
+namespace pcr {
+
+int fail(pcr_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
+
+#define PCR_HIP(ctx, call)                                                   \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return pcr::fail((ctx), PCR_ERR_HIP, #call, e__); \
+    } while (0)
+
+int ensure_keys(pcr_ctx* ctx, size_t n);
+int ensure_scratch(pcr_ctx* ctx, size_t bytes);
+int ensure_stage(pcr_ctx* ctx, size_t bytes);
+int64_t tune_get(const pcr_ctx* ctx, const char* key, int64_t dflt);
+
+// profiling: record a (start, stop) event pair around a launch on ctx->stream
+struct ProfScope {
+    pcr_ctx* ctx;
+    const char* name;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(pcr_ctx* c, const char* n);
+    ~ProfScope();
+};
+void prof_flush(pcr_ctx* ctx);
+
+// ---- kernel launchers (defined in the .hip files) --------------------------------------------------
+int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
+int nn1_unpack(pcr_ctx* ctx, size_t n, uint32_t* idx_dev, float* d2_dev);
+int launch_transform(pcr_ctx* ctx, pcr_cloud* c, const float R[9], const float t[3]);
+int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr);
+int launch_plane_count(pcr_ctx* ctx, const pcr_cloud* pts, const double* planes4_dev, size_t n_planes,
+                       double thr, unsigned long long* counts_dev);
+int launch_plane_mask(pcr_ctx* ctx, const pcr_cloud* pts, const double plane4[4], double thr,
+                      uint8_t* mask_dev, unsigned long long* count_dev);
+int launch_knn_f64(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m,
+                   int k, int32_t* idx_dev, double* dist_dev);
+int launch_radius_count(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa,
+                        size_t m, double r, unsigned long long* counts_dev);
+int launch_radius_fill(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa,
+                       size_t m, double r, const long long* row_ptr_dev, int32_t* idx_dev, double* dist_dev);
+
+// ---- host numerics ------------------------------------------------------------------------------------
+void svd3(const double A[9], double U[9], double S[3], double V[9]);
+int kabsch_solve(const double sums[16], float R[9], float t[3]);
+void mat4_mul_f32(const float A[16], const float B[16], float out[16]);
+
+// ---- collectives ----------------------------------------------------------------------------------------
+int comm_allreduce_f64(pcr_ctx* ctx, double* host_buf, double* dev_buf, int n);
+
+}  // namespace pcr

@@ -1,0 +1,288 @@
+// search_f64.hip — batched k-NN and radius-NN with the hw2 arithmetic (A2/A4/A11) for gfx950.
+// Reference (one query per call, pointer-chasing kd-tree): Homework2/hw2/include/kdtree.hpp:329-402 with the
+// result sets of resultSet.hpp:28-142; batched consumer Homework7/hw7/src/iss_detector.cpp:48-56.
+//   d = sqrt(((0 + (t0-q0)^2) + (t1-q1)^2) + (t2-q2)^2)   in f64 (kdtree.hpp:341-346)
+//   k-NN:   the k smallest d, canonical order (d ascending, then index ascending)
+//   radius: every j with d <= r (inclusive, resultSet.hpp:133), ascending index, CSR
+// The tree is replaced by an exhaustive LDS-tiled scan (same answers; the tree is only an index).
+// One query per lane; the database streams through LDS in SoA f64 tiles and is read as wave-wide
+// broadcasts.  The scan visits indices in ascending order and only a strictly smaller distance displaces an
+// entry, which is exactly the canonical tie rule.
+// Radius membership avoids the sqrt: sqrt is monotone and correctly rounded, so d <= r  <=>  s <= r2max
+// with r2max = max{ s : sqrt(s) <= r }, computed once on the host; sqrt runs only for reported neighbours.
+#include "pcr_internal.hpp"
+
+#include <cmath>
+
+#pragma clang fp contract(off)
+
+namespace pcr {
+
+constexpr int SF_BLOCK = 256;
+constexpr int SF_TILE = 512;   // db points per LDS tile: 3 * 4 KiB of f64
+
+__device__ __forceinline__ double dist2_f64(double t0, double t1, double t2, double q0, double q1, double q2)
+{
+    const double e0 = t0 - q0, e1 = t1 - q1, e2 = t2 - q2;
+    return (e0 * e0 + e1 * e1) + e2 * e2;
+}
+
+template <int K>
+__global__ __launch_bounds__(SF_BLOCK) void knn_f64_kernel(
+    const double* __restrict__ db, uint32_t n, uint32_t n_cap, const double* __restrict__ q, uint32_t m,
+    uint32_t m_cap, int k_out, int32_t* __restrict__ idx_out, double* __restrict__ dist_out)
+{
+    __shared__ double l0[SF_TILE], l1[SF_TILE], l2[SF_TILE];
+    const uint32_t qi = blockIdx.x * SF_BLOCK + threadIdx.x;
+    const uint32_t qc = min(qi, m - 1);
+    const double q0 = q[qc], q1 = q[m_cap + qc], q2 = q[2 * (size_t)m_cap + qc];
+    double bd[K];
+    int32_t bi[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) { bd[s] = 1e10; bi[s] = 0; }      // resultSet.hpp:35-42
+    for (uint32_t base = 0; base < n; base += SF_TILE) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < SF_TILE; t += SF_BLOCK) {
+            const uint32_t j = base + t;    // < n_cap by construction (n_cap is a multiple of SF_TILE)
+            l0[t] = db[j]; l1[t] = db[n_cap + j]; l2[t] = db[2 * (size_t)n_cap + j];
+        }
+        __syncthreads();
+        const uint32_t cnt = min((uint32_t)SF_TILE, n - base);
+        for (uint32_t t = 0; t < cnt; t++) {
+            const double d = sqrt(dist2_f64(l0[t], l1[t], l2[t], q0, q1, q2));
+            // resultSet.hpp:69 rejects only d > worst; the canonical rule additionally keeps the earlier
+            // (lower) index on equality, i.e. insert only when strictly smaller than the current worst
+            if (d < bd[K - 1]) {
+                const int32_t j = (int32_t)(base + t);
+                double cd = d;
+                int32_t ci = j;
+#pragma unroll
+                for (int s = 0; s < K; s++) {
+                    // bubble the candidate down: strictly smaller goes in front, equal stays behind
+                    const bool sw = cd < bd[s];
+                    const double td = bd[s];
+                    const int32_t ti = bi[s];
+                    bd[s] = sw ? cd : td;
+                    bi[s] = sw ? ci : ti;
+                    cd = sw ? td : cd;
+                    ci = sw ? ti : ci;
+                }
+            }
+        }
+    }
+    if (qi < m) {
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            if (s < k_out) {
+                idx_out[(size_t)qi * k_out + s] = bi[s];
+                dist_out[(size_t)qi * k_out + s] = bd[s];
+            }
+        }
+    }
+}
+
+// FILL = false: counts[q] = #{j : s_j <= r2max}; FILL = true: write idx/dist at row_ptr[q]...
+template <bool FILL>
+__global__ __launch_bounds__(SF_BLOCK) void radius_f64_kernel(
+    const double* __restrict__ db, uint32_t n, uint32_t n_cap, const double* __restrict__ q, uint32_t m,
+    uint32_t m_cap, double r2max, unsigned long long* __restrict__ counts, const long long* __restrict__ row_ptr,
+    int32_t* __restrict__ idx_out, double* __restrict__ dist_out)
+{
+    __shared__ double l0[SF_TILE], l1[SF_TILE], l2[SF_TILE];
+    const uint32_t qi = blockIdx.x * SF_BLOCK + threadIdx.x;
+    const uint32_t qc = min(qi, m - 1);
+    const double q0 = q[qc], q1 = q[m_cap + qc], q2 = q[2 * (size_t)m_cap + qc];
+    unsigned long long c = 0;
+    long long w = 0;
+    if (FILL) w = row_ptr[qc];
+    for (uint32_t base = 0; base < n; base += SF_TILE) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < SF_TILE; t += SF_BLOCK) {
+            const uint32_t j = base + t;
+            l0[t] = db[j]; l1[t] = db[n_cap + j]; l2[t] = db[2 * (size_t)n_cap + j];
+        }
+        __syncthreads();
+        const uint32_t cnt = min((uint32_t)SF_TILE, n - base);
+        for (uint32_t t = 0; t < cnt; t++) {
+            const double s = dist2_f64(l0[t], l1[t], l2[t], q0, q1, q2);
+            if (s <= r2max) {
+                if (FILL) {
+                    if (qi < m) {
+                        idx_out[w] = (int32_t)(base + t);
+                        dist_out[w] = sqrt(s);
+                        w++;
+                    }
+                } else {
+                    c++;
+                }
+            }
+        }
+    }
+    if (!FILL && qi < m) counts[qi] = c;
+}
+
+int launch_knn_f64(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m, int k,
+                   int32_t* idx_dev, double* dist_dev)
+{
+    const uint32_t blocks = (uint32_t)((m + SF_BLOCK - 1) / SF_BLOCK);
+    const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
+    ProfScope p(ctx, "knn_f64");
+#define PCR_KNN(K)                                                                                              \
+    hipLaunchKernelGGL(knn_f64_kernel<K>, dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, db_soa, (uint32_t)n,     \
+                       (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, k, idx_dev, dist_dev)
+    if (k <= 1) PCR_KNN(1);
+    else if (k <= 4) PCR_KNN(4);
+    else if (k <= 8) PCR_KNN(8);
+    else if (k <= 16) PCR_KNN(16);
+    else PCR_KNN(32);
+#undef PCR_KNN
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+int launch_radius_count(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m,
+                        double r2max, unsigned long long* counts_dev)
+{
+    const uint32_t blocks = (uint32_t)((m + SF_BLOCK - 1) / SF_BLOCK);
+    const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
+    ProfScope p(ctx, "radius_count");
+    hipLaunchKernelGGL(radius_f64_kernel<false>, dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, db_soa, (uint32_t)n,
+                       (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, r2max, counts_dev,
+                       (const long long*)nullptr, (int32_t*)nullptr, (double*)nullptr);
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+int launch_radius_fill(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m,
+                       double r2max, const long long* row_ptr_dev, int32_t* idx_dev, double* dist_dev)
+{
+    const uint32_t blocks = (uint32_t)((m + SF_BLOCK - 1) / SF_BLOCK);
+    const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
+    ProfScope p(ctx, "radius_fill");
+    hipLaunchKernelGGL(radius_f64_kernel<true>, dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, db_soa, (uint32_t)n,
+                       (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, r2max, (unsigned long long*)nullptr,
+                       row_ptr_dev, idx_dev, dist_dev);
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+// max{ s >= 0 : sqrt(s) <= r } for r >= 0 (host sqrt is IEEE correctly rounded)
+static double radius_sq_bound(double r)
+{
+    if (!(r >= 0.0)) return -1.0;                 // nothing qualifies (also NaN)
+    if (std::isinf(r)) return r;
+    double s = r * r;
+    while (std::sqrt(s) > r) s = std::nextafter(s, 0.0);
+    for (;;) {
+        const double up = std::nextafter(s, INFINITY);
+        if (std::isinf(up) || std::sqrt(up) > r) break;
+        s = up;
+    }
+    return s;
+}
+
+// host AoS (n x 3) -> device SoA with capacity `cap` (a multiple of SF_TILE); padding = 0
+static int upload_soa_f64(pcr_ctx* ctx, const double* aos, size_t n, size_t cap, double* dev)
+{
+    int rc = ensure_stage(ctx, 3 * cap * sizeof(double));
+    if (rc) return rc;
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double* st = (double*)ctx->host_stage;
+    for (size_t i = 0; i < n; i++) {
+        st[i] = aos[3 * i];
+        st[cap + i] = aos[3 * i + 1];
+        st[2 * cap + i] = aos[3 * i + 2];
+    }
+    for (size_t i = n; i < cap; i++) { st[i] = 0.0; st[cap + i] = 0.0; st[2 * cap + i] = 0.0; }
+    PCR_HIP(ctx, hipMemcpyAsync(dev, st, 3 * cap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+static size_t tile_cap(size_t n) { return ((n + SF_TILE - 1) / SF_TILE) * SF_TILE + SF_TILE; }
+
+}  // namespace pcr
+
+using namespace pcr;
+
+extern "C" int pcr_knn_f64(pcr_ctx* ctx, const double* db, size_t n, const double* q, size_t m, int k, int32_t* idx,
+                           double* dist)
+{
+    if (!ctx || k < 1 || k > 32 || (n && !db) || (m && (!q || !idx || !dist))) return fail(ctx, PCR_ERR_ARG, "pcr_knn_f64");
+    if (m == 0) return PCR_OK;
+    if (n > 0x7FFFFFF0ull || m > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_knn_f64: too large for i32 indices");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n_cap = tile_cap(n), m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
+    const size_t bytes_db = 3 * n_cap * 8, bytes_q = 3 * m_cap * 8, bytes_i = m * (size_t)k * 4, bytes_d = m * (size_t)k * 8;
+    const size_t off_q = bytes_db, off_d = off_q + bytes_q, off_i = off_d + ((bytes_d + 63) & ~(size_t)63);
+    int rc = ensure_scratch(ctx, off_i + bytes_i + 64);
+    if (rc) return rc;
+    char* s = (char*)ctx->scratch;
+    if ((rc = upload_soa_f64(ctx, db, n, n_cap, (double*)s))) return rc;
+    if ((rc = upload_soa_f64(ctx, q, m, m_cap, (double*)(s + off_q)))) return rc;
+    if ((rc = launch_knn_f64(ctx, (double*)s, n, n_cap, (double*)(s + off_q), m, k, (int32_t*)(s + off_i), (double*)(s + off_d)))) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(idx, s + off_i, bytes_i, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipMemcpyAsync(dist, s + off_d, bytes_d, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+extern "C" int pcr_radius_f64(pcr_ctx* ctx, const double* db, size_t n, const double* q, size_t m, double r,
+                              int64_t* row_ptr, int32_t* idx, double* dist)
+{
+    if (!ctx || !row_ptr || (n && !db) || (m && !q) || ((idx == nullptr) != (dist == nullptr)))
+        return fail(ctx, PCR_ERR_ARG, "pcr_radius_f64");
+    row_ptr[0] = 0;
+    if (m == 0) return PCR_OK;
+    if (n > 0x7FFFFFF0ull || m > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_radius_f64: too large for i32 indices");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    const double r2max = radius_sq_bound(r);
+    const size_t n_cap = tile_cap(n), m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
+    const size_t bytes_db = 3 * n_cap * 8, bytes_q = 3 * m_cap * 8, bytes_c = (m + 1) * 8;
+    const size_t off_q = bytes_db, off_c = off_q + bytes_q;
+    int rc = ensure_scratch(ctx, off_c + bytes_c + 64);
+    if (rc) return rc;
+    char* s = (char*)ctx->scratch;
+    if ((rc = upload_soa_f64(ctx, db, n, n_cap, (double*)s))) return rc;
+    if ((rc = upload_soa_f64(ctx, q, m, m_cap, (double*)(s + off_q)))) return rc;
+    // pass 1: counts -> exclusive scan on the host (m+1 words)
+    if ((rc = launch_radius_count(ctx, (double*)s, n, n_cap, (double*)(s + off_q), m, r2max, (unsigned long long*)(s + off_c)))) return rc;
+    std::vector<unsigned long long> cnt(m);
+    PCR_HIP(ctx, hipMemcpyAsync(cnt.data(), s + off_c, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t acc = 0;
+    for (size_t i = 0; i < m; i++) { row_ptr[i] = acc; acc += (int64_t)cnt[i]; }
+    row_ptr[m] = acc;
+    if (!idx || acc == 0) return PCR_OK;
+    // pass 2: fill
+    const size_t total = (size_t)acc;
+    const size_t off_i = off_c + ((bytes_c + 63) & ~(size_t)63), off_d = off_i + ((total * 4 + 63) & ~(size_t)63);
+    const size_t need = off_d + total * 8 + 64;
+    if (need > ctx->scratch_cap) {
+        // growing the scratch would drop the uploaded arrays: allocate result buffers separately
+        int32_t* idx_dev = nullptr;
+        double* dist_dev = nullptr;
+        PCR_HIP(ctx, hipMalloc((void**)&idx_dev, total * 4));
+        hipError_t e = hipMalloc((void**)&dist_dev, total * 8);
+        if (e != hipSuccess) { hipFree(idx_dev); return fail(ctx, PCR_ERR_HIP, "hipMalloc(radius)", e); }
+        hipMemcpyAsync(s + off_c, row_ptr, (m + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        rc = launch_radius_fill(ctx, (double*)s, n, n_cap, (double*)(s + off_q), m, r2max, (const long long*)(s + off_c), idx_dev, dist_dev);
+        if (rc == PCR_OK) {
+            hipMemcpyAsync(idx, idx_dev, total * 4, hipMemcpyDeviceToHost, ctx->stream);
+            hipMemcpyAsync(dist, dist_dev, total * 8, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        e = hipStreamSynchronize(ctx->stream);
+        hipFree(idx_dev);
+        hipFree(dist_dev);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "radius fill", e);
+        return PCR_OK;
+    }
+    PCR_HIP(ctx, hipMemcpyAsync(s + off_c, row_ptr, (m + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_radius_fill(ctx, (double*)s, n, n_cap, (double*)(s + off_q), m, r2max, (const long long*)(s + off_c),
+                                 (int32_t*)(s + off_i), (double*)(s + off_d)))) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(idx, s + off_i, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipMemcpyAsync(dist, s + off_d, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}

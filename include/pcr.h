@@ -1,0 +1,158 @@
+/*
+ * pcr.h — C ABI of libpcr_hip.so: the MI355X-native (gfx950) k-NN correspondence + ICP + plane-inlier
+ * hot path of yf26/Hands-On-Point-Cloud-Processing.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, caller-owned memory, `int`
+ * status (0 = ok, negative = error; never exit()), one context per GPU / per process.  The source-level
+ * replacement headers in include/pcr/ (kdtree.hpp, resultSet.hpp, KDTreeVectorOfVectorsAdaptor.h,
+ * registration.hpp) forward to these entry points; INTEGRATION.md shows the reference-side bindings.
+ * All file:line citations are relative to the reference repository root.
+ *
+ * Arithmetic contracts (bit-exact parity with the reference's CPU path):
+ *   A1  f32 squared distance ((dx*dx + dy*dy) + dz*dz), d = q - t, every op rounded, no FMA
+ *       — nanoflann::L2_Adaptor::evalMetric, Homework9/hw9/include/nanoflann.hpp:383-408
+ *   A2  f64 d = sqrt(((dx*dx) + dy*dy) + dz*dz), d = t - q
+ *       — KDTreeKNNSearch leaf loop, Homework2/hw2/include/kdtree.hpp:339-348
+ *   ties: minimum distance, then lowest index (canonical rule)
+ */
+#ifndef PCR_H
+#define PCR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCR_OK 0
+#define PCR_ERR_ARG (-1)     /* bad argument */
+#define PCR_ERR_HIP (-2)     /* a HIP runtime call failed; see pcr_ctx_last_error */
+#define PCR_ERR_NOMEM (-3)
+#define PCR_ERR_STATE (-4)   /* e.g. collective requested before pcr_comm_init */
+#define PCR_ERR_COMM (-5)    /* RCCL failure */
+#define PCR_ERR_EMPTY (-6)   /* ICP iteration kept no pair (the reference would divide by zero) */
+
+typedef struct pcr_ctx pcr_ctx;
+typedef struct pcr_cloud pcr_cloud;   /* an N-point f32 cloud resident in HBM as SoA x[N] | y[N] | z[N] */
+
+/* host layouts accepted / produced at the boundary */
+enum pcr_layout {
+    PCR_SOA = 0,   /* x[n], y[n], z[n] contiguous — Eigen column-major N x 3 MatrixXf (registration.cpp:903) */
+    PCR_AOS3 = 1,  /* xyzxyz...        — KITTI rows without intensity */
+    PCR_AOS4 = 2   /* xyz?xyz?...      — pcl::PointXYZ (16 B) and KITTI .bin rows (test.hpp:26-28) */
+};
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int pcr_ctx_create(int device, pcr_ctx** out);
+int pcr_ctx_destroy(pcr_ctx* ctx);
+int pcr_ctx_sync(pcr_ctx* ctx);                       /* wait for the context's HIP stream */
+const char* pcr_ctx_last_error(const pcr_ctx* ctx);   /* text of the last failure on this context */
+const char* pcr_version(void);
+/* device facts for the bench / roofline: name (e.g. "gfx950"), CU count, HBM bytes */
+int pcr_ctx_device_info(const pcr_ctx* ctx, char* arch, size_t arch_cap, int* n_cu, uint64_t* hbm_bytes);
+
+/* ---- clouds --------------------------------------------------------------------------------------- */
+int pcr_cloud_create(pcr_ctx* ctx, const float* host_xyz, size_t n, int layout, pcr_cloud** out);
+int pcr_cloud_clone(pcr_ctx* ctx, const pcr_cloud* src, pcr_cloud** out);
+int pcr_cloud_assign(pcr_ctx* ctx, pcr_cloud* dst, const pcr_cloud* src);   /* dst <- src, same size, on device */
+int pcr_cloud_read(pcr_ctx* ctx, const pcr_cloud* c, float* host_xyz, int layout);
+size_t pcr_cloud_size(const pcr_cloud* c);
+int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c);
+
+/* ---- A6 (search): 1-NN correspondence, brute force over LDS-tiled targets ----------------------------
+ * replaces the loop `for i: tar_mat_index.index->findNeighbors(result_set, query, ...)`,
+ * Homework9/hw9/src/registration.cpp:925-934, and KDTreeVectorOfVectorsAdaptor::query(q, 1, ...),
+ * Homework3/nano_vs_my/include/KDTreeVectorOfVectorsAdaptor.h:80-85.
+ * idx[i] = argmin_j d2(src_i, tgt_j) (A1, canonical ties), d2[i] the squared distance.
+ * A query with no acceptable candidate (n_tgt == 0, NaN input, d2 >= FLT_MAX — nanoflann.hpp:163,1360)
+ * gets idx = UINT32_MAX, d2 = +inf. */
+int pcr_nn1_f32(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t* idx, float* d2);
+/* same, results stay in HBM (context workspace) for the Kabsch step; asynchronous on the ctx stream */
+int pcr_nn1_f32_async(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
+/* fetch the results of the last pcr_nn1_f32_async for n queries */
+int pcr_nn1_fetch(pcr_ctx* ctx, size_t n, uint32_t* idx, float* d2);
+
+/* ---- A8: transformCloudInplace, Homework9/hw9/src/registration.cpp:165-178 ---------------------------
+ * p <- R p + t per point, f32, unfused, row-wise ((R_i0 x + R_i1 y) + R_i2 z) + t_i.  T row-major 4x4. */
+int pcr_transform_f32(pcr_ctx* ctx, pcr_cloud* cloud, const float T[16]);
+
+/* ---- A7 (accumulate): cross-covariance sums over the kept pairs of the last pcr_nn1_f32_async ---------
+ * sums[0..2] = sum p, [3..5] = sum q, [6..14] = sum q_r p_c (row-major, rows = target), [15] = count,
+ * f64, over pairs with d2 < max_corr (squared distance vs un-squared parameter, registration.cpp:936).
+ * last_kept: index of the last kept source or -1; last_d2: its squared distance (loss, :939). */
+int pcr_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr,
+                    double sums[16], int64_t* last_kept, float* last_d2);
+/* ---- A7 (solve): registration.cpp:979-998 incl. the det<0 branch (:990-996). Host, f64. -------------- */
+int pcr_kabsch_solve(const double sums[16], float R[9], float t[3]);
+
+/* ---- A9: Registration::ICPpoint2point, Homework9/hw9/src/registration.cpp:862-1011 -------------------
+ * (after its normal-space sampling: the clouds passed here are the sampled clouds). */
+typedef struct {
+    float max_corr;       /* setICPparams max_corres_dist (registration.hpp:126-137); vs SQUARED distance */
+    uint64_t max_iter;    /* setICPparams max_iter */
+    float eps;            /* setICPparams loss_epsilon */
+} pcr_icp_params;
+
+typedef struct {
+    uint64_t iters_run;   /* iterations whose update was applied */
+    int32_t converged;    /* the `unchanged_count > 15` break fired (:954) */
+    int32_t empty_pairs;  /* an iteration kept no pair */
+    uint64_t last_pairs;  /* kept pairs (whole job, after the all-reduce) in the last NN pass */
+    float last_loss;
+    float reserved;
+    double ms_total;      /* wall time of the loop */
+    double ms_nn;         /* HIP-event time of the 1-NN kernel, summed over iterations */
+    uint64_t nn_launches;
+} pcr_icp_stats;
+
+/* src is not modified (a working copy is transformed in place, :872-874). init_T / out_T row-major 4x4.
+ * With a communicator attached (pcr_comm_*), src is this rank's shard: the 16 f64 sums are all-reduced
+ * once per iteration and every rank computes the identical pose. */
+int pcr_icp_p2p_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, const float init_T[16],
+                    const pcr_icp_params* prm, float out_T[16], pcr_icp_stats* stats);
+
+/* ---- A10: plane-inlier count, Homework4/ground_detection_ransac.py:138-139,152-153 -------------------
+ * dist_i = |((x a + y b) + z c) + d| in f64; counts[h] = #{i : dist_i < thr} for n_planes hypotheses in
+ * ONE pass over the points. planes4: n_planes x 4 f64. */
+int pcr_plane_count_f64(pcr_ctx* ctx, const pcr_cloud* pts, const double* planes4, size_t n_planes,
+                        double thr, int64_t* counts);
+/* final mask of one plane (:152-153): mask[i] = dist_i < thr (uint8), n_inliers optional */
+int pcr_plane_mask_f64(pcr_ctx* ctx, const pcr_cloud* pts, const double plane4[4], double thr,
+                       uint8_t* mask, int64_t* n_inliers);
+
+/* ---- A2/A4: batched k-NN with the hw2 arithmetic (f64, sqrt), canonical order ------------------------
+ * replaces `KNNResultSet rs(k); KDTreeKNNSearch(root, db, rs, query)` per query
+ * (Homework2/hw2/include/kdtree.hpp:329-364, benchmark.hpp:59-66).
+ * db: n x 3 f64 AoS (vector<vector<double>> flattened), q: m x 3. idx/dist: m x k; empty slots (n < k)
+ * hold (1e10, 0) like the pre-filled result set (resultSet.hpp:35-42). k <= 32. */
+int pcr_knn_f64(pcr_ctx* ctx, const double* db, size_t n, const double* q, size_t m, int k,
+                int32_t* idx, double* dist);
+/* ---- A11: radius search (kdtree.hpp:367-402, resultSet.hpp:130-140): all j with d <= r, CSR, ascending
+ * index. Pass idx = dist = NULL to get row_ptr (m+1) only, then call again with arrays of row_ptr[m]. */
+int pcr_radius_f64(pcr_ctx* ctx, const double* db, size_t n, const double* q, size_t m, double r,
+                   int64_t* row_ptr, int32_t* idx, double* dist);
+
+/* ---- multi-GPU: one process per GPU, sources sharded, targets replicated ------------------------------
+ * Exactly one collective per ICP iteration: all-reduce(sum) of 16 f64 (+2 bookkeeping words). */
+#define PCR_COMM_ID_BYTES 128
+int pcr_comm_unique_id(char id[PCR_COMM_ID_BYTES]);                     /* rank 0; broadcast it out of band */
+int pcr_comm_init_rccl(pcr_ctx* ctx, int nranks, int rank, const char id[PCR_COMM_ID_BYTES]);
+/* alternative transport: a host callback that sums buf[0..n) over ranks in place and returns 0
+ * (lets the caller use its own process group, e.g. torch.distributed gloo on CPU boxes) */
+typedef int (*pcr_allreduce_fn)(void* user, double* buf, int n);
+int pcr_comm_init_callback(pcr_ctx* ctx, int nranks, int rank, pcr_allreduce_fn fn, void* user);
+int pcr_comm_destroy(pcr_ctx* ctx);
+/* contiguous shard [begin, end) of n items for `rank` of `nranks` (sizes differ by at most one) */
+void pcr_shard_range(size_t n, int nranks, int rank, size_t* begin, size_t* end);
+
+/* ---- profiling hooks for bench.py: HIP-event timing of the dominant kernel on the ctx stream ---------- */
+int pcr_prof_reset(pcr_ctx* ctx);
+int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* total_ms);
+/* tuning knobs of the 1-NN kernel (0 = default): target slices per query block */
+int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCR_H */

@@ -1,0 +1,309 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI of libpcr_hip.so, against
+(1) the golden fixtures generated from the reference itself, (2) the CPU oracle on seeded inputs,
+(3) size-independent properties at BASELINE sizes.  Bar: bit-exact for indices / distances / counts,
+1e-5 Frobenius for the ICP pose (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits32(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def bits64(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def ctx(pcr):
+    c = pcr.Context(0)
+    yield c
+    c.close()
+
+
+# ------------------------------------------------------------------ 1-NN (A1/A3/A6) vs reference goldens
+@pytest.mark.parametrize("case", ["synth1000", "synth4096", "kitti4096", "lattice1000"])
+def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case):
+    g = golden(f"nn1_nanoflann_{case}.npz")
+    cs, ct = ctx.cloud(g["src"]), ctx.cloud(g["tgt"])
+    idx, d2 = ctx.nn1(ct, cs)
+    assert np.array_equal(bits32(d2), bits32(g["d2"]))            # distance bit-equal to nanoflann's
+    ties = orc.nn1_tiecount_f32(g["tgt"], g["src"])
+    single = ties == 1
+    assert np.array_equal(idx[single], g["idx"][single])          # index equal on singleton tie sets
+    oidx, _ = orc.nn1_f32(g["tgt"], g["src"])
+    assert np.array_equal(idx, oidx)                              # canonical rule everywhere (= oracle)
+    cs.free(); ct.free()
+
+
+@pytest.mark.parametrize("qpl", [1, 2, 4])
+@pytest.mark.parametrize("ns,nt", [(1, 1), (63, 5), (257, 1023), (1000, 1025), (3001, 7000), (5000, 2049)])
+def test_nn1_ragged_sizes_vs_oracle(ctx, orc, synth, qpl, ns, nt):
+    ctx.tune("nn1_qpl", qpl)
+    src, _ = synth.kitti_like_pair(max(ns, 64), seed_target=7 + ns, seed_pair=11 + nt)
+    tgt = synth.kitti_like_scan(max(nt, 64), seed=13 + nt)
+    src, tgt = np.ascontiguousarray(src[:, :ns]), np.ascontiguousarray(tgt[:, :nt])
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    idx, d2 = ctx.nn1(ct, cs)
+    oidx, od2 = orc.nn1_f32(tgt, src)
+    assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
+    cs.free(); ct.free()
+    ctx.tune("nn1_qpl", 0)
+
+
+@pytest.mark.parametrize("tps", [1, 3, 1000])
+def test_nn1_slice_merge_is_order_independent(ctx, orc, synth, tps):
+    # 1 tile per slice -> many atomicMin merges; 1000 -> single slice, plain stores
+    src, tgt = synth.kitti_like_pair(6000, seed_target=21, seed_pair=22)
+    ctx.tune("nn1_tiles_per_slice", tps)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    idx, d2 = ctx.nn1(ct, cs)
+    ctx.tune("nn1_tiles_per_slice", 0)
+    oidx, od2 = orc.nn1_f32(tgt, src)
+    assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
+    cs.free(); ct.free()
+
+
+def test_nn1_ties_and_duplicates_pick_lowest_index(ctx, orc, synth):
+    lat = synth.lattice_cloud(5000, 3, 10.0, seed=5, levels=10).astype(np.float32)
+    q = synth.lattice_cloud(3000, 3, 10.0, seed=6, levels=10).astype(np.float32)
+    tgt, src = np.ascontiguousarray(lat.T), np.ascontiguousarray(q.T)
+    ctx.tune("nn1_tiles_per_slice", 1)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    idx, d2 = ctx.nn1(ct, cs)
+    ctx.tune("nn1_tiles_per_slice", 0)
+    oidx, od2 = orc.nn1_f32(tgt, src)
+    assert (orc.nn1_tiecount_f32(tgt, src) > 1).sum() > 1000
+    assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
+    cs.free(); ct.free()
+
+
+def test_nn1_edge_cases(ctx, orc):
+    # empty source, empty target, non-finite input
+    tgt = np.array([[0, 1, 2], [0, 0, 0], [0, 0, 0]], np.float32)
+    src = np.array([[0.4, 1.6, np.nan, np.inf], [0, 0, 0, 0], [0, 0, 0, 0]], np.float32)
+    ct, cs = ctx.cloud(tgt), ctx.cloud(src)
+    idx, d2 = ctx.nn1(ct, cs)
+    oidx, od2 = orc.nn1_f32(tgt, src)
+    assert idx.tolist() == oidx.tolist() == [0, 2, 0xFFFFFFFF, 0xFFFFFFFF]
+    assert np.array_equal(bits32(d2), bits32(od2)) and np.isinf(d2[2]) and np.isinf(d2[3])
+    e = ctx.cloud(np.zeros((3, 0), np.float32))
+    idx, d2 = ctx.nn1(ct, e)
+    assert idx.size == 0
+    idx, d2 = ctx.nn1(e, cs)
+    assert (idx == 0xFFFFFFFF).all() and np.isinf(d2).all()
+    for c in (ct, cs, e):
+        c.free()
+
+
+def test_cloud_layouts_roundtrip(ctx, pcr, synth):
+    src, _ = synth.kitti_like_pair(1234)
+    c = ctx.cloud(src)
+    assert np.array_equal(c.numpy(), src)
+    aos3 = np.ascontiguousarray(src.T)
+    aos4 = np.concatenate([aos3, np.ones((1234, 1), np.float32)], axis=1)
+    for arr, lay in ((aos3, pcr.PCR_AOS3), (aos4, pcr.PCR_AOS4)):
+        c2 = ctx.cloud(arr, lay)
+        assert np.array_equal(c2.numpy(), src)
+        c2.free()
+    c.free()
+
+
+# ------------------------------------------------------------------ A8 transform, A7 sums
+@pytest.mark.parametrize("n", [1, 3, 4, 1021, 4096, 50001])
+def test_transform_bit_exact(ctx, orc, synth, n):
+    src, _ = synth.kitti_like_pair(max(n, 64))
+    src = np.ascontiguousarray(src[:, :n])
+    T = synth.gt_pose().astype(np.float32)
+    c = ctx.cloud(src)
+    ctx.transform(c, T)
+    got = c.numpy()
+    want = orc.transform_f32(src, T[:3, :3], T[:3, 3])
+    assert np.array_equal(bits32(got), bits32(want))
+    # a transformed cloud is still a valid target (padding invariant restored)
+    q = ctx.cloud(want[:, : min(n, 50)])
+    idx, d2 = ctx.nn1(c, q)
+    assert np.array_equal(idx, np.arange(min(n, 50), dtype=np.uint32)) and (d2 == 0).all()
+    c.free(); q.free()
+
+
+def test_kabsch_sums_vs_oracle(ctx, orc, synth):
+    src, tgt = synth.kitti_like_pair(20000)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    ctx.nn1_async(ct, cs)
+    sums, last, last_d2 = ctx.kabsch_sums(ct, cs, 0.05)
+    idx, d2 = ctx.nn1_fetch(20000)
+    osums, olast = orc.kabsch_accumulate(src, tgt, idx, d2, 0.05)
+    assert sums[15] == osums[15] and last == olast and 0 < sums[15] < 20000
+    assert np.float32(last_d2) == d2[olast]
+    assert np.allclose(sums, osums, rtol=1e-13, atol=0)           # f64, different summation order only
+    rc, R, t = orc.kabsch_solve(osums)
+    import importlib
+    rc2, R2, t2 = importlib.import_module("hands-on-point-cloud-processing_amd").kabsch_solve(sums)
+    assert rc == rc2 == 0 and np.array_equal(R, R2) and np.array_equal(t, t2)
+    cs.free(); ct.free()
+
+
+# ------------------------------------------------------------------ A9 ICP
+def test_icp_vs_selfgolden_and_oracle(ctx, orc, golden):
+    g = golden("icp_selfgolden.npz")
+    cs, ct = ctx.cloud(g["src"]), ctx.cloud(g["tgt"])
+    T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=20, eps=1e-8)
+    assert np.linalg.norm(T.astype(np.float64) - g["T"]) <= 1e-5
+    assert st["iters_run"] == int(g["iters_run"]) and st["converged"] == int(g["converged"])
+    assert st["last_pairs"] == int(g["per_iter_pairs"][st["iters_run"] - 1 if st["converged"] == 0 else st["iters_run"]])
+    assert np.array_equal(cs.numpy(), g["src"])                   # the input cloud is not modified
+    cs.free(); ct.free()
+
+
+def test_icp_state_machine_matches_oracle(ctx, orc, synth):
+    src, tgt = synth.kitti_like_pair(2500, seed_target=31, seed_pair=32)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    init = np.eye(4, dtype=np.float32); init[0, 3] = 0.1
+    for kw in (dict(max_iter=40, eps=1e30), dict(max_iter=7, eps=0.0), dict(max_iter=12, eps=1e-8, max_corr=0.3)):
+        T, st = ctx.icp_point2point(cs, ct, init_T=init, **kw)
+        oT, ost = orc.icp_p2p_f32(src, tgt, init_T=init, **kw)
+        assert st["iters_run"] == ost["iters_run"] and st["converged"] == ost["converged"]
+        assert st["last_pairs"] == ost["last_pairs"]
+        assert np.linalg.norm(T.astype(np.float64) - oT) <= 1e-5
+    far = ctx.cloud(src + np.float32(1000.0))
+    T, st = ctx.icp_point2point(far, ct, max_iter=5)
+    assert st["empty_pairs"] == 1 and np.array_equal(T, np.eye(4, dtype=np.float32))
+    cs.free(); ct.free(); far.free()
+
+
+def test_icp_full_size_120k_recovers_ground_truth(ctx, synth):
+    # BASELINE config 3 (120k pair, 20 iterations): the oracle is O(N^2), so check properties instead:
+    # pose moves monotonically towards the known ground truth and all pairs are kept at the end
+    src, tgt = synth.kitti_like_pair(120000)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    gt = synth.gt_pose()
+    errs = []
+    for it in (5, 20):
+        T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=it, eps=1e-8)
+        errs.append(np.linalg.norm(T - gt))
+    assert errs[1] < errs[0] < np.linalg.norm(np.eye(4) - gt) and errs[1] < 0.01
+    assert st["last_pairs"] == 120000 and st["iters_run"] == 20
+    cs.free(); ct.free()
+
+
+def test_nn1_full_size_120k_properties(ctx, orc, synth):
+    # BASELINE config 2: 120k x 120k. (a) self-query returns identity with d2 == 0 (sortedness/idempotence);
+    # (b) a 2 000-query sample agrees bit-for-bit with the oracle.
+    src, tgt = synth.kitti_like_pair(120000)
+    ct = ctx.cloud(tgt)
+    idx, d2 = ctx.nn1(ct, ct)
+    assert (d2 == 0).all()
+    assert (idx <= np.arange(120000)).all()                       # lowest index among exact duplicates
+    moved = idx != np.arange(120000)
+    assert np.array_equal(tgt[:, idx[moved]], tgt[:, moved])      # ... which are bit-identical points
+    cs = ctx.cloud(src)
+    idx, d2 = ctx.nn1(ct, cs)
+    sel = np.arange(0, 120000, 60)
+    oidx, od2 = orc.nn1_f32(tgt, np.ascontiguousarray(src[:, sel]))
+    assert np.array_equal(idx[sel], oidx) and np.array_equal(bits32(d2[sel]), bits32(od2))
+    cs.free(); ct.free()
+
+
+# ------------------------------------------------------------------ A10 plane-inlier count
+def test_plane_count_vs_hw4_golden(ctx, golden):
+    g = golden("plane_hw4.npz")
+    c = ctx.cloud(g["pts_f32"], 1)
+    counts = ctx.plane_count(c, g["params"], float(g["thr"]))
+    assert np.array_equal(counts, g["counts"])
+    masks = np.unpackbits(g["masks"], axis=1)[:, : g["pts_f32"].shape[0]]
+    for h in range(16):
+        mask, cnt = ctx.plane_mask(c, g["params"][h], float(g["thr"]))
+        assert np.array_equal(mask, masks[h]) and cnt == g["counts"][h]
+    c.free()
+
+
+def test_plane_count_120k_80_hypotheses_vs_oracle(ctx, orc, synth):
+    # BASELINE config 4: one 120k scan, 80 hypotheses (40 per x-segment, ground_detection_ransac.py:54,71-72)
+    scan = synth.kitti_like_scan(120000)
+    ground = np.where(np.abs(scan[2] + 1.73) < 0.3)[0]
+    pick = (synth.splitmix64(9, np.arange(240, dtype=np.uint64)) % np.uint64(ground.size)).astype(np.int64).reshape(80, 3)
+    planes = np.stack([orc.plane_from_3pts(scan[:, ground[p]].T.astype(np.float64)) for p in pick])
+    planes = planes[np.isfinite(planes).all(axis=1)]
+    c = ctx.cloud(scan)
+    counts = ctx.plane_count(c, planes, 0.15)
+    assert np.array_equal(counts, orc.plane_count(scan, planes, 0.15))
+    assert counts.max() > 20000
+    # more than one launch worth of hypotheses, and none
+    many = np.tile(planes, (3, 1))[:200]
+    assert np.array_equal(ctx.plane_count(c, many, 0.15), orc.plane_count(scan, many, 0.15))
+    assert ctx.plane_count(c, np.zeros((0, 4)), 0.15).size == 0
+    c.free()
+
+
+# ------------------------------------------------------------------ A2/A4/A11 k-NN + radius (hw2 contract)
+def test_knn_kat_query5(ctx, golden):
+    g = golden("kat_kitti_q5.npz")
+    db = g["db_f32"].astype(np.float64)
+    idx, dist = ctx.knn_f64(db, db[5:6], 8)
+    assert idx[0].tolist() == [5, 1972, 6, 1971, 1970, 3946, 8, 3945]          # result_cpp.txt:13-20
+    assert np.array_equal(bits64(dist[0]), bits64(g["knn_dist"]))
+    row, ridx, rdist = ctx.radius_f64(db, db[5:6], 1.66)
+    assert ridx.tolist() == [5, 6, 8, 1970, 1971, 1972, 3945, 3946]            # result_cpp.txt:26-33
+    o = np.argsort(g["radius_idx_visit_order"])
+    assert np.array_equal(bits64(rdist), bits64(g["radius_dist_visit_order"][o]))
+
+
+@pytest.mark.parametrize("case", ["synth1000", "kitti4096", "lattice"])
+@pytest.mark.parametrize("k", [1, 8])
+def test_knn_vs_hw2_golden(ctx, orc, golden, case, k):
+    g = golden(f"knn_hw2_{case}.npz")
+    idx, dist = ctx.knn_f64(g["db"], g["q"], k)
+    assert np.array_equal(bits64(dist), bits64(g[f"dist_k{k}"]))               # distances bit-equal to hw2's
+    oidx, odist = orc.knn_f64(g["db"], g["q"], k)
+    assert np.array_equal(idx, oidx)                                           # canonical order (= oracle)
+    if case != "lattice":
+        assert np.array_equal(idx, g[f"idx_k{k}"])                             # tie-free: equal to hw2's indices
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 13, 32])
+def test_knn_other_k_and_short_db(ctx, orc, synth, k):
+    db = synth.uniform_cloud(700, seed=3)
+    q = synth.uniform_cloud(300, seed=4)
+    idx, dist = ctx.knn_f64(db, q, k)
+    oidx, odist = orc.knn_f64(db, q, k)
+    assert np.array_equal(idx, oidx) and np.array_equal(bits64(dist), bits64(odist))
+    idx, dist = ctx.knn_f64(db[:5], q[:7], k)                                  # n < k: slots keep (1e10, 0)
+    oidx, odist = orc.knn_f64(db[:5], q[:7], k)
+    assert np.array_equal(idx, oidx) and np.array_equal(bits64(dist), bits64(odist))
+
+
+@pytest.mark.parametrize("case", ["synth1000", "kitti4096"])
+@pytest.mark.parametrize("r", [0.5, 1.0])
+def test_radius_vs_hw2_golden(ctx, golden, case, r):
+    g = golden(f"radius_hw2_{case}.npz")
+    tag = str(r).replace(".", "p")
+    row, idx, dist = ctx.radius_f64(g["db"], g["q"], r)
+    assert np.array_equal(row, g[f"row_r{tag}"]) and np.array_equal(idx, g[f"idx_r{tag}"])
+    assert np.array_equal(bits64(dist), bits64(g[f"dist_r{tag}"]))
+
+
+def test_radius_boundary_is_inclusive_and_sqrt_exact(ctx, orc, synth):
+    # radii that coincide with realised distances: d <= r must include them (resultSet.hpp:133)
+    db = synth.lattice_cloud(2000, 3, 10.0, seed=8, levels=20)
+    q = synth.lattice_cloud(200, 3, 10.0, seed=9, levels=20)
+    for r in (0.5, 1.0, float(np.sqrt(0.5)), 1.5, 0.0):
+        row, idx, dist = ctx.radius_f64(db, q, r)
+        orow, oidx, odist = orc.radius_f64(db, q, r)
+        assert np.array_equal(row, orow) and np.array_equal(idx, oidx)
+        assert np.array_equal(bits64(dist), bits64(odist))
+
+
+def test_radius_self_query_full_scan(ctx, synth):
+    # BASELINE config 4 (radius-NN r = 1.0, every point queries its own scan) at 30k (the 120k run is the
+    # bench's job): every row contains its own index, rows are ascending, symmetric membership
+    scan = synth.kitti_like_scan(30000).T.astype(np.float64)
+    row, idx, dist = ctx.radius_f64(scan, scan, 1.0)
+    assert row[-1] == idx.size and (np.diff(row) >= 1).all()
+    own = np.repeat(np.arange(30000), np.diff(row)) == idx
+    assert own.sum() >= 30000 and (dist[own] == 0).all()
+    seg_start = np.zeros(idx.size, bool); seg_start[row[:-1]] = True
+    assert (np.diff(idx)[~seg_start[1:]] > 0).all()
+    assert (dist <= 1.0).all()
