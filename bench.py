@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--qpl", type=int, default=0)
     ap.add_argument("--tiles-per-slice", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0, help="nn1 kernel variant (0 = library default; -8 = LDS-tiled TRACK)")
     args = ap.parse_args()
 
     import numpy as np
@@ -104,6 +105,8 @@ def main():
         ctx.tune("nn1_qpl", args.qpl)
     if args.tiles_per_slice:
         ctx.tune("nn1_tiles_per_slice", args.tiles_per_slice)
+    if args.variant:
+        ctx.tune("nn1_variant", args.variant)
     cs, ct = ctx.cloud(src), ctx.cloud(tgt)
 
     collective = "none"
@@ -146,6 +149,11 @@ def main():
 
     nn_launches, nn_ms = ctx.prof_get("nn1_brute")
     if rank == 0:
+        pmc = None
+        try:   # HBM traffic of the same kernel from a separate rocprofv3 --pmc pass (tools/gpu_check.sh), committed
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        except Exception:   # noqa: BLE001
+            pmc = None
         total_corr = world * n * args.steps
         kern_s = nn_ms / 1e3 / max(nn_launches, 1)
         pairs = float(n) * float(n)
@@ -165,8 +173,14 @@ def main():
                        "collective": collective, "pose_err_vs_gt_fro": gt_err,
                        "kept_pairs_last_iter": int(st["last_pairs"])},
             "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS_NOFMA,
-                         "unit": "TFLOP/s", "frac": achieved_tflops / VALU_PEAK_TFLOPS_NOFMA, "traffic": None,
-                         "kernel": "nn1_brute_kernel", "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3,
+                         "unit": "TFLOP/s", "frac": achieved_tflops / VALU_PEAK_TFLOPS_NOFMA,
+                         "traffic": (pmc["fetch_bytes_per_launch_corrected_x2"] + pmc["write_bytes_per_launch"]) if pmc else None,
+                         "traffic_note": ("HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from a separate "
+                                          "rocprofv3 --pmc pass of this kernel, " + pmc["source"]) if pmc else "not collected",
+                         "clock_ghz_profiled": pmc.get("clock_ghz_profiled") if pmc else None,
+                         "kernel": "pcr::nn1_track_kernel<2, 16, true> (brute force, scalar-cache broadcast of targets)"
+                                   if not (args.qpl or args.variant) else f"nn1 variant={args.variant} qpl={args.qpl}",
+                         "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3,
                          "kernel_M_corr_per_s": n / kern_s / 1e6,
                          "algorithmic": f"{OPS_PER_PAIR} f32 lane-ops per (query,target) pair x {pairs:.3e} pairs/launch; "
                                         "peak = 157.3 TF/s / 2 because the bit-exact contract forbids FMA",

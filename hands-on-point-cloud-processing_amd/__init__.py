@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcr_hip.so")
+LIB_PATH = os.environ.get("PCR_LIB_PATH") or os.path.join(_HERE, "libpcr_hip.so")   # override: A/B builds of the same ABI
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 PCR_SOA, PCR_AOS3, PCR_AOS4 = 0, 1, 2

@@ -11,9 +11,19 @@
 //    the next tile's global loads are issued before the current tile is consumed (software pipeline);
 //  * every lane reads the same LDS address (ds_read_b128 broadcast: 4 targets per coordinate per read),
 //    so LDS traffic is 12 B per 64*QPL pair evaluations and never bank-conflicts;
-//  * inner loop per 8 targets and query: 64 VALU ops of distance arithmetic + 4 v_min3_u32 on the raw bit
-//    patterns (d2 >= 0, so IEEE bits are order preserving; NaN bits sort above +inf and never win) + one
-//    compare; the index is only resolved inside a rarely taken branch;
+//    (variant SGPR: the uniform target reads become s_load_dwordx4 through the scalar cache instead of LDS);
+//  * inner loop per CH targets and query: distance arithmetic + a v_min3_u32 tree on the raw bit patterns
+//    (d2 >= 0, so IEEE bits are order preserving; NaN bits sort above +inf and never win);
+//    default (TRACK): branch-free - the lane remembers only the running minimum and the FIRST chunk that
+//    attained it (v_cmp + v_min + v_cndmask per chunk); the index inside that chunk is resolved once per
+//    query after the scan by re-evaluating its CH targets.  Profiling showed why: with scan-ordered
+//    targets a divergent "resolve now" branch is taken by some lane of the wave for a large share of the
+//    chunks (+24 % VALU instructions, profiles/r01_pmc_nn1.md);
+//    RESOLVE variants keep the older scheme (index resolved inside a rarely taken branch);
+//  * variant FILTER: the hot loop evaluates a cheaper fused form a = fma(dz,dz,fma(dy,dy,dx*dx)) (6 ops
+//    instead of 8).  |a - d2| <= 7u*d2 (u = 2^-24; all terms are non-negative), so every target that can
+//    beat the current best satisfies a <= best*(1 + 2^-20) + 1e-30; only chunks passing this gate are
+//    re-evaluated with the exact unfused arithmetic, which alone decides.  Results are bit-identical.
 //  * the target set is cut into slices (gridDim.y) so that >> 256 workgroups exist even for one scan;
 //    slices merge through one 64-bit atomicMin per query on key = d2_bits << 32 | idx, which implements
 //    "min d2, then lowest index" exactly and independently of arrival order.
@@ -34,33 +44,212 @@ __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
     return min(min(a, b), c);   // -> v_min3_u32
 }
 
-template <int QPL>
+// exact A1 distance as raw bits
+__device__ __forceinline__ uint32_t d2_exact_bits(float qx, float qy, float qz, float x, float y, float z)
+{
+    const float dx = qx - x, dy = qy - y, dz = qz - z;
+    return __float_as_uint((dx * dx + dy * dy) + dz * dz);
+}
+
+// fused filter value as raw bits (never decides, only gates)
+__device__ __forceinline__ uint32_t d2_fused_bits(float qx, float qy, float qz, float x, float y, float z)
+{
+    const float dx = qx - x, dy = qy - y, dz = qz - z;
+    return __float_as_uint(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+}
+
+__device__ __forceinline__ uint32_t gate_bits(uint32_t best_bits)
+{
+    // best*(1 + 2^-20) + 1e-30, saturating at +inf; with best == FLT_MAX-init this is +inf: accept anything
+    const float t = __uint_as_float(best_bits) * 1.00000095367431640625f + 1e-30f;
+    return __float_as_uint(t);
+}
+
+template <int QPL, bool FILTER>
+struct Lane {
+    float qx[QPL], qy[QPL], qz[QPL];
+    uint32_t best[QPL], bidx[QPL], gate[QPL];
+
+    __device__ __forceinline__ void chunk8(const float (&X)[8], const float (&Y)[8], const float (&Z)[8], uint32_t j0)
+    {
+#pragma unroll
+        for (int k = 0; k < QPL; k++) {
+            uint32_t d[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                d[j] = FILTER ? d2_fused_bits(qx[k], qy[k], qz[k], X[j], Y[j], Z[j])
+                              : d2_exact_bits(qx[k], qy[k], qz[k], X[j], Y[j], Z[j]);
+            uint32_t m = umin3(d[0], d[1], d[2]);
+            m = umin3(m, d[3], d[4]);
+            m = umin3(m, d[5], d[6]);
+            m = min(m, d[7]);
+            const bool hit = FILTER ? (m <= gate[k]) : (m < best[k]);
+            if (__builtin_expect(hit, 0)) {
+                // rare: ascending scan with strict < keeps the lowest index among equal minima
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t e = FILTER ? d2_exact_bits(qx[k], qy[k], qz[k], X[j], Y[j], Z[j]) : d[j];
+                    if (e < best[k]) { best[k] = e; bidx[k] = j0 + j; }
+                }
+                if (FILTER) gate[k] = gate_bits(best[k]);
+            }
+        }
+    }
+};
+
+// branch-free variant: running minimum + first chunk attaining it
+template <int QPL, int CH>
+struct TrackLane {
+    float qx[QPL], qy[QPL], qz[QPL];
+    uint32_t best[QPL], bchunk[QPL];
+
+    __device__ __forceinline__ void chunk(const float (&X)[CH], const float (&Y)[CH], const float (&Z)[CH], uint32_t j0)
+    {
+#pragma unroll
+        for (int k = 0; k < QPL; k++) {
+            uint32_t d[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) d[j] = d2_exact_bits(qx[k], qy[k], qz[k], X[j], Y[j], Z[j]);
+            uint32_t m = umin3(d[0], d[1], d[2]);
+#pragma unroll
+            for (int j = 3; j + 1 < CH; j += 2) m = umin3(m, d[j], d[j + 1]);
+            m = min(m, d[CH - 1]);
+            const bool better = m < best[k];          // strict: the FIRST chunk attaining the minimum is kept
+            best[k] = min(best[k], m);
+            bchunk[k] = better ? j0 : bchunk[k];
+        }
+    }
+};
+
+template <int QPL, int CH, bool SGPR>
+__global__ __launch_bounds__(NN_BLOCK) void nn1_track_kernel(
+    const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
+    const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+    uint32_t ns, uint32_t n_tiles, uint32_t tiles_per_slice,
+    unsigned long long* __restrict__ keys, int merge_atomic)
+{
+    __shared__ float4 lx[SGPR ? 1 : NN_TILE / 4];
+    __shared__ float4 ly[SGPR ? 1 : NN_TILE / 4];
+    __shared__ float4 lz[SGPR ? 1 : NN_TILE / 4];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t qbase = blockIdx.x * (NN_BLOCK * QPL);
+    TrackLane<QPL, CH> L;
+#pragma unroll
+    for (int k = 0; k < QPL; k++) {
+        uint32_t i = min(qbase + k * NN_BLOCK + tid, ns - 1);
+        L.qx[k] = sx[i]; L.qy[k] = sy[i]; L.qz[k] = sz[i];
+        L.best[k] = 0x7F7FFFFFu;        // FLT_MAX: nanoflann.hpp:163; accept only d2 < worst (:1360)
+        L.bchunk[k] = 0xFFFFFFFFu;
+    }
+    const uint32_t tile0 = blockIdx.y * tiles_per_slice;
+    const uint32_t tile1 = min(tile0 + tiles_per_slice, n_tiles);
+    if (SGPR) {
+        const uint32_t j_begin = tile0 * NN_TILE, j_end = tile1 * NN_TILE;
+#pragma unroll 2
+        for (uint32_t j0 = j_begin; j0 < j_end; j0 += CH) {
+            float X[CH], Y[CH], Z[CH];
+#pragma unroll
+            for (int g = 0; g < CH / 4; g++) {
+                const float4 a = *reinterpret_cast<const float4*>(tx + j0 + 4 * g);
+                const float4 b = *reinterpret_cast<const float4*>(ty + j0 + 4 * g);
+                const float4 c = *reinterpret_cast<const float4*>(tz + j0 + 4 * g);
+                X[4 * g] = a.x; X[4 * g + 1] = a.y; X[4 * g + 2] = a.z; X[4 * g + 3] = a.w;
+                Y[4 * g] = b.x; Y[4 * g + 1] = b.y; Y[4 * g + 2] = b.z; Y[4 * g + 3] = b.w;
+                Z[4 * g] = c.x; Z[4 * g + 1] = c.y; Z[4 * g + 2] = c.z; Z[4 * g + 3] = c.w;
+            }
+            L.chunk(X, Y, Z, j0);
+        }
+    } else if (tile0 < tile1) {
+        const float4* gx = reinterpret_cast<const float4*>(tx) + (size_t)tile0 * (NN_TILE / 4);
+        const float4* gy = reinterpret_cast<const float4*>(ty) + (size_t)tile0 * (NN_TILE / 4);
+        const float4* gz = reinterpret_cast<const float4*>(tz) + (size_t)tile0 * (NN_TILE / 4);
+        float4 rx = gx[tid], ry = gy[tid], rz = gz[tid];
+        for (uint32_t tile = tile0; tile < tile1; tile++) {
+            lx[tid] = rx; ly[tid] = ry; lz[tid] = rz;
+            __syncthreads();
+            if (tile + 1 < tile1) {     // prefetch the next tile while this one is consumed
+                gx += NN_TILE / 4; gy += NN_TILE / 4; gz += NN_TILE / 4;
+                rx = gx[tid]; ry = gy[tid]; rz = gz[tid];
+            }
+            const uint32_t jbase = tile * NN_TILE;
+#pragma unroll 2
+            for (int c = 0; c < NN_TILE / CH; c++) {
+                float X[CH], Y[CH], Z[CH];
+#pragma unroll
+                for (int g = 0; g < CH / 4; g++) {
+                    const float4 a = lx[(CH / 4) * c + g], b = ly[(CH / 4) * c + g], cc = lz[(CH / 4) * c + g];
+                    X[4 * g] = a.x; X[4 * g + 1] = a.y; X[4 * g + 2] = a.z; X[4 * g + 3] = a.w;
+                    Y[4 * g] = b.x; Y[4 * g + 1] = b.y; Y[4 * g + 2] = b.z; Y[4 * g + 3] = b.w;
+                    Z[4 * g] = cc.x; Z[4 * g + 1] = cc.y; Z[4 * g + 2] = cc.z; Z[4 * g + 3] = cc.w;
+                }
+                L.chunk(X, Y, Z, jbase + CH * c);
+            }
+            __syncthreads();
+        }
+    }
+    // once per query: which target of the remembered chunk attained the minimum (lowest index first)
+#pragma unroll
+    for (int k = 0; k < QPL; k++) {
+        const uint32_t i = qbase + k * NN_BLOCK + tid;
+        uint32_t bidx = 0xFFFFFFFFu;
+        if (L.bchunk[k] != 0xFFFFFFFFu) {
+            const uint32_t j0 = L.bchunk[k];
+#pragma unroll
+            for (int j = CH - 1; j >= 0; j--) {
+                const uint32_t e = d2_exact_bits(L.qx[k], L.qy[k], L.qz[k], tx[j0 + j], ty[j0 + j], tz[j0 + j]);
+                if (e == L.best[k]) bidx = j0 + j;
+            }
+        }
+        if (i < ns) {
+            const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : L.best[k];
+            const unsigned long long key = ((unsigned long long)bits << 32) | bidx;
+            if (merge_atomic) atomicMin(&keys[i], key);
+            else keys[i] = key;
+        }
+    }
+}
+
+template <int QPL, bool FILTER, bool SGPR>
 __global__ __launch_bounds__(NN_BLOCK) void nn1_brute_kernel(
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
     const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     uint32_t ns, uint32_t n_tiles, uint32_t tiles_per_slice,
     unsigned long long* __restrict__ keys, int merge_atomic)
 {
-    __shared__ float4 lx[NN_TILE / 4];
-    __shared__ float4 ly[NN_TILE / 4];
-    __shared__ float4 lz[NN_TILE / 4];
+    __shared__ float4 lx[SGPR ? 1 : NN_TILE / 4];
+    __shared__ float4 ly[SGPR ? 1 : NN_TILE / 4];
+    __shared__ float4 lz[SGPR ? 1 : NN_TILE / 4];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t qbase = blockIdx.x * (NN_BLOCK * QPL);
 
-    float qx[QPL], qy[QPL], qz[QPL];
-    uint32_t best[QPL], bidx[QPL];
+    Lane<QPL, FILTER> L;
 #pragma unroll
     for (int k = 0; k < QPL; k++) {
         uint32_t i = min(qbase + k * NN_BLOCK + tid, ns - 1);
-        qx[k] = sx[i]; qy[k] = sy[i]; qz[k] = sz[i];
-        best[k] = 0x7F7FFFFFu;          // FLT_MAX: nanoflann.hpp:163; accept only d2 < worst (:1360)
-        bidx[k] = 0xFFFFFFFFu;
+        L.qx[k] = sx[i]; L.qy[k] = sy[i]; L.qz[k] = sz[i];
+        L.best[k] = 0x7F7FFFFFu;        // FLT_MAX: nanoflann.hpp:163; accept only d2 < worst (:1360)
+        L.bidx[k] = 0xFFFFFFFFu;
+        L.gate[k] = 0x7F800000u;        // +inf: everything finite passes until a first candidate is accepted
     }
 
     const uint32_t tile0 = blockIdx.y * tiles_per_slice;
     const uint32_t tile1 = min(tile0 + tiles_per_slice, n_tiles);
-    if (tile0 < tile1) {
+    if (SGPR) {
+        // wave-uniform addresses on read-only, non-aliased pointers: the loads below compile to s_load_dwordx4
+        const uint32_t j_begin = tile0 * NN_TILE, j_end = tile1 * NN_TILE;
+#pragma unroll 2
+        for (uint32_t j0 = j_begin; j0 < j_end; j0 += 8) {
+            const float4 xa = *reinterpret_cast<const float4*>(tx + j0), xb = *reinterpret_cast<const float4*>(tx + j0 + 4);
+            const float4 ya = *reinterpret_cast<const float4*>(ty + j0), yb = *reinterpret_cast<const float4*>(ty + j0 + 4);
+            const float4 za = *reinterpret_cast<const float4*>(tz + j0), zb = *reinterpret_cast<const float4*>(tz + j0 + 4);
+            const float X[8] = { xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w };
+            const float Y[8] = { ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w };
+            const float Z[8] = { za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w };
+            L.chunk8(X, Y, Z, j0);
+        }
+    } else if (tile0 < tile1) {
         const float4* gx = reinterpret_cast<const float4*>(tx) + (size_t)tile0 * (NN_TILE / 4);
         const float4* gy = reinterpret_cast<const float4*>(ty) + (size_t)tile0 * (NN_TILE / 4);
         const float4* gz = reinterpret_cast<const float4*>(tz) + (size_t)tile0 * (NN_TILE / 4);
@@ -81,29 +270,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_brute_kernel(
                 const float X[8] = { xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w };
                 const float Y[8] = { ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w };
                 const float Z[8] = { za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w };
-#pragma unroll
-                for (int k = 0; k < QPL; k++) {
-                    uint32_t d[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const float dx = qx[k] - X[j];
-                        const float dy = qy[k] - Y[j];
-                        const float dz = qz[k] - Z[j];
-                        const float s = (dx * dx + dy * dy) + dz * dz;      // A1, unfused
-                        d[j] = __float_as_uint(s);
-                    }
-                    uint32_t m = umin3(d[0], d[1], d[2]);
-                    m = umin3(m, d[3], d[4]);
-                    m = umin3(m, d[5], d[6]);
-                    m = min(m, d[7]);
-                    if (__builtin_expect(m < best[k], 0)) {
-                        // rare: ascending scan with strict < keeps the lowest index among equal minima
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            if (d[j] < best[k]) { best[k] = d[j]; bidx[k] = jbase + 8 * c + j; }
-                        }
-                    }
-                }
+                L.chunk8(X, Y, Z, jbase + 8 * c);
             }
             __syncthreads();
         }
@@ -113,8 +280,8 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_brute_kernel(
     for (int k = 0; k < QPL; k++) {
         const uint32_t i = qbase + k * NN_BLOCK + tid;
         if (i < ns) {
-            const uint32_t bits = (bidx[k] == 0xFFFFFFFFu) ? 0x7F800000u : best[k];   // nothing accepted: +inf
-            const unsigned long long key = ((unsigned long long)bits << 32) | bidx[k];
+            const uint32_t bits = (L.bidx[k] == 0xFFFFFFFFu) ? 0x7F800000u : L.best[k];   // nothing accepted: +inf
+            const unsigned long long key = ((unsigned long long)bits << 32) | L.bidx[k];
             if (merge_atomic) atomicMin(&keys[i], key);
             else keys[i] = key;
         }
@@ -133,6 +300,40 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
     }
 }
 
+template <int QPL, bool FILTER, bool SGPR>
+static void launch_variant(pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t ns,
+                           uint32_t n_tiles, uint32_t tps, int merge_atomic)
+{
+    hipLaunchKernelGGL((nn1_brute_kernel<QPL, FILTER, SGPR>), grid, dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(),
+                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic);
+}
+
+template <int CH, bool SGPR>
+static void launch_track(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t ns,
+                         uint32_t n_tiles, uint32_t tps, int merge_atomic)
+{
+#define PCR_TRACK(Q)                                                                                               \
+    hipLaunchKernelGGL((nn1_track_kernel<Q, CH, SGPR>), grid, dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(),    \
+                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic)
+    switch (qpl) {
+    case 1: PCR_TRACK(1); break;
+    case 4: PCR_TRACK(4); break;
+    default: PCR_TRACK(2); break;
+    }
+#undef PCR_TRACK
+}
+
+template <bool FILTER, bool SGPR>
+static void launch_qpl(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t ns,
+                       uint32_t n_tiles, uint32_t tps, int merge_atomic)
+{
+    switch (qpl) {
+    case 1: launch_variant<1, FILTER, SGPR>(ctx, grid, tgt, src, ns, n_tiles, tps, merge_atomic); break;
+    case 4: launch_variant<4, FILTER, SGPR>(ctx, grid, tgt, src, ns, n_tiles, tps, merge_atomic); break;
+    default: launch_variant<2, FILTER, SGPR>(ctx, grid, tgt, src, ns, n_tiles, tps, merge_atomic); break;
+    }
+}
+
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
 {
     const size_t ns = src->n;
@@ -142,7 +343,13 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
     if (rc) return rc;
     ctx->keys_n = ns;
 
-    const int qpl = (int)tune_get(ctx, "nn1_qpl", 2);
+    int qpl = (int)tune_get(ctx, "nn1_qpl", 2);
+    if (qpl != 1 && qpl != 4) qpl = 2;
+    // variant: 2 = TRACK, targets through the scalar cache (default: fastest measured, profiles/r01_tune_nn1.txt);
+    //          0 (set as -8) = TRACK, targets through LDS tiles; 4 = RESOLVE exact (LDS), 5 = RESOLVE + fused
+    //          filter, 6/7 = the same with scalar-load targets
+    const int variant = (int)tune_get(ctx, "nn1_variant", 2) & 7;
+    const int chunk = (int)tune_get(ctx, "nn1_chunk", 16);
     const uint32_t n_tiles = (uint32_t)((tgt->n + NN_TILE - 1) / NN_TILE);
     const uint32_t qblocks = (uint32_t)((ns + (size_t)NN_BLOCK * qpl - 1) / ((size_t)NN_BLOCK * qpl));
     // enough workgroups to balance 256 CUs x 8 resident blocks over several rounds
@@ -159,21 +366,21 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
     const int merge_atomic = slices > 1;
     if (merge_atomic) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
 
-    dim3 grid(qblocks, slices), block(NN_BLOCK);
+    dim3 grid(qblocks, slices);
     {
         ProfScope p(ctx, "nn1_brute");
-        switch (qpl) {
-        case 1:
-            hipLaunchKernelGGL(nn1_brute_kernel<1>, grid, block, 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
-                               src->x(), src->y(), src->z(), (uint32_t)ns, n_tiles, (uint32_t)tps, ctx->keys, merge_atomic);
-            break;
-        case 4:
-            hipLaunchKernelGGL(nn1_brute_kernel<4>, grid, block, 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
-                               src->x(), src->y(), src->z(), (uint32_t)ns, n_tiles, (uint32_t)tps, ctx->keys, merge_atomic);
+        switch (variant) {
+        case 4: launch_qpl<false, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
+        case 5: launch_qpl<true, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
+        case 6: launch_qpl<false, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
+        case 7: launch_qpl<true, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
+        case 2: case 3:
+            if (chunk == 16) launch_track<16, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
+            else launch_track<8, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
             break;
         default:
-            hipLaunchKernelGGL(nn1_brute_kernel<2>, grid, block, 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
-                               src->x(), src->y(), src->z(), (uint32_t)ns, n_tiles, (uint32_t)tps, ctx->keys, merge_atomic);
+            if (chunk == 16) launch_track<16, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
+            else launch_track<8, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
             break;
         }
     }

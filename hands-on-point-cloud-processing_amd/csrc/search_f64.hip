@@ -56,10 +56,13 @@ __global__ __launch_bounds__(SF_BLOCK) void knn_f64_kernel(
                 const int32_t j = (int32_t)(base + t);
                 double cd = d;
                 int32_t ci = j;
+                bool placed = false;
 #pragma unroll
                 for (int s = 0; s < K; s++) {
-                    // bubble the candidate down: strictly smaller goes in front, equal stays behind
-                    const bool sw = cd < bd[s];
+                    // sorted insertion: the candidate goes in front of the first strictly larger entry (equal
+                    // entries have lower indices and stay in front); everything behind shifts by one slot
+                    const bool sw = placed || cd < bd[s];
+                    placed = sw;
                     const double td = bd[s];
                     const int32_t ti = bi[s];
                     bd[s] = sw ? cd : td;

@@ -38,10 +38,23 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case):
     cs.free(); ct.free()
 
 
+# variant 0: branch-free TRACK kernel (default); 2: same with scalar-load targets; 4..7: RESOLVE kernels
+# (4 exact, 5 fused filter, 6/7 the same with scalar-load targets); chunk = targets per min-tree
+VARIANTS = [(0, 8), (0, 16), (2, 8), (2, 16), (4, 8), (5, 8), (6, 8), (7, 8)]
+
+
+def set_variant(ctx, vc):
+    v, ch = vc
+    ctx.tune("nn1_variant", v if v else -8)   # -8 & 7 == 0 (0 itself means "library default")
+    ctx.tune("nn1_chunk", ch)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("qpl", [1, 2, 4])
 @pytest.mark.parametrize("ns,nt", [(1, 1), (63, 5), (257, 1023), (1000, 1025), (3001, 7000), (5000, 2049)])
-def test_nn1_ragged_sizes_vs_oracle(ctx, orc, synth, qpl, ns, nt):
+def test_nn1_ragged_sizes_vs_oracle(ctx, orc, synth, qpl, ns, nt, variant):
     ctx.tune("nn1_qpl", qpl)
+    set_variant(ctx, variant)
     src, _ = synth.kitti_like_pair(max(ns, 64), seed_target=7 + ns, seed_pair=11 + nt)
     tgt = synth.kitti_like_scan(max(nt, 64), seed=13 + nt)
     src, tgt = np.ascontiguousarray(src[:, :ns]), np.ascontiguousarray(tgt[:, :nt])
@@ -51,6 +64,7 @@ def test_nn1_ragged_sizes_vs_oracle(ctx, orc, synth, qpl, ns, nt):
     assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
     cs.free(); ct.free()
     ctx.tune("nn1_qpl", 0)
+    ctx.tune("nn1_variant", 0)
 
 
 @pytest.mark.parametrize("tps", [1, 3, 1000])
@@ -66,7 +80,9 @@ def test_nn1_slice_merge_is_order_independent(ctx, orc, synth, tps):
     cs.free(); ct.free()
 
 
-def test_nn1_ties_and_duplicates_pick_lowest_index(ctx, orc, synth):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_nn1_ties_and_duplicates_pick_lowest_index(ctx, orc, synth, variant):
+    set_variant(ctx, variant)
     lat = synth.lattice_cloud(5000, 3, 10.0, seed=5, levels=10).astype(np.float32)
     q = synth.lattice_cloud(3000, 3, 10.0, seed=6, levels=10).astype(np.float32)
     tgt, src = np.ascontiguousarray(lat.T), np.ascontiguousarray(q.T)
@@ -75,13 +91,22 @@ def test_nn1_ties_and_duplicates_pick_lowest_index(ctx, orc, synth):
     idx, d2 = ctx.nn1(ct, cs)
     ctx.tune("nn1_tiles_per_slice", 0)
     oidx, od2 = orc.nn1_f32(tgt, src)
+    ctx.tune("nn1_variant", 0)
     assert (orc.nn1_tiecount_f32(tgt, src) > 1).sum() > 1000
     assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
     cs.free(); ct.free()
 
 
-def test_nn1_edge_cases(ctx, orc):
-    # empty source, empty target, non-finite input
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_nn1_edge_cases(ctx, orc, variant):
+    # empty source, empty target, non-finite input, huge and tiny magnitudes (filter gate must stay conservative)
+    set_variant(ctx, variant)
+    big = np.array([[1e19, -1e19, 3e18, 1e-20, 0, 1e-23], [0, 1e19, 0, 0, 1e-20, 0], [0, 0, 0, 0, 0, 0]], np.float32)
+    cb = ctx.cloud(big)
+    idx, d2 = ctx.nn1(cb, cb)
+    oidx, od2 = orc.nn1_f32(big, big)
+    assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
+    cb.free()
     tgt = np.array([[0, 1, 2], [0, 0, 0], [0, 0, 0]], np.float32)
     src = np.array([[0.4, 1.6, np.nan, np.inf], [0, 0, 0, 0], [0, 0, 0, 0]], np.float32)
     ct, cs = ctx.cloud(tgt), ctx.cloud(src)
@@ -94,6 +119,7 @@ def test_nn1_edge_cases(ctx, orc):
     assert idx.size == 0
     idx, d2 = ctx.nn1(e, cs)
     assert (idx == 0xFFFFFFFF).all() and np.isinf(d2).all()
+    ctx.tune("nn1_variant", 0)
     for c in (ct, cs, e):
         c.free()
 

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Launch the brute-force 1-NN kernel a few times on the BASELINE pair (for rocprofv3 runs).
+usage: run_nn1.py [n] [launches] [variant] [qpl] [tiles_per_slice] [order: scan|shuffle]"""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+pcr = importlib.import_module("hands-on-point-cloud-processing_amd")
+synth = importlib.import_module("hands-on-point-cloud-processing_amd.synth")
+a = sys.argv[1:]
+n = int(a[0]) if len(a) > 0 else 120000
+launches = int(a[1]) if len(a) > 1 else 5
+variant = int(a[2]) if len(a) > 2 else None   # None: library default
+qpl = int(a[3]) if len(a) > 3 else 0
+tps = int(a[4]) if len(a) > 4 else 0
+order = a[5] if len(a) > 5 else "scan"
+src, tgt = synth.kitti_like_pair(n)
+if order == "shuffle":
+    perm = np.argsort(synth.splitmix64(4242, np.arange(n, dtype=np.uint64)), kind="stable")
+    tgt = np.ascontiguousarray(tgt[:, perm])
+ctx = pcr.Context(0)
+if variant is not None:
+    ctx.tune("nn1_variant", variant if variant else -8)
+ctx.tune("nn1_chunk", int(os.environ.get("NN1_CHUNK", "0")))
+ctx.tune("nn1_qpl", qpl)
+ctx.tune("nn1_tiles_per_slice", tps)
+cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+ctx.nn1_async(ct, cs); ctx.sync(); ctx.prof_reset()
+for _ in range(launches):
+    ctx.nn1_async(ct, cs)
+k, ms = ctx.prof_get("nn1_brute")
+print(f"n={n} variant={variant} qpl={qpl} tps={tps} order={order}: {ms/k:.4f} ms/launch over {k} launches")
