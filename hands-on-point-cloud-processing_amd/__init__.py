@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
+    "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
 
@@ -86,6 +87,12 @@ def lib():
     L.pcr_plane_mask_f64.argtypes = [vp, vp, vp, C.c_double, vp, C.POINTER(C.c_int64)]
     L.pcr_knn_f64.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, vp]
     L.pcr_radius_f64.argtypes = [vp, vp, sz, vp, sz, C.c_double, vp, vp, vp]
+    L.pcr_db64_create.argtypes = [vp, vp, sz, C.POINTER(vp)]
+    L.pcr_db64_destroy.argtypes = [vp, vp]
+    L.pcr_db64_size.restype = sz
+    L.pcr_db64_size.argtypes = [vp]
+    L.pcr_db64_knn.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, vp, vp]
+    L.pcr_db64_radius.argtypes = [vp, vp, vp, sz, C.c_double, vp, vp, vp]
     L.pcr_comm_unique_id.argtypes = [vp]
     L.pcr_comm_init_rccl.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pcr_comm_init_callback.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp]
@@ -141,6 +148,42 @@ class Cloud:
     def free(self):
         if self.h:
             lib().pcr_cloud_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class Db64:
+    """An n x 3 f64 database resident in HBM: built once, queried many times (k-NN / radius)."""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx = ctx
+        self.h = handle
+
+    def __len__(self):
+        return int(lib().pcr_db64_size(self.h))
+
+    def knn(self, q, k: int, squared: bool = False):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        idx = np.zeros((q.shape[0], k), np.int32)
+        dist = np.zeros((q.shape[0], k), np.float64)
+        self.ctx._ck(lib().pcr_db64_knn(self.ctx.h, self.h, q.ctypes.data, q.shape[0], k, int(squared),
+                                        idx.ctypes.data, dist.ctypes.data))
+        return idx, dist
+
+    def radius(self, q, r: float):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        row = np.zeros(q.shape[0] + 1, np.int64)
+        self.ctx._ck(lib().pcr_db64_radius(self.ctx.h, self.h, q.ctypes.data, q.shape[0], r, row.ctypes.data, None, None))
+        total = int(row[-1])
+        idx = np.zeros(max(total, 1), np.int32)
+        dist = np.zeros(max(total, 1), np.float64)
+        if total:
+            self.ctx._ck(lib().pcr_db64_radius(self.ctx.h, self.h, q.ctypes.data, q.shape[0], r, row.ctypes.data,
+                                               idx.ctypes.data, dist.ctypes.data))
+        return row, idx[:total], dist[:total]
+
+    def free(self):
+        if self.h:
+            lib().pcr_db64_destroy(self.ctx.h, self.h)
             self.h = None
 
 
@@ -274,6 +317,13 @@ class Context:
             self._ck(lib().pcr_radius_f64(self.h, db.ctypes.data, db.shape[0], q.ctypes.data, q.shape[0], r,
                                           row.ctypes.data, idx.ctypes.data, dist.ctypes.data))
         return row, idx[:total], dist[:total]
+
+    def db64(self, db) -> "Db64":
+        """Keep an n x 3 f64 database resident in HBM (the GPU-side 'tree')."""
+        a = np.ascontiguousarray(db, np.float64).reshape(-1, 3)
+        h = C.c_void_p()
+        self._ck(lib().pcr_db64_create(self.h, a.ctypes.data if a.size else None, a.shape[0], C.byref(h)))
+        return Db64(self, h)
 
     # ---- multi-GPU
     def comm_init_rccl(self, nranks: int, rank: int, unique_id: bytes):

@@ -103,7 +103,7 @@ int launch_plane_count(pcr_ctx* ctx, const pcr_cloud* pts, const double* planes4
 int launch_plane_mask(pcr_ctx* ctx, const pcr_cloud* pts, const double plane4[4], double thr,
                       uint8_t* mask_dev, unsigned long long* count_dev);
 int launch_knn_f64(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m,
-                   int k, int32_t* idx_dev, double* dist_dev);
+                   int k, int32_t* idx_dev, double* dist_dev, bool squared);
 int launch_radius_count(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa,
                         size_t m, double r, unsigned long long* counts_dev);
 int launch_radius_fill(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa,

@@ -27,7 +27,9 @@ __device__ __forceinline__ double dist2_f64(double t0, double t1, double t2, dou
     return (e0 * e0 + e1 * e1) + e2 * e2;
 }
 
-template <int K>
+// SQ = false: hw2 contract (d = sqrt(s), kdtree.hpp:346); SQ = true: nanoflann contract (squared L2, no sqrt,
+// nanoflann.hpp:403-406 with T = double) - ordering then happens on s itself.
+template <int K, bool SQ>
 __global__ __launch_bounds__(SF_BLOCK) void knn_f64_kernel(
     const double* __restrict__ db, uint32_t n, uint32_t n_cap, const double* __restrict__ q, uint32_t m,
     uint32_t m_cap, int k_out, int32_t* __restrict__ idx_out, double* __restrict__ dist_out)
@@ -39,7 +41,8 @@ __global__ __launch_bounds__(SF_BLOCK) void knn_f64_kernel(
     double bd[K];
     int32_t bi[K];
 #pragma unroll
-    for (int s = 0; s < K; s++) { bd[s] = 1e10; bi[s] = 0; }      // resultSet.hpp:35-42
+    // hw2: slots pre-filled with (1e10, 0), resultSet.hpp:35-42; nanoflann: worst = DBL_MAX (nanoflann.hpp:163)
+    for (int s = 0; s < K; s++) { bd[s] = SQ ? 1.7976931348623157e308 : 1e10; bi[s] = SQ ? -1 : 0; }
     for (uint32_t base = 0; base < n; base += SF_TILE) {
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < SF_TILE; t += SF_BLOCK) {
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(SF_BLOCK) void knn_f64_kernel(
         __syncthreads();
         const uint32_t cnt = min((uint32_t)SF_TILE, n - base);
         for (uint32_t t = 0; t < cnt; t++) {
-            const double d = sqrt(dist2_f64(l0[t], l1[t], l2[t], q0, q1, q2));
+            const double s2 = dist2_f64(l0[t], l1[t], l2[t], q0, q1, q2);
+            const double d = SQ ? s2 : sqrt(s2);
             // resultSet.hpp:69 rejects only d > worst; the canonical rule additionally keeps the earlier
             // (lower) index on equality, i.e. insert only when strictly smaller than the current worst
             if (d < bd[K - 1]) {
@@ -125,14 +129,20 @@ __global__ __launch_bounds__(SF_BLOCK) void radius_f64_kernel(
 }
 
 int launch_knn_f64(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m, int k,
-                   int32_t* idx_dev, double* dist_dev)
+                   int32_t* idx_dev, double* dist_dev, bool squared)
 {
     const uint32_t blocks = (uint32_t)((m + SF_BLOCK - 1) / SF_BLOCK);
     const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
     ProfScope p(ctx, "knn_f64");
 #define PCR_KNN(K)                                                                                              \
-    hipLaunchKernelGGL(knn_f64_kernel<K>, dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, db_soa, (uint32_t)n,     \
-                       (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, k, idx_dev, dist_dev)
+    do {                                                                                                        \
+        if (squared)                                                                                            \
+            hipLaunchKernelGGL((knn_f64_kernel<K, true>), dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, db_soa,  \
+                               (uint32_t)n, (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, k, idx_dev, dist_dev); \
+        else                                                                                                    \
+            hipLaunchKernelGGL((knn_f64_kernel<K, false>), dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, db_soa, \
+                               (uint32_t)n, (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, k, idx_dev, dist_dev); \
+    } while (0)
     if (k <= 1) PCR_KNN(1);
     else if (k <= 4) PCR_KNN(4);
     else if (k <= 8) PCR_KNN(8);
@@ -206,50 +216,84 @@ static size_t tile_cap(size_t n) { return ((n + SF_TILE - 1) / SF_TILE) * SF_TIL
 
 }  // namespace pcr
 
+// a database resident in HBM (SoA f64), the GPU-side counterpart of the tree KDTreeConstruction returns
+struct pcr_db64 {
+    size_t n = 0;
+    size_t cap = 0;
+    double* dev = nullptr;
+};
+
 using namespace pcr;
 
-extern "C" int pcr_knn_f64(pcr_ctx* ctx, const double* db, size_t n, const double* q, size_t m, int k, int32_t* idx,
-                           double* dist)
+extern "C" int pcr_db64_create(pcr_ctx* ctx, const double* db, size_t n, pcr_db64** out)
 {
-    if (!ctx || k < 1 || k > 32 || (n && !db) || (m && (!q || !idx || !dist))) return fail(ctx, PCR_ERR_ARG, "pcr_knn_f64");
-    if (m == 0) return PCR_OK;
-    if (n > 0x7FFFFFF0ull || m > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_knn_f64: too large for i32 indices");
+    if (!ctx || !out || (n && !db)) return fail(ctx, PCR_ERR_ARG, "pcr_db64_create");
+    if (n > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_db64_create: too large for i32 indices");
     PCR_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t n_cap = tile_cap(n), m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
-    const size_t bytes_db = 3 * n_cap * 8, bytes_q = 3 * m_cap * 8, bytes_i = m * (size_t)k * 4, bytes_d = m * (size_t)k * 8;
-    const size_t off_q = bytes_db, off_d = off_q + bytes_q, off_i = off_d + ((bytes_d + 63) & ~(size_t)63);
+    pcr_db64* h = new (std::nothrow) pcr_db64();
+    if (!h) return fail(ctx, PCR_ERR_NOMEM, "pcr_db64_create");
+    h->n = n;
+    h->cap = tile_cap(n);
+    hipError_t e = hipMalloc((void**)&h->dev, 3 * h->cap * sizeof(double));
+    if (e != hipSuccess) { delete h; return fail(ctx, PCR_ERR_HIP, "hipMalloc(db64)", e); }
+    int rc = upload_soa_f64(ctx, db, n, h->cap, h->dev);
+    if (rc) { hipFree(h->dev); delete h; return rc; }
+    *out = h;
+    return PCR_OK;
+}
+
+extern "C" int pcr_db64_destroy(pcr_ctx* ctx, pcr_db64* db)
+{
+    if (!db) return PCR_OK;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (db->dev) hipFree(db->dev);
+    delete db;
+    return PCR_OK;
+}
+
+extern "C" size_t pcr_db64_size(const pcr_db64* db) { return db ? db->n : 0; }
+
+extern "C" int pcr_db64_knn(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, int k, int squared,
+                            int32_t* idx, double* dist)
+{
+    if (!ctx || !db || k < 1 || k > 32 || (m && (!q || !idx || !dist))) return fail(ctx, PCR_ERR_ARG, "pcr_db64_knn");
+    if (m == 0) return PCR_OK;
+    if (m > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_db64_knn: too many queries");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
+    const size_t bytes_q = 3 * m_cap * 8, bytes_i = m * (size_t)k * 4, bytes_d = m * (size_t)k * 8;
+    const size_t off_d = bytes_q, off_i = off_d + ((bytes_d + 63) & ~(size_t)63);
     int rc = ensure_scratch(ctx, off_i + bytes_i + 64);
     if (rc) return rc;
     char* s = (char*)ctx->scratch;
-    if ((rc = upload_soa_f64(ctx, db, n, n_cap, (double*)s))) return rc;
-    if ((rc = upload_soa_f64(ctx, q, m, m_cap, (double*)(s + off_q)))) return rc;
-    if ((rc = launch_knn_f64(ctx, (double*)s, n, n_cap, (double*)(s + off_q), m, k, (int32_t*)(s + off_i), (double*)(s + off_d)))) return rc;
+    if ((rc = upload_soa_f64(ctx, q, m, m_cap, (double*)s))) return rc;
+    if ((rc = launch_knn_f64(ctx, db->dev, db->n, db->cap, (double*)s, m, k, (int32_t*)(s + off_i), (double*)(s + off_d), squared != 0))) return rc;
     PCR_HIP(ctx, hipMemcpyAsync(idx, s + off_i, bytes_i, hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipMemcpyAsync(dist, s + off_d, bytes_d, hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PCR_OK;
 }
 
-extern "C" int pcr_radius_f64(pcr_ctx* ctx, const double* db, size_t n, const double* q, size_t m, double r,
-                              int64_t* row_ptr, int32_t* idx, double* dist)
+extern "C" int pcr_db64_radius(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, double r,
+                               int64_t* row_ptr, int32_t* idx, double* dist)
 {
-    if (!ctx || !row_ptr || (n && !db) || (m && !q) || ((idx == nullptr) != (dist == nullptr)))
-        return fail(ctx, PCR_ERR_ARG, "pcr_radius_f64");
+    if (!ctx || !db || !row_ptr || (m && !q) || ((idx == nullptr) != (dist == nullptr)))
+        return fail(ctx, PCR_ERR_ARG, "pcr_db64_radius");
     row_ptr[0] = 0;
     if (m == 0) return PCR_OK;
-    if (n > 0x7FFFFFF0ull || m > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_radius_f64: too large for i32 indices");
+    if (m > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_db64_radius: too many queries");
     PCR_HIP(ctx, hipSetDevice(ctx->device));
     const double r2max = radius_sq_bound(r);
-    const size_t n_cap = tile_cap(n), m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
-    const size_t bytes_db = 3 * n_cap * 8, bytes_q = 3 * m_cap * 8, bytes_c = (m + 1) * 8;
-    const size_t off_q = bytes_db, off_c = off_q + bytes_q;
+    const size_t n = db->n, n_cap = db->cap;
+    const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
+    const size_t bytes_q = 3 * m_cap * 8, bytes_c = (m + 1) * 8;
+    const size_t off_c = bytes_q;
     int rc = ensure_scratch(ctx, off_c + bytes_c + 64);
     if (rc) return rc;
     char* s = (char*)ctx->scratch;
-    if ((rc = upload_soa_f64(ctx, db, n, n_cap, (double*)s))) return rc;
-    if ((rc = upload_soa_f64(ctx, q, m, m_cap, (double*)(s + off_q)))) return rc;
+    if ((rc = upload_soa_f64(ctx, q, m, m_cap, (double*)s))) return rc;
     // pass 1: counts -> exclusive scan on the host (m+1 words)
-    if ((rc = launch_radius_count(ctx, (double*)s, n, n_cap, (double*)(s + off_q), m, r2max, (unsigned long long*)(s + off_c)))) return rc;
+    if ((rc = launch_radius_count(ctx, db->dev, n, n_cap, (double*)s, m, r2max, (unsigned long long*)(s + off_c)))) return rc;
     std::vector<unsigned long long> cnt(m);
     PCR_HIP(ctx, hipMemcpyAsync(cnt.data(), s + off_c, m * 8, hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -257,35 +301,48 @@ extern "C" int pcr_radius_f64(pcr_ctx* ctx, const double* db, size_t n, const do
     for (size_t i = 0; i < m; i++) { row_ptr[i] = acc; acc += (int64_t)cnt[i]; }
     row_ptr[m] = acc;
     if (!idx || acc == 0) return PCR_OK;
-    // pass 2: fill
+    // pass 2: fill (result buffers are separate allocations: growing the scratch would drop the uploaded queries)
     const size_t total = (size_t)acc;
-    const size_t off_i = off_c + ((bytes_c + 63) & ~(size_t)63), off_d = off_i + ((total * 4 + 63) & ~(size_t)63);
-    const size_t need = off_d + total * 8 + 64;
-    if (need > ctx->scratch_cap) {
-        // growing the scratch would drop the uploaded arrays: allocate result buffers separately
-        int32_t* idx_dev = nullptr;
-        double* dist_dev = nullptr;
-        PCR_HIP(ctx, hipMalloc((void**)&idx_dev, total * 4));
-        hipError_t e = hipMalloc((void**)&dist_dev, total * 8);
-        if (e != hipSuccess) { hipFree(idx_dev); return fail(ctx, PCR_ERR_HIP, "hipMalloc(radius)", e); }
-        hipMemcpyAsync(s + off_c, row_ptr, (m + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-        rc = launch_radius_fill(ctx, (double*)s, n, n_cap, (double*)(s + off_q), m, r2max, (const long long*)(s + off_c), idx_dev, dist_dev);
-        if (rc == PCR_OK) {
-            hipMemcpyAsync(idx, idx_dev, total * 4, hipMemcpyDeviceToHost, ctx->stream);
-            hipMemcpyAsync(dist, dist_dev, total * 8, hipMemcpyDeviceToHost, ctx->stream);
-        }
-        e = hipStreamSynchronize(ctx->stream);
-        hipFree(idx_dev);
-        hipFree(dist_dev);
-        if (rc) return rc;
-        if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "radius fill", e);
-        return PCR_OK;
-    }
-    PCR_HIP(ctx, hipMemcpyAsync(s + off_c, row_ptr, (m + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = launch_radius_fill(ctx, (double*)s, n, n_cap, (double*)(s + off_q), m, r2max, (const long long*)(s + off_c),
-                                 (int32_t*)(s + off_i), (double*)(s + off_d)))) return rc;
-    PCR_HIP(ctx, hipMemcpyAsync(idx, s + off_i, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipMemcpyAsync(dist, s + off_d, total * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t* idx_dev = nullptr;
+    double* dist_dev = nullptr;
+    PCR_HIP(ctx, hipMalloc((void**)&idx_dev, total * 4));
+    hipError_t e = hipMalloc((void**)&dist_dev, total * 8);
+    if (e != hipSuccess) { hipFree(idx_dev); return fail(ctx, PCR_ERR_HIP, "hipMalloc(radius)", e); }
+    e = hipMemcpyAsync(s + off_c, row_ptr, (m + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        rc = launch_radius_fill(ctx, db->dev, n, n_cap, (double*)s, m, r2max, (const long long*)(s + off_c), idx_dev, dist_dev);
+    if (e == hipSuccess && rc == PCR_OK) e = hipMemcpyAsync(idx, idx_dev, total * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == PCR_OK) e = hipMemcpyAsync(dist, dist_dev, total * 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    hipFree(idx_dev);
+    hipFree(dist_dev);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "radius fill", e);
+    if (e2 != hipSuccess) return fail(ctx, PCR_ERR_HIP, "radius fill sync", e2);
     return PCR_OK;
+}
+
+extern "C" int pcr_knn_f64(pcr_ctx* ctx, const double* db, size_t n, const double* q, size_t m, int k, int32_t* idx,
+                           double* dist)
+{
+    if (!ctx || k < 1 || k > 32 || (n && !db) || (m && (!q || !idx || !dist))) return fail(ctx, PCR_ERR_ARG, "pcr_knn_f64");
+    pcr_db64* h = nullptr;
+    int rc = pcr_db64_create(ctx, db, n, &h);
+    if (rc) return rc;
+    rc = pcr_db64_knn(ctx, h, q, m, k, 0, idx, dist);
+    pcr_db64_destroy(ctx, h);
+    return rc;
+}
+
+extern "C" int pcr_radius_f64(pcr_ctx* ctx, const double* db, size_t n, const double* q, size_t m, double r,
+                              int64_t* row_ptr, int32_t* idx, double* dist)
+{
+    if (!ctx || !row_ptr || (n && !db) || (m && !q) || ((idx == nullptr) != (dist == nullptr)))
+        return fail(ctx, PCR_ERR_ARG, "pcr_radius_f64");
+    pcr_db64* h = nullptr;
+    int rc = pcr_db64_create(ctx, db, n, &h);
+    if (rc) return rc;
+    rc = pcr_db64_radius(ctx, h, q, m, r, row_ptr, idx, dist);
+    pcr_db64_destroy(ctx, h);
+    return rc;
 }

@@ -1,0 +1,90 @@
+"""Host-side mirror of the Homework4 RANSAC ground-plane interface, running the inlier counts on the GPU.
+
+Mirrors (same names, argument meaning and return values):
+  estimate_plane_params   Homework4/ground_detection_ransac.py:158-169   (host, f64; 3 points)
+  my_ransac               Homework4/ground_detection_ransac.py:104-155
+  ransac_on_segments      Homework4/ground_detection_ransac.py:54-73
+  extract_initial_seeds   Homework4/ground_detection_SVD.py:46-69        (host numpy; the step BEFORE the hot path)
+
+The hot loop of my_ransac — `dists = |[X 1] . params|; inliers = sum(dists < thr)` evaluated once per hypothesis
+(:138-139) — becomes ONE launch of pcr_plane_count_f64 over all `max_iteration` hypotheses: the points are read
+from HBM once instead of `max_iteration` times.  The final inlier mask (:152-153) is pcr_plane_mask_f64.
+
+The reference draws its 3-point samples from a fresh, unseeded `np.random.default_rng()` per iteration (:132);
+this mirror takes an explicit generator so that runs are reproducible (and equal to the reference's for an
+identical sample sequence).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def estimate_plane_params(selected_points: np.ndarray) -> np.ndarray:
+    """Plane (a, b, c, d)/|n| through 3 points — ground_detection_ransac.py:158-169."""
+    p = np.asarray(selected_points)
+    vector1 = p[1, :] - p[0, :]
+    vector2 = p[2, :] - p[0, :]
+    a = (vector1[1] * vector2[2]) - (vector1[2] * vector2[1])
+    b = (vector1[2] * vector2[0]) - (vector1[0] * vector2[2])
+    c = (vector1[0] * vector2[1]) - (vector1[1] * vector2[0])
+    d = -(a * p[0, 0] + b * p[0, 1] + c * p[0, 2])
+    n = math.sqrt(a ** 2 + b ** 2 + c ** 2)
+    return np.array([a / n, b / n, c / n, d / n])
+
+
+def extract_initial_seeds(pcd_points: np.ndarray, LPR_size: int, threshold_seeds: float) -> np.ndarray:
+    """ground_detection_SVD.py:46-69: points below z_high, lowest-point-representative mean of the LPR_size
+    lowest z, then everything below LPR.z + threshold_seeds.  (np.argpartition instead of bottleneck's.)"""
+    z_high = -1.73 + 0.5
+    possible = pcd_points[pcd_points[:, 2] < z_high, :]
+    if LPR_size > possible.shape[0]:
+        lpr_idx = np.arange(possible.shape[0])
+    else:
+        lpr_idx = np.argpartition(possible[:, 2], LPR_size - 1)[:LPR_size]
+    lpr = np.mean(possible[lpr_idx, :], axis=0)
+    return possible[possible[:, 2] < lpr[2] + threshold_seeds, :]
+
+
+def my_ransac(ctx, data: np.ndarray, indices: np.ndarray, max_iteration: int, threshold: float, rng=None):
+    """ground_detection_ransac.py:104-155 -> (inliers_idx, best_model_params).  `ctx` is a pcr Context."""
+    assert data.shape[0] == indices.shape[0]
+    rng = np.random.default_rng() if rng is None else rng
+    filtered_data = extract_initial_seeds(data, 40000, 1)                       # :125
+    if filtered_data.shape[0] < 3:
+        return indices[:0], []
+    hyps = np.zeros((max_iteration, 4), np.float64)
+    for it in range(max_iteration):                                             # :131-135
+        sel = rng.choice(range(filtered_data.shape[0]), 3, replace=False)
+        hyps[it] = estimate_plane_params(filtered_data[sel, :].astype(np.float64))
+    valid = np.isfinite(hyps).all(axis=1)       # collinear samples give n = 0 -> NaN params; NaN < thr is False (:139)
+    seeds = ctx.cloud(np.ascontiguousarray(filtered_data[:, :3], np.float32), 1)
+    try:
+        counts = np.zeros(max_iteration, np.int64)
+        if valid.any():
+            counts[valid] = ctx.plane_count(seeds, hyps[valid], float(threshold))   # :138-139, all hypotheses at once
+    finally:
+        seeds.free()
+    best_set_size, best_model_params = 0, []
+    for it in range(max_iteration):                                             # :140-142 (strict >: first maximum wins)
+        if counts[it] > best_set_size:
+            best_set_size = counts[it]
+            best_model_params = hyps[it]
+    if len(best_model_params) == 0:
+        return indices[:0], []
+    allpts = ctx.cloud(np.ascontiguousarray(data[:, :3], np.float32), 1)
+    try:
+        mask, _ = ctx.plane_mask(allpts, best_model_params, float(threshold))   # :152-153
+    finally:
+        allpts.free()
+    return indices[mask.astype(bool)], best_model_params
+
+
+def ransac_on_segments(ctx, data: np.ndarray, segment_x=0, max_iteration=40, threshold=0.15, rng=None):
+    """ground_detection_ransac.py:54-73: RANSAC on the two x-segments, stacked inlier indices."""
+    total = np.array(range(data.shape[0]))
+    fwd = data[:, 0] >= segment_x
+    idx1, _ = my_ransac(ctx, data[fwd], total[fwd], max_iteration, threshold, rng)
+    idx2, _ = my_ransac(ctx, data[np.logical_not(fwd)], total[np.logical_not(fwd)], max_iteration, threshold, rng)
+    return np.r_[idx1, idx2]

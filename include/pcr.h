@@ -133,6 +133,19 @@ int pcr_knn_f64(pcr_ctx* ctx, const double* db, size_t n, const double* q, size_
 int pcr_radius_f64(pcr_ctx* ctx, const double* db, size_t n, const double* q, size_t m, double r,
                    int64_t* row_ptr, int32_t* idx, double* dist);
 
+/* ---- the same searches on a database kept resident in HBM: the counterpart of the tree object the
+ * reference builds once (KDTreeConstruction, kdtree.hpp:419; nanoflann buildIndex, nanoflann.hpp:1191) and
+ * queries many times.  squared = 0: hw2 contract (d = sqrt(s)); squared = 1: nanoflann contract for
+ * T = double (squared L2, nanoflann.hpp:403-406; empty slots hold (DBL_MAX, -1)). */
+typedef struct pcr_db64 pcr_db64;
+int pcr_db64_create(pcr_ctx* ctx, const double* db, size_t n, pcr_db64** out);
+int pcr_db64_destroy(pcr_ctx* ctx, pcr_db64* db);
+size_t pcr_db64_size(const pcr_db64* db);
+int pcr_db64_knn(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, int k, int squared,
+                 int32_t* idx, double* dist);
+int pcr_db64_radius(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, double r,
+                    int64_t* row_ptr, int32_t* idx, double* dist);
+
 /* ---- multi-GPU: one process per GPU, sources sharded, targets replicated ------------------------------
  * Exactly one collective per ICP iteration: all-reduce(sum) of 16 f64 (+2 bookkeeping words). */
 #define PCR_COMM_ID_BYTES 128

@@ -1,0 +1,44 @@
+"""N > 1 path: world_size-2 runs over gloo (127.0.0.1).  CPU: the reduce-buffer protocol + host logic;
+GPU box: the real sharded ICP through the C ABI with the callback transport (2 ranks share the one GPU)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_workers(mode, nproc=2, timeout=300):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "mr_worker.py"), mode]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_sharded_kabsch_protocol_world2_gloo():
+    out = run_workers("protocol", 2)
+    assert out.count("protocol ok") == 2
+
+
+def test_sharded_kabsch_protocol_world3_gloo():
+    out = run_workers("protocol", 3)
+    assert out.count("protocol ok") == 3
+
+
+@pytest.mark.gpu
+def test_sharded_icp_two_ranks_one_gpu():
+    out = run_workers("gpu", 2)
+    assert out.count("gpu sharded icp ok") == 2
