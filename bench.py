@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--qpl", type=int, default=0)
     ap.add_argument("--tiles-per-slice", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0, help="nn1 kernel variant (0 = library default; -8 = LDS-tiled TRACK)")
+    ap.add_argument("--no-grid-extra", action="store_true", help="skip the additional exact-grid pass")
+    ap.add_argument("--nn", choices=["brute", "grid"], default="brute",
+                    help="correspondence search: brute = BASELINE configs[1] (LDS-tiled brute force), grid = exact grid index")
     args = ap.parse_args()
 
     import numpy as np
@@ -132,22 +135,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up: W untimed iterations from the same initial state
-    if args.warmup > 0:
-        ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=args.warmup, eps=0.0)
-    ctx.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=args.steps, eps=0.0)   # eps = 0: never early-exits
-    barrier()
-    dt = time.perf_counter() - t0
-    assert st["iters_run"] == args.steps, st
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed_icp(method):
+        """W untimed + exactly K timed ICP iterations with the given correspondence search; max over ranks."""
+        ctx.tune("nn_method", method)
+        if args.warmup > 0:
+            ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=args.warmup, eps=0.0)
+        ctx.prof_reset()
+        barrier()
+        t0 = time.perf_counter()
+        T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=args.steps, eps=0.0)   # eps = 0: never early-exits
+        barrier()
+        dt = time.perf_counter() - t0
+        assert st["iters_run"] == args.steps, st
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return T, st, dt
 
-    nn_launches, nn_ms = ctx.prof_get("nn1_brute")
+    main_method = 1 if args.nn == "brute" else 2
+    T, st, dt = timed_icp(main_method)
+    nn_name = "nn1_brute" if args.nn == "brute" else "nn1_grid"
+    nn_launches, nn_ms = ctx.prof_get(nn_name)
+    # second, separately timed pass with the exact grid index (same answers, different search): extra info only
+    grid_extra = None
+    if args.nn == "brute" and not args.no_grid_extra:
+        Tg, stg, dtg = timed_icp(2)
+        gl, gms = ctx.prof_get("nn1_grid")
+        grid_extra = {"value": world * n * args.steps / dtg / 1e6, "unit": "M corr/s", "icp_iter_per_s": args.steps / dtg,
+                      "ms_per_step": dtg * 1e3 / args.steps, "avg_nn_kernel_ms": gms / max(gl, 1),
+                      "pose_bit_identical_to_brute_force": bool(np.array_equal(T.view(np.uint32), Tg.view(np.uint32))),
+                      "note": "same ICP with pcr nn_method = grid (exact uniform-grid index, csrc/grid.hip); NOT the "
+                              "BASELINE configs[1] workload, reported for information"}
     if rank == 0:
         pmc = None
         try:   # HBM traffic of the same kernel from a separate rocprofv3 --pmc pass (tools/gpu_check.sh), committed
@@ -189,6 +208,8 @@ def main():
                                          "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
                                          "note": "compulsory bytes (32 B/point); brute force is VALU-bound, see DESIGN.md"}},
         }
+        if grid_extra is not None:
+            out["exact_grid"] = grid_extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(src, tgt)
         print(json.dumps(out))

@@ -61,9 +61,9 @@ int64_t tune_get(const pcr_ctx* ctx, const char* key, int64_t dflt)
     return (it == ctx->tune.end() || it->second == 0) ? dflt : it->second;
 }
 
-ProfScope::ProfScope(pcr_ctx* c, const char* n) : ctx(c), name(n)
+ProfScope::ProfScope(pcr_ctx* c, const char* n, int level) : ctx(c), name(n)
 {
-    if (!ctx->prof_on) return;
+    if (ctx->prof_level < level) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
     hipEventRecord(a, ctx->stream);
 }
@@ -89,6 +89,18 @@ void prof_flush(pcr_ctx* ctx)
         }
         kv.second.pending.clear();
     }
+}
+
+void cloud_modified(pcr_cloud* c)
+{
+    if (c && c->grid) { grid_free(c->grid); c->grid = nullptr; }
+}
+
+int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm)
+{
+    const int64_t method = tune_get(ctx, "nn_method", 0);
+    const bool grid = method == 2 || (method != 1 && tgt->n >= 2048);
+    return grid ? launch_nn1_grid(ctx, tgt, src, reuse_perm) : launch_nn1_brute(ctx, tgt, src);
 }
 
 static int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out)
@@ -149,6 +161,10 @@ int pcr_ctx_destroy(pcr_ctx* ctx)
     prof_flush(ctx);
     pcr_comm_destroy(ctx);
     if (ctx->keys) hipFree(ctx->keys);
+    if (ctx->icp_state_dev) hipFree(ctx->icp_state_dev);
+    if (ctx->icp_state_host) hipHostFree(ctx->icp_state_host);
+    for (hipEvent_t ev : ctx->icp_events) if (ev) hipEventDestroy(ev);
+    if (ctx->qperm) hipFree(ctx->qperm);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->dev_out) hipFree(ctx->dev_out);
     if (ctx->host_out) hipHostFree(ctx->host_out);
@@ -229,6 +245,7 @@ int pcr_cloud_clone(pcr_ctx* ctx, const pcr_cloud* src, pcr_cloud** out)
 int pcr_cloud_assign(pcr_ctx* ctx, pcr_cloud* dst, const pcr_cloud* src)
 {
     if (!ctx || !dst || !src || dst->n != src->n) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_assign");
+    cloud_modified(dst);
     PCR_HIP(ctx, hipMemcpyAsync(dst->base, src->base, 3 * src->cap * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     return PCR_OK;
 }
@@ -265,6 +282,8 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
 {
     if (!c) return PCR_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
+    if (ctx && ctx->qperm_src == c) ctx->qperm_src = nullptr;
+    cloud_modified(c);
     if (c->base) hipFree(c->base);
     delete c;
     return PCR_OK;
@@ -274,7 +293,7 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
 int pcr_nn1_f32_async(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
 {
     if (!ctx || !tgt || !src) return fail(ctx, PCR_ERR_ARG, "pcr_nn1_f32_async");
-    return launch_nn1_brute(ctx, tgt, src);
+    return launch_nn1(ctx, tgt, src, false);
 }
 
 int pcr_nn1_fetch(pcr_ctx* ctx, size_t n, uint32_t* idx, float* d2)
@@ -306,6 +325,7 @@ int pcr_transform_f32(pcr_ctx* ctx, pcr_cloud* cloud, const float T[16])
     if (!ctx || !cloud || !T) return fail(ctx, PCR_ERR_ARG, "pcr_transform_f32");
     const float R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
     const float t[3] = { T[3], T[7], T[11] };
+    cloud_modified(cloud);
     return launch_transform(ctx, cloud, R, t);
 }
 
@@ -359,7 +379,7 @@ int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* t
 int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value)
 {
     if (!ctx || !key) return PCR_ERR_ARG;
-    if (!strcmp(key, "prof")) { ctx->prof_on = value != 0; return PCR_OK; }
+    if (!strcmp(key, "prof")) { ctx->prof_level = (int)value; return PCR_OK; }   // 0 off, 1 nn kernels, 2 all
     ctx->tune[key] = value;
     return PCR_OK;
 }

@@ -78,6 +78,20 @@ int comm_allreduce_f64(pcr_ctx* ctx, double* host_buf, double* dev_buf, int n)
     return fail(ctx, PCR_ERR_STATE, "nranks > 1 but no transport attached");
 }
 
+int comm_allreduce_f64_device(pcr_ctx* ctx, double* dev_buf, int n)
+{
+    Comm& c = ctx->comm;
+    if (c.nranks <= 1) return PCR_OK;
+    if (!c.rccl) return fail(ctx, PCR_ERR_STATE, "device all-reduce needs the RCCL transport");
+    Rccl& r = rccl();
+    int rc = r.AllReduce(dev_buf, dev_buf, (size_t)n, kNcclFloat64, kNcclSum, c.rccl, ctx->stream);
+    if (rc != 0) {
+        ctx->err = std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
+        return PCR_ERR_COMM;
+    }
+    return PCR_OK;
+}
+
 }  // namespace pcr
 
 using namespace pcr;

@@ -1,0 +1,596 @@
+// grid.hip — EXACT grid-accelerated 1-NN for gfx950: the HBM/L2-bound variant of the correspondence search
+// (SURVEY.md §7.1 step 9, §8d "1-NN exact grid").  Same contract as nn1_brute.hip: A1 arithmetic
+// (nanoflann.hpp:403-406, unfused f32) and the canonical tie rule, so results are bit-identical to brute force
+// and to the reference's kd-tree on tie-free data; only the set of candidates a query looks at is pruned.
+//
+// Index (built once per target cloud, cached on the cloud, dropped when the cloud is transformed):
+//   * uniform grid over the bounding box of the finite targets, cell edge h ~ cbrt(V / 4n) (tunable),
+//     cell id = (cz * ny + cy) * nx + cx; counting sort by cell id: histogram (atomicAdd) -> exclusive scan
+//     -> scatter into float4 records {x, y, z, original index}: ONE 16-byte load per candidate;
+//     cells that are adjacent in x are adjacent in memory, so a query walks whole x-rows of cells as one
+//     contiguous range [cell_start[row + xlo], cell_start[row + xhi + 1]).
+//   * the order of records inside a cell depends on atomic arrival order; results do not, because every
+//     comparison is on the 64-bit key (d2_bits << 32 | original index).
+// Query (one per lane; lanes are handed queries sorted by cell so that a wave stays spatially coherent):
+//   scan the cube of cells within Chebyshev radius r of the query's cell, r = r0, 2 r0, 4 r0, ... and stop as
+//   soon as the best d2 is strictly below LB(r) = ((r - slack) * h)^2 * (1 - 1e-5), a lower bound on the f32
+//   distance of every target outside the cube (two points whose cells differ by >= r+1 in some axis are more
+//   than (r - slack) * h apart; slack covers the f32 rounding of the cell computation), or when the cube
+//   covers the whole grid.  Exactness proof and cost model: DESIGN.md §5b.
+// Traffic (algorithmic): 12 B query + 8 B key + 16 B per visited candidate + 8 B per visited cell row.
+#include "pcr_internal.hpp"
+
+#include <cfloat>
+#include <cmath>
+
+#pragma clang fp contract(off)
+
+namespace pcr {
+
+constexpr int GR_BLOCK = 256;
+
+struct GridParams {
+    float lo[3];
+    float inv_h;
+    float h;
+    int n[3];          // cells per axis
+    float slack;       // in cells
+};
+
+struct Grid {
+    GridParams p;
+    size_t n_points = 0;
+    size_t n_cells = 0;
+    float4* records = nullptr;        // n_points, sorted by cell
+    uint32_t* cell_start = nullptr;   // n_cells + 1
+};
+
+__device__ __forceinline__ int cell_coord(float v, float lo, float inv_h)
+{
+    const float a = floorf((v - lo) * inv_h);
+    // clamp far-away values before the int conversion; +-2^22 cells is beyond any grid we build
+    return (int)fminf(fmaxf(a, -4194304.0f), 4194304.0f);
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+    return (fabsf(x) <= FLT_MAX) && (fabsf(y) <= FLT_MAX) && (fabsf(z) <= FLT_MAX);   // false for NaN / inf
+}
+
+__device__ __forceinline__ uint32_t clamped_cell_id(const GridParams& g, float x, float y, float z)
+{
+    if (!finite3(x, y, z)) return 0;   // never wins a comparison (d2 = inf / NaN), any cell will do
+    const int cx = min(max(cell_coord(x, g.lo[0], g.inv_h), 0), g.n[0] - 1);
+    const int cy = min(max(cell_coord(y, g.lo[1], g.inv_h), 0), g.n[1] - 1);
+    const int cz = min(max(cell_coord(z, g.lo[2], g.inv_h), 0), g.n[2] - 1);
+    return (uint32_t)((cz * g.n[1] + cy) * g.n[0] + cx);
+}
+
+// ---------------------------------------------------------------------------------------- bounding box
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// out[block][6] = {min x,y,z, max x,y,z} over the finite points of the block's range
+__global__ __launch_bounds__(GR_BLOCK) void bbox_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ z, uint32_t n, float* __restrict__ out)
+{
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x; i < n; i += gridDim.x * GR_BLOCK) {
+        const float px = x[i], py = y[i], pz = z[i];
+        if (finite3(px, py, pz)) {
+            mn[0] = fminf(mn[0], px); mn[1] = fminf(mn[1], py); mn[2] = fminf(mn[2], pz);
+            mx[0] = fmaxf(mx[0], px); mx[1] = fmaxf(mx[1], py); mx[2] = fmaxf(mx[2], pz);
+        }
+    }
+    __shared__ float red[GR_BLOCK / 64][6];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float a = wave_min_f(mn[c]), b = wave_max_f(mx[c]);
+        if (lane == 0) { red[wave][c] = a; red[wave][3 + c] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        float v = red[0][c];
+        for (int w = 1; w < GR_BLOCK / 64; w++) v = c < 3 ? fminf(v, red[w][c]) : fmaxf(v, red[w][c]);
+        out[blockIdx.x * 6 + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- counting sort
+__global__ __launch_bounds__(GR_BLOCK) void cell_count_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ z, uint32_t n, GridParams g,
+                                                              uint32_t* __restrict__ cell_of, uint32_t* __restrict__ count)
+{
+    const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = clamped_cell_id(g, x[i], y[i], z[i]);
+    cell_of[i] = c;
+    atomicAdd(&count[c], 1u);
+}
+
+constexpr int SC_ITEMS = 8;                       // per thread
+constexpr int SC_TILE = GR_BLOCK * SC_ITEMS;      // 2048 per block
+
+// block-local exclusive scan; block totals to `totals`
+__global__ __launch_bounds__(GR_BLOCK) void scan_local_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                              uint32_t n, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t wsum[GR_BLOCK / 64];
+    const uint32_t base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+    uint32_t v[SC_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) { v[k] = (base + k < n) ? in[base + k] : 0u; s += v[k]; }
+    // inclusive scan of the per-thread sums across the wave, then across waves
+    uint32_t inc = s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += wsum[w];
+    uint32_t run = woff + inc - s;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == GR_BLOCK - 1) totals[blockIdx.x] = run;
+}
+
+// exclusive scan of up to GR_BLOCK * 64 block totals in one workgroup (in place)
+__global__ __launch_bounds__(GR_BLOCK) void scan_totals_kernel(uint32_t* __restrict__ totals, uint32_t nb, uint32_t* __restrict__ grand)
+{
+    __shared__ uint32_t wsum[GR_BLOCK / 64];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < nb; base += GR_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? totals[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = carry;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        if (i < nb) totals[i] = woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == GR_BLOCK - 1) carry = woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *grand = carry;
+}
+
+__global__ __launch_bounds__(GR_BLOCK) void scan_add_kernel(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ totals)
+{
+    const uint32_t off = totals[blockIdx.x];
+    const uint32_t base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++)
+        if (base + k < n) out[base + k] += off;
+}
+
+// records[cell_start[c] + cursor[c]++] = {x, y, z, index}
+__global__ __launch_bounds__(GR_BLOCK) void scatter_records_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                   const float* __restrict__ z, uint32_t n,
+                                                                   const uint32_t* __restrict__ cell_of,
+                                                                   const uint32_t* __restrict__ cell_start,
+                                                                   uint32_t* __restrict__ cursor, float4* __restrict__ records)
+{
+    const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cell_of[i];
+    const uint32_t pos = cell_start[c] + atomicAdd(&cursor[c], 1u);
+    records[pos] = make_float4(x[i], y[i], z[i], __uint_as_float(i));
+}
+
+// perm[cell_start[c] + cursor[c]++] = i   (queries grouped by cell)
+__global__ __launch_bounds__(GR_BLOCK) void scatter_perm_kernel(uint32_t n, const uint32_t* __restrict__ cell_of,
+                                                                const uint32_t* __restrict__ cell_start,
+                                                                uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm)
+{
+    const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cell_of[i];
+    perm[cell_start[c] + atomicAdd(&cursor[c], 1u)] = i;
+}
+
+// ---------------------------------------------------------------------------------------- query
+constexpr unsigned long long KEY_NONE = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;   // (FLT_MAX, no index)
+
+// candidates [b, e) of one x-row, strided over the G lanes of the query's sub-group: 16 B per lane, G*16 B contiguous
+template <int G>
+__device__ __forceinline__ void scan_range(const float4* __restrict__ records, uint32_t b, uint32_t e, int l,
+                                           float qx, float qy, float qz, unsigned long long& best)
+{
+    for (uint32_t p = b + l; p < e; p += G) {
+        const float4 rec = records[p];
+        const float dx = qx - rec.x, dy = qy - rec.y, dz = qz - rec.z;
+        const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);   // A1, unfused
+        const unsigned long long k = ((unsigned long long)d << 32) | __float_as_uint(rec.w);
+        // accept only d2 < FLT_MAX (nanoflann.hpp:163,1360); min over (d2 bits, original index) = canonical rule
+        if (d < 0x7F7FFFFFu && k < best) best = k;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ unsigned long long group_min(unsigned long long v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+// G lanes cooperate on one query (G divides 64).  Stage 1 scans the 3 x 3 x-rows of the radius-1 cube with all
+// row bounds fetched up front (18 independent loads in flight); later stages double the radius.
+template <int G>
+__global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
+    const float4* __restrict__ records, const uint32_t* __restrict__ cell_start, GridParams g,
+    const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+    const uint32_t* __restrict__ perm, uint32_t ns, unsigned long long* __restrict__ keys, const int* __restrict__ stop)
+{
+    if (stop && (stop[0] | stop[1])) return;      // pipelined ICP: the loop has ended, the enqueued tail is a no-op
+    const uint32_t gt = blockIdx.x * GR_BLOCK + threadIdx.x;
+    const uint32_t t = min(gt / G, ns - 1);          // clamp: surplus sub-groups redo the last query (same value written)
+    const int l = (int)(threadIdx.x % G);
+    const uint32_t i = perm ? perm[t] : t;
+    const float qx = sx[i], qy = sy[i], qz = sz[i];
+    unsigned long long best = KEY_NONE;
+    if (finite3(qx, qy, qz)) {
+        const int ux = cell_coord(qx, g.lo[0], g.inv_h), uy = cell_coord(qy, g.lo[1], g.inv_h), uz = cell_coord(qz, g.lo[2], g.inv_h);
+        // Chebyshev distance (in cells) from the query's cell to the grid box: smaller cubes hold no cell
+        const int r0 = max(max(max(-ux, ux - (g.n[0] - 1)), max(-uy, uy - (g.n[1] - 1))), max(max(-uz, uz - (g.n[2] - 1)), 0));
+        int r = max(r0, 1);
+        bool done = false;
+        if (r == 1) {
+            // ---- stage 1: static 3 x 3 rows, bounds first
+            const int xlo = max(ux - 1, 0), xhi = min(ux + 1, g.n[0] - 1);
+            uint32_t rb[9], re[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int cy = uy + (k % 3) - 1, cz = uz + (k / 3) - 1;
+                const bool ok = (cy >= 0) && (cy < g.n[1]) && (cz >= 0) && (cz < g.n[2]) && (xlo <= xhi);
+                const uint32_t row = ok ? (uint32_t)((cz * g.n[1] + cy) * g.n[0]) : 0u;
+                rb[k] = ok ? cell_start[row + xlo] : 0u;
+                re[k] = ok ? cell_start[row + xhi + 1] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) scan_range<G>(records, rb[k], re[k], l, qx, qy, qz, best);
+            best = group_min<G>(best);
+            const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
+                                (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
+            const float reach = (1.0f - g.slack) * g.h;
+            done = covers || (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f);
+            r = 2;
+        }
+        // ---- later stages.  rp = radius of the cube already scanned (0: none).  The next radius is the smallest one
+        // that can PROVE the current best (best < LB(r)), or 2 * r when nothing was found yet.  Inside the new cube,
+        // cells of the old cube are skipped, and so are cells that lie farther from the query than the current best
+        // (ball clipping, conservative by one cell + slack; such cells cannot hold a better or equal candidate).
+        // |u| <= 2^22 and every grid dimension is <= 4002, so a cube of radius 2^23 covers the grid from any query:
+        // the radius at least doubles whenever nothing is proven, so `covers` holds after <= 24 steps; the step bound
+        // makes termination unconditional.
+        int rp = (r == 2) ? 1 : 0;
+        for (int step = 0; step < 28 && !done; step++) {
+            const bool have = best != KEY_NONE;
+            const float bestf = __uint_as_float((uint32_t)(best >> 32));
+            if (have) {
+                // smallest r with ((r - slack) h)^2 * 0.99999 > best
+                const int need = (int)(sqrtf(bestf * 1.00002f) * g.inv_h + g.slack) + 1;
+                r = max(min(need, 1 << 24), rp + 1);
+            }
+            const int xlo = max(ux - r, 0), xhi = min(ux + r, g.n[0] - 1);
+            const int ylo = max(uy - r, 0), yhi = min(uy + r, g.n[1] - 1);
+            const int zlo = max(uz - r, 0), zhi = min(uz + r, g.n[2] - 1);
+            const float clip2 = bestf * 1.0001f;
+            if (xlo <= xhi && ylo <= yhi && zlo <= zhi) {
+                // far searches walk many sparse rows: one ROW per lane (G independent dependent-load chains in flight
+                // per query instead of one), each lane scanning its row's candidates serially
+                const int ny_rows = yhi - ylo + 1;
+                const int n_rows = ny_rows * (zhi - zlo + 1);
+                for (int k = l; k < n_rows; k += G) {
+                    const int cy = ylo + k % ny_rows, cz = zlo + k / ny_rows;
+                    const int ady = abs(cy - uy), adz = abs(cz - uz);
+                    int xa = xlo, xb = xhi;
+                    if (have) {
+                        const float fy = fmaxf((float)ady - 1.0f - g.slack, 0.0f) * g.h;
+                        const float fz = fmaxf((float)adz - 1.0f - g.slack, 0.0f) * g.h;
+                        const float rem2 = clip2 - (fy * fy + fz * fz);
+                        if (rem2 < 0.0f) continue;                       // the whole row is outside the ball
+                        const int wx = (int)(sqrtf(rem2) * g.inv_h + g.slack) + 2;
+                        xa = max(xa, ux - wx);
+                        xb = min(xb, ux + wx);
+                    }
+                    if (xa > xb) continue;
+                    const uint32_t row = (uint32_t)((cz * g.n[1] + cy) * g.n[0]);
+                    if (ady <= rp && adz <= rp) {
+                        // this row crossed the old cube: only the two end pieces are new
+                        const int la = xa, lb = min(xb, ux - rp - 1);
+                        const int ra = max(xa, ux + rp + 1), rb2 = xb;
+                        if (la <= lb) scan_range<1>(records, cell_start[row + la], cell_start[row + lb + 1], 0, qx, qy, qz, best);
+                        if (ra <= rb2) scan_range<1>(records, cell_start[row + ra], cell_start[row + rb2 + 1], 0, qx, qy, qz, best);
+                    } else {
+                        scan_range<1>(records, cell_start[row + xa], cell_start[row + xb + 1], 0, qx, qy, qz, best);
+                    }
+                }
+            }
+            best = group_min<G>(best);
+            const bool covers = (ux - r <= 0) && (ux + r >= g.n[0] - 1) && (uy - r <= 0) && (uy + r >= g.n[1] - 1) &&
+                                (uz - r <= 0) && (uz + r >= g.n[2] - 1);
+            // every target outside the cube is farther than (r - slack) * h in some axis
+            const float reach = ((float)r - g.slack) * g.h;
+            done = covers || (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f);
+            rp = r;
+            r = min(r * 2, 1 << 24);
+        }
+    }
+    if (l == 0 && gt / G < ns) {
+        const uint32_t bidx = (uint32_t)(best & 0xFFFFFFFFull);
+        const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : (uint32_t)(best >> 32);
+        keys[i] = ((unsigned long long)bits << 32) | bidx;
+    }
+}
+
+__global__ __launch_bounds__(GR_BLOCK) void count_nonzero_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ out)
+{
+    uint32_t c = 0;
+    for (uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x; i < n; i += gridDim.x * GR_BLOCK) c += count[i] != 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// ---------------------------------------------------------------------------------------- host side
+static int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* totals, uint32_t* grand)
+{
+    const uint32_t nb = (uint32_t)((n + SC_TILE - 1) / SC_TILE);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(GR_BLOCK), 0, ctx->stream, in, out, (uint32_t)n, totals);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(GR_BLOCK), 0, ctx->stream, totals, nb, grand);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(GR_BLOCK), 0, ctx->stream, out, (uint32_t)n, totals);
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+void grid_free(Grid* g)
+{
+    if (!g) return;
+    if (g->records) hipFree(g->records);
+    if (g->cell_start) hipFree(g->cell_start);
+    delete g;
+}
+
+// scratch layout for builds / query sorting: [cell_of n][count cells+1][totals nb+1]
+static int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out)
+{
+    *out = nullptr;
+    const size_t n = c->n;
+    Grid* g = new (std::nothrow) Grid();
+    if (!g) return fail(ctx, PCR_ERR_NOMEM, "grid");
+    g->n_points = n;
+    // 1. bounding box of the finite points
+    const uint32_t bb_blocks = (uint32_t)std::min<size_t>(256, (n + GR_BLOCK - 1) / GR_BLOCK ? (n + GR_BLOCK - 1) / GR_BLOCK : 1);
+    int rc = ensure_scratch(ctx, bb_blocks * 6 * sizeof(float));
+    if (rc) { delete g; return rc; }
+    float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+    if (n) {
+        hipLaunchKernelGGL(bbox_kernel, dim3(bb_blocks), dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)n, (float*)ctx->scratch);
+        std::vector<float> hb(bb_blocks * 6);
+        hipError_t e = hipMemcpyAsync(hb.data(), ctx->scratch, hb.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { delete g; return fail(ctx, PCR_ERR_HIP, "bbox", e); }
+        for (int k = 0; k < 3; k++) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; }
+        for (uint32_t b = 0; b < bb_blocks; b++)
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], hb[b * 6 + k]); hi[k] = std::max(hi[k], hb[b * 6 + 3 + k]); }
+        if (lo[0] > hi[0]) { for (int k = 0; k < 3; k++) lo[k] = hi[k] = 0.f; }   // no finite point at all
+    }
+    // 2. cell size.  First guess ~ 4 n cells in the bounding volume; LiDAR clouds are surfaces, so most of those
+    //    cells are empty and the occupied ones are crowded: measure the occupancy and shrink h once so that an
+    //    occupied cell holds ~ grid_occupancy_x10 / 10 points (points per occupied cell ~ h^2 on surfaces).
+    double ext[3], vol = 1.0;
+    for (int k = 0; k < 3; k++) { ext[k] = std::max((double)hi[k] - (double)lo[k], 1e-6); vol *= ext[k]; }
+    const double hmin = std::max(std::max(ext[0], ext[1]), ext[2]) / 4000.0;   // <= 4001 cells per axis
+    double max_cells = (double)tune_get(ctx, "grid_max_cells", 0);
+    if (max_cells <= 0) max_cells = std::min(std::max(64.0 * (double)n, (double)(1 << 22)), (double)(1 << 28));
+    auto fit = [&](double h) {
+        h = std::max(h, hmin);
+        for (;;) {
+            double cells = 1.0;
+            for (int k = 0; k < 3; k++) cells *= std::floor(ext[k] / h) + 2.0;
+            if (cells <= max_cells) return h;
+            h *= 1.1;
+        }
+    };
+    auto set_params = [&](double h) {
+        g->p.h = (float)h;
+        g->p.inv_h = 1.0f / g->p.h;
+        size_t cells = 1;
+        for (int k = 0; k < 3; k++) {
+            g->p.lo[k] = lo[k];
+            g->p.n[k] = (int)std::floor(((double)hi[k] - (double)lo[k]) * (double)g->p.inv_h) + 2;   // +1 covers rounding at the top face
+            cells *= (size_t)g->p.n[k];
+        }
+        g->p.slack = 0.01f + 2e-6f * (float)std::max(std::max(g->p.n[0], g->p.n[1]), g->p.n[2]);
+        g->n_cells = cells;
+    };
+    const int64_t user_um = tune_get(ctx, "grid_cell_um", 0);
+    double h = fit(user_um > 0 ? (double)user_um * 1e-6 : std::cbrt(vol / (4.0 * (double)std::max<size_t>(n, 1))));
+    set_params(h);
+    if (user_um <= 0 && n >= 1024) {
+        const size_t cells0 = g->n_cells;
+        const size_t off_count0 = ((n * 4 + 255) & ~(size_t)255);
+        rc = ensure_scratch(ctx, off_count0 + (cells0 + 1) * 4 + 512);
+        if (rc) { delete g; return rc; }
+        uint32_t* cell_of0 = (uint32_t*)ctx->scratch;
+        uint32_t* count0 = (uint32_t*)((char*)ctx->scratch + off_count0);
+        uint32_t* nz = count0 + cells0 + 1;
+        hipError_t e0 = hipMemsetAsync(count0, 0, (cells0 + 2) * 4, ctx->stream);
+        if (e0 != hipSuccess) { delete g; return fail(ctx, PCR_ERR_HIP, "memset(grid)", e0); }
+        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream,
+                           c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of0, count0);
+        hipLaunchKernelGGL(count_nonzero_kernel, dim3(256), dim3(GR_BLOCK), 0, ctx->stream, count0, (uint32_t)cells0, nz);
+        uint32_t occupied = 0;
+        e0 = hipMemcpyAsync(&occupied, nz, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(ctx->stream);
+        if (e0 != hipSuccess) { delete g; return fail(ctx, PCR_ERR_HIP, "grid occupancy", e0); }
+        const double occ = (double)n / (double)std::max<uint32_t>(occupied, 1);
+        const double want = (double)tune_get(ctx, "grid_occupancy_x10", 20) / 10.0;
+        if (occ > 1.5 * want) {
+            h = fit(h * std::sqrt(want / occ));
+            set_params(h);
+        }
+    }
+    const size_t cells = g->n_cells;
+    // 3. counting sort
+    const size_t nb = (cells + 1 + SC_TILE - 1) / SC_TILE;
+    const size_t off_count = ((n * 4 + 255) & ~(size_t)255);
+    const size_t off_tot = off_count + (((cells + 1) * 4 + 255) & ~(size_t)255);
+    rc = ensure_scratch(ctx, off_tot + (nb + 2) * 4 + 256);
+    if (rc) { delete g; return rc; }
+    uint32_t* cell_of = (uint32_t*)ctx->scratch;
+    uint32_t* count = (uint32_t*)((char*)ctx->scratch + off_count);
+    uint32_t* totals = (uint32_t*)((char*)ctx->scratch + off_tot);
+    hipError_t e = hipMalloc((void**)&g->cell_start, (cells + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->records, std::max<size_t>(n, 1) * sizeof(float4));
+    if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "hipMalloc(grid)", e); }
+    e = hipMemsetAsync(count, 0, (cells + 1) * 4, ctx->stream);
+    if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "memset(grid)", e); }
+    if (n) {
+        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream,
+                           c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of, count);
+    }
+    rc = exclusive_scan_u32(ctx, count, g->cell_start, cells + 1, totals, totals + nb);
+    if (rc) { grid_free(g); return rc; }
+    e = hipMemsetAsync(count, 0, (cells + 1) * 4, ctx->stream);   // reuse as the scatter cursor
+    if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "memset(grid)", e); }
+    if (n) {
+        hipLaunchKernelGGL(scatter_records_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream,
+                           c->x(), c->y(), c->z(), (uint32_t)n, cell_of, g->cell_start, count, g->records);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the scratch is reused by the caller right away
+    if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "grid build", e); }
+    *out = g;
+    return PCR_OK;
+}
+
+// group the queries by a COARSE cell of the target grid (>= 4 x 4 x 4 fine cells, at most 128 K bins): enough to make the
+// queries of a wave neighbours in space, with a histogram that stays small.  perm[] goes to ctx->qperm.
+static int sort_queries(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
+{
+    GridParams cp = g->p;
+    int f = 4;
+    for (;;) {
+        size_t cells = 1;
+        for (int k = 0; k < 3; k++) cells *= (size_t)((g->p.n[k] + f - 1) / f + 1);
+        if (cells <= ((size_t)1 << 17) || f >= 4096) break;
+        f *= 2;
+    }
+    cp.h = g->p.h * (float)f;
+    cp.inv_h = 1.0f / cp.h;
+    size_t cells = 1;
+    for (int k = 0; k < 3; k++) { cp.n[k] = (g->p.n[k] + f - 1) / f + 1; cells *= (size_t)cp.n[k]; }
+    const size_t n = src->n;
+    const size_t nb = (cells + 1 + SC_TILE - 1) / SC_TILE;
+    const size_t off_count = ((n * 4 + 255) & ~(size_t)255);
+    const size_t off_start = off_count + (((cells + 1) * 4 + 255) & ~(size_t)255);
+    const size_t off_tot = off_start + (((cells + 1) * 4 + 255) & ~(size_t)255);
+    int rc = ensure_scratch(ctx, off_tot + (nb + 2) * 4 + 256);
+    if (rc) return rc;
+    if (ctx->qperm_cap < n) {
+        if (ctx->qperm) PCR_HIP(ctx, hipFree(ctx->qperm));
+        ctx->qperm = nullptr; ctx->qperm_cap = 0;
+        PCR_HIP(ctx, hipMalloc((void**)&ctx->qperm, padded(n) * sizeof(uint32_t)));
+        ctx->qperm_cap = padded(n);
+    }
+    uint32_t* cell_of = (uint32_t*)ctx->scratch;
+    uint32_t* count = (uint32_t*)((char*)ctx->scratch + off_count);
+    uint32_t* start = (uint32_t*)((char*)ctx->scratch + off_start);
+    uint32_t* totals = (uint32_t*)((char*)ctx->scratch + off_tot);
+    PCR_HIP(ctx, hipMemsetAsync(count, 0, (cells + 1) * 4, ctx->stream));
+    const dim3 gridn((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK));
+    hipLaunchKernelGGL(cell_count_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), (uint32_t)n, cp, cell_of, count);
+    rc = exclusive_scan_u32(ctx, count, start, cells + 1, totals, totals + nb);
+    if (rc) return rc;
+    PCR_HIP(ctx, hipMemsetAsync(count, 0, (cells + 1) * 4, ctx->stream));
+    hipLaunchKernelGGL(scatter_perm_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, (uint32_t)n, cell_of, start, count, ctx->qperm);
+    PCR_HIP(ctx, hipGetLastError());
+    ctx->qperm_n = n;
+    ctx->qperm_src = src;
+    return PCR_OK;
+}
+
+int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
+{
+    if (!tgt->grid) {
+        Grid* g = nullptr;
+        ProfScope p(ctx, "grid_build");
+        int rc = grid_build(ctx, tgt, &g);
+        if (rc) return rc;
+        const_cast<pcr_cloud*>(tgt)->grid = g;
+    }
+    if (src->n == 0) return PCR_OK;
+    ProfScope p(ctx, "grid_sort_queries");
+    return sort_queries(ctx, tgt->grid, src);
+}
+
+int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm)
+{
+    const size_t ns = src->n;
+    if (ns == 0) { ctx->keys_n = 0; return PCR_OK; }
+    if (ns > 0xFFFFFFF0ull || tgt->n > 0xFFFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "cloud too large for u32 indices");
+    int rc = ensure_keys(ctx, ns);
+    if (rc) return rc;
+    ctx->keys_n = ns;
+    const bool have_perm = reuse_perm && tgt->grid && ctx->qperm && ctx->qperm_n == ns && ctx->qperm_src == src;
+    if (!have_perm) {
+        rc = grid_prepare_queries(ctx, tgt, src);
+        if (rc) return rc;
+    }
+    const Grid* g = tgt->grid;
+    const uint32_t* perm = tune_get(ctx, "grid_sort_queries", 1) > 0 ? ctx->qperm : nullptr;
+    const int G = (int)tune_get(ctx, "grid_lanes", 16);   // measured: profiles/r01_tune_grid.txt
+    {
+        ProfScope p(ctx, "nn1_grid", 1);
+#define PCR_GRID(GG)                                                                                                   \
+    hipLaunchKernelGGL(nn1_grid_kernel<GG>, dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0,  \
+                       ctx->stream, g->records, g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev)
+        switch (G) {
+        case 1: PCR_GRID(1); break;
+        case 2: PCR_GRID(2); break;
+        case 4: PCR_GRID(4); break;
+        case 8: PCR_GRID(8); break;
+        case 32: PCR_GRID(32); break;
+        case 64: PCR_GRID(64); break;
+        default: PCR_GRID(16); break;
+        }
+#undef PCR_GRID
+    }
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+}  // namespace pcr

@@ -11,11 +11,11 @@
 
 using namespace pcr;
 
-extern "C" int pcr_icp_p2p_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, const float init_T[16],
-                               const pcr_icp_params* prm, float out_T[16], pcr_icp_stats* stats)
+// ---- synchronous loop: one host round trip per iteration (needed by the host-callback transport; also the
+// reference implementation of the loop the pipelined variant below must reproduce bit for bit)
+static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, const float init_T[16],
+                    const pcr_icp_params* prm, float out_T[16], pcr_icp_stats* stats)
 {
-    if (!ctx || !src || !tgt || !init_T || !prm || !out_T) return fail(ctx, PCR_ERR_ARG, "pcr_icp_p2p_f32");
-    PCR_HIP(ctx, hipSetDevice(ctx->device));
     const auto t_begin = std::chrono::steady_clock::now();
     pcr_icp_stats st;
     memset(&st, 0, sizeof st);
@@ -23,8 +23,8 @@ extern "C" int pcr_icp_p2p_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr_clo
     // prof bookkeeping: report only this call's nn1 time
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_flush(ctx);
-    const uint64_t nn_l0 = ctx->prof["nn1_brute"].launches;
-    const double nn_ms0 = ctx->prof["nn1_brute"].total_ms;
+    const uint64_t nn_l0 = ctx->prof["nn1_brute"].launches + ctx->prof["nn1_grid"].launches;
+    const double nn_ms0 = ctx->prof["nn1_brute"].total_ms + ctx->prof["nn1_grid"].total_ms;
 
     pcr_cloud* work = nullptr;
     int rc = pcr_cloud_clone(ctx, src, &work);                                   // :872
@@ -41,7 +41,7 @@ extern "C" int pcr_icp_p2p_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr_clo
     if (nred > 64) { pcr_cloud_destroy(ctx, work); return fail(ctx, PCR_ERR_ARG, "too many ranks"); }
 
     for (uint64_t iter = 0; rc == PCR_OK && iter < prm->max_iter; iter++) {      // :917
-        if ((rc = launch_nn1_brute(ctx, tgt, work))) break;                      // :925-934
+        if ((rc = launch_nn1(ctx, tgt, work, true))) break;                      // :925-934
         double* h = ctx->host_out;
         if (work->n) {
             if ((rc = launch_kabsch_sums(ctx, tgt, work, prm->max_corr))) break; // :936-940,:964-985
@@ -84,9 +84,122 @@ extern "C" int pcr_icp_p2p_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr_clo
     if (rc) return rc;
     memcpy(out_T, T_total, sizeof T_total);                                      // :1008-1009
     prof_flush(ctx);
-    st.nn_launches = ctx->prof["nn1_brute"].launches - nn_l0;
-    st.ms_nn = ctx->prof["nn1_brute"].total_ms - nn_ms0;
+    st.nn_launches = ctx->prof["nn1_brute"].launches + ctx->prof["nn1_grid"].launches - nn_l0;
+    st.ms_nn = ctx->prof["nn1_brute"].total_ms + ctx->prof["nn1_grid"].total_ms - nn_ms0;
     st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (stats) *stats = st;
     return PCR_OK;
+}
+
+// ---- pipelined loop: the state machine, the Kabsch solve and the pose composition live on the GPU (IcpState,
+// kabsch.hip); iterations are enqueued back to back on the context stream in chunks, the host only looks at a copy
+// of the state two chunks behind to learn when to stop enqueuing.  With RCCL the per-iteration all-reduce is
+// enqueued on the same stream, so even the sharded loop needs no host round trip.
+static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, const float init_T[16],
+                         const pcr_icp_params* prm, float out_T[16], pcr_icp_stats* stats)
+{
+    const auto t_begin = std::chrono::steady_clock::now();
+    pcr_icp_stats st;
+    memset(&st, 0, sizeof st);
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_flush(ctx);
+    const uint64_t nn_l0 = ctx->prof["nn1_brute"].launches + ctx->prof["nn1_grid"].launches;
+    const double nn_ms0 = ctx->prof["nn1_brute"].total_ms + ctx->prof["nn1_grid"].total_ms;
+
+    constexpr int RING = 4;
+    if (!ctx->icp_state_dev) {
+        PCR_HIP(ctx, hipMalloc((void**)&ctx->icp_state_dev, sizeof(IcpState)));
+        PCR_HIP(ctx, hipHostMalloc((void**)&ctx->icp_state_host, (RING + 1) * sizeof(IcpState), hipHostMallocDefault));
+        for (int k = 0; k < RING; k++) PCR_HIP(ctx, hipEventCreateWithFlags(&ctx->icp_events[k], hipEventDisableTiming));
+    }
+    IcpState* dev = ctx->icp_state_dev;
+    IcpState* host = ctx->icp_state_host;      // [0..RING) ring of snapshots, [RING] upload / final download
+
+    pcr_cloud* work = nullptr;
+    int rc = pcr_cloud_clone(ctx, src, &work);                                   // :872
+    if (rc) return rc;
+    const float R0[9] = { init_T[0], init_T[1], init_T[2], init_T[4], init_T[5], init_T[6], init_T[8], init_T[9], init_T[10] };
+    const float t0[3] = { init_T[3], init_T[7], init_T[11] };
+    rc = launch_transform(ctx, work, R0, t0);                                    // :874
+    IcpState& h0 = host[RING];
+    memset(&h0, 0, sizeof h0);
+    const float T0[16] = { R0[0], R0[1], R0[2], t0[0], R0[3], R0[4], R0[5], t0[1], R0[6], R0[7], R0[8], t0[2], 0, 0, 0, 1 };
+    memcpy(h0.T_total, T0, sizeof T0);                                           // :910-913
+    h0.eps = prm->eps;
+    h0.max_iter = prm->max_iter;
+    if (prm->max_iter == 0) h0.stop = 1;
+    hipError_t e = hipMemcpyAsync(dev, &h0, sizeof h0, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) rc = fail(ctx, PCR_ERR_HIP, "icp state upload", e);
+
+    const int nranks = ctx->comm.nranks, rank = ctx->comm.rank;
+    const int nred = 16 + 2 * nranks;
+    int64_t chunk = tune_get(ctx, "icp_chunk", 4);
+    if (chunk < 1) chunk = 1;
+    uint64_t enq = 0, chunks = 0;
+    bool stopped = false;
+    while (rc == PCR_OK && !stopped && enq < prm->max_iter) {
+        for (int64_t c = 0; rc == PCR_OK && c < chunk && enq < prm->max_iter; c++, enq++) {   // :917
+            ctx->stop_flag_dev = &dev->stop;     // correspondence kernels no-op once stop or stop_after_transform is set
+            if ((rc = launch_nn1(ctx, tgt, work, true))) break;                             // :925-934
+            uint32_t blocks = 0;
+            if (work->n && (rc = launch_kabsch_partial(ctx, tgt, work, prm->max_corr, &blocks))) break;   // :936-940,:964-985
+            if (nranks == 1 && work->n && tune_get(ctx, "icp_force_slots", 0) <= 0) {
+                if ((rc = launch_icp_update(ctx, blocks, dev))) break;                      // :948-1002
+            } else {
+                if ((rc = launch_icp_reduce_slots(ctx, blocks, nranks, rank, work->n != 0))) break;
+                if ((rc = comm_allreduce_f64_device(ctx, ctx->dev_out, nred))) break;       // the ONE collective
+                if ((rc = launch_icp_update_from_sums(ctx, nranks, dev))) break;
+            }
+            if ((rc = launch_transform_state(ctx, work, dev))) break;                       // :1003
+        }
+        ctx->stop_flag_dev = nullptr;
+        if (rc) break;
+        const int slot = (int)(chunks % RING);
+        e = hipMemcpyAsync(&host[slot], dev, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->icp_events[slot], ctx->stream);
+        if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "icp snapshot", e); break; }
+        chunks++;
+        if (chunks >= 2) {
+            // look two chunks back: deterministic (the same on every rank), and the GPU never runs dry
+            const int old = (int)((chunks - 2) % RING);
+            e = hipEventSynchronize(ctx->icp_events[old]);
+            if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "icp snapshot wait", e); break; }
+            if (host[old].stop || host[old].stop_after_transform) stopped = true;
+        }
+    }
+    ctx->stop_flag_dev = nullptr;
+    if (rc == PCR_OK) {
+        e = hipMemcpyAsync(&host[RING], dev, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, PCR_ERR_HIP, "icp state download", e);
+    } else {
+        hipStreamSynchronize(ctx->stream);
+    }
+    pcr_cloud_destroy(ctx, work);
+    if (rc) return rc;
+    const IcpState& f = host[RING];
+    memcpy(out_T, f.T_total, sizeof f.T_total);                                  // :1008-1009
+    st.iters_run = f.iters_run;
+    st.converged = f.converged;
+    st.empty_pairs = f.empty;
+    st.last_pairs = f.last_pairs;
+    st.last_loss = f.loss;
+    prof_flush(ctx);
+    st.nn_launches = ctx->prof["nn1_brute"].launches + ctx->prof["nn1_grid"].launches - nn_l0;
+    st.ms_nn = ctx->prof["nn1_brute"].total_ms + ctx->prof["nn1_grid"].total_ms - nn_ms0;
+    st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (stats) *stats = st;
+    return PCR_OK;
+}
+
+extern "C" int pcr_icp_p2p_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, const float init_T[16],
+                               const pcr_icp_params* prm, float out_T[16], pcr_icp_stats* stats)
+{
+    if (!ctx || !src || !tgt || !init_T || !prm || !out_T) return fail(ctx, PCR_ERR_ARG, "pcr_icp_p2p_f32");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    // tune "icp_pipeline": 0 / 1 = device-resident pipelined loop (default), -1 = synchronous loop.
+    // The host-callback transport reduces on the host and therefore always runs synchronously.
+    const bool callback = ctx->comm.nranks > 1 && ctx->comm.cb != nullptr;
+    if (callback || tune_get(ctx, "icp_pipeline", 1) < 0) return icp_sync(ctx, src, tgt, init_T, prm, out_T, stats);
+    return icp_pipelined(ctx, src, tgt, init_T, prm, out_T, stats);
 }

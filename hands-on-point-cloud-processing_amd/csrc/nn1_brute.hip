@@ -126,12 +126,13 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_track_kernel(
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
     const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     uint32_t ns, uint32_t n_tiles, uint32_t tiles_per_slice,
-    unsigned long long* __restrict__ keys, int merge_atomic)
+    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop)
 {
     __shared__ float4 lx[SGPR ? 1 : NN_TILE / 4];
     __shared__ float4 ly[SGPR ? 1 : NN_TILE / 4];
     __shared__ float4 lz[SGPR ? 1 : NN_TILE / 4];
 
+    if (stop && (stop[0] | stop[1])) return;      // pipelined ICP: the loop has ended, the enqueued tail is a no-op
     const uint32_t tid = threadIdx.x;
     const uint32_t qbase = blockIdx.x * (NN_BLOCK * QPL);
     TrackLane<QPL, CH> L;
@@ -215,12 +216,13 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_brute_kernel(
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
     const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     uint32_t ns, uint32_t n_tiles, uint32_t tiles_per_slice,
-    unsigned long long* __restrict__ keys, int merge_atomic)
+    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop)
 {
     __shared__ float4 lx[SGPR ? 1 : NN_TILE / 4];
     __shared__ float4 ly[SGPR ? 1 : NN_TILE / 4];
     __shared__ float4 lz[SGPR ? 1 : NN_TILE / 4];
 
+    if (stop && (stop[0] | stop[1])) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t qbase = blockIdx.x * (NN_BLOCK * QPL);
 
@@ -305,7 +307,7 @@ static void launch_variant(pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt, const 
                            uint32_t n_tiles, uint32_t tps, int merge_atomic)
 {
     hipLaunchKernelGGL((nn1_brute_kernel<QPL, FILTER, SGPR>), grid, dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(),
-                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic);
+                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic, ctx->stop_flag_dev);
 }
 
 template <int CH, bool SGPR>
@@ -314,7 +316,7 @@ static void launch_track(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt,
 {
 #define PCR_TRACK(Q)                                                                                               \
     hipLaunchKernelGGL((nn1_track_kernel<Q, CH, SGPR>), grid, dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(),    \
-                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic)
+                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic, ctx->stop_flag_dev)
     switch (qpl) {
     case 1: PCR_TRACK(1); break;
     case 4: PCR_TRACK(4); break;
@@ -368,7 +370,7 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
 
     dim3 grid(qblocks, slices);
     {
-        ProfScope p(ctx, "nn1_brute");
+        ProfScope p(ctx, "nn1_brute", 1);
         switch (variant) {
         case 4: launch_qpl<false, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
         case 5: launch_qpl<true, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;

@@ -1,145 +1,16 @@
-// numerics.cpp — host-side 3x3 numerics of the Kabsch step (A7 solve) and pose composition, f64/f32.
-// Follows Homework9/hw9/src/registration.cpp:979-1002; Eigen's JacobiSVD<Matrix3f> is replaced by an f64
-// one-sided Jacobi SVD with singular values sorted descending (the order Eigen delivers, which matters for
-// the reference's det<0 branch, :990-996).
+// numerics.cpp — host entry points of the shared 3x3 numerics (numerics.hpp).
 #include "pcr_internal.hpp"
-
-#include <cfloat>
-#include <cmath>
+#include "numerics.hpp"
 
 namespace pcr {
 
-namespace {
-
-struct M3 {
-    double a[3][3];
-};
-
-inline double col_dot(const M3& m, int p, int q)
-{
-    return m.a[0][p] * m.a[0][q] + m.a[1][p] * m.a[1][q] + m.a[2][p] * m.a[2][q];
-}
-
-inline void rotate_cols(M3& m, int p, int q, double c, double s)
-{
-    for (int r = 0; r < 3; r++) {
-        const double mp = m.a[r][p], mq = m.a[r][q];
-        m.a[r][p] = c * mp - s * mq;
-        m.a[r][q] = s * mp + c * mq;
-    }
-}
-
-}  // namespace
-
-void svd3(const double A[9], double U[9], double S[3], double V[9])
-{
-    M3 W, R;
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) { W.a[r][c] = A[3 * r + c]; R.a[r][c] = r == c ? 1.0 : 0.0; }
-    static const int pairs[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
-    for (int sweep = 0; sweep < 60; sweep++) {
-        bool rotated = false;
-        for (const auto& pq : pairs) {
-            const int p = pq[0], q = pq[1];
-            const double alpha = col_dot(W, p, p), beta = col_dot(W, q, q), gamma = col_dot(W, p, q);
-            if (gamma == 0.0 || std::fabs(gamma) <= DBL_EPSILON * std::sqrt(alpha * beta)) continue;
-            const double zeta = (beta - alpha) / (2.0 * gamma);
-            const double tn = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-            const double c = 1.0 / std::sqrt(1.0 + tn * tn), s = c * tn;
-            rotate_cols(W, p, q, c, s);
-            rotate_cols(R, p, q, c, s);
-            rotated = true;
-        }
-        if (!rotated) break;
-    }
-    double sv[3];
-    int ord[3] = { 0, 1, 2 };
-    for (int c = 0; c < 3; c++) sv[c] = std::sqrt(col_dot(W, c, c));
-    for (int a = 0; a < 2; a++)
-        for (int b = a + 1; b < 3; b++)
-            if (sv[ord[b]] > sv[ord[a]]) { int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
-    const double smax = sv[ord[0]];
-    bool have[3] = { false, false, false };
-    for (int c = 0; c < 3; c++) {
-        const int o = ord[c];
-        S[c] = sv[o];
-        for (int r = 0; r < 3; r++) V[3 * r + c] = R.a[r][o];
-        if (sv[o] > 0.0 && sv[o] > smax * DBL_EPSILON * 8.0) {
-            for (int r = 0; r < 3; r++) U[3 * r + c] = W.a[r][o] / sv[o];
-            have[c] = true;
-        } else {
-            for (int r = 0; r < 3; r++) U[3 * r + c] = 0.0;
-        }
-    }
-    if (!have[0]) {   // A == 0
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++) U[3 * r + c] = r == c ? 1.0 : 0.0;
-        return;
-    }
-    if (!have[1]) {   // rank 1: any unit vector orthogonal to u0
-        const double u0[3] = { U[0], U[3], U[6] };
-        int k = 0;
-        if (std::fabs(u0[1]) < std::fabs(u0[k])) k = 1;
-        if (std::fabs(u0[2]) < std::fabs(u0[k])) k = 2;
-        double v[3] = { -u0[k] * u0[0], -u0[k] * u0[1], -u0[k] * u0[2] };
-        v[k] += 1.0;
-        const double nv = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        U[1] = v[0] / nv; U[4] = v[1] / nv; U[7] = v[2] / nv;
-    }
-    if (!have[2]) {   // u2 = u0 x u1
-        U[2] = U[3] * U[7] - U[6] * U[4];
-        U[5] = U[6] * U[1] - U[0] * U[7];
-        U[8] = U[0] * U[4] - U[3] * U[1];
-    }
-}
-
-static void mul3(const double A[9], const double B[9], double C[9])
-{
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++)
-            C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
-}
+void svd3(const double A[9], double U[9], double S[3], double V[9]) { num::svd3(A, U, S, V); }
 
 int kabsch_solve(const double sums[16], float R[9], float t[3])
 {
-    const double M = sums[15];
-    if (!(M > 0.0)) return PCR_ERR_EMPTY;
-    double pbar[3], qbar[3], H[9];
-    for (int c = 0; c < 3; c++) { pbar[c] = sums[c] / M; qbar[c] = sums[3 + c] / M; }        // :979-980
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) H[3 * r + c] = sums[6 + 3 * r + c] - M * qbar[r] * pbar[c];   // :982-985
-    double U[9], S[3], V[9], Vt[9], Ut[9], Rd[9];
-    svd3(H, U, S, V);
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) { Vt[3 * r + c] = V[3 * c + r]; Ut[3 * r + c] = U[3 * c + r]; }
-    mul3(U, Vt, Rd);                                                                            // :988
-    const double det = Rd[0] * (Rd[4] * Rd[8] - Rd[5] * Rd[7]) - Rd[1] * (Rd[3] * Rd[8] - Rd[5] * Rd[6])
-                     + Rd[2] * (Rd[3] * Rd[7] - Rd[4] * Rd[6]);
-    if (det < 0) {                                                                              // :990-996
-        double VB[9];
-        for (int r = 0; r < 3; r++) { VB[3 * r] = V[3 * r]; VB[3 * r + 1] = V[3 * r + 1]; VB[3 * r + 2] = V[3 * r + 2] * det; }
-        mul3(VB, Ut, Rd);   // V * B * U^T, as the reference writes it
-    }
-    for (int k = 0; k < 9; k++) R[k] = (float)Rd[k];
-    for (int r = 0; r < 3; r++) {                                                               // :998
-        const double Rp = ((double)R[3 * r] * pbar[0] + (double)R[3 * r + 1] * pbar[1]) + (double)R[3 * r + 2] * pbar[2];
-        t[r] = (float)(qbar[r] - Rp);
-    }
-    return PCR_OK;
+    return num::kabsch_solve(sums, R, t) == 0 ? PCR_OK : PCR_ERR_EMPTY;
 }
 
-void mat4_mul_f32(const float A[16], const float B[16], float out[16])
-{
-    float tmp[16];
-    for (int r = 0; r < 4; r++)
-        for (int c = 0; c < 4; c++) {
-            float acc = A[4 * r] * B[c];
-            acc = acc + A[4 * r + 1] * B[4 + c];
-            acc = acc + A[4 * r + 2] * B[8 + c];
-            acc = acc + A[4 * r + 3] * B[12 + c];
-            tmp[4 * r + c] = acc;
-        }
-    memcpy(out, tmp, sizeof tmp);
-}
+void mat4_mul_f32(const float A[16], const float B[16], float out[16]) { num::mat4_mul_f32(A, B, out); }
 
 }  // namespace pcr

@@ -26,6 +26,24 @@ struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+// device-resident state of the pipelined ICP loop (registration.cpp:910-1006); mirrored in pinned host memory
+struct IcpState {
+    float Rd[9];
+    float td[3];
+    float T_total[16];
+    float last_loss;
+    float loss;
+    float eps;
+    int converged;
+    int empty;
+    int stop;                    // set by the update kernel: later kernels of the stream become no-ops
+    int stop_after_transform;    // max_iter reached: stop once the last transform has been applied
+    unsigned long long unchanged;
+    unsigned long long iters_run;
+    unsigned long long max_iter;
+    unsigned long long last_pairs;
+};
+
 struct Comm {
     int nranks = 1;
     int rank = 0;
@@ -36,7 +54,10 @@ struct Comm {
 
 }  // namespace pcr
 
+namespace pcr { struct Grid; void grid_free(Grid*); }
+
 struct pcr_cloud {
+    pcr::Grid* grid = nullptr;   // exact-NN index over this cloud as a target; built lazily, dropped on modification
     size_t n = 0;
     size_t cap = 0;     // padded length of each of x, y, z
     float* base = nullptr;   // device; x = base, y = base + cap, z = base + 2*cap
@@ -54,6 +75,10 @@ struct pcr_ctx {
     unsigned long long* keys = nullptr;   // (d2_bits << 32 | idx) per query of the last nn1 pass
     size_t keys_cap = 0;
     size_t keys_n = 0;
+    uint32_t* qperm = nullptr;            // queries grouped by target-grid cell (grid NN)
+    size_t qperm_cap = 0;
+    size_t qperm_n = 0;
+    const pcr_cloud* qperm_src = nullptr;
     double* partials = nullptr;           // block partial sums of the Kabsch pass
     size_t partials_cap = 0;
     double* dev_out = nullptr;            // 32 doubles: reduced sums + bookkeeping
@@ -62,9 +87,13 @@ struct pcr_ctx {
     size_t scratch_cap = 0;
     void* host_stage = nullptr;           // pinned staging for uploads / downloads
     size_t host_stage_cap = 0;
+    pcr::IcpState* icp_state_dev = nullptr;    // pipelined ICP: device state, pinned snapshots, snapshot events
+    pcr::IcpState* icp_state_host = nullptr;
+    hipEvent_t icp_events[4] = { nullptr, nullptr, nullptr, nullptr };
+    const int* stop_flag_dev = nullptr;        // when set, the correspondence kernels exit early once *flag != 0
     pcr::Comm comm;
     std::map<std::string, pcr::ProfEntry> prof;
-    bool prof_on = true;
+    int prof_level = 1;                   // 0 off, 1 correspondence kernels only (default), 2 every kernel
     std::map<std::string, int64_t> tune;
 };
 
@@ -88,16 +117,26 @@ struct ProfScope {
     pcr_ctx* ctx;
     const char* name;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(pcr_ctx* c, const char* n);
+    ProfScope(pcr_ctx* c, const char* n, int level = 2);
     ~ProfScope();
 };
 void prof_flush(pcr_ctx* ctx);
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
+int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm);
+// dispatcher: tune "nn_method" 0 = auto (grid for targets >= 2048 points), 1 = brute force, 2 = grid
+int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm);
+void cloud_modified(pcr_cloud* c);
 int nn1_unpack(pcr_ctx* ctx, size_t n, uint32_t* idx_dev, float* d2_dev);
 int launch_transform(pcr_ctx* ctx, pcr_cloud* c, const float R[9], const float t[3]);
 int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr);
+int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr, uint32_t* n_blocks);
+int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev);
+int launch_icp_reduce_slots(pcr_ctx* ctx, uint32_t n_blocks, int nranks, int rank, bool have_points);
+int launch_icp_update_from_sums(pcr_ctx* ctx, int nranks, IcpState* st_dev);
+int launch_transform_state(pcr_ctx* ctx, pcr_cloud* c, IcpState* st_dev);
+int comm_allreduce_f64_device(pcr_ctx* ctx, double* dev_buf, int n);   // RCCL on the ctx stream, no host round trip
 int launch_plane_count(pcr_ctx* ctx, const pcr_cloud* pts, const double* planes4_dev, size_t n_planes,
                        double thr, unsigned long long* counts_dev);
 int launch_plane_mask(pcr_ctx* ctx, const pcr_cloud* pts, const double plane4[4], double thr,

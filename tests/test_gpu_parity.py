@@ -24,11 +24,14 @@ def ctx(pcr):
 
 
 # ------------------------------------------------------------------ 1-NN (A1/A3/A6) vs reference goldens
+@pytest.mark.parametrize("method", [1, 2])            # 1 = brute force, 2 = exact grid
 @pytest.mark.parametrize("case", ["synth1000", "synth4096", "kitti4096", "lattice1000"])
-def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case):
+def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
     g = golden(f"nn1_nanoflann_{case}.npz")
+    ctx.tune("nn_method", method)
     cs, ct = ctx.cloud(g["src"]), ctx.cloud(g["tgt"])
     idx, d2 = ctx.nn1(ct, cs)
+    ctx.tune("nn_method", 0)
     assert np.array_equal(bits32(d2), bits32(g["d2"]))            # distance bit-equal to nanoflann's
     ties = orc.nn1_tiecount_f32(g["tgt"], g["src"])
     single = ties == 1
@@ -45,6 +48,7 @@ VARIANTS = [(0, 8), (0, 16), (2, 8), (2, 16), (4, 8), (5, 8), (6, 8), (7, 8)]
 
 def set_variant(ctx, vc):
     v, ch = vc
+    ctx.tune("nn_method", 1)                  # brute force (auto would pick the grid for large targets)
     ctx.tune("nn1_variant", v if v else -8)   # -8 & 7 == 0 (0 itself means "library default")
     ctx.tune("nn1_chunk", ch)
 
@@ -65,6 +69,7 @@ def test_nn1_ragged_sizes_vs_oracle(ctx, orc, synth, qpl, ns, nt, variant):
     cs.free(); ct.free()
     ctx.tune("nn1_qpl", 0)
     ctx.tune("nn1_variant", 0)
+    ctx.tune("nn_method", 0)
 
 
 @pytest.mark.parametrize("tps", [1, 3, 1000])
@@ -72,9 +77,11 @@ def test_nn1_slice_merge_is_order_independent(ctx, orc, synth, tps):
     # 1 tile per slice -> many atomicMin merges; 1000 -> single slice, plain stores
     src, tgt = synth.kitti_like_pair(6000, seed_target=21, seed_pair=22)
     ctx.tune("nn1_tiles_per_slice", tps)
+    ctx.tune("nn_method", 1)
     cs, ct = ctx.cloud(src), ctx.cloud(tgt)
     idx, d2 = ctx.nn1(ct, cs)
     ctx.tune("nn1_tiles_per_slice", 0)
+    ctx.tune("nn_method", 0)
     oidx, od2 = orc.nn1_f32(tgt, src)
     assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
     cs.free(); ct.free()
@@ -92,6 +99,7 @@ def test_nn1_ties_and_duplicates_pick_lowest_index(ctx, orc, synth, variant):
     ctx.tune("nn1_tiles_per_slice", 0)
     oidx, od2 = orc.nn1_f32(tgt, src)
     ctx.tune("nn1_variant", 0)
+    ctx.tune("nn_method", 0)
     assert (orc.nn1_tiecount_f32(tgt, src) > 1).sum() > 1000
     assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
     cs.free(); ct.free()
@@ -120,8 +128,115 @@ def test_nn1_edge_cases(ctx, orc, variant):
     idx, d2 = ctx.nn1(e, cs)
     assert (idx == 0xFFFFFFFF).all() and np.isinf(d2).all()
     ctx.tune("nn1_variant", 0)
+    ctx.tune("nn_method", 0)
     for c in (ct, cs, e):
         c.free()
+
+
+# ------------------------------------------------------------------ exact grid NN (same contract as brute force)
+def _grid_vs_oracle(ctx, orc, src, tgt, **tune):
+    ctx.tune("nn_method", 2)
+    for k, v in tune.items():
+        ctx.tune(k, v)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    idx, d2 = ctx.nn1(ct, cs)
+    idx2, d22 = ctx.nn1(ct, cs)                      # second call reuses the cached index
+    for k in tune:
+        ctx.tune(k, 0)
+    ctx.tune("nn_method", 0)
+    cs.free(); ct.free()
+    oidx, od2 = orc.nn1_f32(tgt, src)
+    assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
+    assert np.array_equal(idx2, oidx) and np.array_equal(bits32(d22), bits32(od2))
+
+
+@pytest.mark.parametrize("ns,nt", [(1, 1), (63, 5), (257, 1023), (1000, 1025), (3001, 7000), (5000, 2049)])
+@pytest.mark.parametrize("sort_q,lanes", [(1, 8), (-1, 8), (1, 1), (1, 4), (1, 16), (1, 64)])
+def test_grid_ragged_sizes_vs_oracle(ctx, orc, synth, ns, nt, sort_q, lanes):
+    src, _ = synth.kitti_like_pair(max(ns, 64), seed_target=7 + ns, seed_pair=11 + nt)
+    tgt = synth.kitti_like_scan(max(nt, 64), seed=13 + nt)
+    _grid_vs_oracle(ctx, orc, np.ascontiguousarray(src[:, :ns]), np.ascontiguousarray(tgt[:, :nt]),
+                    grid_sort_queries=sort_q, grid_lanes=lanes)
+
+
+@pytest.mark.parametrize("cell_um", [20000, 250000, 3000000, 50000000])   # 2 cm ... 50 m cells
+def test_grid_any_cell_size_is_exact(ctx, orc, synth, cell_um):
+    src, tgt = synth.kitti_like_pair(5000, seed_target=41, seed_pair=42)
+    _grid_vs_oracle(ctx, orc, src, tgt, grid_cell_um=cell_um)
+
+
+def test_grid_ties_duplicates_and_far_queries(ctx, orc, synth):
+    lat = synth.lattice_cloud(6000, 3, 10.0, seed=5, levels=10).astype(np.float32)
+    q = synth.lattice_cloud(3000, 3, 10.0, seed=6, levels=10).astype(np.float32)
+    tgt, src = np.ascontiguousarray(lat.T), np.ascontiguousarray(q.T)
+    assert (orc.nn1_tiecount_f32(tgt, src) > 1).sum() > 1000
+    _grid_vs_oracle(ctx, orc, src, tgt)
+    # queries far outside the target's bounding box (ring fast-forward), on its faces and in empty regions
+    far = src.copy()
+    far[0, :1000] += 500.0; far[1, 1000:2000] -= 73.5; far[2, 2000:] *= 40.0
+    _grid_vs_oracle(ctx, orc, far, tgt)
+    # degenerate targets: all identical / collinear / coplanar (zero-extent bounding boxes)
+    same = np.repeat(np.array([[1.5], [2.5], [-3.0]], np.float32), 3000, axis=1)
+    _grid_vs_oracle(ctx, orc, src, same)
+    line = np.zeros((3, 3000), np.float32); line[0] = np.linspace(-5, 5, 3000, dtype=np.float32)
+    _grid_vs_oracle(ctx, orc, src, line)
+    plane = tgt.copy(); plane[2] = 0.25
+    _grid_vs_oracle(ctx, orc, src, plane)
+
+
+def test_grid_non_finite_and_extreme_inputs(ctx, orc, synth):
+    src, tgt = synth.kitti_like_pair(4000, seed_target=43, seed_pair=44)
+    tgt = tgt.copy(); src = src.copy()
+    tgt[0, 5] = np.nan; tgt[1, 6] = np.inf; tgt[2, 7] = -np.inf
+    src[0, 0] = np.nan; src[1, 1] = np.inf; src[2, 2] = -np.inf; src[:, 3] = 3e30; src[:, 4] = -1e-30
+    _grid_vs_oracle(ctx, orc, src, tgt)
+    # a few huge outliers blow the bounding box up: cells get coarse, answers stay exact
+    tgt2 = tgt.copy(); tgt2[:, 100] = [1e6, -1e6, 1e5]; tgt2[:, 101] = [-3e5, 2e5, 9e5]
+    _grid_vs_oracle(ctx, orc, src, tgt2)
+
+
+def test_grid_index_invalidated_by_transform(ctx, orc, synth):
+    src, tgt = synth.kitti_like_pair(4000, seed_target=45, seed_pair=46)
+    ctx.tune("nn_method", 2)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    ctx.nn1(ct, cs)                                   # builds the index on ct
+    T = synth.gt_pose().astype(np.float32)
+    ctx.transform(ct, T)                              # must drop it
+    idx, d2 = ctx.nn1(ct, cs)
+    ctx.tune("nn_method", 0)
+    moved = orc.transform_f32(tgt, T[:3, :3], T[:3, 3])
+    oidx, od2 = orc.nn1_f32(moved, src)
+    assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
+    cs.free(); ct.free()
+
+
+def test_grid_equals_brute_force_at_120k(ctx, synth):
+    # BASELINE config 2 size: both exact methods must agree bit for bit on every query (pre- and post-alignment)
+    src, tgt = synth.kitti_like_pair(120000)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    ctx.tune("nn_method", 1); bi, bd = ctx.nn1(ct, cs)
+    ctx.tune("nn_method", 2); gi, gd = ctx.nn1(ct, cs)
+    assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd))
+    ctx.transform(cs, synth.gt_pose().astype(np.float32))
+    ctx.tune("nn_method", 1); bi, bd = ctx.nn1(ct, cs)
+    ctx.tune("nn_method", 2); gi, gd = ctx.nn1(ct, cs)
+    ctx.tune("nn_method", 0)
+    assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd))
+    assert np.median(bd) < 1e-3
+    cs.free(); ct.free()
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_icp_same_pose_with_either_nn_method(ctx, orc, synth, method):
+    src, tgt = synth.kitti_like_pair(9000, seed_target=47, seed_pair=48)
+    ctx.tune("nn_method", method)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=10, eps=1e-8)
+    ctx.tune("nn_method", 0)
+    oT, ost = orc.icp_p2p_f32(src, tgt, max_corr=1.0, max_iter=10, eps=1e-8)
+    assert st["iters_run"] == ost["iters_run"] and st["last_pairs"] == ost["last_pairs"]
+    assert np.linalg.norm(T.astype(np.float64) - oT) <= 1e-5
+    cs.free(); ct.free()
 
 
 def test_cloud_layouts_roundtrip(ctx, pcr, synth):
@@ -197,6 +312,33 @@ def test_icp_state_machine_matches_oracle(ctx, orc, synth):
     far = ctx.cloud(src + np.float32(1000.0))
     T, st = ctx.icp_point2point(far, ct, max_iter=5)
     assert st["empty_pairs"] == 1 and np.array_equal(T, np.eye(4, dtype=np.float32))
+    cs.free(); ct.free(); far.free()
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_icp_pipelined_equals_synchronous_loop(ctx, synth, method):
+    """The device-resident pipelined loop (default) and the synchronous host loop share one numerics header:
+    pose, iteration count, flags and loss must be identical, bit for bit, in every exit path."""
+    src, tgt = synth.kitti_like_pair(7000, seed_target=81, seed_pair=82)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    far = ctx.cloud(src + np.float32(1000.0))
+    init = np.eye(4, dtype=np.float32); init[1, 3] = -0.07
+    ctx.tune("nn_method", method)
+    cases = [(cs, dict(max_iter=12, eps=1e-8)), (cs, dict(max_iter=40, eps=1e30)), (cs, dict(max_iter=1, eps=0.0)),
+             (cs, dict(max_iter=0, eps=0.0)), (cs, dict(max_iter=9, eps=1e-8, max_corr=0.2, init_T=init)),
+             (far, dict(max_iter=5, eps=1e-8)), (cs, dict(max_iter=23, eps=0.0))]
+    for cloud, kw in cases:
+        ctx.tune("icp_pipeline", -1)
+        Ts, ss = ctx.icp_point2point(cloud, ct, **kw)
+        for chunk, slots in ((1, 0), (4, 0), (7, 0), (4, 1)):
+            ctx.tune("icp_pipeline", 1); ctx.tune("icp_chunk", chunk); ctx.tune("icp_force_slots", slots)
+            Tp, sp = ctx.icp_point2point(cloud, ct, **kw)
+            assert np.array_equal(Ts.view(np.uint32), Tp.view(np.uint32)), (kw, chunk, slots)
+            for k in ("iters_run", "converged", "empty_pairs", "last_pairs"):
+                assert ss[k] == sp[k], (k, kw, chunk, slots, ss, sp)
+            assert np.float32(ss["last_loss"]).view(np.uint32) == np.float32(sp["last_loss"]).view(np.uint32)
+    for k in ("icp_pipeline", "icp_chunk", "icp_force_slots", "nn_method"):
+        ctx.tune(k, 0)
     cs.free(); ct.free(); far.free()
 
 

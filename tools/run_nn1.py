@@ -23,9 +23,18 @@ if variant is not None:
 ctx.tune("nn1_chunk", int(os.environ.get("NN1_CHUNK", "0")))
 ctx.tune("nn1_qpl", qpl)
 ctx.tune("nn1_tiles_per_slice", tps)
+method = int(os.environ.get("NN_METHOD", "1"))     # 1 = brute force, 2 = exact grid
+ctx.tune("nn_method", method)
+if os.environ.get("GRID_CELL_UM"):
+    ctx.tune("grid_cell_um", int(os.environ["GRID_CELL_UM"]))
+aligned = os.environ.get("ALIGNED", "0") == "1"
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+if aligned:
+    ctx.transform(cs, synth.gt_pose().astype(np.float32))
 ctx.nn1_async(ct, cs); ctx.sync(); ctx.prof_reset()
 for _ in range(launches):
     ctx.nn1_async(ct, cs)
-k, ms = ctx.prof_get("nn1_brute")
-print(f"n={n} variant={variant} qpl={qpl} tps={tps} order={order}: {ms/k:.4f} ms/launch over {k} launches")
+names = ["nn1_brute", "nn1_grid", "grid_sort_queries", "grid_build"]
+out = {nm: ctx.prof_get(nm) for nm in names}
+desc = ", ".join(f"{nm}: {ms/k:.4f} ms x{k}" for nm, (k, ms) in out.items() if k)
+print(f"n={n} method={method} aligned={aligned} variant={variant} qpl={qpl} tps={tps} order={order}: {desc}")
