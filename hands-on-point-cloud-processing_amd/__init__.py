@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
-    "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
+    "pcr_grid_stats", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
 
@@ -102,6 +102,7 @@ def lib():
     L.pcr_prof_reset.argtypes = [vp]
     L.pcr_prof_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.pcr_tune_set.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.pcr_grid_stats.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -220,6 +221,11 @@ class Context:
 
     def tune(self, key: str, value: int):
         self._ck(lib().pcr_tune_set(self.h, key.encode(), int(value)))
+
+    def grid_stats(self):
+        out = (C.c_uint64 * 4)()
+        self._ck(lib().pcr_grid_stats(self.h, out))
+        return {"candidates": out[0], "fine_rows": out[1], "coarse_rows": out[2], "far_stages": out[3]}
 
     def prof_reset(self):
         self._ck(lib().pcr_prof_reset(self.h))

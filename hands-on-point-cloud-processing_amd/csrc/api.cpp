@@ -98,6 +98,7 @@ void cloud_modified(pcr_cloud* c)
 
 int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm)
 {
+    // nn_method: 0 auto (grid for targets >= 2048 points), 1 brute force, 2 uniform grid
     const int64_t method = tune_get(ctx, "nn_method", 0);
     const bool grid = method == 2 || (method != 1 && tgt->n >= 2048);
     return grid ? launch_nn1_grid(ctx, tgt, src, reuse_perm) : launch_nn1_brute(ctx, tgt, src);
@@ -144,8 +145,8 @@ int pcr_ctx_create(int device, pcr_ctx** out)
     CK(hipSetDevice(device));
     CK(hipGetDeviceProperties(&ctx->prop, device));
     CK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    CK(hipMalloc((void**)&ctx->partials, 1024 * 17 * sizeof(double)));
-    ctx->partials_cap = 1024 * 17;
+    CK(hipMalloc((void**)&ctx->partials, 8192 * 17 * sizeof(double)));   // KB_MAX_BLOCKS x (16 moments + last kept)
+    ctx->partials_cap = 8192 * 17;
     CK(hipMalloc((void**)&ctx->dev_out, 64 * sizeof(double)));
     CK(hipHostMalloc((void**)&ctx->host_out, 64 * sizeof(double), hipHostMallocDefault));
 #undef CK
@@ -165,6 +166,7 @@ int pcr_ctx_destroy(pcr_ctx* ctx)
     if (ctx->icp_state_host) hipHostFree(ctx->icp_state_host);
     for (hipEvent_t ev : ctx->icp_events) if (ev) hipEventDestroy(ev);
     if (ctx->qperm) hipFree(ctx->qperm);
+    if (ctx->grid_stats_dev) hipFree(ctx->grid_stats_dev);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->dev_out) hipFree(ctx->dev_out);
     if (ctx->host_out) hipHostFree(ctx->host_out);
@@ -373,6 +375,18 @@ int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* t
     auto it = ctx->prof.find(kernel);
     if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
     if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.total_ms;
+    return PCR_OK;
+}
+
+int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4])
+{
+    if (!ctx || !out) return PCR_ERR_ARG;
+    for (int k = 0; k < 4; k++) out[k] = 0;
+    if (!ctx->grid_stats_dev) return PCR_OK;
+    unsigned long long h[8];
+    PCR_HIP(ctx, hipMemcpyAsync(h, ctx->grid_stats_dev, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; k++) out[k] = h[k];
     return PCR_OK;
 }
 

@@ -28,6 +28,9 @@
 namespace pcr {
 
 constexpr int GR_BLOCK = 256;
+constexpr int SC_ITEMS = 8;                       // scan: items per thread
+constexpr int SC_TILE = SCAN_TILE;                // 2048 per block (pcr_internal.hpp)
+static_assert(SC_TILE == GR_BLOCK * SC_ITEMS, "scan tile");
 
 struct GridParams {
     float lo[3];
@@ -120,8 +123,6 @@ __global__ __launch_bounds__(GR_BLOCK) void cell_count_kernel(const float* __res
     atomicAdd(&count[c], 1u);
 }
 
-constexpr int SC_ITEMS = 8;                       // per thread
-constexpr int SC_TILE = GR_BLOCK * SC_ITEMS;      // 2048 per block
 
 // block-local exclusive scan; block totals to `totals`
 __global__ __launch_bounds__(GR_BLOCK) void scan_local_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
@@ -247,13 +248,15 @@ __device__ __forceinline__ unsigned long long group_min(unsigned long long v)
 
 // G lanes cooperate on one query (G divides 64).  Stage 1 scans the 3 x 3 x-rows of the radius-1 cube with all
 // row bounds fetched up front (18 independent loads in flight); later stages double the radius.
-template <int G>
+template <int G, bool STATS>
 __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
-    const float4* __restrict__ records, const uint32_t* __restrict__ cell_start, GridParams g,
-    const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-    const uint32_t* __restrict__ perm, uint32_t ns, unsigned long long* __restrict__ keys, const int* __restrict__ stop)
+    const float4* __restrict__ records, const uint32_t* __restrict__ cell_start,
+    GridParams g, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+    const uint32_t* __restrict__ perm, uint32_t ns, unsigned long long* __restrict__ keys, const int* __restrict__ stop,
+    unsigned long long* __restrict__ stats)
 {
     if (stop && (stop[0] | stop[1])) return;      // pipelined ICP: the loop has ended, the enqueued tail is a no-op
+    unsigned long long st_cand = 0, st_rows = 0, st_stages = 0;   // diagnostics (STATS builds only)
     const uint32_t gt = blockIdx.x * GR_BLOCK + threadIdx.x;
     const uint32_t t = min(gt / G, ns - 1);          // clamp: surplus sub-groups redo the last query (same value written)
     const int l = (int)(threadIdx.x % G);
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             }
 #pragma unroll
             for (int k = 0; k < 9; k++) scan_range<G>(records, rb[k], re[k], l, qx, qy, qz, best);
+            if (STATS && l == 0) { for (int k = 0; k < 9; k++) st_cand += re[k] - rb[k]; st_rows += 9; }
             best = group_min<G>(best);
             const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
                                 (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
@@ -308,36 +312,59 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             const int zlo = max(uz - r, 0), zhi = min(uz + r, g.n[2] - 1);
             const float clip2 = bestf * 1.0001f;
             if (xlo <= xhi && ylo <= yhi && zlo <= zhi) {
-                // far searches walk many sparse rows: one ROW per lane (G independent dependent-load chains in flight
-                // per query instead of one), each lane scanning its row's candidates serially
+                // Far searches open many x-rows, most of them short.  Rows are taken G at a time: every lane resolves
+                // ONE row (clipping + its cell_start bounds: G independent loads in flight per query), then the whole
+                // sub-group scans the G ranges one after the other with coalesced 16-byte loads.
                 const int ny_rows = yhi - ylo + 1;
                 const int n_rows = ny_rows * (zhi - zlo + 1);
-                for (int k = l; k < n_rows; k += G) {
-                    const int cy = ylo + k % ny_rows, cz = zlo + k / ny_rows;
-                    const int ady = abs(cy - uy), adz = abs(cz - uz);
-                    int xa = xlo, xb = xhi;
-                    if (have) {
-                        const float fy = fmaxf((float)ady - 1.0f - g.slack, 0.0f) * g.h;
-                        const float fz = fmaxf((float)adz - 1.0f - g.slack, 0.0f) * g.h;
-                        const float rem2 = clip2 - (fy * fy + fz * fz);
-                        if (rem2 < 0.0f) continue;                       // the whole row is outside the ball
-                        const int wx = (int)(sqrtf(rem2) * g.inv_h + g.slack) + 2;
-                        xa = max(xa, ux - wx);
-                        xb = min(xb, ux + wx);
+                for (int k0 = 0; k0 < n_rows; k0 += G) {
+                    const int k = k0 + l;
+                    uint32_t b1 = 0, e1 = 0, b2 = 0, e2 = 0;       // up to two pieces per row
+                    if (k < n_rows) {
+                        const int cy = ylo + k % ny_rows, cz = zlo + k / ny_rows;
+                        const int ady = abs(cy - uy), adz = abs(cz - uz);
+                        int xa = xlo, xb = xhi;
+                        bool open = true;
+                        if (have) {
+                            const float fy = fmaxf((float)ady - 1.0f - g.slack, 0.0f) * g.h;
+                            const float fz = fmaxf((float)adz - 1.0f - g.slack, 0.0f) * g.h;
+                            const float rem2 = clip2 - (fy * fy + fz * fz);
+                            if (rem2 < 0.0f) {
+                                open = false;                                  // the whole row is outside the ball
+                            } else {
+                                const int wx = (int)(sqrtf(rem2) * g.inv_h + g.slack) + 2;
+                                xa = max(xa, ux - wx);
+                                xb = min(xb, ux + wx);
+                            }
+                        }
+                        if (open && xa <= xb) {
+                            const uint32_t row = (uint32_t)((cz * g.n[1] + cy) * g.n[0]);
+                            if (ady <= rp && adz <= rp) {
+                                // this row crossed the old cube: only the two end pieces are new
+                                const int la = xa, lb = min(xb, ux - rp - 1);
+                                const int ra = max(xa, ux + rp + 1), rb2 = xb;
+                                if (la <= lb) { b1 = cell_start[row + la]; e1 = cell_start[row + lb + 1]; }
+                                if (ra <= rb2) { b2 = cell_start[row + ra]; e2 = cell_start[row + rb2 + 1]; }
+                            } else {
+                                b1 = cell_start[row + xa]; e1 = cell_start[row + xb + 1];
+                            }
+                            if (STATS) { st_rows++; st_cand += (e1 - b1) + (e2 - b2); }
+                        }
                     }
-                    if (xa > xb) continue;
-                    const uint32_t row = (uint32_t)((cz * g.n[1] + cy) * g.n[0]);
-                    if (ady <= rp && adz <= rp) {
-                        // this row crossed the old cube: only the two end pieces are new
-                        const int la = xa, lb = min(xb, ux - rp - 1);
-                        const int ra = max(xa, ux + rp + 1), rb2 = xb;
-                        if (la <= lb) scan_range<1>(records, cell_start[row + la], cell_start[row + lb + 1], 0, qx, qy, qz, best);
-                        if (ra <= rb2) scan_range<1>(records, cell_start[row + ra], cell_start[row + rb2 + 1], 0, qx, qy, qz, best);
-                    } else {
-                        scan_range<1>(records, cell_start[row + xa], cell_start[row + xb + 1], 0, qx, qy, qz, best);
+                    // visit only the lanes that hold a non-empty piece (far searches are mostly empty space)
+                    const unsigned long long any = __ballot((b1 < e1) || (b2 < e2));
+                    unsigned long long mine = (any >> ((threadIdx.x & 63) / G * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
+                    while (mine) {
+                        const int j = __builtin_ctzll(mine);
+                        mine &= mine - 1;
+                        const uint32_t jb1 = __shfl(b1, j, G), je1 = __shfl(e1, j, G);
+                        const uint32_t jb2 = __shfl(b2, j, G), je2 = __shfl(e2, j, G);
+                        if (jb1 < je1) scan_range<G>(records, jb1, je1, l, qx, qy, qz, best);
+                        if (jb2 < je2) scan_range<G>(records, jb2, je2, l, qx, qy, qz, best);
                     }
                 }
             }
+            if (STATS && l == 0) st_stages++;
             best = group_min<G>(best);
             const bool covers = (ux - r <= 0) && (ux + r >= g.n[0] - 1) && (uy - r <= 0) && (uy + r >= g.n[1] - 1) &&
                                 (uz - r <= 0) && (uz + r >= g.n[2] - 1);
@@ -347,6 +374,11 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             rp = r;
             r = min(r * 2, 1 << 24);
         }
+    }
+    if (STATS && gt / G < ns) {
+        if (st_cand) atomicAdd(&stats[0], st_cand);
+        if (st_rows) atomicAdd(&stats[1], st_rows);
+        if (st_stages) atomicAdd(&stats[3], st_stages);
     }
     if (l == 0 && gt / G < ns) {
         const uint32_t bidx = (uint32_t)(best & 0xFFFFFFFFull);
@@ -365,7 +397,7 @@ __global__ __launch_bounds__(GR_BLOCK) void count_nonzero_kernel(const uint32_t*
 }
 
 // ---------------------------------------------------------------------------------------- host side
-static int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* totals, uint32_t* grand)
+int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* totals, uint32_t* grand)
 {
     const uint32_t nb = (uint32_t)((n + SC_TILE - 1) / SC_TILE);
     hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(GR_BLOCK), 0, ctx->stream, in, out, (uint32_t)n, totals);
@@ -572,12 +604,22 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     }
     const Grid* g = tgt->grid;
     const uint32_t* perm = tune_get(ctx, "grid_sort_queries", 1) > 0 ? ctx->qperm : nullptr;
+    unsigned long long* stats_dev = nullptr;
+    if (tune_get(ctx, "grid_stats", 0) > 0) {     // diagnostics: candidates / fine rows / coarse rows / far stages of this launch
+        if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
+        PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        stats_dev = ctx->grid_stats_dev;
+    }
     const int G = (int)tune_get(ctx, "grid_lanes", 16);   // measured: profiles/r01_tune_grid.txt
     {
         ProfScope p(ctx, "nn1_grid", 1);
 #define PCR_GRID(GG)                                                                                                   \
-    hipLaunchKernelGGL(nn1_grid_kernel<GG>, dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0,  \
-                       ctx->stream, g->records, g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev)
+    if (stats_dev)                                                                                                     \
+        hipLaunchKernelGGL((nn1_grid_kernel<GG, true>), dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0,  \
+                           ctx->stream, g->records, g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev); \
+    else                                                                                                               \
+        hipLaunchKernelGGL((nn1_grid_kernel<GG, false>), dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0,  \
+                       ctx->stream, g->records, g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev)
         switch (G) {
         case 1: PCR_GRID(1); break;
         case 2: PCR_GRID(2); break;

@@ -15,7 +15,7 @@ namespace pcr {
 
 constexpr int KB_BLOCK = 256;
 constexpr int KB_NV = 16;          // 3 + 3 + 9 sums + count
-constexpr int KB_MAX_BLOCKS = 1024;
+constexpr int KB_MAX_BLOCKS = 8192;   // == the capacity of ctx->partials (api.cpp)
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -129,13 +129,20 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_final_kernel(
     }
 }
 
+// a pure function of n: the order of the f64 additions (and so the bits of the sums) depends only on n
+static uint32_t kabsch_blocks(size_t ns)
+{
+    uint32_t blocks = (uint32_t)((ns + KB_BLOCK * 4 - 1) / (KB_BLOCK * 4));
+    if (blocks < 1) blocks = 1;
+    if (blocks > KB_MAX_BLOCKS) blocks = KB_MAX_BLOCKS;
+    return blocks;
+}
+
 int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr)
 {
     const size_t ns = src->n;
     if (ctx->keys_n != ns) return fail(ctx, PCR_ERR_STATE, "kabsch: no matching correspondence pass");
-    uint32_t blocks = (uint32_t)((ns + KB_BLOCK * 4 - 1) / (KB_BLOCK * 4));
-    if (blocks < 1) blocks = 1;
-    if (blocks > KB_MAX_BLOCKS) blocks = KB_MAX_BLOCKS;
+    uint32_t blocks = kabsch_blocks(ns);
     {
         ProfScope p(ctx, "kabsch_partial");
         hipLaunchKernelGGL(kabsch_partial_kernel, dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream,
@@ -303,9 +310,7 @@ int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* s
 {
     const size_t ns = src->n;
     if (ctx->keys_n != ns) return fail(ctx, PCR_ERR_STATE, "kabsch: no matching correspondence pass");
-    uint32_t blocks = (uint32_t)((ns + KB_BLOCK * 4 - 1) / (KB_BLOCK * 4));
-    if (blocks < 1) blocks = 1;
-    if (blocks > KB_MAX_BLOCKS) blocks = KB_MAX_BLOCKS;
+    uint32_t blocks = kabsch_blocks(ns);
     {
         ProfScope p(ctx, "kabsch_partial");
         hipLaunchKernelGGL(kabsch_partial_kernel, dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream,

@@ -90,6 +90,7 @@ struct pcr_ctx {
     pcr::IcpState* icp_state_dev = nullptr;    // pipelined ICP: device state, pinned snapshots, snapshot events
     pcr::IcpState* icp_state_host = nullptr;
     hipEvent_t icp_events[4] = { nullptr, nullptr, nullptr, nullptr };
+    unsigned long long* grid_stats_dev = nullptr;   // diagnostics of the grid search (tune grid_stats)
     const int* stop_flag_dev = nullptr;        // when set, the correspondence kernels exit early once *flag != 0
     pcr::Comm comm;
     std::map<std::string, pcr::ProfEntry> prof;
@@ -125,6 +126,9 @@ void prof_flush(pcr_ctx* ctx);
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
 int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm);
+// device-wide exclusive scan of u32 (grid.hip): totals needs ceil(n / SCAN_TILE) + 1 words
+constexpr int SCAN_TILE = 2048;
+int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* totals, uint32_t* grand);
 // dispatcher: tune "nn_method" 0 = auto (grid for targets >= 2048 points), 1 = brute force, 2 = grid
 int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm);
 void cloud_modified(pcr_cloud* c);

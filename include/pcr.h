@@ -162,6 +162,9 @@ void pcr_shard_range(size_t n, int nranks, int rank, size_t* begin, size_t* end)
 /* ---- profiling hooks for bench.py: HIP-event timing of the dominant kernel on the ctx stream ---------- */
 int pcr_prof_reset(pcr_ctx* ctx);
 int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* total_ms);
+/* diagnostics of the last grid search launched with tune "grid_stats" = 1:
+ * out = { candidates evaluated, fine x-rows opened, coarse rows tested, far stages run } summed over the queries */
+int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4]);
 /* tuning knobs of the 1-NN kernel (0 = default): target slices per query block */
 int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value);
 

@@ -134,8 +134,8 @@ def test_nn1_edge_cases(ctx, orc, variant):
 
 
 # ------------------------------------------------------------------ exact grid NN (same contract as brute force)
-def _grid_vs_oracle(ctx, orc, src, tgt, **tune):
-    ctx.tune("nn_method", 2)
+def _grid_vs_oracle(ctx, orc, src, tgt, method=2, **tune):
+    ctx.tune("nn_method", method)
     for k, v in tune.items():
         ctx.tune(k, v)
     cs, ct = ctx.cloud(src), ctx.cloud(tgt)
@@ -165,39 +165,42 @@ def test_grid_any_cell_size_is_exact(ctx, orc, synth, cell_um):
     _grid_vs_oracle(ctx, orc, src, tgt, grid_cell_um=cell_um)
 
 
-def test_grid_ties_duplicates_and_far_queries(ctx, orc, synth):
+@pytest.mark.parametrize("method", [2])
+def test_grid_ties_duplicates_and_far_queries(ctx, orc, synth, method):
     lat = synth.lattice_cloud(6000, 3, 10.0, seed=5, levels=10).astype(np.float32)
     q = synth.lattice_cloud(3000, 3, 10.0, seed=6, levels=10).astype(np.float32)
     tgt, src = np.ascontiguousarray(lat.T), np.ascontiguousarray(q.T)
     assert (orc.nn1_tiecount_f32(tgt, src) > 1).sum() > 1000
-    _grid_vs_oracle(ctx, orc, src, tgt)
+    _grid_vs_oracle(ctx, orc, src, tgt, method=method)
     # queries far outside the target's bounding box (ring fast-forward), on its faces and in empty regions
     far = src.copy()
     far[0, :1000] += 500.0; far[1, 1000:2000] -= 73.5; far[2, 2000:] *= 40.0
-    _grid_vs_oracle(ctx, orc, far, tgt)
+    _grid_vs_oracle(ctx, orc, far, tgt, method=method)
     # degenerate targets: all identical / collinear / coplanar (zero-extent bounding boxes)
     same = np.repeat(np.array([[1.5], [2.5], [-3.0]], np.float32), 3000, axis=1)
-    _grid_vs_oracle(ctx, orc, src, same)
+    _grid_vs_oracle(ctx, orc, src, same, method=method)
     line = np.zeros((3, 3000), np.float32); line[0] = np.linspace(-5, 5, 3000, dtype=np.float32)
-    _grid_vs_oracle(ctx, orc, src, line)
+    _grid_vs_oracle(ctx, orc, src, line, method=method)
     plane = tgt.copy(); plane[2] = 0.25
-    _grid_vs_oracle(ctx, orc, src, plane)
+    _grid_vs_oracle(ctx, orc, src, plane, method=method)
 
 
-def test_grid_non_finite_and_extreme_inputs(ctx, orc, synth):
+@pytest.mark.parametrize("method", [2])
+def test_grid_non_finite_and_extreme_inputs(ctx, orc, synth, method):
     src, tgt = synth.kitti_like_pair(4000, seed_target=43, seed_pair=44)
     tgt = tgt.copy(); src = src.copy()
     tgt[0, 5] = np.nan; tgt[1, 6] = np.inf; tgt[2, 7] = -np.inf
     src[0, 0] = np.nan; src[1, 1] = np.inf; src[2, 2] = -np.inf; src[:, 3] = 3e30; src[:, 4] = -1e-30
-    _grid_vs_oracle(ctx, orc, src, tgt)
+    _grid_vs_oracle(ctx, orc, src, tgt, method=method)
     # a few huge outliers blow the bounding box up: cells get coarse, answers stay exact
     tgt2 = tgt.copy(); tgt2[:, 100] = [1e6, -1e6, 1e5]; tgt2[:, 101] = [-3e5, 2e5, 9e5]
-    _grid_vs_oracle(ctx, orc, src, tgt2)
+    _grid_vs_oracle(ctx, orc, src, tgt2, method=method)
 
 
-def test_grid_index_invalidated_by_transform(ctx, orc, synth):
+@pytest.mark.parametrize("method", [2])
+def test_grid_index_invalidated_by_transform(ctx, orc, synth, method):
     src, tgt = synth.kitti_like_pair(4000, seed_target=45, seed_pair=46)
-    ctx.tune("nn_method", 2)
+    ctx.tune("nn_method", method)
     cs, ct = ctx.cloud(src), ctx.cloud(tgt)
     ctx.nn1(ct, cs)                                   # builds the index on ct
     T = synth.gt_pose().astype(np.float32)
@@ -215,13 +218,15 @@ def test_grid_equals_brute_force_at_120k(ctx, synth):
     src, tgt = synth.kitti_like_pair(120000)
     cs, ct = ctx.cloud(src), ctx.cloud(tgt)
     ctx.tune("nn_method", 1); bi, bd = ctx.nn1(ct, cs)
-    ctx.tune("nn_method", 2); gi, gd = ctx.nn1(ct, cs)
-    assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd))
+    for m in (2,):
+        ctx.tune("nn_method", m); gi, gd = ctx.nn1(ct, cs)
+        assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd))
     ctx.transform(cs, synth.gt_pose().astype(np.float32))
     ctx.tune("nn_method", 1); bi, bd = ctx.nn1(ct, cs)
-    ctx.tune("nn_method", 2); gi, gd = ctx.nn1(ct, cs)
+    for m in (2,):
+        ctx.tune("nn_method", m); gi, gd = ctx.nn1(ct, cs)
+        assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd))
     ctx.tune("nn_method", 0)
-    assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd))
     assert np.median(bd) < 1e-3
     cs.free(); ct.free()
 

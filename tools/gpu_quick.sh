@@ -1,16 +1,3 @@
 set -o pipefail
 mkdir -p gpurun_out
-python bench.py --no-cpu-baseline --nn grid --steps 20 2>&1 | tee gpurun_out/bench_grid.json | python -c "
-import sys, json
-for l in sys.stdin:
-    try:
-        d = json.loads(l); print({k: d[k] for k in ('value','icp_iter_per_s','ms_per_step')}, d['roofline']['avg_launch_ms'], d['config']['pose_err_vs_gt_fro'])
-    except Exception as e: print(l[:300])
-"
-python bench.py --no-cpu-baseline --nn grid --steps 40 2>&1 | python -c "
-import sys, json
-for l in sys.stdin:
-    try:
-        d = json.loads(l); print({k: d[k] for k in ('value','icp_iter_per_s','ms_per_step')}, d['roofline']['avg_launch_ms'], d['config']['pose_err_vs_gt_fro'])
-    except Exception as e: print(l[:300])
-"
+for n in 120000 1000000; do NN_METHOD=2 GRID_STATS=1 timeout -k 10 120 python tools/run_nn1.py $n 3; NN_METHOD=2 GRID_STATS=1 ALIGNED=1 timeout -k 10 120 python tools/run_nn1.py $n 3; done 2>&1 | grep -v "^first" | tee gpurun_out/grid_stats.txt

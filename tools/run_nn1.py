@@ -31,10 +31,15 @@ aligned = os.environ.get("ALIGNED", "0") == "1"
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
 if aligned:
     ctx.transform(cs, synth.gt_pose().astype(np.float32))
-ctx.nn1_async(ct, cs); ctx.sync(); ctx.prof_reset()
+ctx.tune("prof", 2)
+ctx.nn1_async(ct, cs); ctx.sync(); print("first call:", {nm: ctx.prof_get(nm) for nm in ("grid_build",) if ctx.prof_get(nm)[0]}); ctx.prof_reset()
 for _ in range(launches):
     ctx.nn1_async(ct, cs)
+if os.environ.get("GRID_STATS"):
+    ctx.tune("grid_stats", 1); ctx.nn1_async(ct, cs); ctx.sync(); gs = ctx.grid_stats(); ctx.tune("grid_stats", 0)
+    print("grid stats per query:", {k: round(v / n, 2) for k, v in gs.items()})
 names = ["nn1_brute", "nn1_grid", "grid_sort_queries", "grid_build"]
+ctx.tune("prof", 2)
 out = {nm: ctx.prof_get(nm) for nm in names}
 desc = ", ".join(f"{nm}: {ms/k:.4f} ms x{k}" for nm, (k, ms) in out.items() if k)
 print(f"n={n} method={method} aligned={aligned} variant={variant} qpl={qpl} tps={tps} order={order}: {desc}")
