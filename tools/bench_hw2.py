@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""The hw2 benchmark() protocol (Homework2/hw2/include/benchmark.hpp:6-78: first 10 000 points, k = 8, leaf 1, every point
+queries its own cloud) on the GPU drop-in vs the reference's own kd-tree (oracle/_ref) on this box's host CPU."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+pcr = importlib.import_module("hands-on-point-cloud-processing_amd")
+g = np.load(os.path.join(ROOT, "tests", "golden", "kat_kitti_q5.npz"))
+for npts in (10000, 100000):
+    db = np.unique(g["db_f32"][:npts].astype(np.float64), axis=0)   # the reference's build cannot take duplicates
+    ctx = pcr.Context(0); ctx.tune("prof", 2)
+    t0 = time.perf_counter(); h = ctx.db64(db); tb = time.perf_counter() - t0
+    h.knn(db[:256], 8)
+    t0 = time.perf_counter(); idx, dist = h.knn(db, 8); tq = time.perf_counter() - t0
+    k, ms = ctx.prof_get("knn_f64")
+    print(f"GPU  n={db.shape[0]}: upload {tb*1e3:.2f} ms, batched 8-NN of all points {tq*1e3:.2f} ms ({tq*1e3/db.shape[0]:.6f} ms/query; kernel {ms/k:.3f} ms avg)")
+    t0 = time.perf_counter(); row, ri, rd = h.radius(db, 1.0); tr = time.perf_counter() - t0
+    print(f"     radius r=1.0 of all points {tr*1e3:.2f} ms ({tr*1e3/db.shape[0]:.6f} ms/query), {row[-1]} neighbours")
+    try:
+        import orc
+        if orc.have_ref():
+            ridx, rdist, cmp, bms, qms = orc.ref_hw2_kd_knn(db, db, 8, leaf=1, want_cmp=True)
+            print(f"CPU  reference hw2 kd-tree (1 thread): build {bms:.2f} ms, 8-NN {qms/db.shape[0]:.6f} ms/query; distances bit-equal: "
+                  f"{np.array_equal(rdist.view(np.uint64), dist.view(np.uint64))}")
+    except Exception as e:  # noqa: BLE001
+        print("reference unavailable:", e)
+    ctx.close()

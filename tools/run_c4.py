@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: RANSAC ground plane (Homework4) + radius-NN on one 120k-point KITTI-like scan, 1 GPU.
+Times the GPU path next to the CPU oracle's evaluation of the same expressions (numpy-like f64 loop in C)."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+pcr = importlib.import_module("hands-on-point-cloud-processing_amd")
+synth = importlib.import_module("hands-on-point-cloud-processing_amd.synth")
+hw4 = importlib.import_module("hands-on-point-cloud-processing_amd.hw4")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
+scan = synth.kitti_like_scan(n)
+pts = np.ascontiguousarray(scan.T)
+ctx = pcr.Context(0)
+ctx.tune("prof", 2)
+# --- plane-inlier count: 80 hypotheses (40 per x-segment, ground_detection_ransac.py:54,71-72) in one pass
+ground = np.where(np.abs(scan[2] + 1.73) < 0.3)[0]
+pick = (synth.splitmix64(9, np.arange(240, dtype=np.uint64)) % np.uint64(ground.size)).astype(np.int64).reshape(80, 3)
+planes = np.stack([hw4.estimate_plane_params(pts[ground[p]].astype(np.float64)) for p in pick])
+planes = planes[np.isfinite(planes).all(axis=1)]
+c = ctx.cloud(scan)
+ctx.plane_count(c, planes, 0.15); ctx.prof_reset()
+reps = 20
+t0 = time.perf_counter()
+for _ in range(reps):
+    counts = ctx.plane_count(c, planes, 0.15)
+dt = (time.perf_counter() - t0) / reps
+k, ms = ctx.prof_get("plane_count")
+print(f"plane_count: {planes.shape[0]} hypotheses x {n} pts: kernel {ms/k*1e3:.1f} us ({12*n/(ms/k*1e-3)/1e9:.1f} GB/s of 12 B/pt), "
+      f"call incl. H2D/D2H+sync {dt*1e3:.3f} ms; best count {counts.max()}")
+try:
+    import orc
+    t0 = time.perf_counter(); oc = orc.plane_count(scan, planes, 0.15); tc = time.perf_counter() - t0
+    print(f"  CPU oracle (1 thread, f64): {tc*1e3:.1f} ms -> x{tc/dt:.0f}; counts equal: {np.array_equal(oc, counts)}")
+except Exception as e:  # noqa: BLE001
+    print("  oracle unavailable:", e)
+t0 = time.perf_counter(); idx, params = hw4.my_ransac(ctx, pts, np.arange(n), 40, 0.15, rng=np.random.default_rng(1)); t1 = time.perf_counter() - t0
+print(f"my_ransac (40 iterations, one segment): {t1*1e3:.2f} ms, {idx.size} ground points, plane {np.round(params, 4)}")
+# --- radius-NN r = 1.0 (the value benchmark.hpp:14 intended), every point queries its own scan
+db = pts.astype(np.float64)
+h = ctx.db64(db)
+m = int(os.environ.get("RADIUS_QUERIES", n))
+t0 = time.perf_counter(); row, ridx, rdist = h.radius(db[:m], 1.0); t1 = time.perf_counter() - t0
+kc, msc = ctx.prof_get("radius_count"); kf, msf = ctx.prof_get("radius_fill")
+print(f"radius-NN r=1.0: {m} queries x {n} pts: {row[-1]} neighbours, count kernel {msc/max(kc,1):.2f} ms + fill kernel {msf/max(kf,1):.2f} ms, "
+      f"call {t1*1e3:.1f} ms -> {m*n/((msc/max(kc,1)+msf/max(kf,1))*1e-3)/1e9:.1f} G pair-evals/s over both passes")
