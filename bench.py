@@ -197,12 +197,19 @@ def main():
                          "traffic_note": ("HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from a separate "
                                           "rocprofv3 --pmc pass of this kernel, " + pmc["source"]) if pmc else "not collected",
                          "clock_ghz_profiled": pmc.get("clock_ghz_profiled") if pmc else None,
-                         "kernel": "pcr::nn1_track_kernel<2, 16, true> (brute force, scalar-cache broadcast of targets)"
+                         "kernel": "pcr::nn1_ftrack_kernel<2, 16> (brute force; targets broadcast through the scalar cache; fused "
+                                   "pre-filter tracked branch-free, winner decided with the exact unfused arithmetic)"
                                    if not (args.qpl or args.variant) else f"nn1 variant={args.variant} qpl={args.qpl}",
+                         "executed_lane_ops_per_pair": (pmc["valu_insts_per_launch"] * 64 / pairs) if pmc and pmc.get("valu_insts_per_launch") else None,
+                         "issue_frac": (pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TFLOPS_NOFMA)
+                                       if pmc and pmc.get("valu_insts_per_launch") else None,
                          "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3,
                          "kernel_M_corr_per_s": n / kern_s / 1e6,
-                         "algorithmic": f"{OPS_PER_PAIR} f32 lane-ops per (query,target) pair x {pairs:.3e} pairs/launch; "
-                                        "peak = 157.3 TF/s / 2 because the bit-exact contract forbids FMA",
+                         "algorithmic": f"{OPS_PER_PAIR} f32 lane-ops per (query,target) pair (SURVEY.md 8d) x {pairs:.3e} pairs/launch; "
+                                        "peak = 157.3 TF/s / 2: one op per lane per issue slot (the exact arithmetic has no FMA). "
+                                        "frac can exceed 1 because the kernel needs fewer than 9 issue slots per pair: its hot loop "
+                                        "evaluates a fused 6-op filter and only the winning chunk exactly; issue_frac = executed "
+                                        "lane-ops (PMC) / time / peak is the share of VALU issue slots actually used",
                          "hbm_literal": {"bound": "hbm", "achieved": compulsory_bytes / kern_s / 1e9,
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,

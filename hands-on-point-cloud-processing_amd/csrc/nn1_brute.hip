@@ -211,6 +211,103 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_track_kernel(
     }
 }
 
+// ---- FTRACK: branch-free tracking on the FUSED filter value (6 instead of 8 distance ops per pair).
+// Per query the hot loop keeps a1 = smallest chunk-minimum of a = fma(dz,dz,fma(dy,dy,dx*dx)), c1 = the first chunk
+// attaining it, and a2 = the smallest chunk-minimum over all OTHER chunks.  Since |a - d2| <= 7u*d2 (u = 2^-24, all
+// terms non-negative), a2 > a1*(1 + 2^-20) + 1e-30 proves that every target outside c1 has an exact d2 strictly
+// above the exact minimum of c1: the answer is then decided by evaluating c1's CH targets with the exact unfused
+// arithmetic.  If the proof fails for some lane (near-ties between chunks, duplicates, overflow), the wave rescans
+// the slice with the exact TRACK loop.  Either way the result is bit-identical to brute force.
+template <int QPL, int CH>
+__global__ __launch_bounds__(NN_BLOCK) void nn1_ftrack_kernel(
+    const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
+    const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+    uint32_t ns, uint32_t n_tiles, uint32_t tiles_per_slice,
+    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop)
+{
+    if (stop && (stop[0] | stop[1])) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t qbase = blockIdx.x * (NN_BLOCK * QPL);
+    float qx[QPL], qy[QPL], qz[QPL];
+    uint32_t a1[QPL], a2[QPL], c1[QPL];
+#pragma unroll
+    for (int k = 0; k < QPL; k++) {
+        uint32_t i = min(qbase + k * NN_BLOCK + tid, ns - 1);
+        qx[k] = sx[i]; qy[k] = sy[i]; qz[k] = sz[i];
+        a1[k] = 0x7F800000u; a2[k] = 0x7F800000u; c1[k] = 0xFFFFFFFFu;
+    }
+    const uint32_t tile0 = blockIdx.y * tiles_per_slice;
+    const uint32_t tile1 = min(tile0 + tiles_per_slice, n_tiles);
+    const uint32_t j_begin = tile0 * NN_TILE, j_end = tile1 * NN_TILE;
+#pragma unroll 2
+    for (uint32_t j0 = j_begin; j0 < j_end; j0 += CH) {
+        float X[CH], Y[CH], Z[CH];
+#pragma unroll
+        for (int g = 0; g < CH / 4; g++) {      // wave-uniform addresses: s_load_dwordx4
+            const float4 a = *reinterpret_cast<const float4*>(tx + j0 + 4 * g);
+            const float4 b = *reinterpret_cast<const float4*>(ty + j0 + 4 * g);
+            const float4 c = *reinterpret_cast<const float4*>(tz + j0 + 4 * g);
+            X[4 * g] = a.x; X[4 * g + 1] = a.y; X[4 * g + 2] = a.z; X[4 * g + 3] = a.w;
+            Y[4 * g] = b.x; Y[4 * g + 1] = b.y; Y[4 * g + 2] = b.z; Y[4 * g + 3] = b.w;
+            Z[4 * g] = c.x; Z[4 * g + 1] = c.y; Z[4 * g + 2] = c.z; Z[4 * g + 3] = c.w;
+        }
+#pragma unroll
+        for (int k = 0; k < QPL; k++) {
+            uint32_t d[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) d[j] = d2_fused_bits(qx[k], qy[k], qz[k], X[j], Y[j], Z[j]);
+            uint32_t m = umin3(d[0], d[1], d[2]);
+#pragma unroll
+            for (int j = 3; j + 1 < CH; j += 2) m = umin3(m, d[j], d[j + 1]);
+            m = min(m, d[CH - 1]);
+            a2[k] = min(a2[k], max(a1[k], m));       // smallest chunk-minimum among the chunks that are not c1
+            const bool better = m < a1[k];
+            a1[k] = min(a1[k], m);
+            c1[k] = better ? j0 : c1[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < QPL; k++) {
+        uint32_t best = 0x7F7FFFFFu, bidx = 0xFFFFFFFFu;      // FLT_MAX gate, nanoflann.hpp:163,1360
+        const bool proven = (c1[k] != 0xFFFFFFFFu) && (a2[k] > gate_bits(a1[k]));
+        if (__all(proven || j_begin >= j_end)) {
+            if (c1[k] != 0xFFFFFFFFu) {
+                const uint32_t j0 = c1[k];
+#pragma unroll
+                for (int j = 0; j < CH; j++) {
+                    const uint32_t e = d2_exact_bits(qx[k], qy[k], qz[k], tx[j0 + j], ty[j0 + j], tz[j0 + j]);
+                    if (e < best) { best = e; bidx = j0 + j; }
+                }
+            }
+        } else {
+            // exact rescan of the slice for this query (the whole wave: lanes that were proven get the same answer)
+            uint32_t bchunk = 0xFFFFFFFFu;
+            for (uint32_t j0 = j_begin; j0 < j_end; j0 += CH) {
+                uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < CH; j++) m = min(m, d2_exact_bits(qx[k], qy[k], qz[k], tx[j0 + j], ty[j0 + j], tz[j0 + j]));
+                const bool better = m < best;
+                best = min(best, m);
+                bchunk = better ? j0 : bchunk;
+            }
+            if (bchunk != 0xFFFFFFFFu) {
+#pragma unroll
+                for (int j = CH - 1; j >= 0; j--) {
+                    const uint32_t e = d2_exact_bits(qx[k], qy[k], qz[k], tx[bchunk + j], ty[bchunk + j], tz[bchunk + j]);
+                    if (e == best) bidx = bchunk + j;
+                }
+            }
+        }
+        const uint32_t i = qbase + k * NN_BLOCK + tid;
+        if (i < ns) {
+            const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : best;
+            const unsigned long long key = ((unsigned long long)bits << 32) | bidx;
+            if (merge_atomic) atomicMin(&keys[i], key);
+            else keys[i] = key;
+        }
+    }
+}
+
 template <int QPL, bool FILTER, bool SGPR>
 __global__ __launch_bounds__(NN_BLOCK) void nn1_brute_kernel(
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
@@ -325,6 +422,21 @@ static void launch_track(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt,
 #undef PCR_TRACK
 }
 
+template <int CH>
+static void launch_ftrack(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t ns,
+                          uint32_t n_tiles, uint32_t tps, int merge_atomic)
+{
+#define PCR_FTRACK(Q)                                                                                              \
+    hipLaunchKernelGGL((nn1_ftrack_kernel<Q, CH>), grid, dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(),         \
+                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic, ctx->stop_flag_dev)
+    switch (qpl) {
+    case 1: PCR_FTRACK(1); break;
+    case 4: PCR_FTRACK(4); break;
+    default: PCR_FTRACK(2); break;
+    }
+#undef PCR_FTRACK
+}
+
 template <bool FILTER, bool SGPR>
 static void launch_qpl(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t ns,
                        uint32_t n_tiles, uint32_t tps, int merge_atomic)
@@ -347,17 +459,17 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
 
     int qpl = (int)tune_get(ctx, "nn1_qpl", 2);
     if (qpl != 1 && qpl != 4) qpl = 2;
-    // variant: 2 = TRACK, targets through the scalar cache (default: fastest measured, profiles/r01_tune_nn1.txt);
-    //          0 (set as -8) = TRACK, targets through LDS tiles; 4 = RESOLVE exact (LDS), 5 = RESOLVE + fused
+    // variant: 2 = TRACK, targets through the scalar cache; 1 = FTRACK (fused filter tracking + exact decision, scalar
+    //          cache); 0 (set as -8) = TRACK, targets through LDS tiles; 4 = RESOLVE exact (LDS), 5 = RESOLVE + fused
     //          filter, 6/7 = the same with scalar-load targets
-    const int variant = (int)tune_get(ctx, "nn1_variant", 2) & 7;
+    const int variant = (int)tune_get(ctx, "nn1_variant", 1) & 7;   // default FTRACK: fastest measured (profiles/r01_tune_nn1_ftrack.txt)
     const int chunk = (int)tune_get(ctx, "nn1_chunk", 16);
     const uint32_t n_tiles = (uint32_t)((tgt->n + NN_TILE - 1) / NN_TILE);
     const uint32_t qblocks = (uint32_t)((ns + (size_t)NN_BLOCK * qpl - 1) / ((size_t)NN_BLOCK * qpl));
     // enough workgroups to balance 256 CUs x 8 resident blocks over several rounds
     int64_t tps = tune_get(ctx, "nn1_tiles_per_slice", 0);
     if (tps <= 0) {
-        const int64_t want_blocks = tune_get(ctx, "nn1_target_blocks", 8192);
+        const int64_t want_blocks = tune_get(ctx, "nn1_target_blocks", 16384);
         int64_t slices = (want_blocks + qblocks - 1) / qblocks;
         if (slices < 1) slices = 1;
         tps = n_tiles ? (n_tiles + slices - 1) / slices : 1;
@@ -376,7 +488,11 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
         case 5: launch_qpl<true, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
         case 6: launch_qpl<false, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
         case 7: launch_qpl<true, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
-        case 2: case 3:
+        case 1: case 3:
+            if (chunk == 16) launch_ftrack<16>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
+            else launch_ftrack<8>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
+            break;
+        case 2:
             if (chunk == 16) launch_track<16, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
             else launch_track<8, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
             break;

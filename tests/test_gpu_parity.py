@@ -41,9 +41,9 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
     cs.free(); ct.free()
 
 
-# variant 0: branch-free TRACK kernel (default); 2: same with scalar-load targets; 4..7: RESOLVE kernels
+# variant 0: branch-free TRACK kernel (LDS); 2: same with scalar-load targets; 1: FTRACK (fused-filter tracking); 4..7: RESOLVE kernels
 # (4 exact, 5 fused filter, 6/7 the same with scalar-load targets); chunk = targets per min-tree
-VARIANTS = [(0, 8), (0, 16), (2, 8), (2, 16), (4, 8), (5, 8), (6, 8), (7, 8)]
+VARIANTS = [(0, 8), (0, 16), (1, 8), (1, 16), (2, 8), (2, 16), (4, 8), (5, 8), (6, 8), (7, 8)]
 
 
 def set_variant(ctx, vc):

@@ -11,11 +11,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 src, tgt = synth.kitti_like_pair(n)
 ctx = pcr.Context(0)
+ctx.tune("nn_method", 1)
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
 configs = []
-for var in ((0, 8), (0, 16), (2, 8), (2, 16), (4, 8)):
+for var in ((1, 8), (1, 16), (2, 8), (2, 16)):
     for qpl in (1, 2, 4):
-        for tps in (2, 4, 8, 15, 30):
+        for tps in (2, 4, 8):
             configs.append((var, qpl, tps))
 res = {c: [] for c in configs}
 def setcfg(c):
