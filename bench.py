@@ -93,17 +93,27 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # one rank per GPU (the driver's launch); PCR_BENCH_BACKEND=gloo lets several ranks REHEARSE the multi-rank code
+    # path on a box with fewer GPUs (ranks then share devices and the collective runs over gloo / torch.distributed)
+    backend = os.environ.get("PCR_BENCH_BACKEND", "nccl")
+    n_dev = max(torch.cuda.device_count(), 1)
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"{world} ranks but {n_dev} GPU(s): RCCL needs one GPU per rank (PCR_BENCH_BACKEND=gloo rehearses)")
+    device_index = local_rank % n_dev
     dist = None
+    torch.cuda.set_device(device_index)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
+            if args.collective == "rccl":
+                args.collective = "torch"
 
     n = args.points
     src, tgt = synth.kitti_like_pair(n, n_src=n, shard=rank)
-    ctx = pcr.Context(local_rank)
+    ctx = pcr.Context(device_index)
     if args.qpl:
         ctx.tune("nn1_qpl", args.qpl)
     if args.tiles_per_slice:
@@ -125,9 +135,12 @@ def main():
                 collective = "torch"
         if collective == "torch":
             def allreduce(arr):
-                t = torch.from_numpy(arr.copy()).cuda()
-                dist.all_reduce(t)
-                arr[:] = t.cpu().numpy()
+                if backend == "nccl":
+                    t = torch.from_numpy(arr.copy()).cuda()
+                    dist.all_reduce(t)
+                    arr[:] = t.cpu().numpy()
+                else:
+                    dist.all_reduce(torch.from_numpy(arr))      # in place on the host buffer
             ctx.comm_init_callback(world, rank, allreduce)
 
     def barrier():
@@ -148,7 +161,7 @@ def main():
         dt = time.perf_counter() - t0
         assert st["iters_run"] == args.steps, st
         if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return T, st, dt

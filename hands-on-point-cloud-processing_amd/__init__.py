@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "pcr_cloud_create", "pcr_cloud_clone", "pcr_cloud_assign", "pcr_cloud_read", "pcr_cloud_size", "pcr_cloud_destroy",
     "pcr_nn1_f32", "pcr_nn1_f32_async", "pcr_nn1_fetch", "pcr_transform_f32", "pcr_kabsch_sums", "pcr_kabsch_solve",
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
-    "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_shard_range",
+    "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
     "pcr_grid_stats", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
@@ -97,6 +97,7 @@ def lib():
     L.pcr_comm_init_rccl.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pcr_comm_init_callback.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp]
     L.pcr_comm_destroy.argtypes = [vp]
+    L.pcr_comm_selftest.argtypes = [vp]
     L.pcr_shard_range.restype = None
     L.pcr_shard_range.argtypes = [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]
     L.pcr_prof_reset.argtypes = [vp]
@@ -349,6 +350,9 @@ class Context:
                 return 1
         self._cb_keepalive = ALLREDUCE_FN(_cb)
         self._ck(lib().pcr_comm_init_callback(self.h, nranks, rank, self._cb_keepalive, None))
+
+    def comm_selftest(self):
+        self._ck(lib().pcr_comm_selftest(self.h))
 
     def comm_destroy(self):
         lib().pcr_comm_destroy(self.h)

@@ -143,6 +143,30 @@ int pcr_comm_init_callback(pcr_ctx* ctx, int nranks, int rank, pcr_allreduce_fn 
     return PCR_OK;
 }
 
+// Runs one real ncclAllReduce(sum, f64) of 8 values on the attached RCCL communicator (also with nranks == 1, where
+// the loop itself skips the collective) and checks the result: exercises the dlopen'ed ABI end to end.
+int pcr_comm_selftest(pcr_ctx* ctx)
+{
+    if (!ctx) return PCR_ERR_ARG;
+    Comm& c = ctx->comm;
+    if (!c.rccl) return fail(ctx, PCR_ERR_STATE, "pcr_comm_selftest: no RCCL communicator attached");
+    Rccl& r = rccl();
+    double h[8];
+    for (int k = 0; k < 8; k++) h[k] = (double)(k + 1) * (c.rank + 1);
+    PCR_HIP(ctx, hipMemcpyAsync(ctx->dev_out, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    int rc = r.AllReduce(ctx->dev_out, ctx->dev_out, 8, kNcclFloat64, kNcclSum, c.rccl, ctx->stream);
+    if (rc != 0) {
+        ctx->err = std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
+        return PCR_ERR_COMM;
+    }
+    PCR_HIP(ctx, hipMemcpyAsync(h, ctx->dev_out, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double tri = (double)c.nranks * (c.nranks + 1) / 2.0;   // sum over ranks of (rank + 1)
+    for (int k = 0; k < 8; k++)
+        if (h[k] != (double)(k + 1) * tri) return fail(ctx, PCR_ERR_COMM, "pcr_comm_selftest: wrong all-reduce result");
+    return PCR_OK;
+}
+
 int pcr_comm_destroy(pcr_ctx* ctx)
 {
     if (!ctx) return PCR_ERR_ARG;

@@ -156,6 +156,8 @@ int pcr_comm_init_rccl(pcr_ctx* ctx, int nranks, int rank, const char id[PCR_COM
 typedef int (*pcr_allreduce_fn)(void* user, double* buf, int n);
 int pcr_comm_init_callback(pcr_ctx* ctx, int nranks, int rank, pcr_allreduce_fn fn, void* user);
 int pcr_comm_destroy(pcr_ctx* ctx);
+/* one real ncclAllReduce on the attached RCCL communicator (any nranks, also 1), result checked */
+int pcr_comm_selftest(pcr_ctx* ctx);
 /* contiguous shard [begin, end) of n items for `rank` of `nranks` (sizes differ by at most one) */
 void pcr_shard_range(size_t n, int nranks, int rank, size_t* begin, size_t* end);
 

@@ -42,3 +42,27 @@ def test_sharded_kabsch_protocol_world3_gloo():
 def test_sharded_icp_two_ranks_one_gpu():
     out = run_workers("gpu", 2)
     assert out.count("gpu sharded icp ok") == 2
+
+
+@pytest.mark.gpu
+def test_native_rccl_communicator_single_rank(pcr, synth):
+    """RCCL is bound with dlopen (ncclGetUniqueId / ncclCommInitRank with a by-value 128-byte id / ncclAllReduce):
+    a one-rank communicator exercises that ABI end to end, and ICP runs unchanged with it attached."""
+    import numpy as np
+    ctx = pcr.Context(0)
+    try:
+        uid = pcr.comm_unique_id()
+        assert len(uid) == 128
+        ctx.comm_init_rccl(1, 0, uid)
+        ctx.comm_selftest()
+        src, tgt = synth.kitti_like_pair(5000, seed_target=91, seed_pair=92)
+        cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+        T1, st1 = ctx.icp_point2point(cs, ct, max_iter=6)
+        ctx.tune("icp_force_slots", 1)          # the multi-rank kernel path (reduce slots -> all-reduce -> update)
+        T2, st2 = ctx.icp_point2point(cs, ct, max_iter=6)
+        ctx.tune("icp_force_slots", 0)
+        ctx.comm_destroy()
+        T3, st3 = ctx.icp_point2point(cs, ct, max_iter=6)
+        assert np.array_equal(T1, T2) and np.array_equal(T1, T3) and st1["last_pairs"] == st2["last_pairs"] == st3["last_pairs"]
+    finally:
+        ctx.close()

@@ -1,3 +1,3 @@
 set -o pipefail
 mkdir -p gpurun_out
-( timeout -k 10 300 python tools/tune_nn1.py 120000 5 2>&1 | tee gpurun_out/tune3.txt | head -20 )
+( timeout -k 10 300 python -m pytest tests/test_multirank.py -m gpu -q -x -rs > gpurun_out/pytest_mr.log 2>&1; rc=$?; echo "pytest mr rc=$rc"; tail -15 gpurun_out/pytest_mr.log; [ $rc -le 1 ] )
