@@ -253,7 +253,8 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     const float4* __restrict__ records, const uint32_t* __restrict__ cell_start,
     GridParams g, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     const uint32_t* __restrict__ perm, uint32_t ns, unsigned long long* __restrict__ keys, const int* __restrict__ stop,
-    unsigned long long* __restrict__ stats)
+    unsigned long long* __restrict__ stats, const float* __restrict__ tx, const float* __restrict__ ty,
+    const float* __restrict__ tz, uint32_t nt, int warm_start)
 {
     if (stop && (stop[0] | stop[1])) return;      // pipelined ICP: the loop has ended, the enqueued tail is a no-op
     unsigned long long st_cand = 0, st_rows = 0, st_stages = 0;   // diagnostics (STATS builds only)
@@ -264,6 +265,17 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     const float qx = sx[i], qy = sy[i], qz = sz[i];
     unsigned long long best = KEY_NONE;
     if (finite3(qx, qy, qz)) {
+        if (warm_start) {
+            // ICP: keys[] still holds this query's correspondence of the previous iteration.  That target, evaluated
+            // exactly against the moved query, is a genuine candidate: it bounds the search from the first stage on
+            // (the radius jumps straight to the proving one, rows are clipped to its ball) without changing the result.
+            const uint32_t pj = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+            if (pj < nt) {
+                const float dx = qx - tx[pj], dy = qy - ty[pj], dz = qz - tz[pj];
+                const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                if (d < 0x7F7FFFFFu) best = ((unsigned long long)d << 32) | pj;
+            }
+        }
         const int ux = cell_coord(qx, g.lo[0], g.inv_h), uy = cell_coord(qy, g.lo[1], g.inv_h), uz = cell_coord(qz, g.lo[2], g.inv_h);
         // Chebyshev distance (in cells) from the query's cell to the grid box: smaller cubes hold no cell
         const int r0 = max(max(max(-ux, ux - (g.n[0] - 1)), max(-uy, uy - (g.n[1] - 1))), max(max(-uz, uz - (g.n[2] - 1)), 0));
@@ -610,16 +622,19 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
         stats_dev = ctx->grid_stats_dev;
     }
+    // warm start: only inside an ICP loop (reuse_perm), from its second search on, when keys[] belongs to this source
+    const int warm = (reuse_perm && have_perm && ctx->keys_warm && tune_get(ctx, "grid_warm_start", 1) > 0) ? 1 : 0;
+    ctx->keys_warm = reuse_perm;
     const int G = (int)tune_get(ctx, "grid_lanes", 16);   // measured: profiles/r01_tune_grid.txt
     {
         ProfScope p(ctx, "nn1_grid", 1);
 #define PCR_GRID(GG)                                                                                                   \
     if (stats_dev)                                                                                                     \
         hipLaunchKernelGGL((nn1_grid_kernel<GG, true>), dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0,  \
-                           ctx->stream, g->records, g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev); \
+                           ctx->stream, g->records, g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(), tgt->y(), tgt->z(), (uint32_t)tgt->n, warm); \
     else                                                                                                               \
         hipLaunchKernelGGL((nn1_grid_kernel<GG, false>), dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0,  \
-                       ctx->stream, g->records, g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev)
+                       ctx->stream, g->records, g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(), tgt->y(), tgt->z(), (uint32_t)tgt->n, warm)
         switch (G) {
         case 1: PCR_GRID(1); break;
         case 2: PCR_GRID(2); break;

@@ -456,6 +456,7 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
     int rc = ensure_keys(ctx, ns);
     if (rc) return rc;
     ctx->keys_n = ns;
+    ctx->keys_warm = false;
 
     int qpl = (int)tune_get(ctx, "nn1_qpl", 2);
     if (qpl != 1 && qpl != 4) qpl = 2;

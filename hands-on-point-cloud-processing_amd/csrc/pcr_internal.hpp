@@ -75,6 +75,7 @@ struct pcr_ctx {
     unsigned long long* keys = nullptr;   // (d2_bits << 32 | idx) per query of the last nn1 pass
     size_t keys_cap = 0;
     size_t keys_n = 0;
+    bool keys_warm = false;               // keys[] holds the previous ICP iteration's result for the same source cloud
     uint32_t* qperm = nullptr;            // queries grouped by target-grid cell (grid NN)
     size_t qperm_cap = 0;
     size_t qperm_n = 0;
