@@ -136,3 +136,45 @@ def test_reference_drivers_run_on_the_gpu_path(tmp_path, golden):
     nn = [int(l.split("=")[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("ret_index[")]
     mine = [int(l.split("Index = ")[1]) for l in r.stdout.splitlines() if l.startswith("Distance = ")]
     assert len(nn) == 8 and sorted(nn) == sorted(mine)
+
+
+def _build_driver(tmp_path):
+    exe = tmp_path / "hw9_registration_driver"
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-I" + INC, os.path.join(ROOT, "examples", "hw9_registration_driver.cpp"),
+                        "-o", str(exe)] + LINK, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_hw9_driver_compiles(tmp_path):
+    need_lib()
+    _build_driver(tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fpp", [4, 6])
+def test_hw9_driver_pose_csv_matches_oracle(tmp_path, orc, synth, fpp):
+    """examples/hw9_registration_driver.cpp = Homework9/hw9/main.cpp's doRegistration / CSV row on the GPU path
+    (H4 of SURVEY.md 8a): pose as t(3) + quaternion(w, x, y, z) (main.cpp:121-122,152)."""
+    need_lib()
+    exe = _build_driver(tmp_path)
+    src, tgt = synth.kitti_like_pair(5000, seed_target=111, seed_pair=112)
+    for name, a in (("src.bin", src), ("tgt.bin", tgt)):
+        rows = np.concatenate([a.T, np.zeros((a.shape[1], fpp - 3), np.float32)], axis=1)
+        rows.astype(np.float32).tofile(tmp_path / name)
+    r = subprocess.run([str(exe), str(tmp_path / "src.bin"), str(tmp_path / "tgt.bin"), str(fpp), "7", "3", "25"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "idx1,idx2,t_x,t_y,t_z,q_w,q_x,q_y,q_z"
+    f = lines[1].split(",")
+    assert f[0] == "3" and f[1] == "7"
+    t = np.array([float(v) for v in f[2:5]]); q = np.array([float(v) for v in f[5:9]])
+    T, st = orc.icp_p2p_f32(src, tgt, max_corr=1.0, max_iter=25, eps=1e-8)
+    assert np.allclose(t, T[:3, 3], atol=1e-5)
+    w, x, y, z = q
+    Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    assert abs(np.linalg.norm(q) - 1) < 1e-5 and w > 0
+    assert np.allclose(Rq, T[:3, :3], atol=2e-5)
