@@ -126,12 +126,40 @@ def main():
     if world > 1:
         collective = args.collective
         if collective == "rccl":
-            try:
-                uid = [pcr.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                ctx.comm_init_rccl(world, rank, uid[0])
-            except Exception as e:   # noqa: BLE001 — a different (slower) transport for the same collective
-                print(f"[rank {rank}] native RCCL communicator failed ({e}); using torch.distributed", file=sys.stderr)
+            # native transport: the library's own RCCL communicator (one ncclAllReduce of <= 32 f64 per iteration, enqueued
+            # on the context stream).  Every step below is collective-safe: rank 0 ALWAYS broadcasts (the id or None),
+            # and the ranks agree on the outcome before anybody uses the communicator.
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [pcr.comm_unique_id()]
+                except Exception as e:   # noqa: BLE001
+                    print(f"[rank 0] pcr_comm_unique_id failed: {e}", file=sys.stderr)
+            dist.broadcast_object_list(uid, src=0)
+            def all_agree(ok):
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag.item()) == 1
+
+            ok = False
+            if uid[0] is not None:
+                try:
+                    ctx.comm_init_rccl(world, rank, uid[0])     # collective rendezvous
+                    ok = True
+                except Exception as e:   # noqa: BLE001
+                    print(f"[rank {rank}] native RCCL communicator failed: {e}", file=sys.stderr)
+            if all_agree(ok):
+                try:
+                    ctx.comm_selftest()                          # one real ncclAllReduce, result checked
+                except Exception as e:   # noqa: BLE001
+                    ok = False
+                    print(f"[rank {rank}] RCCL self-test failed: {e}", file=sys.stderr)
+                ok = all_agree(ok)
+            else:
+                ok = False
+            if not ok:
+                # same collective over a different (slower) transport — never a different computation
+                ctx.comm_destroy()
                 collective = "torch"
         if collective == "torch":
             def allreduce(arr):
