@@ -16,7 +16,7 @@
 
 #include "registration.hpp"
 
-// file layout: registration.cpp:25-26 (6 floats) or test.hpp:26-28 (4 floats); returns xyz? records (16 B, PCR_AOS4)
+// file layout: registration.cpp:25-26 (6 floats) or test.hpp:26-28 (4 floats); returns the rows unchanged
 static std::vector<float> read_cloud(const std::string& path, int floats_per_point)
 {
     std::ifstream in(path, std::ios::binary);
@@ -26,11 +26,8 @@ static std::vector<float> read_cloud(const std::string& path, int floats_per_poi
     in.seekg(0, std::ios::beg);
     std::vector<float> raw(bytes / sizeof(float));
     in.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)(raw.size() * sizeof(float)));
-    const size_t n = raw.size() / (size_t)floats_per_point;
-    std::vector<float> pts(4 * n, 1.0f);
-    for (size_t i = 0; i < n; i++)
-        for (int c = 0; c < 3; c++) pts[4 * i + c] = raw[i * (size_t)floats_per_point + c];
-    return pts;
+    raw.resize(raw.size() / (size_t)floats_per_point * (size_t)floats_per_point);
+    return raw;      // handed to the library as is: PCR_AOS4 / PCR_AOS6 rows
 }
 
 // Eigen::Quaternionf(R) (main.cpp:121): the standard trace-based conversion, w >= 0 branch first
@@ -73,7 +70,7 @@ int main(int argc, char** argv)
     pcr::IcpPoint2Point reg;
     reg.setICPparams(10, 4000, 1.0f, max_iter, 1e-8f);              // main.cpp:88-95
     float R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, t[3] = { 0, 0, 0 };
-    const int rc = reg.run(src.data(), src.size() / 4, tgt.data(), tgt.size() / 4, PCR_AOS4, R, t);
+    const int rc = reg.run(src.data(), src.size() / (size_t)fpp, tgt.data(), tgt.size() / (size_t)fpp, fpp == 4 ? PCR_AOS4 : PCR_AOS6, R, t);
     if (rc != PCR_OK) { std::cerr << "ICP failed, rc = " << rc << std::endl; return 1; }
     float q[4];
     quaternion_from_R(R, q);

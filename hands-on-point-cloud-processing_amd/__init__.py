@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PCR_LIB_PATH") or os.path.join(_HERE, "libpcr_hip.so")   # override: A/B builds of the same ABI
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
-PCR_SOA, PCR_AOS3, PCR_AOS4 = 0, 1, 2
+PCR_SOA, PCR_AOS3, PCR_AOS4, PCR_AOS6 = 0, 1, 2, 6
 ERRORS = {0: "ok", -1: "bad argument", -2: "HIP error", -3: "out of memory", -4: "bad state",
           -5: "RCCL/collective error", -6: "no correspondence kept"}
 
@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
+    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
 
@@ -104,6 +104,7 @@ def lib():
     L.pcr_prof_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.pcr_tune_set.argtypes = [vp, C.c_char_p, C.c_int64]
     L.pcr_grid_stats.argtypes = [vp, vp]
+    L.pcr_voxel_filter_f32.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
     _lib = L
     return L
 
@@ -189,6 +190,15 @@ class Db64:
             self.h = None
 
 
+def read_kitti_bin(path: str, floats_per_point: int = 4) -> np.ndarray:
+    """A velodyne .bin as the reference reads it: N x 4 f32 rows x, y, z, intensity (read_velodyne_bin,
+    Homework4/ground_detection_ransac.py:23-34; Homework2/hw2/include/test.hpp:26-28 without its EOF duplicate) or the hw9
+    registration format N x 6 f32 xyz + normal (Homework9/hw9/src/registration.cpp:25-26).  Returns the (n, k) f32 rows;
+    pass them to Context.cloud(rows, PCR_AOS4 / PCR_AOS6)."""
+    a = np.fromfile(path, dtype=np.float32)
+    return a[: a.size // floats_per_point * floats_per_point].reshape(-1, floats_per_point)
+
+
 class Context:
     """One GPU, one HIP stream, one workspace (pcr_ctx)."""
 
@@ -238,7 +248,7 @@ class Context:
 
     # ---- clouds
     def cloud(self, xyz: np.ndarray, layout: int = PCR_SOA) -> Cloud:
-        """SOA: (3, n) f32; AOS3: (n, 3); AOS4: (n, 4)."""
+        """SOA: (3, n) f32; AOS3: (n, 3); AOS4: (n, 4) (KITTI .bin rows, pcl::PointXYZ); AOS6: (n, 6) (hw9 xyz + normal rows)."""
         a = np.ascontiguousarray(xyz, np.float32)
         n = a.shape[1] if layout == PCR_SOA else a.shape[0]
         if a.size == 0:
@@ -263,6 +273,13 @@ class Context:
         d2 = np.empty(n, np.float32)
         self._ck(lib().pcr_nn1_fetch(self.h, n, idx.ctypes.data, d2.ctypes.data))
         return idx, d2
+
+    # ---- N3
+    def voxel_filter(self, cloud: Cloud, leaf_size: float) -> Cloud:
+        """Homework1 voxel_filter(point_cloud, leaf_size) (centroid mode) -> new device cloud."""
+        h = C.c_void_p()
+        self._ck(lib().pcr_voxel_filter_f32(self.h, cloud.h, float(leaf_size), C.byref(h)))
+        return Cloud(self, h)
 
     # ---- A8 / A7
     def transform(self, cloud: Cloud, T):

@@ -201,7 +201,8 @@ int pcr_ctx_device_info(const pcr_ctx* ctx, char* arch, size_t arch_cap, int* n_
 // ---------------------------------------------------------------------------------------------- clouds
 int pcr_cloud_create(pcr_ctx* ctx, const float* host_xyz, size_t n, int layout, pcr_cloud** out)
 {
-    if (!ctx || !out || (n && !host_xyz) || layout < PCR_SOA || layout > PCR_AOS4) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_create");
+    if (!ctx || !out || (n && !host_xyz) || !(layout == PCR_SOA || layout == PCR_AOS3 || layout == PCR_AOS4 || layout == PCR_AOS6))
+        return fail(ctx, PCR_ERR_ARG, "pcr_cloud_create");
     PCR_HIP(ctx, hipSetDevice(ctx->device));
     pcr_cloud* c = nullptr;
     int rc = cloud_alloc(ctx, n, &c);
@@ -217,7 +218,7 @@ int pcr_cloud_create(pcr_ctx* ctx, const float* host_xyz, size_t n, int layout, 
         memcpy(sy, host_xyz + n, n * sizeof(float));
         memcpy(sz, host_xyz + 2 * n, n * sizeof(float));
     } else {
-        const size_t stride = layout == PCR_AOS3 ? 3 : 4;
+        const size_t stride = layout == PCR_AOS3 ? 3 : (layout == PCR_AOS4 ? 4 : 6);
         for (size_t i = 0; i < n; i++) {
             sx[i] = host_xyz[i * stride];
             sy[i] = host_xyz[i * stride + 1];
@@ -254,7 +255,8 @@ int pcr_cloud_assign(pcr_ctx* ctx, pcr_cloud* dst, const pcr_cloud* src)
 
 int pcr_cloud_read(pcr_ctx* ctx, const pcr_cloud* c, float* host_xyz, int layout)
 {
-    if (!ctx || !c || (c->n && !host_xyz) || layout < PCR_SOA || layout > PCR_AOS4) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_read");
+    if (!ctx || !c || (c->n && !host_xyz) || !(layout == PCR_SOA || layout == PCR_AOS3 || layout == PCR_AOS4 || layout == PCR_AOS6))
+        return fail(ctx, PCR_ERR_ARG, "pcr_cloud_read");
     const size_t n = c->n;
     if (n == 0) return PCR_OK;
     int rc = ensure_stage(ctx, 3 * c->cap * sizeof(float));
@@ -268,7 +270,7 @@ int pcr_cloud_read(pcr_ctx* ctx, const pcr_cloud* c, float* host_xyz, int layout
         memcpy(host_xyz + n, sy, n * sizeof(float));
         memcpy(host_xyz + 2 * n, sz, n * sizeof(float));
     } else {
-        const size_t stride = layout == PCR_AOS3 ? 3 : 4;
+        const size_t stride = layout == PCR_AOS3 ? 3 : (layout == PCR_AOS4 ? 4 : 6);
         for (size_t i = 0; i < n; i++) {
             host_xyz[i * stride] = sx[i];
             host_xyz[i * stride + 1] = sy[i];

@@ -40,7 +40,8 @@ typedef struct pcr_cloud pcr_cloud;   /* an N-point f32 cloud resident in HBM as
 enum pcr_layout {
     PCR_SOA = 0,   /* x[n], y[n], z[n] contiguous — Eigen column-major N x 3 MatrixXf (registration.cpp:903) */
     PCR_AOS3 = 1,  /* xyzxyz...        — KITTI rows without intensity */
-    PCR_AOS4 = 2   /* xyz?xyz?...      — pcl::PointXYZ (16 B) and KITTI .bin rows (test.hpp:26-28) */
+    PCR_AOS4 = 2,  /* xyz?xyz?...      — pcl::PointXYZ (16 B) and KITTI .bin rows (test.hpp:26-28) */
+    PCR_AOS6 = 6   /* xyz???xyz???...  — hw9 registration .bin rows: xyz + normal (registration.cpp:25-26) */
 };
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -145,6 +146,12 @@ int pcr_db64_knn(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, in
                  int32_t* idx, double* dist);
 int pcr_db64_radius(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, double r,
                     int64_t* row_ptr, int32_t* idx, double* dist);
+
+/* ---- next row N3: voxel-grid down-sampling, Homework1 voxel_filter.py:17-52 (centroid mode) -----------------
+ * One centroid per occupied voxel of edge leaf_size, in ascending voxel-index order; f32 arithmetic and summation
+ * order of the reference (bit-exact), including its quirk that the last voxel of the sorted order is never emitted
+ * (:41-50).  The result is a new device cloud (feed it to pcr_icp_p2p_f32 without leaving HBM). */
+int pcr_voxel_filter_f32(pcr_ctx* ctx, const pcr_cloud* in, double leaf_size, pcr_cloud** out);
 
 /* ---- multi-GPU: one process per GPU, sources sharded, targets replicated ------------------------------
  * Exactly one collective per ICP iteration: all-reduce(sum) of 16 f64 (+2 bookkeeping words). */

@@ -67,6 +67,8 @@ def lib():
         L.orc_plane_count_f64pts.argtypes = [f64p, f64p, f64p, sz, f64p, sz, C.c_double, i64p]
         L.orc_plane_mask_f32pts.argtypes = [f32p, f32p, f32p, sz, f64p, C.c_double, u8p]
         L.orc_plane_from_3pts.argtypes = [f64p, f64p]
+        L.orc_voxel_filter_f32.restype = sz
+        L.orc_voxel_filter_f32.argtypes = [f32p, f32p, f32p, sz, C.c_double, f32p, f32p, f32p]
         L.orc_hw2_knn_add.argtypes = [f64p, i32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                       C.c_double, C.c_int]
         L.orc_nano_knn_add.argtypes = [f32p, u64p, sz, C.POINTER(sz), C.c_float, sz]
@@ -235,6 +237,14 @@ def plane_from_3pts(p):
     out = np.zeros(4)
     lib().orc_plane_from_3pts(np.ascontiguousarray(p, np.float64).reshape(9), out)
     return out
+
+
+def voxel_filter_f32(soa, leaf_size):
+    """Homework1 voxel_filter (centroid mode) -> (3, m) f32."""
+    x, y, z = _soa(soa)
+    ox, oy, oz = np.empty_like(x), np.empty_like(y), np.empty_like(z)
+    m = lib().orc_voxel_filter_f32(x, y, z, x.size, float(leaf_size), ox, oy, oz)
+    return np.stack([ox[:m], oy[:m], oz[:m]])
 
 
 # ----------------------------------------------------------------------------- reference harness

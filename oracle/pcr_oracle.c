@@ -468,3 +468,51 @@ void orc_plane_from_3pts(const double p[9], double params[4])
     double n = sqrt(a * a + b * b + c * c);
     params[0] = a / n; params[1] = b / n; params[2] = c / n; params[3] = d / n;
 }
+
+/* ------------------------------------------------------------------ N3 */
+typedef struct { long long h; size_t i; } orc_hi;
+
+static int orc_hi_cmp(const void* a, const void* b)
+{
+    const orc_hi* p = (const orc_hi*)a; const orc_hi* q = (const orc_hi*)b;
+    if (p->h != q->h) return p->h < q->h ? -1 : 1;
+    return p->i < q->i ? -1 : (p->i > q->i ? 1 : 0);      /* list.sort is stable: ascending index inside a voxel */
+}
+
+size_t orc_voxel_filter_f32(const float* x, const float* y, const float* z, size_t n, double leaf_size,
+                            float* ox, float* oy, float* oz)
+{
+    if (n == 0) return 0;
+    float x_max = x[0], y_max = y[0], x_min = x[0], y_min = y[0], z_min = z[0];      /* voxel_filter.py:22-26 */
+    for (size_t i = 1; i < n; i++) {
+        if (x[i] > x_max) x_max = x[i];
+        if (y[i] > y_max) y_max = y[i];
+        if (x[i] < x_min) x_min = x[i];
+        if (y[i] < y_min) y_min = y[i];
+        if (z[i] < z_min) z_min = z[i];
+    }
+    const long long Dx = (long long)ceil((double)(float)(x_max - x_min) / leaf_size);   /* :28 */
+    const long long Dy = (long long)ceil((double)(float)(y_max - y_min) / leaf_size);   /* :29 */
+    orc_hi* hl = (orc_hi*)malloc(sizeof(orc_hi) * n);
+    for (size_t i = 0; i < n; i++) {                                                     /* :32-36 */
+        const long long hx = (long long)floor((double)(float)(x[i] - x_min) / leaf_size);
+        const long long hy = (long long)floor((double)(float)(y[i] - y_min) / leaf_size);
+        const long long hz = (long long)floor((double)(float)(z[i] - z_min) / leaf_size);
+        hl[i].h = hx + hy * Dx + hz * Dx * Dy;
+        hl[i].i = i;
+    }
+    qsort(hl, n, sizeof(orc_hi), orc_hi_cmp);                                            /* :37 */
+    size_t out = 0, start = 0;
+    for (size_t k = 1; k <= n; k++) {
+        if (k < n && hl[k].h == hl[start].h) continue;
+        if (k == n) break;                            /* :41-50: the last group is never flushed */
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (size_t t = start; t < k; t++) { sx += x[hl[t].i]; sy += y[hl[t].i]; sz += z[hl[t].i]; }
+        const float cnt = (float)(k - start);
+        ox[out] = sx / cnt; oy[out] = sy / cnt; oz[out] = sz / cnt;
+        out++;
+        start = k;
+    }
+    free(hl);
+    return out;
+}

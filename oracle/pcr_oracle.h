@@ -137,6 +137,14 @@ void orc_plane_mask_f32pts(const float* x, const float* y, const float* z, size_
 /* ---- estimate_plane_params (ground_detection_ransac.py:158-169) in f64. p: 3 points x 3, row-major. */
 void orc_plane_from_3pts(const double p[9], double params[4]);
 
+/* ---- N3: voxel_filter, centroid mode (Homework1 voxel_filter.py:17-52) on an n x 3 f32 cloud (SoA), leaf as f64
+ * (a strong np.float64, i.e. the numpy-1.x promotion the author ran: f32 subtraction, f64 division).
+ * Quirk kept: a voxel is emitted when the NEXT voxel starts (:43-50), so the last voxel of the sorted order is never
+ * emitted.  Centroid = sequential f32 sum in ascending point index / count (np.sum over axis 0 of f32 rows).
+ * out: up to n points (SoA, f32 values as the reference stores them before the f64 cast); returns the count. */
+size_t orc_voxel_filter_f32(const float* x, const float* y, const float* z, size_t n, double leaf_size,
+                            float* ox, float* oy, float* oz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ Fixtures:
   F5 plane_hw4.npz           Homework4 plane-inlier counts + masks (numpy expression of
                              ground_detection_ransac.py:138-139,152-153; params from the reference's own
                              estimate_plane_params, :158-169, executed from its source)
+  F7 voxel_filter_hw1.npz    Homework1 voxel_filter (centroid mode) outputs on a KITTI subset and a synthetic scan
   F6 icp_selfgolden.npz      ICP trace from the repo's own f64 restatement (SELF-GOLDEN: hw9 cannot be
                              built here — PCL/Eigen absent — so this pins regression, not reference parity)
 """
@@ -154,7 +155,8 @@ def load_reference_function(pyfile, fname):
     open3d/bottleneck/mylib, which are absent; the function itself is pure numpy/math)."""
     tree = ast.parse(open(pyfile).read())
     fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == fname][0]
-    ns = {"np": np, "math": math}
+    import random
+    ns = {"np": np, "math": math, "random": random}
     exec(compile(ast.Module(body=[fn], type_ignores=[]), pyfile, "exec"), ns)
     return ns[fname]
 
@@ -194,7 +196,29 @@ def f6():
          last_loss=np.float32(st["last_loss"]))
 
 
+# ------------------------------------------------------------------ F7 (next row N3)
+def f7():
+    """Homework1 voxel_filter.py:17-52 (centroid mode), executed from the reference source (the module imports open3d /
+    pandas / pyntcloud, absent here; the function is pure numpy + math).  leaf_size is passed as np.float64 so that the
+    division promotes to f64 as under the author's numpy 1.18 (NumPy 2 would keep a Python float weak -> f32)."""
+    import contextlib, io
+    pyfile = f"{REF}/Homework1/YuF_KIT-第1章作业/voxel_filter.py"
+    voxel_filter = load_reference_function(pyfile, "voxel_filter")
+    raw = read_kitti_bin(f"{REF}/Homework2/hw2/000000.bin")
+    cases = {"kitti": raw[:: raw.shape[0] // 6000][:6000], "synth": np.ascontiguousarray(synth.kitti_like_scan(5000).T)}
+    out = {}
+    for name, pts in cases.items():
+        for leaf in (0.5, 2.0):
+            with contextlib.redirect_stdout(io.StringIO()):
+                f = voxel_filter(pts.astype(np.float32), np.float64(leaf))
+            tag = f"{name}_leaf{str(leaf).replace('.', 'p')}"
+            out[f"in_{name}"] = pts.astype(np.float32)
+            out[f"out_{tag}"] = f                       # float64 array of f32-valued centroids
+            assert np.array_equal(f, f.astype(np.float32).astype(np.float64))
+    save("voxel_filter_hw1.npz", **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not present"
     orc.build(ref=True)
-    f1(); f2_f3_f4(); f5(); f6()
+    f1(); f2_f3_f4(); f5(); f6(); f7()

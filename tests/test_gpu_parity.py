@@ -250,7 +250,8 @@ def test_cloud_layouts_roundtrip(ctx, pcr, synth):
     assert np.array_equal(c.numpy(), src)
     aos3 = np.ascontiguousarray(src.T)
     aos4 = np.concatenate([aos3, np.ones((1234, 1), np.float32)], axis=1)
-    for arr, lay in ((aos3, pcr.PCR_AOS3), (aos4, pcr.PCR_AOS4)):
+    aos6 = np.concatenate([aos3, np.full((1234, 3), 0.5, np.float32)], axis=1)
+    for arr, lay in ((aos3, pcr.PCR_AOS3), (aos4, pcr.PCR_AOS4), (aos6, pcr.PCR_AOS6)):
         c2 = ctx.cloud(arr, lay)
         assert np.array_equal(c2.numpy(), src)
         c2.free()
