@@ -70,7 +70,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=120000, help="source points per GPU and target points")
+    ap.add_argument("--points", type=int, default=0, help="target points (and source points per GPU for c2); 0 = workload default")
+    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
+                    help="c2 (default, BASELINE configs[1]/[2]): 120k x 120k pair per GPU, weak scaling, brute force; "
+                         "c5 (BASELINE configs[4]): ONE 10M x 10M pair, sources sharded over the GPUs (strong scaling), exact grid")
     ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--qpl", type=int, default=0)
@@ -111,8 +114,19 @@ def main():
             if args.collective == "rccl":
                 args.collective = "torch"
 
-    n = args.points
-    src, tgt = synth.kitti_like_pair(n, n_src=n, shard=rank)
+    if args.workload == "c5":
+        # one pair for the whole job: every rank builds the same source cloud and keeps its contiguous shard
+        n = args.points or 10_000_000
+        args.nn = "grid"
+        full_src, tgt = synth.kitti_like_pair(n)
+        b, e = pcr.shard_range(n, world, rank)
+        src = np.ascontiguousarray(full_src[:, b:e])
+        del full_src
+        scaling, total_src = "strong", n
+    else:
+        n = args.points or 120000
+        src, tgt = synth.kitti_like_pair(n, n_src=n, shard=rank)
+        scaling, total_src = "weak", world * n
     ctx = pcr.Context(device_index)
     if args.qpl:
         ctx.tune("nn1_qpl", args.qpl)
@@ -203,7 +217,7 @@ def main():
     if args.nn == "brute" and not args.no_grid_extra:
         Tg, stg, dtg = timed_icp(2)
         gl, gms = ctx.prof_get("nn1_grid")
-        grid_extra = {"value": world * n * args.steps / dtg / 1e6, "unit": "M corr/s", "icp_iter_per_s": args.steps / dtg,
+        grid_extra = {"value": total_src * args.steps / dtg / 1e6, "unit": "M corr/s", "icp_iter_per_s": args.steps / dtg,
                       "ms_per_step": dtg * 1e3 / args.steps, "avg_nn_kernel_ms": gms / max(gl, 1),
                       "pose_bit_identical_to_brute_force": bool(np.array_equal(T.view(np.uint32), Tg.view(np.uint32))),
                       "note": "same ICP with pcr nn_method = grid (exact uniform-grid index, csrc/grid.hip); NOT the "
@@ -214,47 +228,78 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
         except Exception:   # noqa: BLE001
             pmc = None
-        total_corr = world * n * args.steps
+        total_corr = total_src * args.steps
         kern_s = nn_ms / 1e3 / max(nn_launches, 1)
-        pairs = float(n) * float(n)
-        achieved_tflops = OPS_PER_PAIR * pairs / kern_s / 1e12
-        compulsory_bytes = 12.0 * n + 12.0 * n + 8.0 * n           # targets + sources + (idx, d2) key
+        n_q, n_t = src.shape[1], tgt.shape[1]
         gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
+        if args.nn == "brute":
+            pairs = float(n_q) * float(n_t)
+            achieved_tflops = OPS_PER_PAIR * pairs / kern_s / 1e12
+            compulsory_bytes = 12.0 * n_t + 12.0 * n_q + 8.0 * n_q        # targets + sources + (idx, d2) key
+            have_pmc = pmc and pmc.get("valu_insts_per_launch") and "ftrack" in pmc.get("kernel", "") and n_q == 120000 == n_t
+            roofline = {
+                "bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS_NOFMA, "unit": "TFLOP/s",
+                "frac": achieved_tflops / VALU_PEAK_TFLOPS_NOFMA,
+                "traffic": (pmc["fetch_bytes_per_launch_corrected_x2"] + pmc["write_bytes_per_launch"]) if have_pmc else None,
+                "traffic_note": ("HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from a separate "
+                                 "rocprofv3 --pmc pass of this kernel, " + pmc["source"]) if have_pmc else "not collected",
+                "clock_ghz_profiled": pmc.get("clock_ghz_profiled") if have_pmc else None,
+                "kernel": "pcr::nn1_ftrack_kernel<2, 16> (brute force; targets broadcast through the scalar cache; fused "
+                          "pre-filter tracked branch-free, winner decided with the exact unfused arithmetic)"
+                          if not (args.qpl or args.variant) else f"nn1 variant={args.variant} qpl={args.qpl}",
+                "executed_lane_ops_per_pair": (pmc["valu_insts_per_launch"] * 64 / pairs) if have_pmc else None,
+                "issue_frac": (pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TFLOPS_NOFMA) if have_pmc else None,
+                "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
+                "algorithmic": f"{OPS_PER_PAIR} f32 lane-ops per (query,target) pair (SURVEY.md 8d) x {pairs:.3e} pairs/launch; "
+                               "peak = 157.3 TF/s / 2: one op per lane per issue slot (the exact arithmetic has no FMA). "
+                               "frac can exceed 1 because the kernel needs fewer than 9 issue slots per pair: its hot loop "
+                               "evaluates a fused 6-op filter and only the winning chunk exactly; issue_frac = executed "
+                               "lane-ops (PMC) / time / peak is the share of VALU issue slots actually used",
+                "hbm_literal": {"bound": "hbm", "achieved": compulsory_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
+                                "note": "compulsory bytes (32 B/point); brute force is VALU-bound, see DESIGN.md"}}
+            workload = ("point-to-point ICP iteration = 1-NN correspondence 120k x 120k (LDS-tiled brute force) + Kabsch + "
+                        "transform; BASELINE.json configs[1]/[2]")
+        else:
+            # steady state of the exact grid search: the source at the final pose, a few launches timed with HIP events,
+            # one more launch with the diagnostics counters for the algorithmic bytes (SURVEY.md 8d "1-NN exact grid")
+            ca = cs.clone()
+            ctx.transform(ca, T)
+            ctx.tune("nn_method", 2)
+            ctx.nn1_async(ct, ca); ctx.sync(); ctx.prof_reset()
+            for _ in range(5):
+                ctx.nn1_async(ct, ca)
+            gl, gms = ctx.prof_get("nn1_grid")
+            ctx.tune("grid_stats", 1); ctx.nn1_async(ct, ca); ctx.sync(); gs = ctx.grid_stats(); ctx.tune("grid_stats", 0)
+            ca.free()
+            steady_s = gms / 1e3 / max(gl, 1)
+            alg_bytes = n_q * (12.0 + 4.0 + 8.0) + 8.0 * gs["fine_rows"] + 16.0 * gs["candidates"]
+            L2_PEAK_GBS = 34500.0    # aggregate L2 bandwidth measured on MI355X (MI355X_MICROARCH.md, L2 section)
+            roofline = {
+                "bound": "l2-gather", "achieved": alg_bytes / steady_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / steady_s / 1e9 / L2_PEAK_GBS, "traffic": None, "traffic_note": "not collected for this kernel yet",
+                "vs_hbm_stream_peak": alg_bytes / steady_s / 1e9 / HBM_PEAK_GBS,
+                "kernel": "pcr::nn1_grid_kernel<16, false> (exact uniform-grid 1-NN) at the converged pose",
+                "launches": int(gl), "avg_launch_ms": steady_s * 1e3, "kernel_M_corr_per_s": n_q / steady_s / 1e6,
+                "avg_launch_ms_over_the_timed_icp": kern_s * 1e3,
+                "algorithmic": f"per query 12 B point + 4 B order + 8 B key, 8 B per opened x-row ({gs['fine_rows'] / n_q:.1f}/query) and "
+                               f"16 B per visited candidate ({gs['candidates'] / n_q:.1f}/query), counted by the kernel's diagnostics "
+                               "build.  Neighbouring queries visit the same cells, so most candidate records are served by L2 (the algorithmic "
+                               "byte rate exceeds the 8 TB/s HBM stream peak): the bound is the L2 gather rate"}
+            workload = (f"point-to-point ICP iteration on ONE {n_t} x {total_src} pair = exact grid 1-NN + Kabsch + transform"
+                        + ("; BASELINE.json configs[4] (sources sharded over the GPUs)" if args.workload == "c5" else ""))
         out = {
             "metric": "M correspondences/sec + ICP iter/sec, 120k-pt KITTI pair, 1/2/4/8 MI355X",
             "value": total_corr / dt / 1e6, "unit": "M corr/s",
             "icp_iter_per_s": args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "point-to-point ICP iteration = 1-NN correspondence 120k x 120k (LDS-tiled brute "
-                                   "force) + Kabsch + transform; BASELINE.json configs[1]/[2]",
-                       "n_src_per_gpu": n, "n_tgt": n, "max_corr": 1.0, "sharding": f"sources x{world}, target replicated",
+            "config": {"workload": workload, "nn": args.nn, "n_src_this_rank": n_q, "n_src_total": total_src, "n_tgt": n_t,
+                       "max_corr": 1.0, "sharding": f"sources x{world}, target replicated",
                        "collective": collective, "pose_err_vs_gt_fro": gt_err,
                        "kept_pairs_last_iter": int(st["last_pairs"])},
-            "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS_NOFMA,
-                         "unit": "TFLOP/s", "frac": achieved_tflops / VALU_PEAK_TFLOPS_NOFMA,
-                         "traffic": (pmc["fetch_bytes_per_launch_corrected_x2"] + pmc["write_bytes_per_launch"]) if pmc else None,
-                         "traffic_note": ("HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from a separate "
-                                          "rocprofv3 --pmc pass of this kernel, " + pmc["source"]) if pmc else "not collected",
-                         "clock_ghz_profiled": pmc.get("clock_ghz_profiled") if pmc else None,
-                         "kernel": "pcr::nn1_ftrack_kernel<2, 16> (brute force; targets broadcast through the scalar cache; fused "
-                                   "pre-filter tracked branch-free, winner decided with the exact unfused arithmetic)"
-                                   if not (args.qpl or args.variant) else f"nn1 variant={args.variant} qpl={args.qpl}",
-                         "executed_lane_ops_per_pair": (pmc["valu_insts_per_launch"] * 64 / pairs) if pmc and pmc.get("valu_insts_per_launch") else None,
-                         "issue_frac": (pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TFLOPS_NOFMA)
-                                       if pmc and pmc.get("valu_insts_per_launch") else None,
-                         "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3,
-                         "kernel_M_corr_per_s": n / kern_s / 1e6,
-                         "algorithmic": f"{OPS_PER_PAIR} f32 lane-ops per (query,target) pair (SURVEY.md 8d) x {pairs:.3e} pairs/launch; "
-                                        "peak = 157.3 TF/s / 2: one op per lane per issue slot (the exact arithmetic has no FMA). "
-                                        "frac can exceed 1 because the kernel needs fewer than 9 issue slots per pair: its hot loop "
-                                        "evaluates a fused 6-op filter and only the winning chunk exactly; issue_frac = executed "
-                                        "lane-ops (PMC) / time / peak is the share of VALU issue slots actually used",
-                         "hbm_literal": {"bound": "hbm", "achieved": compulsory_bytes / kern_s / 1e9,
-                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
-                                         "note": "compulsory bytes (32 B/point); brute force is VALU-bound, see DESIGN.md"}},
+            "roofline": roofline,
         }
         if grid_extra is not None:
             out["exact_grid"] = grid_extra
