@@ -1,11 +1,14 @@
-// resultSet.hpp — drop-in replacement for Homework2/hw2/include/resultSet.hpp (same classes, members and
-// behaviour), so that the hw2 / nano_vs_my drivers and the reference's own octree.hpp compile unchanged.
-//   DistIndex            resultSet.hpp:7-18
-//   KNNResultSet         resultSet.hpp:28-93   (capacity slots pre-filled with (1e10, 0); a candidate is rejected
-//                                               only when dist > worst, so among equal distances the LAST
-//                                               inserted one ends up in front of the run it joins)
-//   RadiusNNResultSet    resultSet.hpp:96-142  (inclusive dist <= radius, insertion order)
-// The GPU search (kdtree.hpp) fills a set through assign(): canonical order (distance, then index).
+// resultSet.hpp — drop-in replacement for Homework2/hw2/include/resultSet.hpp: the same three types with the same
+// public members and behaviour, so that the hw2 / nano_vs_my drivers AND the reference's own octree.hpp (which feeds
+// these sets point by point through addPoint) compile unchanged against it.
+//
+//   DistIndex            resultSet.hpp:7-18    {distance, index}, ordered by distance
+//   KNNResultSet         resultSet.hpp:28-93   k slots pre-filled with (1e10, 0); addPoint() rejects only dist > worst,
+//                                              so among equal distances the LAST inserted one ends up in front of the
+//                                              run it joins; worst = distance in the last slot
+//   RadiusNNResultSet    resultSet.hpp:96-142  keeps dist <= radius (inclusive) in insertion order
+//
+// Extension: assign() installs a finished result computed on the GPU (kdtree.hpp), in canonical order.
 #ifndef PCR_DROPIN_RESULTSET_HPP
 #define PCR_DROPIN_RESULTSET_HPP
 
@@ -13,101 +16,118 @@
 #include <iostream>
 #include <vector>
 
+namespace pcr {
+namespace dropin {
+constexpr double kUnsetDistance = 1e10;   // the reference's placeholder distance for an empty k-NN slot
+
+template <class List>
+inline void print_dist_index_list(const List& entries)
+{
+    std::cout << "Distance-Index list: " << std::endl;
+    for (const auto& e : entries) std::cout << e << std::endl;
+}
+}  // namespace dropin
+}  // namespace pcr
+
 class DistIndex
 {
 public:
+    DistIndex(double dist, int idx) : distance(dist), index(idx) {}
+
     double distance;
     int index;
-    DistIndex(double dist, int idx) : distance(dist), index(idx) {}
-    bool operator<(const DistIndex& other) const { return distance < other.distance; }
+
+    bool operator<(const DistIndex& rhs) const { return distance < rhs.distance; }
 };
 
-inline std::ostream& operator<<(std::ostream& os, const DistIndex& di)
+inline std::ostream& operator<<(std::ostream& out, const DistIndex& entry)
 {
-    return os << "Distance = " << di.distance << ", Index = " << di.index;
+    out << "Distance = " << entry.distance << ", Index = " << entry.index;
+    return out;
 }
 
 class KNNResultSet
 {
-    int capacity;
-    double worstDist;
-
 public:
-    int count = 0;
-    int comparisionCount = 0;   // (sic) spelling of the reference's public field
-    std::vector<DistIndex> distIndexList;
-
-    explicit KNNResultSet(int capa) : capacity(capa), worstDist(1e10), distIndexList(capa > 0 ? capa : 0, DistIndex(1e10, 0)) {}
-
-    int size() { return capacity; }
-    double getWorstDist() { return worstDist; }
-
-    void list()
+    explicit KNNResultSet(int capa)
+        : distIndexList(capa > 0 ? (size_t)capa : 0, DistIndex(pcr::dropin::kUnsetDistance, 0)),
+          slots_(capa), farthest_(pcr::dropin::kUnsetDistance)
     {
-        std::cout << "Distance-Index list: " << std::endl;
-        for (const DistIndex& di : distIndexList) std::cout << di << std::endl;
     }
 
-    void addPoint(double dist, int index)
-    {
-        ++comparisionCount;
-        if (dist > worstDist || capacity <= 0) return;
-        if (count < capacity) ++count;
-        // open a slot at the tail of the filled part, then walk it towards the front past every entry that is
-        // strictly farther than the newcomer
-        int slot = count - 1;
-        for (; slot > 0 && distIndexList[slot - 1].distance > dist; --slot) distIndexList[slot] = distIndexList[slot - 1];
-        distIndexList[slot] = DistIndex(dist, index);
-        worstDist = distIndexList[capacity - 1].distance;
-    }
-
-    // extension used by the GPU path: take a finished, canonically ordered result (n_valid <= capacity entries)
-    void assign(const double* dist, const int* index, int n_valid, int compared)
-    {
-        for (int s = 0; s < capacity; ++s) distIndexList[s] = s < n_valid ? DistIndex(dist[s], index[s]) : DistIndex(1e10, 0);
-        count = n_valid;
-        comparisionCount += compared;
-        worstDist = capacity > 0 ? distIndexList[capacity - 1].distance : 1e10;
-    }
-};
-
-class RadiusNNResultSet
-{
-    double worstDist;
-    double radius;
-
-public:
+    // public state, spelled as in the reference (drivers read these directly)
     int count = 0;
     int comparisionCount = 0;
     std::vector<DistIndex> distIndexList;
 
-    explicit RadiusNNResultSet(double r) : worstDist(r), radius(r) {}
-
-    int size() { return count; }
-    double getWorstDist() { return worstDist; }
-
-    void list()
-    {
-        std::cout << "Distance-Index list: " << std::endl;
-        for (const DistIndex& di : distIndexList) std::cout << di << std::endl;
-    }
+    int size() { return slots_; }
+    double getWorstDist() { return farthest_; }
+    void list() { pcr::dropin::print_dist_index_list(distIndexList); }
 
     void addPoint(double dist, int index)
     {
-        ++comparisionCount;
-        if (dist <= worstDist) {
-            distIndexList.emplace_back(dist, index);
-            ++count;
+        comparisionCount += 1;
+        if (slots_ <= 0 || dist > farthest_) return;           // equal to the worst is still accepted
+        if (count < slots_) count += 1;
+        // the newcomer starts in the last filled slot and moves forward past every strictly farther entry
+        int at = count - 1;
+        while (at > 0 && distIndexList[at - 1].distance > dist) {
+            distIndexList[at] = distIndexList[at - 1];
+            at -= 1;
+        }
+        distIndexList[at] = DistIndex(dist, index);
+        farthest_ = distIndexList[slots_ - 1].distance;
+    }
+
+    // extension (GPU path): n_valid <= capacity entries in canonical order (distance, then index); `compared` points
+    // were examined to produce them
+    void assign(const double* dist, const int* index, int n_valid, int compared)
+    {
+        for (int s = 0; s < slots_; ++s)
+            distIndexList[s] = s < n_valid ? DistIndex(dist[s], index[s]) : DistIndex(pcr::dropin::kUnsetDistance, 0);
+        count = n_valid;
+        comparisionCount += compared;
+        farthest_ = slots_ > 0 ? distIndexList[slots_ - 1].distance : pcr::dropin::kUnsetDistance;
+    }
+
+private:
+    int slots_;
+    double farthest_;
+};
+
+class RadiusNNResultSet
+{
+public:
+    explicit RadiusNNResultSet(double r) : limit_(r) {}
+
+    int count = 0;
+    int comparisionCount = 0;
+    std::vector<DistIndex> distIndexList;
+
+    int size() { return count; }
+    double getWorstDist() { return limit_; }               // the radius never shrinks
+    void list() { pcr::dropin::print_dist_index_list(distIndexList); }
+
+    void addPoint(double dist, int index)
+    {
+        comparisionCount += 1;
+        if (dist <= limit_) {                               // inclusive, resultSet.hpp:133
+            distIndexList.push_back(DistIndex(dist, index));
+            count += 1;
         }
     }
 
-    // extension used by the GPU path: neighbours in ascending index order
+    // extension (GPU path): n neighbours in ascending index order
     void assign(const double* dist, const int* index, size_t n, int compared)
     {
-        for (size_t s = 0; s < n; ++s) distIndexList.emplace_back(dist[s], index[s]);
+        distIndexList.reserve(distIndexList.size() + n);
+        for (size_t s = 0; s < n; ++s) distIndexList.push_back(DistIndex(dist[s], index[s]));
         count += (int)n;
         comparisionCount += compared;
     }
+
+private:
+    double limit_;
 };
 
 #endif  // PCR_DROPIN_RESULTSET_HPP
