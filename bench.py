@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--qpl", type=int, default=0)
     ap.add_argument("--tiles-per-slice", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=0, help="nn1 kernel variant (0 = library default; -8 = LDS-tiled TRACK)")
+    ap.add_argument("--variant", type=int, default=0, help="nn1 kernel variant (0 = library default FTRACK; 2 = exact TRACK; 3 = exact TRACK through LDS tiles)")
     ap.add_argument("--no-grid-extra", action="store_true", help="skip the additional exact-grid pass")
     ap.add_argument("--nn", choices=["brute", "grid"], default="brute",
                     help="correspondence search: brute = BASELINE configs[1] (LDS-tiled brute force), grid = exact grid index")

@@ -197,9 +197,16 @@ extern "C" int pcr_icp_p2p_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr_clo
 {
     if (!ctx || !src || !tgt || !init_T || !prm || !out_T) return fail(ctx, PCR_ERR_ARG, "pcr_icp_p2p_f32");
     PCR_HIP(ctx, hipSetDevice(ctx->device));
-    // tune "icp_pipeline": 0 / 1 = device-resident pipelined loop (default), -1 = synchronous loop.
-    // The host-callback transport reduces on the host and therefore always runs synchronously.
+    // tune "icp_pipeline": 1 = device-resident pipelined loop, -1 = synchronous loop (one host round trip per iteration),
+    // 0 = auto: pipelined when the correspondence search is the grid (tens of microseconds per search: launch gaps and
+    // round trips dominate), synchronous for brute force — measured on MI355X: the ~45 us of idle per iteration let the
+    // chip hold a higher clock through the VALU-bound 1.6 ms kernel (1.57 ms vs 1.71 ms back to back; 32.7 vs 35.0 ms for
+    // 20 iterations, profiles/r01_icp_pipeline_vs_sync.txt).  The host-callback transport reduces on the host and
+    // therefore always runs synchronously.  Both loops give bit-identical results.
     const bool callback = ctx->comm.nranks > 1 && ctx->comm.cb != nullptr;
-    if (callback || tune_get(ctx, "icp_pipeline", 1) < 0) return icp_sync(ctx, src, tgt, init_T, prm, out_T, stats);
-    return icp_pipelined(ctx, src, tgt, init_T, prm, out_T, stats);
+    const int64_t mode = tune_get(ctx, "icp_pipeline", 0);
+    const int64_t nn_method = tune_get(ctx, "nn_method", 0);
+    const bool grid = nn_method == 2 || (nn_method != 1 && tgt->n >= 2048);
+    const bool pipelined = !callback && (mode > 0 || (mode == 0 && grid));
+    return pipelined ? icp_pipelined(ctx, src, tgt, init_T, prm, out_T, stats) : icp_sync(ctx, src, tgt, init_T, prm, out_T, stats);
 }

@@ -11,19 +11,16 @@
 //    the next tile's global loads are issued before the current tile is consumed (software pipeline);
 //  * every lane reads the same LDS address (ds_read_b128 broadcast: 4 targets per coordinate per read),
 //    so LDS traffic is 12 B per 64*QPL pair evaluations and never bank-conflicts;
-//    (variant SGPR: the uniform target reads become s_load_dwordx4 through the scalar cache instead of LDS);
+//    (default transport: the uniform target reads are s_load_dwordx4 through the scalar cache instead of LDS -
+//    measured 3-4 % faster; the LDS path stays selectable);
 //  * inner loop per CH targets and query: distance arithmetic + a v_min3_u32 tree on the raw bit patterns
 //    (d2 >= 0, so IEEE bits are order preserving; NaN bits sort above +inf and never win);
-//    default (TRACK): branch-free - the lane remembers only the running minimum and the FIRST chunk that
+//    TRACK: branch-free - the lane remembers only the running minimum and the FIRST chunk that
 //    attained it (v_cmp + v_min + v_cndmask per chunk); the index inside that chunk is resolved once per
 //    query after the scan by re-evaluating its CH targets.  Profiling showed why: with scan-ordered
-//    targets a divergent "resolve now" branch is taken by some lane of the wave for a large share of the
-//    chunks (+24 % VALU instructions, profiles/r01_pmc_nn1.md);
-//    RESOLVE variants keep the older scheme (index resolved inside a rarely taken branch);
-//  * variant FILTER: the hot loop evaluates a cheaper fused form a = fma(dz,dz,fma(dy,dy,dx*dx)) (6 ops
-//    instead of 8).  |a - d2| <= 7u*d2 (u = 2^-24; all terms are non-negative), so every target that can
-//    beat the current best satisfies a <= best*(1 + 2^-20) + 1e-30; only chunks passing this gate are
-//    re-evaluated with the exact unfused arithmetic, which alone decides.  Results are bit-identical.
+//    targets a divergent "resolve now" branch (the first version of this kernel) is taken by some lane of the
+//    wave for a large share of the chunks: +24 % VALU instructions (profiles/r01_tune_nn1_resolve_variants.txt);
+//    FTRACK (default, see its kernel): the same tracking on a fused 6-op filter value, winner decided exactly;
 //  * the target set is cut into slices (gridDim.y) so that >> 256 workgroups exist even for one scan;
 //    slices merge through one 64-bit atomicMin per query on key = d2_bits << 32 | idx, which implements
 //    "min d2, then lowest index" exactly and independently of arrival order.
@@ -64,38 +61,6 @@ __device__ __forceinline__ uint32_t gate_bits(uint32_t best_bits)
     const float t = __uint_as_float(best_bits) * 1.00000095367431640625f + 1e-30f;
     return __float_as_uint(t);
 }
-
-template <int QPL, bool FILTER>
-struct Lane {
-    float qx[QPL], qy[QPL], qz[QPL];
-    uint32_t best[QPL], bidx[QPL], gate[QPL];
-
-    __device__ __forceinline__ void chunk8(const float (&X)[8], const float (&Y)[8], const float (&Z)[8], uint32_t j0)
-    {
-#pragma unroll
-        for (int k = 0; k < QPL; k++) {
-            uint32_t d[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                d[j] = FILTER ? d2_fused_bits(qx[k], qy[k], qz[k], X[j], Y[j], Z[j])
-                              : d2_exact_bits(qx[k], qy[k], qz[k], X[j], Y[j], Z[j]);
-            uint32_t m = umin3(d[0], d[1], d[2]);
-            m = umin3(m, d[3], d[4]);
-            m = umin3(m, d[5], d[6]);
-            m = min(m, d[7]);
-            const bool hit = FILTER ? (m <= gate[k]) : (m < best[k]);
-            if (__builtin_expect(hit, 0)) {
-                // rare: ascending scan with strict < keeps the lowest index among equal minima
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t e = FILTER ? d2_exact_bits(qx[k], qy[k], qz[k], X[j], Y[j], Z[j]) : d[j];
-                    if (e < best[k]) { best[k] = e; bidx[k] = j0 + j; }
-                }
-                if (FILTER) gate[k] = gate_bits(best[k]);
-            }
-        }
-    }
-};
 
 // branch-free variant: running minimum + first chunk attaining it
 template <int QPL, int CH>
@@ -308,85 +273,6 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ftrack_kernel(
     }
 }
 
-template <int QPL, bool FILTER, bool SGPR>
-__global__ __launch_bounds__(NN_BLOCK) void nn1_brute_kernel(
-    const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
-    const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-    uint32_t ns, uint32_t n_tiles, uint32_t tiles_per_slice,
-    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop)
-{
-    __shared__ float4 lx[SGPR ? 1 : NN_TILE / 4];
-    __shared__ float4 ly[SGPR ? 1 : NN_TILE / 4];
-    __shared__ float4 lz[SGPR ? 1 : NN_TILE / 4];
-
-    if (stop && (stop[0] | stop[1])) return;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t qbase = blockIdx.x * (NN_BLOCK * QPL);
-
-    Lane<QPL, FILTER> L;
-#pragma unroll
-    for (int k = 0; k < QPL; k++) {
-        uint32_t i = min(qbase + k * NN_BLOCK + tid, ns - 1);
-        L.qx[k] = sx[i]; L.qy[k] = sy[i]; L.qz[k] = sz[i];
-        L.best[k] = 0x7F7FFFFFu;        // FLT_MAX: nanoflann.hpp:163; accept only d2 < worst (:1360)
-        L.bidx[k] = 0xFFFFFFFFu;
-        L.gate[k] = 0x7F800000u;        // +inf: everything finite passes until a first candidate is accepted
-    }
-
-    const uint32_t tile0 = blockIdx.y * tiles_per_slice;
-    const uint32_t tile1 = min(tile0 + tiles_per_slice, n_tiles);
-    if (SGPR) {
-        // wave-uniform addresses on read-only, non-aliased pointers: the loads below compile to s_load_dwordx4
-        const uint32_t j_begin = tile0 * NN_TILE, j_end = tile1 * NN_TILE;
-#pragma unroll 2
-        for (uint32_t j0 = j_begin; j0 < j_end; j0 += 8) {
-            const float4 xa = *reinterpret_cast<const float4*>(tx + j0), xb = *reinterpret_cast<const float4*>(tx + j0 + 4);
-            const float4 ya = *reinterpret_cast<const float4*>(ty + j0), yb = *reinterpret_cast<const float4*>(ty + j0 + 4);
-            const float4 za = *reinterpret_cast<const float4*>(tz + j0), zb = *reinterpret_cast<const float4*>(tz + j0 + 4);
-            const float X[8] = { xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w };
-            const float Y[8] = { ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w };
-            const float Z[8] = { za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w };
-            L.chunk8(X, Y, Z, j0);
-        }
-    } else if (tile0 < tile1) {
-        const float4* gx = reinterpret_cast<const float4*>(tx) + (size_t)tile0 * (NN_TILE / 4);
-        const float4* gy = reinterpret_cast<const float4*>(ty) + (size_t)tile0 * (NN_TILE / 4);
-        const float4* gz = reinterpret_cast<const float4*>(tz) + (size_t)tile0 * (NN_TILE / 4);
-        float4 rx = gx[tid], ry = gy[tid], rz = gz[tid];
-        for (uint32_t tile = tile0; tile < tile1; tile++) {
-            lx[tid] = rx; ly[tid] = ry; lz[tid] = rz;
-            __syncthreads();
-            if (tile + 1 < tile1) {     // prefetch the next tile while this one is consumed
-                gx += NN_TILE / 4; gy += NN_TILE / 4; gz += NN_TILE / 4;
-                rx = gx[tid]; ry = gy[tid]; rz = gz[tid];
-            }
-            const uint32_t jbase = tile * NN_TILE;
-#pragma unroll 2
-            for (int c = 0; c < NN_TILE / 8; c++) {
-                const float4 xa = lx[2 * c], xb = lx[2 * c + 1];
-                const float4 ya = ly[2 * c], yb = ly[2 * c + 1];
-                const float4 za = lz[2 * c], zb = lz[2 * c + 1];
-                const float X[8] = { xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w };
-                const float Y[8] = { ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w };
-                const float Z[8] = { za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w };
-                L.chunk8(X, Y, Z, jbase + 8 * c);
-            }
-            __syncthreads();
-        }
-    }
-
-#pragma unroll
-    for (int k = 0; k < QPL; k++) {
-        const uint32_t i = qbase + k * NN_BLOCK + tid;
-        if (i < ns) {
-            const uint32_t bits = (L.bidx[k] == 0xFFFFFFFFu) ? 0x7F800000u : L.best[k];   // nothing accepted: +inf
-            const unsigned long long key = ((unsigned long long)bits << 32) | L.bidx[k];
-            if (merge_atomic) atomicMin(&keys[i], key);
-            else keys[i] = key;
-        }
-    }
-}
-
 // keys -> (idx, d2) split for the host-facing API
 __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, uint32_t n,
                                   uint32_t* __restrict__ idx, float* __restrict__ d2)
@@ -397,14 +283,6 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
         idx[i] = (uint32_t)(k & 0xFFFFFFFFull);
         d2[i] = __uint_as_float((uint32_t)(k >> 32));
     }
-}
-
-template <int QPL, bool FILTER, bool SGPR>
-static void launch_variant(pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t ns,
-                           uint32_t n_tiles, uint32_t tps, int merge_atomic)
-{
-    hipLaunchKernelGGL((nn1_brute_kernel<QPL, FILTER, SGPR>), grid, dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(),
-                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic, ctx->stop_flag_dev);
 }
 
 template <int CH, bool SGPR>
@@ -437,17 +315,6 @@ static void launch_ftrack(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt
 #undef PCR_FTRACK
 }
 
-template <bool FILTER, bool SGPR>
-static void launch_qpl(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t ns,
-                       uint32_t n_tiles, uint32_t tps, int merge_atomic)
-{
-    switch (qpl) {
-    case 1: launch_variant<1, FILTER, SGPR>(ctx, grid, tgt, src, ns, n_tiles, tps, merge_atomic); break;
-    case 4: launch_variant<4, FILTER, SGPR>(ctx, grid, tgt, src, ns, n_tiles, tps, merge_atomic); break;
-    default: launch_variant<2, FILTER, SGPR>(ctx, grid, tgt, src, ns, n_tiles, tps, merge_atomic); break;
-    }
-}
-
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
 {
     const size_t ns = src->n;
@@ -460,10 +327,9 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
 
     int qpl = (int)tune_get(ctx, "nn1_qpl", 2);
     if (qpl != 1 && qpl != 4) qpl = 2;
-    // variant: 2 = TRACK, targets through the scalar cache; 1 = FTRACK (fused filter tracking + exact decision, scalar
-    //          cache); 0 (set as -8) = TRACK, targets through LDS tiles; 4 = RESOLVE exact (LDS), 5 = RESOLVE + fused
-    //          filter, 6/7 = the same with scalar-load targets
-    const int variant = (int)tune_get(ctx, "nn1_variant", 1) & 7;   // default FTRACK: fastest measured (profiles/r01_tune_nn1_ftrack.txt)
+    // variant: 1 = FTRACK (default: fused-filter tracking + exact decision, targets through the scalar cache);
+    //          2 = TRACK (exact arithmetic only, scalar cache); 3 (or any other value) = TRACK with targets through LDS tiles
+    const int variant = (int)tune_get(ctx, "nn1_variant", 1);   // default FTRACK: fastest measured (profiles/r01_tune_nn1_ftrack.txt)
     const int chunk = (int)tune_get(ctx, "nn1_chunk", 16);
     const uint32_t n_tiles = (uint32_t)((tgt->n + NN_TILE - 1) / NN_TILE);
     const uint32_t qblocks = (uint32_t)((ns + (size_t)NN_BLOCK * qpl - 1) / ((size_t)NN_BLOCK * qpl));
@@ -485,11 +351,7 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
     {
         ProfScope p(ctx, "nn1_brute", 1);
         switch (variant) {
-        case 4: launch_qpl<false, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
-        case 5: launch_qpl<true, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
-        case 6: launch_qpl<false, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
-        case 7: launch_qpl<true, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic); break;
-        case 1: case 3:
+        case 1:
             if (chunk == 16) launch_ftrack<16>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
             else launch_ftrack<8>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
             break;

@@ -41,15 +41,15 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
     cs.free(); ct.free()
 
 
-# variant 0: branch-free TRACK kernel (LDS); 2: same with scalar-load targets; 1: FTRACK (fused-filter tracking); 4..7: RESOLVE kernels
+# variant 1: FTRACK (default: fused-filter tracking, exact decision); 2: TRACK (exact only), scalar-cache targets; 3: TRACK, LDS tiles
 # (4 exact, 5 fused filter, 6/7 the same with scalar-load targets); chunk = targets per min-tree
-VARIANTS = [(0, 8), (0, 16), (1, 8), (1, 16), (2, 8), (2, 16), (4, 8), (5, 8), (6, 8), (7, 8)]
+VARIANTS = [(1, 8), (1, 16), (2, 8), (2, 16), (3, 8), (3, 16)]
 
 
 def set_variant(ctx, vc):
     v, ch = vc
     ctx.tune("nn_method", 1)                  # brute force (auto would pick the grid for large targets)
-    ctx.tune("nn1_variant", v if v else -8)   # -8 & 7 == 0 (0 itself means "library default")
+    ctx.tune("nn1_variant", v)
     ctx.tune("nn1_chunk", ch)
 
 

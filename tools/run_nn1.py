@@ -19,7 +19,7 @@ if order == "shuffle":
     tgt = np.ascontiguousarray(tgt[:, perm])
 ctx = pcr.Context(0)
 if variant is not None:
-    ctx.tune("nn1_variant", variant if variant else -8)
+    ctx.tune("nn1_variant", variant)
 ctx.tune("nn1_chunk", int(os.environ.get("NN1_CHUNK", "0")))
 ctx.tune("nn1_qpl", qpl)
 ctx.tune("nn1_tiles_per_slice", tps)

@@ -14,14 +14,14 @@ ctx = pcr.Context(0)
 ctx.tune("nn_method", 1)
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
 configs = []
-for var in ((1, 8), (1, 16), (2, 8), (2, 16)):
+for var in ((1, 8), (1, 16), (2, 16), (3, 16)):
     for qpl in (1, 2, 4):
         for tps in (2, 4, 8):
             configs.append((var, qpl, tps))
 res = {c: [] for c in configs}
 def setcfg(c):
     var, qpl, tps = c
-    ctx.tune("nn1_variant", var[0] if var[0] else -8); ctx.tune("nn1_chunk", var[1]); ctx.tune("nn1_qpl", qpl); ctx.tune("nn1_tiles_per_slice", tps)
+    ctx.tune("nn1_variant", var[0]); ctx.tune("nn1_chunk", var[1]); ctx.tune("nn1_qpl", qpl); ctx.tune("nn1_tiles_per_slice", tps)
 for c in configs:      # warm
     setcfg(c); ctx.nn1_async(ct, cs)
 ctx.sync()
