@@ -81,7 +81,9 @@ int comm_allreduce_f64(pcr_ctx* ctx, double* host_buf, double* dev_buf, int n)
 int comm_allreduce_f64_device(pcr_ctx* ctx, double* dev_buf, int n)
 {
     Comm& c = ctx->comm;
-    if (c.nranks <= 1) return PCR_OK;
+    // a one-rank job needs no collective; with a communicator attached and the test knob "icp_force_slots" set, the
+    // call is made anyway (sum over one rank = identity) so that the path can be exercised on a single GPU
+    if (c.nranks <= 1 && !(c.rccl && tune_get(ctx, "icp_force_slots", 0) > 0)) return PCR_OK;
     if (!c.rccl) return fail(ctx, PCR_ERR_STATE, "device all-reduce needs the RCCL transport");
     Rccl& r = rccl();
     int rc = r.AllReduce(dev_buf, dev_buf, (size_t)n, kNcclFloat64, kNcclSum, c.rccl, ctx->stream);

@@ -43,26 +43,44 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
     for (uint64_t iter = 0; rc == PCR_OK && iter < prm->max_iter; iter++) {      // :917
         if ((rc = launch_nn1(ctx, tgt, work, true))) break;                      // :925-934
         double* h = ctx->host_out;
-        if (work->n) {
-            if ((rc = launch_kabsch_sums(ctx, tgt, work, prm->max_corr))) break; // :936-940,:964-985
-        } else {
-            hipError_t e = hipMemsetAsync(ctx->dev_out, 0, 18 * sizeof(double), ctx->stream);
-            if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "memset", e); break; }
-        }
-        hipError_t e = hipMemcpyAsync(h, ctx->dev_out, 18 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "icp d2h", e); break; }
-        double last_kept = work->n ? h[16] : -1.0, last_d2 = work->n ? h[17] : 0.0;
-        if (nranks > 1) {
-            // the ONE collective of the iteration: sum of the 16 moments; the per-rank (flag, d2) slots ride
-            // along so that `loss` is that of the globally last kept pair (highest rank that kept any)
-            for (int r = 0; r < nranks; r++) { h[16 + 2 * r] = 0.0; h[17 + 2 * r] = 0.0; }
-            h[16 + 2 * rank] = last_kept >= 0 ? 1.0 : 0.0;
-            h[17 + 2 * rank] = last_d2;
-            if ((rc = comm_allreduce_f64(ctx, h, ctx->dev_out, nred))) break;
-            last_kept = -1.0;
+        double last_kept, last_d2;
+        hipError_t e = hipSuccess;
+        if (ctx->comm.rccl && (nranks > 1 || tune_get(ctx, "icp_force_slots", 0) > 0)) {
+            // RCCL: the partial moments are reduced on the device, all-reduced in place on the context stream (the ONE
+            // collective of the iteration: 16 moments + one (kept flag, last d2) slot per rank so that `loss` is that of
+            // the globally last kept pair) and only then copied to the host
+            uint32_t blocks = 0;
+            if (work->n && (rc = launch_kabsch_partial(ctx, tgt, work, prm->max_corr, &blocks))) break;   // :936-940,:964-985
+            if ((rc = launch_icp_reduce_slots(ctx, blocks, nranks, rank, work->n != 0))) break;
+            if ((rc = comm_allreduce_f64_device(ctx, ctx->dev_out, nred))) break;
+            e = hipMemcpyAsync(h, ctx->dev_out, nred * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "icp d2h", e); break; }
+            last_kept = -1.0; last_d2 = 0.0;
             for (int r = 0; r < nranks; r++)
                 if (h[16 + 2 * r] > 0.5) { last_kept = 1.0; last_d2 = h[17 + 2 * r]; }
+        } else {
+            if (work->n) {
+                if ((rc = launch_kabsch_sums(ctx, tgt, work, prm->max_corr))) break; // :936-940,:964-985
+            } else {
+                e = hipMemsetAsync(ctx->dev_out, 0, 18 * sizeof(double), ctx->stream);
+                if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "memset", e); break; }
+            }
+            e = hipMemcpyAsync(h, ctx->dev_out, 18 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "icp d2h", e); break; }
+            last_kept = work->n ? h[16] : -1.0;
+            last_d2 = work->n ? h[17] : 0.0;
+            if (nranks > 1) {
+                // host-callback transport: same buffer layout, reduced by the caller's process group
+                for (int r = 0; r < nranks; r++) { h[16 + 2 * r] = 0.0; h[17 + 2 * r] = 0.0; }
+                h[16 + 2 * rank] = last_kept >= 0 ? 1.0 : 0.0;
+                h[17 + 2 * rank] = last_d2;
+                if ((rc = comm_allreduce_f64(ctx, h, ctx->dev_out, nred))) break;
+                last_kept = -1.0;
+                for (int r = 0; r < nranks; r++)
+                    if (h[16 + 2 * r] > 0.5) { last_kept = 1.0; last_d2 = h[17 + 2 * r]; }
+            }
         }
         float loss = 0.0f;
         if (last_kept >= 0) { const float d2 = (float)last_d2; loss = d2 * d2; } // :939

@@ -58,11 +58,19 @@ def test_native_rccl_communicator_single_rank(pcr, synth):
         src, tgt = synth.kitti_like_pair(5000, seed_target=91, seed_pair=92)
         cs, ct = ctx.cloud(src), ctx.cloud(tgt)
         T1, st1 = ctx.icp_point2point(cs, ct, max_iter=6)
-        ctx.tune("icp_force_slots", 1)          # the multi-rank kernel path (reduce slots -> all-reduce -> update)
-        T2, st2 = ctx.icp_point2point(cs, ct, max_iter=6)
-        ctx.tune("icp_force_slots", 0)
+        # the multi-rank paths with a real ncclAllReduce per iteration (sum over one rank): reduce slots -> all-reduce ->
+        # update, in the device-resident loop (1) and in the synchronous loop (-1), for both correspondence searches
+        ctx.tune("icp_force_slots", 1)
+        for method in (1, 2):
+            ctx.tune("nn_method", method)
+            for pipe in (1, -1):
+                ctx.tune("icp_pipeline", pipe)
+                T2, st2 = ctx.icp_point2point(cs, ct, max_iter=6)
+                assert np.array_equal(T1, T2) and st1["last_pairs"] == st2["last_pairs"], (method, pipe)
+        for k in ("icp_force_slots", "nn_method", "icp_pipeline"):
+            ctx.tune(k, 0)
         ctx.comm_destroy()
         T3, st3 = ctx.icp_point2point(cs, ct, max_iter=6)
-        assert np.array_equal(T1, T2) and np.array_equal(T1, T3) and st1["last_pairs"] == st2["last_pairs"] == st3["last_pairs"]
+        assert np.array_equal(T1, T3) and st1["last_pairs"] == st3["last_pairs"]
     finally:
         ctx.close()
