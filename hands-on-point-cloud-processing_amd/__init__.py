@@ -32,6 +32,11 @@ class IcpParams(C.Structure):
     _fields_ = [("max_corr", C.c_float), ("max_iter", C.c_uint64), ("eps", C.c_float)]
 
 
+class IssParams(C.Structure):
+    _fields_ = [("local_radius", C.c_float), ("non_max_radius", C.c_float), ("gamma21", C.c_float), ("gamma32", C.c_float),
+                ("min_neighbors", C.c_int), ("weighted_covariance", C.c_int)]
+
+
 class IcpStats(C.Structure):
     _fields_ = [("iters_run", C.c_uint64), ("converged", C.c_int32), ("empty_pairs", C.c_int32),
                 ("last_pairs", C.c_uint64), ("last_loss", C.c_float), ("reserved", C.c_float),
@@ -48,7 +53,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
+    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
 
@@ -105,6 +110,7 @@ def lib():
     L.pcr_tune_set.argtypes = [vp, C.c_char_p, C.c_int64]
     L.pcr_grid_stats.argtypes = [vp, vp]
     L.pcr_voxel_filter_f32.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
+    L.pcr_iss_keypoints_f32.argtypes = [vp, vp, C.POINTER(IssParams), vp, vp, vp, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -280,6 +286,20 @@ class Context:
         h = C.c_void_p()
         self._ck(lib().pcr_voxel_filter_f32(self.h, cloud.h, float(leaf_size), C.byref(h)))
         return Cloud(self, h)
+
+    # ---- N1
+    def iss_keypoints(self, cloud: Cloud, local_radius, non_max_radius, gamma21=0.9, gamma32=0.9, min_neighbors=5, weighted=True):
+        """ISSKeypoint::compute (hw7 iss_detector.cpp:38-110) -> (keypoint indices ascending, lambda3 f32[n], |N_local| u32[n])."""
+        n = len(cloud)
+        key = np.zeros(max(n, 1), np.uint8)
+        l3 = np.zeros(max(n, 1), np.float32)
+        cn = np.zeros(max(n, 1), np.uint32)
+        prm = IssParams(local_radius, non_max_radius, gamma21, gamma32, int(min_neighbors), int(bool(weighted)))
+        cnt = C.c_uint64()
+        self._ck(lib().pcr_iss_keypoints_f32(self.h, cloud.h, C.byref(prm), key.ctypes.data, l3.ctypes.data, cn.ctypes.data, C.byref(cnt)))
+        idx = np.flatnonzero(key[:n])
+        assert idx.size == cnt.value
+        return idx, l3[:n], cn[:n]
 
     # ---- A8 / A7
     def transform(self, cloud: Cloud, T):

@@ -18,9 +18,8 @@
 //   than (r - slack) * h apart; slack covers the f32 rounding of the cell computation), or when the cube
 //   covers the whole grid.  Exactness proof and cost model: DESIGN.md §5b.
 // Traffic (algorithmic): 12 B query + 8 B key + 16 B per visited candidate + 8 B per visited cell row.
-#include "pcr_internal.hpp"
+#include "grid_common.hpp"
 
-#include <cfloat>
 #include <cmath>
 
 #pragma clang fp contract(off)
@@ -31,43 +30,6 @@ constexpr int GR_BLOCK = 256;
 constexpr int SC_ITEMS = 8;                       // scan: items per thread
 constexpr int SC_TILE = SCAN_TILE;                // 2048 per block (pcr_internal.hpp)
 static_assert(SC_TILE == GR_BLOCK * SC_ITEMS, "scan tile");
-
-struct GridParams {
-    float lo[3];
-    float inv_h;
-    float h;
-    int n[3];          // cells per axis
-    float slack;       // in cells
-};
-
-struct Grid {
-    GridParams p;
-    size_t n_points = 0;
-    size_t n_cells = 0;
-    float4* records = nullptr;        // n_points, sorted by cell
-    uint32_t* cell_start = nullptr;   // n_cells + 1
-};
-
-__device__ __forceinline__ int cell_coord(float v, float lo, float inv_h)
-{
-    const float a = floorf((v - lo) * inv_h);
-    // clamp far-away values before the int conversion; +-2^22 cells is beyond any grid we build
-    return (int)fminf(fmaxf(a, -4194304.0f), 4194304.0f);
-}
-
-__device__ __forceinline__ bool finite3(float x, float y, float z)
-{
-    return (fabsf(x) <= FLT_MAX) && (fabsf(y) <= FLT_MAX) && (fabsf(z) <= FLT_MAX);   // false for NaN / inf
-}
-
-__device__ __forceinline__ uint32_t clamped_cell_id(const GridParams& g, float x, float y, float z)
-{
-    if (!finite3(x, y, z)) return 0;   // never wins a comparison (d2 = inf / NaN), any cell will do
-    const int cx = min(max(cell_coord(x, g.lo[0], g.inv_h), 0), g.n[0] - 1);
-    const int cy = min(max(cell_coord(y, g.lo[1], g.inv_h), 0), g.n[1] - 1);
-    const int cz = min(max(cell_coord(z, g.lo[2], g.inv_h), 0), g.n[2] - 1);
-    return (uint32_t)((cz * g.n[1] + cy) * g.n[0] + cx);
-}
 
 // ---------------------------------------------------------------------------------------- bounding box
 __device__ __forceinline__ float wave_min_f(float v)
@@ -428,7 +390,7 @@ void grid_free(Grid* g)
 }
 
 // scratch layout for builds / query sorting: [cell_of n][count cells+1][totals nb+1]
-static int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out)
+int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge)
 {
     *out = nullptr;
     const size_t n = c->n;
@@ -480,8 +442,8 @@ static int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out)
         g->p.slack = 0.01f + 2e-6f * (float)std::max(std::max(g->p.n[0], g->p.n[1]), g->p.n[2]);
         g->n_cells = cells;
     };
-    const int64_t user_um = tune_get(ctx, "grid_cell_um", 0);
-    double h = fit(user_um > 0 ? (double)user_um * 1e-6 : std::cbrt(vol / (4.0 * (double)std::max<size_t>(n, 1))));
+    const int64_t user_um = cell_edge > 0.0 ? (int64_t)1 : tune_get(ctx, "grid_cell_um", 0);
+    double h = fit(cell_edge > 0.0 ? cell_edge : user_um > 0 ? (double)user_um * 1e-6 : std::cbrt(vol / (4.0 * (double)std::max<size_t>(n, 1))));
     set_params(h);
     if (user_um <= 0 && n >= 1024) {
         const size_t cells0 = g->n_cells;
@@ -592,7 +554,7 @@ int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     if (!tgt->grid) {
         Grid* g = nullptr;
         ProfScope p(ctx, "grid_build");
-        int rc = grid_build(ctx, tgt, &g);
+        int rc = grid_build(ctx, tgt, &g, 0.0);
         if (rc) return rc;
         const_cast<pcr_cloud*>(tgt)->grid = g;
     }

@@ -1,0 +1,50 @@
+// grid_common.hpp — the uniform-grid index shared by the exact 1-NN search (grid.hip) and the radius consumers (iss.hip).
+#pragma once
+
+#include "pcr_internal.hpp"
+
+#include <cfloat>
+
+namespace pcr {
+
+struct GridParams {
+    float lo[3];
+    float inv_h;
+    float h;
+    int n[3];          // cells per axis
+    float slack;       // in cells
+};
+
+struct Grid {
+    GridParams p;
+    size_t n_points = 0;
+    size_t n_cells = 0;
+    float4* records = nullptr;        // n_points, sorted by cell
+    uint32_t* cell_start = nullptr;   // n_cells + 1
+};
+
+__device__ __forceinline__ int cell_coord(float v, float lo, float inv_h)
+{
+    const float a = floorf((v - lo) * inv_h);
+    // clamp far-away values before the int conversion; +-2^22 cells is beyond any grid we build
+    return (int)fminf(fmaxf(a, -4194304.0f), 4194304.0f);
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+    return (fabsf(x) <= FLT_MAX) && (fabsf(y) <= FLT_MAX) && (fabsf(z) <= FLT_MAX);   // false for NaN / inf
+}
+
+__device__ __forceinline__ uint32_t clamped_cell_id(const GridParams& g, float x, float y, float z)
+{
+    if (!finite3(x, y, z)) return 0;   // never wins a comparison (d2 = inf / NaN), any cell will do
+    const int cx = min(max(cell_coord(x, g.lo[0], g.inv_h), 0), g.n[0] - 1);
+    const int cy = min(max(cell_coord(y, g.lo[1], g.inv_h), 0), g.n[1] - 1);
+    const int cz = min(max(cell_coord(z, g.lo[2], g.inv_h), 0), g.n[2] - 1);
+    return (uint32_t)((cz * g.n[1] + cy) * g.n[0] + cx);
+}
+
+// builds the index over `c`; cell_edge > 0 forces the cell size (otherwise the heuristic of grid.hip is used)
+int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge);
+
+}  // namespace pcr

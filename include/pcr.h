@@ -153,6 +153,25 @@ int pcr_db64_radius(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m,
  * (:41-50).  The result is a new device cloud (feed it to pcr_icp_p2p_f32 without leaving HBM). */
 int pcr_voxel_filter_f32(pcr_ctx* ctx, const pcr_cloud* in, double leaf_size, pcr_cloud** out);
 
+/* ---- next row N1: ISS keypoints, ISSKeypoint::compute (Homework7/hw7/src/iss_detector.cpp:38-152) ----------------
+ * Batched radius neighbourhoods over a uniform grid instead of one kd-tree search per point.  Membership uses hw7's
+ * float arithmetic (src/kdtree.cpp:310-316) bit for bit; the neighbourhood covariance is accumulated in f64 (the
+ * reference: f32 in tree-visit order through Eigen) and its eigenvalues come from an f64 Jacobi solver, rounded to
+ * f32 before the gamma tests (:79).  Setters mirrored: setLocalRadius / setNonMaxRadius / setThreshold(g21, g32) /
+ * setMinNeighbors / useWeightedCovMat (iss_detector.cpp:8-31).
+ * is_key[i] = 1 iff input point i is a keypoint (the reference emits them in ascending i, :103); lambda3 (optional, n
+ * floats) is lambda3_vec_forall (:67); neighbor_counts (optional, n) is rnn_idx[i].size() (:47-57); n_keypoints
+ * (optional) the number of ones. */
+typedef struct {
+    float local_radius;
+    float non_max_radius;
+    float gamma21, gamma32;
+    int min_neighbors;
+    int weighted_covariance;
+} pcr_iss_params;
+int pcr_iss_keypoints_f32(pcr_ctx* ctx, const pcr_cloud* cloud, const pcr_iss_params* prm, uint8_t* is_key, float* lambda3,
+                          uint32_t* neighbor_counts, uint64_t* n_keypoints);
+
 /* ---- multi-GPU: one process per GPU, sources sharded, targets replicated ------------------------------
  * Exactly one collective per ICP iteration: all-reduce(sum) of 16 f64 (+2 bookkeeping words). */
 #define PCR_COMM_ID_BYTES 128

@@ -69,6 +69,7 @@ def lib():
         L.orc_plane_from_3pts.argtypes = [f64p, f64p]
         L.orc_voxel_filter_f32.restype = sz
         L.orc_voxel_filter_f32.argtypes = [f32p, f32p, f32p, sz, C.c_double, f32p, f32p, f32p]
+        L.orc_iss_f32.argtypes = [f32p, f32p, f32p, sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, u8p, f32p]
         L.orc_hw2_knn_add.argtypes = [f64p, i32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                       C.c_double, C.c_int]
         L.orc_nano_knn_add.argtypes = [f32p, u64p, sz, C.POINTER(sz), C.c_float, sz]
@@ -247,6 +248,15 @@ def voxel_filter_f32(soa, leaf_size):
     return np.stack([ox[:m], oy[:m], oz[:m]])
 
 
+def iss_f32(soa, local_radius, non_max_radius, gamma21=0.9, gamma32=0.9, min_neighbors=5, weighted=True):
+    """ISSKeypoint::compute (hw7) -> (is_key uint8[n], lambda3 f32[n])."""
+    x, y, z = _soa(soa)
+    key = np.zeros(x.size, np.uint8)
+    l3 = np.zeros(x.size, np.float32)
+    lib().orc_iss_f32(x, y, z, x.size, local_radius, non_max_radius, gamma21, gamma32, min_neighbors, int(weighted), key, l3)
+    return key, l3
+
+
 # ----------------------------------------------------------------------------- reference harness
 def ref_nano_nn1_f32(tgt_soa, src_soa, leaf=2, threads=1):
     """vendored nanoflann, f32, as ICPpoint2point instantiates it. Returns (idx, d2, build_ms, query_ms)."""
@@ -305,6 +315,34 @@ def ref_hw2_oct_knn(db, q, k, leaf=32, min_extent=0.0001):
     dist = np.empty((m, k), np.float64)
     ref().ref_hw2_oct_knn(db, db.shape[0], dim, q, m, k, leaf, min_extent, idx, dist)
     return idx, dist
+
+
+def hw7_path() -> str:
+    return os.path.join(_HERE, "_ref", "libhw7_ref.so")
+
+
+def have_hw7() -> bool:
+    return os.path.exists(hw7_path())
+
+
+_HW7 = None
+
+
+def ref_hw7_radius(db, q, r, leaf=12):
+    """The reference's hw7 float kd-tree (KDTreeRadiusNNSearch) -> CSR (row_ptr, idx, dist), tree-visit order."""
+    global _HW7
+    if _HW7 is None:
+        _HW7 = C.CDLL(hw7_path())
+        _HW7.ref_hw7_radius.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, C.c_float, C.c_int, i64p, C.c_void_p, C.c_void_p]
+    db = np.ascontiguousarray(db, np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    m = q.shape[0]
+    row = np.empty(m + 1, np.int64)
+    _HW7.ref_hw7_radius(db, db.shape[0], q, m, r, leaf, row, None, None)
+    idx = np.empty(max(1, int(row[-1])), np.int32)
+    dist = np.empty(max(1, int(row[-1])), np.float32)
+    _HW7.ref_hw7_radius(db, db.shape[0], q, m, r, leaf, row, idx.ctypes.data, dist.ctypes.data)
+    return row, idx[: row[-1]], dist[: row[-1]]
 
 
 def ref_hw2_read_binary(path, cap=200000):

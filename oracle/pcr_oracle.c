@@ -138,7 +138,7 @@ void orc_radius_f32(const float* db, size_t n, int dim, const float* q, size_t m
             float diff = 0.0f;
             for (int c = 0; c < dim; c++) {
                 float e = db[j * (size_t)dim + c] - q[qi * (size_t)dim + c];
-                diff += e * e;
+                diff = (float)((double)diff + (double)e * (double)e);   /* `diff += pow(e, 2)`: double pow, float += */
             }
             diff = sqrtf(diff);
             if (diff <= r) {
@@ -515,4 +515,80 @@ size_t orc_voxel_filter_f32(const float* x, const float* y, const float* z, size
     }
     free(hl);
     return out;
+}
+
+/* ------------------------------------------------------------------ N1 */
+static float hw7_dist_f32(float tx, float ty, float tz, float qx, float qy, float qz)
+{
+    /* Homework7/hw7/src/kdtree.cpp:310-315: `ElemType diff = 0; diff += pow(db - query, 2);` — pow() is the double
+     * overload, the += rounds the double sum back to float */
+    float s = 0.0f;
+    s = (float)((double)s + (double)(tx - qx) * (double)(tx - qx));
+    s = (float)((double)s + (double)(ty - qy) * (double)(ty - qy));
+    s = (float)((double)s + (double)(tz - qz) * (double)(tz - qz));
+    return sqrtf(s);
+}
+
+/* eigenvalues of a symmetric 3x3 (row-major, f64) by cyclic Jacobi, ascending */
+static void sym_eig3(const double A[9], double w[3])
+{
+    double a[3][3] = { { A[0], A[1], A[2] }, { A[3], A[4], A[5] }, { A[6], A[7], A[8] } };
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (a[p][q] == 0.0) continue;
+                double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; k++) { double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - sn * akq; a[k][q] = sn * akp + c * akq; }
+                for (int k = 0; k < 3; k++) { double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - sn * aqk; a[q][k] = sn * apk + c * aqk; }
+            }
+    }
+    w[0] = a[0][0]; w[1] = a[1][1]; w[2] = a[2][2];
+    for (int i = 0; i < 2; i++) for (int j = i + 1; j < 3; j++) if (w[j] < w[i]) { double t = w[i]; w[i] = w[j]; w[j] = t; }
+}
+
+void orc_iss_f32(const float* x, const float* y, const float* z, size_t n, float local_radius, float non_max_radius,
+                 float gamma21, float gamma32, int min_neighbors, int weighted, uint8_t* is_key, float* lambda3_out)
+{
+    uint32_t* cnt = (uint32_t*)calloc(n ? n : 1, sizeof(uint32_t));
+    float* l3 = (float*)malloc(sizeof(float) * (n ? n : 1));
+    for (size_t i = 0; i < n; i++)                                                 /* iss_detector.cpp:47-57 */
+        for (size_t j = 0; j < n; j++)
+            cnt[i] += hw7_dist_f32(x[j], y[j], z[j], x[i], y[i], z[i]) <= local_radius;
+    for (size_t i = 0; i < n; i++) {                                               /* :69-83 */
+        l3[i] = -1.0f;
+        if (cnt[i] < 3) continue;
+        double cov[9] = { 0 }, wsum = 0.0;
+        for (size_t j = 0; j < n; j++) {
+            if (!(hw7_dist_f32(x[j], y[j], z[j], x[i], y[i], z[i]) <= local_radius)) continue;
+            const double w = weighted ? (double)(1.0f / (float)cnt[j]) : 1.0;       /* :130 weight_nn = 1.f / size */
+            const double d[3] = { (double)(float)(x[j] - x[i]), (double)(float)(y[j] - y[i]), (double)(float)(z[j] - z[i]) };
+            for (int r = 0; r < 3; r++) for (int c = r; c < 3; c++) cov[3 * r + c] += (w * d[r]) * d[c];   /* upper triangle */
+            wsum += w;
+        }
+        if (weighted) for (int k = 0; k < 9; k++) cov[k] /= wsum;                  /* :137 */
+        cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];                         /* symmetric by construction */
+        double w3[3];
+        sym_eig3(cov, w3);                                                          /* :148-151, ascending */
+        const float lambda1 = (float)w3[2], lambda2 = (float)w3[1], lambda3 = (float)w3[0];
+        if (lambda2 / lambda1 < gamma21 && lambda3 / lambda2 < gamma32 && lambda3 > 0) l3[i] = lambda3;   /* :79 */
+    }
+    for (size_t i = 0; i < n; i++) {                                               /* :86-105 */
+        is_key[i] = 0;
+        if (l3[i] == -1.0f) continue;
+        size_t m = 0;
+        int is_max = 1;
+        for (size_t j = 0; j < n; j++) {
+            if (!(hw7_dist_f32(x[j], y[j], z[j], x[i], y[i], z[i]) <= non_max_radius)) continue;
+            m++;
+            if (l3[i] < l3[j]) is_max = 0;
+        }
+        if ((int)m < min_neighbors) continue;
+        is_key[i] = (uint8_t)is_max;
+    }
+    if (lambda3_out) memcpy(lambda3_out, l3, sizeof(float) * n);
+    free(cnt); free(l3);
 }

@@ -145,6 +145,19 @@ void orc_plane_from_3pts(const double p[9], double params[4]);
 size_t orc_voxel_filter_f32(const float* x, const float* y, const float* z, size_t n, double leaf_size,
                             float* ox, float* oy, float* oz);
 
+/* ---- N1: ISS keypoints, ISSKeypoint::compute (Homework7/hw7/src/iss_detector.cpp:38-110) on an n x 3 f32 cloud (SoA).
+ * Neighbourhoods use hw7's float kd-tree arithmetic (src/kdtree.cpp:310-316, ElemType float):
+ *   s = 0; s = (float)((double)s + pow((double)(t_c - q_c), 2)) for c = 0..2; d = sqrtf(s); member iff d <= r.
+ * Covariance (getEigenvalues, :113-152): weighted by 1 / |N(j)| and divided by the weight sum when `weighted`,
+ * plain sum otherwise; the reference accumulates in f32 in tree-visit order (order-dependent, Eigen) — restated with
+ * f64 accumulation in ascending index order and an f64 Jacobi eigen-solver, eigenvalues rounded to f32.
+ * lambda3[i] = smallest eigenvalue if lambda2/lambda1 < gamma21 && lambda3/lambda2 < gamma32 && lambda3 > 0, else -1
+ * (needs >= 3 neighbours, :72); keypoint iff lambda3[i] != -1, |N_nms(i)| >= min_neighbors and no neighbour within
+ * non_max_radius has a larger lambda3 (:86-105).  is_key: n bytes; lambda3_out (optional): n floats.  Parity with the
+ * reference is UNPINNED (hw7 needs PCL + Eigen). */
+void orc_iss_f32(const float* x, const float* y, const float* z, size_t n, float local_radius, float non_max_radius,
+                 float gamma21, float gamma32, int min_neighbors, int weighted, uint8_t* is_key, float* lambda3_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,7 +218,62 @@ def f7():
     save("voxel_filter_hw1.npz", **out)
 
 
+# ------------------------------------------------------------------ F8 (next row N1)
+def read_ply_xyz(path):
+    """binary_little_endian PLY with float x y z nx ny nz vertices (Homework7/hw7/test_data/*.ply)."""
+    raw = open(path, "rb").read()
+    end = raw.index(b"end_header\n") + len(b"end_header\n")
+    header = raw[:end].decode()
+    n = int([l for l in header.splitlines() if l.startswith("element vertex")][0].split()[-1])
+    props = [l for l in header.splitlines() if l.startswith("property")]
+    assert all(p.split()[1] == "float" for p in props)
+    a = np.frombuffer(raw, np.float32, n * len(props), end).reshape(n, len(props))
+    return np.ascontiguousarray(a[:, :3])
+
+
+def row_digest(row, idx):
+    """per-query (count, sum of neighbour indices, xor of neighbour indices): pins a neighbourhood SET in 16 bytes."""
+    m = row.size - 1
+    cnt = np.diff(row).astype(np.uint32)
+    ssum = np.zeros(m, np.uint64)
+    sxor = np.zeros(m, np.uint32)
+    for i in range(m):
+        seg = idx[row[i]:row[i + 1]].astype(np.uint32)
+        ssum[i] = seg.astype(np.uint64).sum()
+        sxor[i] = np.bitwise_xor.reduce(seg) if seg.size else 0
+    return cnt, ssum, sxor
+
+
+def f8():
+    """hw7: the radius neighbourhoods of ISSKeypoint::compute (iss_detector.cpp:45-57, :90-92) from the reference's own
+    float kd-tree (oracle/_ref/libhw7_ref.so) on the reference's test clouds, at the driver's radii (main.cpp:84-91:
+    6 * 0.02 and 4 * 0.02, leaf 12).  The Eigen half is unbuildable; the oracle's ISS output is stored as a self-golden."""
+    out = {}
+    for name in ("airplane_0001", "chair_0001"):
+        xyz = read_ply_xyz(f"{REF}/Homework7/hw7/test_data/{name}.ply")
+        out[f"xyz_{name}"] = xyz
+        for tag, r in (("local", np.float32(6 * np.float32(0.02))), ("nms", np.float32(4 * np.float32(0.02)))):
+            row, idx, dist = orc.ref_hw7_radius(xyz, xyz, float(r))
+            cnt, ssum, sxor = row_digest(row, idx)
+            out[f"{tag}_cnt_{name}"] = cnt
+            out[f"{tag}_sum_{name}"] = ssum
+            out[f"{tag}_xor_{name}"] = sxor
+            out[f"{tag}_r"] = r
+            # the oracle agrees with the reference before anything is stored
+            orow, oidx, odist = orc.radius_f32(xyz, xyz, float(r))
+            assert np.array_equal(orow, row)
+            for i in range(0, xyz.shape[0], 97):
+                o = np.argsort(idx[row[i]:row[i + 1]], kind="stable")
+                assert np.array_equal(idx[row[i]:row[i + 1]][o], oidx[row[i]:row[i + 1]])
+                assert np.array_equal(dist[row[i]:row[i + 1]][o].view(np.uint32), odist[row[i]:row[i + 1]].view(np.uint32))
+        key, l3 = orc.iss_f32(np.ascontiguousarray(xyz.T), float(out["local_r"]), float(out["nms_r"]), 0.9, 0.9, 5, True)
+        out[f"selfgolden_keys_{name}"] = np.flatnonzero(key).astype(np.int32)
+        out[f"selfgolden_lambda3_{name}"] = l3
+        print(name, "keypoints", int(key.sum()), "mean |N|", float(out[f"local_cnt_{name}"].mean()))
+    save("iss_hw7.npz", **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not present"
     orc.build(ref=True)
-    f1(); f2_f3_f4(); f5(); f6(); f7()
+    f1(); f2_f3_f4(); f5(); f6(); f7(); f8()
