@@ -178,3 +178,43 @@ def test_hw9_driver_pose_csv_matches_oracle(tmp_path, orc, synth, fpp):
                    [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
     assert abs(np.linalg.norm(q) - 1) < 1e-5 and w > 0
     assert np.allclose(Rq, T[:3, :3], atol=2e-5)
+
+
+def build_iss_check(tmp_path):
+    need_lib()
+    exe = tmp_path / "iss_check"
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-I" + INC, os.path.join(ROOT, "tests", "cpp", "iss_check.cpp"),
+                        "-o", str(exe)] + LINK, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_iss_dropin_driver_compiles(tmp_path):
+    build_iss_check(tmp_path)
+
+
+@pytest.mark.gpu
+def test_iss_dropin_class_gives_the_oracle_keypoints(tmp_path, orc, golden):
+    """include/pcr/iss_detector.hpp driven exactly as Homework7/hw7/main.cpp:82-92 drives the reference class."""
+    exe = build_iss_check(tmp_path)
+    g = golden("iss_hw7.npz")
+    xyz = g["xyz_chair_0001"]
+    n = xyz.shape[0]
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<q", n))
+        f.write(np.ascontiguousarray(xyz, np.float32).tobytes())
+    r = subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    buf = open(tmp_path / "out.bin", "rb").read()
+    k = struct.unpack_from("<q", buf, 0)[0]
+    idx = np.frombuffer(buf, np.int32, k, 8)
+    l3 = np.frombuffer(buf, np.float32, n, 8 + 4 * k)
+    cnt = np.frombuffer(buf, np.uint32, n, 8 + 4 * k + 4 * n)
+    kp = np.frombuffer(buf, np.float32, 3 * k, 8 + 4 * k + 8 * n).reshape(k, 3)
+    assert f"key points size : {k}" in r.stdout
+    assert np.array_equal(cnt, g["local_cnt_chair_0001"])                       # the reference kd-tree's own counts
+    assert np.array_equal(kp, xyz[idx])                                          # keypoints are input points, ascending index
+    assert (np.diff(idx) > 0).all()
+    okey, ol3 = orc.iss_f32(np.ascontiguousarray(xyz.T), float(g["local_r"]), float(g["nms_r"]), 0.9, 0.9, 5, True)
+    assert np.allclose(l3, ol3, rtol=1e-6, atol=0)
+    assert len(set(idx.tolist()) ^ set(np.flatnonzero(okey).tolist())) <= 2
