@@ -53,7 +53,8 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
+    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32",
+    "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
 
@@ -111,6 +112,11 @@ def lib():
     L.pcr_grid_stats.argtypes = [vp, vp]
     L.pcr_voxel_filter_f32.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
     L.pcr_iss_keypoints_f32.argtypes = [vp, vp, C.POINTER(IssParams), vp, vp, vp, C.POINTER(C.c_uint64)]
+    L.pcr_nn1_desc_f32.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, vp]
+    L.pcr_match_union_f32.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.c_float, vp, vp, C.POINTER(sz)]
+    L.pcr_ransac_sample_quads.argtypes = [vp, sz, vp, sz, sz, C.c_uint64, vp]
+    L.pcr_consensus_count_f32.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, C.c_float, vp]
+    L.pcr_ransac_global_f32.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, C.c_float, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int64), vp]
     _lib = L
     return L
 
@@ -120,6 +126,17 @@ def shard_range(n: int, nranks: int, rank: int):
     b, e = C.c_size_t(), C.c_size_t()
     lib().pcr_shard_range(n, nranks, rank, C.byref(b), C.byref(e))
     return b.value, e.value
+
+
+def ransac_sample_quads(src_xyz, pairs, n_hyp, seed):
+    """The sampling loop of Registration::RANSAC (registration.cpp:318-352), explicit seed (host logic, no GPU)."""
+    src = np.ascontiguousarray(src_xyz, np.float32)
+    p = np.ascontiguousarray(pairs, np.uint32)
+    quads = np.zeros((n_hyp, 4), np.uint32)
+    rc = lib().pcr_ransac_sample_quads(src.ctypes.data, src.shape[0], p.ctypes.data, p.shape[0], n_hyp, seed, quads.ctypes.data)
+    if rc != 0:
+        raise PcrError(f"pcr_ransac_sample_quads failed (rc = {rc})")
+    return quads
 
 
 def kabsch_solve(sums):
@@ -300,6 +317,55 @@ class Context:
         idx = np.flatnonzero(key[:n])
         assert idx.size == cnt.value
         return idx, l3[:n], cn[:n]
+
+    # ---- N4
+    def nn1_desc(self, db, q):
+        """1-NN between descriptor sets (rows), nanoflann L2 arithmetic at any dim -> (idx u32, d2 f32)."""
+        db = np.ascontiguousarray(db, np.float32)
+        q = np.ascontiguousarray(q, np.float32)
+        idx = np.zeros(max(q.shape[0], 1), np.uint32)
+        d2 = np.zeros(max(q.shape[0], 1), np.float32)
+        self._ck(lib().pcr_nn1_desc_f32(self.h, db.ctypes.data, db.shape[0], q.ctypes.data, q.shape[0], db.shape[1], idx.ctypes.data, d2.ctypes.data))
+        return idx[: q.shape[0]], d2[: q.shape[0]]
+
+    def match_union(self, desc_src, desc_tgt, rejection_rate):
+        """findRANSACCorrespondencesUnion (registration.cpp:535-615) -> (pairs [K, 2] (src, tgt), dist [K])."""
+        a = np.ascontiguousarray(desc_src, np.float32)
+        b = np.ascontiguousarray(desc_tgt, np.float32)
+        total = a.shape[0] + b.shape[0]
+        pairs = np.zeros((max(total, 1), 2), np.uint32)
+        dist = np.zeros(max(total, 1), np.float32)
+        k = C.c_size_t()
+        self._ck(lib().pcr_match_union_f32(self.h, a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], a.shape[1], rejection_rate,
+                                           pairs.ctypes.data, dist.ctypes.data, C.byref(k)))
+        return pairs[: k.value], dist[: k.value]
+
+    def consensus_count(self, src_xyz, tgt_xyz, pairs, Rt, thr):
+        """consensus-set sizes (registration.cpp:395-421) of poses Rt [H, 12] = (R row-major, t)."""
+        s = np.ascontiguousarray(src_xyz, np.float32)
+        t = np.ascontiguousarray(tgt_xyz, np.float32)
+        p = np.ascontiguousarray(pairs, np.uint32)
+        rt = np.ascontiguousarray(Rt, np.float32).reshape(-1, 12)
+        counts = np.zeros(max(rt.shape[0], 1), np.uint32)
+        self._ck(lib().pcr_consensus_count_f32(self.h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], p.ctypes.data, p.shape[0],
+                                               rt.ctypes.data, rt.shape[0], thr, counts.ctypes.data))
+        return counts[: rt.shape[0]]
+
+    def ransac_global(self, src_xyz, tgt_xyz, pairs, quads, thr):
+        """Registration::RANSAC over given quads -> (winner, R 3x3, t, best count, counts [H])."""
+        s = np.ascontiguousarray(src_xyz, np.float32)
+        t = np.ascontiguousarray(tgt_xyz, np.float32)
+        p = np.ascontiguousarray(pairs, np.uint32)
+        qd = np.ascontiguousarray(quads, np.uint32).reshape(-1, 4)
+        R = np.zeros(9, np.float32)
+        tv = np.zeros(3, np.float32)
+        best = C.c_uint32()
+        win = C.c_int64()
+        counts = np.zeros(max(qd.shape[0], 1), np.uint32)
+        self._ck(lib().pcr_ransac_global_f32(self.h, s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], p.ctypes.data, p.shape[0],
+                                             qd.ctypes.data, qd.shape[0], thr, R.ctypes.data, tv.ctypes.data, C.byref(best), C.byref(win),
+                                             counts.ctypes.data))
+        return win.value, R.reshape(3, 3), tv, best.value, counts[: qd.shape[0]]
 
     # ---- A8 / A7
     def transform(self, cloud: Cloud, T):

@@ -172,6 +172,32 @@ typedef struct {
 int pcr_iss_keypoints_f32(pcr_ctx* ctx, const pcr_cloud* cloud, const pcr_iss_params* prm, uint8_t* is_key, float* lambda3,
                           uint32_t* neighbor_counts, uint64_t* n_keypoints);
 
+/* ---- next row N4: global-registration front half, Homework9/hw9/src/registration.cpp:288-434, :535-615 -----------
+ * N4a: exhaustive 1-NN between two descriptor sets (row-major n x dim / m x dim f32, host memory; dim 33 = FPFH),
+ * nanoflann's evalMetric arithmetic for any dim (nanoflann.hpp:382-405: groups of four + tail, f32, unfused), canonical
+ * tie rule (min d2, lowest index), acceptance d2 < FLT_MAX; idx = UINT32_MAX / d2 = +inf when nothing is accepted. */
+int pcr_nn1_desc_f32(pcr_ctx* ctx, const float* db, size_t n, const float* q, size_t m, int dim, uint32_t* idx, float* d2);
+/* N4b: findRANSACCorrespondencesUnion (:535-615).  pairs: room for 2 * (n_src + n_tgt) u32, (src, tgt) interleaved;
+ * dist: n_src + n_tgt floats (squared descriptor distance of each kept pair); *n_pairs = floor((1 - rate) * total) as
+ * the reference computes it (f32).  Sorted by distance; ties in input order (the reference: std::sort, unspecified). */
+int pcr_match_union_f32(pcr_ctx* ctx, const float* desc_src, size_t n_src, const float* desc_tgt, size_t n_tgt, int dim,
+                        float rejection_rate, uint32_t* pairs, float* dist, size_t* n_pairs);
+/* N4c: Registration::RANSAC (:288-434).  Sampling (host logic, no GPU): n_hyp quads of correspondence indices drawn as
+ * :318-352 draws them (std::mt19937 + uniform_int_distribution, non-coplanar SOURCE keypoints), seeded explicitly
+ * instead of std::random_device.  PCR_ERR_STATE when no admissible quad exists (the reference would loop forever). */
+int pcr_ransac_sample_quads(const float* src_xyz, size_t n_src, const uint32_t* pairs, size_t n_pairs, size_t n_hyp,
+                            uint64_t seed, uint32_t* quads);
+/* consensus-set size (:395-421) of n_hyp given poses Rt[h] = {R row-major 9, t 3} over all correspondences:
+ * counts[h] = #{i : || tgt_i - (R src_i + t) || <= thr}, f32, unfused.  xyz arrays are AoS (n x 3), host memory. */
+int pcr_consensus_count_f32(pcr_ctx* ctx, const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                            const uint32_t* pairs, size_t n_pairs, const float* Rt, size_t n_hyp, float thr, uint32_t* counts);
+/* the whole loop over given quads: 4-point Kabsch per hypothesis (:354-392, f64 moments + the solve of
+ * pcr_kabsch_solve) -> consensus counts -> first hypothesis with the largest count (:423-428).  *winner = -1 (R, t
+ * untouched) when every consensus set is empty; counts (optional): n_hyp. */
+int pcr_ransac_global_f32(pcr_ctx* ctx, const float* src_xyz, size_t n_src, const float* tgt_xyz, size_t n_tgt,
+                          const uint32_t* pairs, size_t n_pairs, const uint32_t* quads, size_t n_hyp, float thr,
+                          float R[9], float t[3], uint32_t* best_count, int64_t* winner, uint32_t* counts);
+
 /* ---- multi-GPU: one process per GPU, sources sharded, targets replicated ------------------------------
  * Exactly one collective per ICP iteration: all-reduce(sum) of 16 f64 (+2 bookkeeping words). */
 #define PCR_COMM_ID_BYTES 128

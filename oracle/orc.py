@@ -69,6 +69,16 @@ def lib():
         L.orc_plane_from_3pts.argtypes = [f64p, f64p]
         L.orc_voxel_filter_f32.restype = sz
         L.orc_voxel_filter_f32.argtypes = [f32p, f32p, f32p, sz, C.c_double, f32p, f32p, f32p]
+        L.orc_d2_dim_f32.argtypes = [f32p, f32p, C.c_int]
+        L.orc_d2_dim_f32.restype = C.c_float
+        L.orc_nn1_dim_f32.argtypes = [f32p, sz, f32p, sz, C.c_int, u32p, f32p]
+        L.orc_match_union_f32.argtypes = [f32p, sz, f32p, sz, C.c_int, C.c_float, u32p, f32p]
+        L.orc_match_union_f32.restype = sz
+        L.orc_ransac_hypothesis.argtypes = [f32p, f32p, u32p, u32p, f32p, f32p]
+        L.orc_consensus_count_f32.argtypes = [f32p, f32p, u32p, sz, f32p, f32p, C.c_float]
+        L.orc_consensus_count_f32.restype = C.c_uint32
+        L.orc_ransac_global_f32.argtypes = [f32p, f32p, u32p, sz, u32p, sz, C.c_float, f32p, f32p, u32p, C.c_void_p]
+        L.orc_ransac_global_f32.restype = C.c_int64
         L.orc_iss_f32.argtypes = [f32p, f32p, f32p, sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, u8p, f32p]
         L.orc_hw2_knn_add.argtypes = [f64p, i32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                       C.c_double, C.c_int]
@@ -94,6 +104,7 @@ def ref():
         dp = C.POINTER(C.c_double)
         L.ref_nano_nn1_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, C.c_int, C.c_int,
                                        u32p, f32p, dp, dp]
+        L.ref_nano_nn1_dim_f32.argtypes = [f32p, sz, f32p, sz, C.c_int, C.c_int, u32p, f32p]
         L.ref_nano_knn_f64.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_int, C.c_int, u64p, f64p]
         L.ref_hw2_kd_knn.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_int, C.c_int, i32p, f64p,
                                      C.c_void_p, dp, dp]
@@ -248,6 +259,54 @@ def voxel_filter_f32(soa, leaf_size):
     return np.stack([ox[:m], oy[:m], oz[:m]])
 
 
+def nn1_dim_f32(db, q):
+    db = np.ascontiguousarray(db, np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    idx = np.empty(q.shape[0], np.uint32)
+    d2 = np.empty(q.shape[0], np.float32)
+    lib().orc_nn1_dim_f32(db, db.shape[0], q, q.shape[0], db.shape[1], idx, d2)
+    return idx, d2
+
+
+def match_union_f32(desc_src, desc_tgt, rejection_rate):
+    """findRANSACCorrespondencesUnion -> (pairs [K, 2] u32 (src, tgt), dist f32[K])."""
+    a = np.ascontiguousarray(desc_src, np.float32)
+    b = np.ascontiguousarray(desc_tgt, np.float32)
+    total = a.shape[0] + b.shape[0]
+    pairs = np.zeros((max(total, 1), 2), np.uint32)
+    dist = np.zeros(max(total, 1), np.float32)
+    k = lib().orc_match_union_f32(a, a.shape[0], b, b.shape[0], a.shape[1], rejection_rate, pairs.reshape(-1), dist)
+    return pairs[:k], dist[:k]
+
+
+def ransac_hypothesis(src_xyz, tgt_xyz, pairs, quad):
+    R = np.zeros(9, np.float32)
+    t = np.zeros(3, np.float32)
+    rc = lib().orc_ransac_hypothesis(np.ascontiguousarray(src_xyz, np.float32).reshape(-1), np.ascontiguousarray(tgt_xyz, np.float32).reshape(-1),
+                                     np.ascontiguousarray(pairs, np.uint32).reshape(-1), np.ascontiguousarray(quad, np.uint32), R, t)
+    return rc, R.reshape(3, 3), t
+
+
+def consensus_count_f32(src_xyz, tgt_xyz, pairs, R, t, thr):
+    p = np.ascontiguousarray(pairs, np.uint32)
+    return int(lib().orc_consensus_count_f32(np.ascontiguousarray(src_xyz, np.float32).reshape(-1), np.ascontiguousarray(tgt_xyz, np.float32).reshape(-1),
+                                             p.reshape(-1), p.shape[0], np.ascontiguousarray(R, np.float32).reshape(9),
+                                             np.ascontiguousarray(t, np.float32).reshape(3), thr))
+
+
+def ransac_global_f32(src_xyz, tgt_xyz, pairs, quads, thr):
+    """Registration::RANSAC over given quads -> (winner index, R, t, best count, counts[n_hyp])."""
+    p = np.ascontiguousarray(pairs, np.uint32)
+    qd = np.ascontiguousarray(quads, np.uint32)
+    R = np.zeros(9, np.float32)
+    t = np.zeros(3, np.float32)
+    best = np.zeros(1, np.uint32)
+    counts = np.zeros(max(qd.shape[0], 1), np.uint32)
+    w = lib().orc_ransac_global_f32(np.ascontiguousarray(src_xyz, np.float32).reshape(-1), np.ascontiguousarray(tgt_xyz, np.float32).reshape(-1),
+                                    p.reshape(-1), p.shape[0], qd.reshape(-1), qd.shape[0], thr, R, t, best, counts.ctypes.data)
+    return int(w), R.reshape(3, 3), t, int(best[0]), counts[: qd.shape[0]]
+
+
 def iss_f32(soa, local_radius, non_max_radius, gamma21=0.9, gamma32=0.9, min_neighbors=5, weighted=True):
     """ISSKeypoint::compute (hw7) -> (is_key uint8[n], lambda3 f32[n])."""
     x, y, z = _soa(soa)
@@ -268,6 +327,16 @@ def ref_nano_nn1_f32(tgt_soa, src_soa, leaf=2, threads=1):
     ref().ref_nano_nn1_f32(tx, ty, tz, tx.size, sx, sy, sz, sx.size, leaf, threads, idx, d2,
                            C.byref(b), C.byref(q))
     return idx, d2, b.value, q.value
+
+
+def ref_nano_nn1_dim_f32(db, q, leaf=2):
+    """vendored nanoflann at any dim (row-major f32), as findRANSACCorrespondencesUnion uses it -> (idx, d2)."""
+    db = np.ascontiguousarray(db, np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    idx = np.empty(q.shape[0], np.uint32)
+    d2 = np.empty(q.shape[0], np.float32)
+    ref().ref_nano_nn1_dim_f32(db, db.shape[0], q, q.shape[0], db.shape[1], leaf, idx, d2)
+    return idx, d2
 
 
 def ref_nano_knn_f64(db, q, k, leaf=10):

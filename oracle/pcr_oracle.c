@@ -592,3 +592,116 @@ void orc_iss_f32(const float* x, const float* y, const float* z, size_t n, float
     if (lambda3_out) memcpy(lambda3_out, l3, sizeof(float) * n);
     free(cnt); free(l3);
 }
+
+/* ------------------------------------------------------------------ N4 */
+float orc_d2_dim_f32(const float* a, const float* b, int dim)
+{
+    float result = 0.0f;
+    int d = 0;
+    for (; d + 3 < dim; d += 4) {                                     /* nanoflann.hpp:390-400 */
+        const float d0 = a[d] - b[d], d1 = a[d + 1] - b[d + 1], d2 = a[d + 2] - b[d + 2], d3 = a[d + 3] - b[d + 3];
+        result += ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+    }
+    for (; d < dim; d++) {                                            /* :402-405 */
+        const float d0 = a[d] - b[d];
+        result += d0 * d0;
+    }
+    return result;
+}
+
+void orc_nn1_dim_f32(const float* db, size_t n, const float* q, size_t m, int dim, uint32_t* idx, float* d2)
+{
+    for (size_t i = 0; i < m; i++) {
+        float best = FLT_MAX;                                         /* nanoflann.hpp:163 */
+        uint32_t bi = UINT32_MAX;
+        for (size_t j = 0; j < n; j++) {
+            const float d = orc_d2_dim_f32(q + i * (size_t)dim, db + j * (size_t)dim, dim);
+            if (d < best) { best = d; bi = (uint32_t)j; }             /* strict: lowest index among equals */
+        }
+        idx[i] = bi;
+        d2[i] = bi == UINT32_MAX ? INFINITY : best;
+    }
+}
+
+typedef struct { uint32_t s, t; float d; size_t pos; } match_rec;
+static int match_cmp(const void* a, const void* b)
+{
+    const match_rec* x = (const match_rec*)a; const match_rec* y = (const match_rec*)b;
+    if (x->d < y->d) return -1;
+    if (y->d < x->d) return 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos ? 1 : 0);
+}
+
+size_t orc_match_union_f32(const float* desc_src, size_t n_src, const float* desc_tgt, size_t n_tgt, int dim,
+                           float rejection_rate, uint32_t* pairs, float* dist)
+{
+    const size_t total = n_src + n_tgt;
+    match_rec* rec = (match_rec*)malloc(sizeof(match_rec) * (total ? total : 1));
+    uint32_t* idx = (uint32_t*)malloc(sizeof(uint32_t) * (total ? total : 1));
+    float* d2 = (float*)malloc(sizeof(float) * (total ? total : 1));
+    orc_nn1_dim_f32(desc_src, n_src, desc_tgt, n_tgt, dim, idx, d2);               /* :561-577 */
+    for (size_t i = 0; i < n_tgt; i++) { rec[i].s = idx[i]; rec[i].t = (uint32_t)i; rec[i].d = d2[i]; rec[i].pos = i; }
+    orc_nn1_dim_f32(desc_tgt, n_tgt, desc_src, n_src, dim, idx, d2);               /* :579-595 */
+    for (size_t i = 0; i < n_src; i++) { rec[n_tgt + i].s = (uint32_t)i; rec[n_tgt + i].t = idx[i]; rec[n_tgt + i].d = d2[i]; rec[n_tgt + i].pos = n_tgt + i; }
+    qsort(rec, total, sizeof(match_rec), match_cmp);                               /* :598-603 */
+    const float keep_f = floorf((1 - rejection_rate) * (float)total);              /* :605, float arithmetic */
+    size_t keep = keep_f > 0 ? (size_t)keep_f : 0;
+    if (keep > total) keep = total;
+    for (size_t i = 0; i < keep; i++) { pairs[2 * i] = rec[i].s; pairs[2 * i + 1] = rec[i].t; dist[i] = rec[i].d; }
+    free(rec); free(idx); free(d2);
+    return keep;
+}
+
+int orc_ransac_hypothesis(const float* src_xyz, const float* tgt_xyz, const uint32_t* pairs, const uint32_t quad[4],
+                          float R[9], float t[3])
+{
+    double sums[16];
+    for (int k = 0; k < 16; k++) sums[k] = 0.0;
+    for (int k = 0; k < 4; k++) {                                                  /* :354-366 */
+        const float* ps = src_xyz + 3 * (size_t)pairs[2 * (size_t)quad[k]];
+        const float* qt = tgt_xyz + 3 * (size_t)pairs[2 * (size_t)quad[k] + 1];
+        const double p[3] = { ps[0], ps[1], ps[2] }, q[3] = { qt[0], qt[1], qt[2] };
+        for (int c = 0; c < 3; c++) { sums[c] += p[c]; sums[3 + c] += q[c]; }
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) sums[6 + 3 * r + c] += q[r] * p[c];
+        sums[15] += 1.0;
+    }
+    return orc_kabsch_solve(sums, R, t);                                           /* :368-392 */
+}
+
+uint32_t orc_consensus_count_f32(const float* src_xyz, const float* tgt_xyz, const uint32_t* pairs, size_t n_pairs,
+                                 const float R[9], const float t[3], float thr)
+{
+    uint32_t c = 0;
+    for (size_t i = 0; i < n_pairs; i++) {                                         /* :395-421 */
+        const float* s = src_xyz + 3 * (size_t)pairs[2 * i];
+        const float* q = tgt_xyz + 3 * (size_t)pairs[2 * i + 1];
+        float e[3];
+        for (int r = 0; r < 3; r++) e[r] = q[r] - (((R[3 * r] * s[0] + R[3 * r + 1] * s[1]) + R[3 * r + 2] * s[2]) + t[r]);
+        const float distance = sqrtf((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+        c += distance <= thr;
+    }
+    return c;
+}
+
+int64_t orc_ransac_global_f32(const float* src_xyz, const float* tgt_xyz, const uint32_t* pairs, size_t n_pairs,
+                              const uint32_t* quads, size_t n_hyp, float thr, float R[9], float t[3],
+                              uint32_t* best_count, uint32_t* counts)
+{
+    uint32_t max_consensus = 0;
+    int64_t winner = -1;
+    for (size_t h = 0; h < n_hyp; h++) {
+        float Rh[9], th[3];
+        uint32_t c = 0;
+        if (orc_ransac_hypothesis(src_xyz, tgt_xyz, pairs, quads + 4 * h, Rh, th) == 0)
+            c = orc_consensus_count_f32(src_xyz, tgt_xyz, pairs, n_pairs, Rh, th, thr);
+        if (counts) counts[h] = c;
+        if (c > max_consensus) {                                                   /* :423-428 */
+            max_consensus = c;
+            winner = (int64_t)h;
+            memcpy(R, Rh, sizeof Rh);
+            memcpy(t, th, sizeof th);
+        }
+    }
+    if (best_count) *best_count = max_consensus;
+    return winner;
+}

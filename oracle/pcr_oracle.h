@@ -158,6 +158,34 @@ size_t orc_voxel_filter_f32(const float* x, const float* y, const float* z, size
 void orc_iss_f32(const float* x, const float* y, const float* z, size_t n, float local_radius, float non_max_radius,
                  float gamma21, float gamma32, int min_neighbors, int weighted, uint8_t* is_key, float* lambda3_out);
 
+/* ---- N4: global-registration front half (Homework9/hw9/src/registration.cpp:288-434, :535-615).
+ * N4a: nanoflann L2_Adaptor::evalMetric for any dim (nanoflann.hpp:382-405), f32, unfused: groups of four
+ *   result += ((d0*d0 + d1*d1) + d2*d2) + d3*d3, then the 0-3 tail components one by one.  (The early exit on
+ *   worst_dist only ever returns a partial sum for a candidate that is rejected anyway.) */
+float orc_d2_dim_f32(const float* a, const float* b, int dim);
+/* brute-force 1-NN over an n x dim row-major database, canonical tie rule (min d2, lowest index); acceptance
+ * d2 < FLT_MAX as in A6.  PINNED against the vendored nanoflann at dim 33 (tests/golden/desc_match_hw9.npz). */
+void orc_nn1_dim_f32(const float* db, size_t n, const float* q, size_t m, int dim, uint32_t* idx, float* d2);
+/* N4b: findRANSACCorrespondencesUnion (:535-615): [nn_src(tgt_i), i] for every target, then [i, nn_tgt(src_i)] for every
+ * source, sorted by distance (std::sort there: tie order unspecified; here stable = by position), the first
+ * floor((1 - rate) * size) kept, the product evaluated in f32 as written (:605).  pairs: 2 x (n_src + n_tgt) u32
+ * (src, tgt interleaved), dist likewise; returns the number kept. */
+size_t orc_match_union_f32(const float* desc_src, size_t n_src, const float* desc_tgt, size_t n_tgt, int dim,
+                           float rejection_rate, uint32_t* pairs, float* dist);
+/* N4c: one RANSAC hypothesis (:366-392): Kabsch over the 4 sampled correspondences `quad` (indices into pairs), f64
+ * moments + orc_kabsch_solve (the reference: f32 Eigen, JacobiSVD — unpinned, as A7). src/tgt: AoS xyz. */
+int orc_ransac_hypothesis(const float* src_xyz, const float* tgt_xyz, const uint32_t* pairs, const uint32_t quad[4],
+                          float R[9], float t[3]);
+/* consensus set size (:395-421): #{pairs : || tgt - (R src + t) || <= thr}, f32, unfused, row-wise
+ * ((R_i0 x + R_i1 y) + R_i2 z) + t_i, norm = sqrtf((ex*ex + ey*ey) + ez*ez). */
+uint32_t orc_consensus_count_f32(const float* src_xyz, const float* tgt_xyz, const uint32_t* pairs, size_t n_pairs,
+                                 const float R[9], const float t[3], float thr);
+/* the RANSAC loop over given quads (n_hyp x 4): first hypothesis with the largest consensus wins (strict >, :423);
+ * counts (optional): n_hyp. Returns the winning hypothesis index or -1 when every consensus set is empty. */
+int64_t orc_ransac_global_f32(const float* src_xyz, const float* tgt_xyz, const uint32_t* pairs, size_t n_pairs,
+                              const uint32_t* quads, size_t n_hyp, float thr, float R[9], float t[3],
+                              uint32_t* best_count, uint32_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,19 @@ struct SoAMat {
     template <class BBOX> bool kdtree_get_bbox(BBOX&) const { return false; }
 };
 
+// row-major n x dim matrix: what KDTreeEigenMatrixAdaptor<MatrixXf> (nanoflann.hpp:1963-2030) presents for the
+// 33-D descriptor matrices of findRANSACCorrespondencesUnion (registration.cpp:562,580): same metric, DIM = -1
+struct RowMat {
+    const float* p;
+    size_t n;
+    int dim;
+    typedef nanoflann::metric_L2::traits<float, RowMat>::distance_t metric_t;
+    typedef nanoflann::KDTreeSingleIndexAdaptor<metric_t, RowMat, -1, size_t> index_t;
+    inline size_t kdtree_get_point_count() const { return n; }
+    inline float kdtree_get_pt(const size_t idx, size_t d) const { return p[idx * (size_t)dim + d]; }
+    template <class BBOX> bool kdtree_get_bbox(BBOX&) const { return false; }
+};
+
 double now_ms()
 {
     return std::chrono::duration<double, std::milli>(
@@ -80,6 +93,27 @@ int ref_nano_nn1_f32(const float* tx, const float* ty, const float* tz, size_t n
     double t2 = now_ms();
     if (build_ms) *build_ms = t1 - t0;
     if (query_ms) *query_ms = t2 - t1;
+    return 0;
+}
+
+// 1-NN of m dim-D queries in an n x dim row-major database through the vendored nanoflann, configured as
+// registration.cpp:562-575 does (leaf 2, KNNResultSet<float>(1), SearchParams(10)).
+int ref_nano_nn1_dim_f32(const float* db, size_t n, const float* q, size_t m, int dim, int leaf_max_size,
+                         uint32_t* idx, float* d2)
+{
+    RowMat mat{ db, n, dim };
+    RowMat::index_t index(dim, mat, nanoflann::KDTreeSingleIndexAdaptorParams(leaf_max_size));
+    index.buildIndex();
+    for (size_t i = 0; i < m; i++) {
+        size_t ri = (size_t)-1;
+        float rd = 0.0f;
+        nanoflann::KNNResultSet<float> rs(1);
+        rs.init(&ri, &rd);
+        std::vector<float> query(q + i * (size_t)dim, q + (i + 1) * (size_t)dim);
+        index.findNeighbors(rs, &query[0], nanoflann::SearchParams(10));
+        idx[i] = (ri == (size_t)-1) ? UINT32_MAX : (uint32_t)ri;
+        d2[i] = rd;
+    }
     return 0;
 }
 

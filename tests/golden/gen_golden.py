@@ -273,7 +273,43 @@ def f8():
     save("iss_hw7.npz", **out)
 
 
+# ------------------------------------------------------------------ F9 (next row N4)
+def fpfh_like(rng, n):
+    """33-D histograms shaped like pcl::FPFHSignature33: three 11-bin blocks, each summing to 100."""
+    h = rng.gamma(0.6, 1.0, (n, 33))
+    for b in range(3):
+        h[:, 11 * b:11 * b + 11] *= 100.0 / h[:, 11 * b:11 * b + 11].sum(1, keepdims=True)
+    return h.astype(np.float32)
+
+
+def f9():
+    """hw9 descriptor matching (registration.cpp:561-595): 1-NN in both directions through the vendored nanoflann
+    configured as there (dim 33, leaf 2, KNNResultSet<float>(1), SearchParams(10))."""
+    rng = np.random.default_rng(20200607)
+    src = fpfh_like(rng, 700)
+    tgt = np.concatenate([src[rng.permutation(700)[:400]] + rng.normal(0, 0.4, (400, 33)).astype(np.float32), fpfh_like(rng, 200)])
+    tgt = np.abs(tgt).astype(np.float32)
+    src[650:700] = src[100:150]                     # duplicated descriptors: tie sets of size 2 in the source set
+    tgt[590:600] = tgt[0:10]
+    tgt[580:590] = src[200:210]                     # exact matches, d2 = 0
+    i_ts, d_ts = orc.ref_nano_nn1_dim_f32(src, tgt)  # every target -> nearest source (:561-577)
+    i_st, d_st = orc.ref_nano_nn1_dim_f32(tgt, src)  # every source -> nearest target (:579-595)
+    # the restatement agrees with nanoflann before anything is stored: same d2 bits, same index outside tie sets
+    for (db, q, ri, rd) in ((src, tgt, i_ts, d_ts), (tgt, src, i_st, d_st)):
+        oi, od = orc.nn1_dim_f32(db, q)
+        assert np.array_equal(od.view(np.uint32), rd.view(np.uint32))
+        diff = np.flatnonzero(oi != ri)
+        for k in diff:
+            assert lib_d2(db[ri[k]], q[k]) == od[k] and oi[k] < ri[k]
+        print("dim-33 1-NN:", q.shape[0], "queries,", diff.size, "answered from a tie set")
+    save("desc_match_hw9.npz", desc_src=src, desc_tgt=tgt, nn_src_of_tgt=i_ts, d2_src_of_tgt=d_ts, nn_tgt_of_src=i_st, d2_tgt_of_src=d_st)
+
+
+def lib_d2(a, b):
+    return orc.lib().orc_d2_dim_f32(np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32), a.size)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not present"
     orc.build(ref=True)
-    f1(); f2_f3_f4(); f5(); f6(); f7(); f8()
+    f1(); f2_f3_f4(); f5(); f6(); f7(); f8(); f9()
