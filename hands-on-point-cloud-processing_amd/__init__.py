@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32",
+    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
@@ -112,6 +112,9 @@ def lib():
     L.pcr_grid_stats.argtypes = [vp, vp]
     L.pcr_voxel_filter_f32.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
     L.pcr_iss_keypoints_f32.argtypes = [vp, vp, C.POINTER(IssParams), vp, vp, vp, C.POINTER(C.c_uint64)]
+    L.pcr_fast_eigen3x3.argtypes = [vp, vp]
+    L.pcr_ground_seeds_f64.argtypes = [vp, vp, sz, C.c_double, vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.pcr_ground_detection_f64.argtypes = [vp, vp, C.c_int, sz, C.c_double, vp, vp, C.POINTER(C.c_uint64)]
     L.pcr_nn1_desc_f32.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, vp]
     L.pcr_match_union_f32.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.c_float, vp, vp, C.POINTER(sz)]
     L.pcr_ransac_sample_quads.argtypes = [vp, sz, vp, sz, sz, C.c_uint64, vp]
@@ -126,6 +129,14 @@ def shard_range(n: int, nranks: int, rank: int):
     b, e = C.c_size_t(), C.c_size_t()
     lib().pcr_shard_range(n, nranks, rank, C.byref(b), C.byref(e))
     return b.value, e.value
+
+
+def fast_eigen3x3(A):
+    """mylib.FastEigen3x3 (Homework1/.../mylib.cpp:105-189): eigenvector of the smallest eigenvalue (host, no GPU)."""
+    a = np.ascontiguousarray(A, np.float64).reshape(9)
+    out = np.zeros(3, np.float64)
+    lib().pcr_fast_eigen3x3(a.ctypes.data, out.ctypes.data)
+    return out
 
 
 def ransac_sample_quads(src_xyz, pairs, n_hyp, seed):
@@ -317,6 +328,26 @@ class Context:
         idx = np.flatnonzero(key[:n])
         assert idx.size == cnt.value
         return idx, l3[:n], cn[:n]
+
+    # ---- N2
+    def ground_seeds(self, cloud: Cloud, lpr_size: int, threshold_seeds: float):
+        """extract_initial_seeds (ground_detection_SVD.py:46-71) -> (seed mask bool[n], LPR_z + threshold)."""
+        n = len(cloud)
+        mask = np.zeros(max(n, 1), np.uint8)
+        ub = C.c_double()
+        cnt = C.c_uint64()
+        self._ck(lib().pcr_ground_seeds_f64(self.h, cloud.h, int(lpr_size), float(threshold_seeds), mask.ctypes.data, C.byref(ub), C.byref(cnt)))
+        return mask[:n].astype(bool), ub.value
+
+    def ground_detection(self, cloud: Cloud, max_iter: int, lpr_size: int, threshold_dist: float):
+        """ground_detection (ground_detection_SVD.py:88-101) -> (params f64[4], inlier mask bool[n])."""
+        n = len(cloud)
+        mask = np.zeros(max(n, 1), np.uint8)
+        params = np.zeros(4, np.float64)
+        cnt = C.c_uint64()
+        self._ck(lib().pcr_ground_detection_f64(self.h, cloud.h, int(max_iter), int(lpr_size), float(threshold_dist), params.ctypes.data,
+                                                mask.ctypes.data, C.byref(cnt)))
+        return params, mask[:n].astype(bool)
 
     # ---- N4
     def nn1_desc(self, db, q):

@@ -4,7 +4,9 @@ Mirrors (same names, argument meaning and return values):
   estimate_plane_params   Homework4/ground_detection_ransac.py:158-169   (host, f64; 3 points)
   my_ransac               Homework4/ground_detection_ransac.py:104-155
   ransac_on_segments      Homework4/ground_detection_ransac.py:54-73
-  extract_initial_seeds   Homework4/ground_detection_SVD.py:46-69        (host numpy; the step BEFORE the hot path)
+  extract_initial_seeds   Homework4/ground_detection_SVD.py:46-71        (GPU: radix-select of the lowest z, pcr_ground_seeds_f64)
+  ground_detection        Homework4/ground_detection_SVD.py:88-101       (GPU: pcr_ground_detection_f64, PCA refit loop)
+  ground_detection_on3segs  Homework4/ground_detection_SVD.py:104-126
 
 The hot loop of my_ransac — `dists = |[X 1] . params|; inliers = sum(dists < thr)` evaluated once per hypothesis
 (:138-139) — becomes ONE launch of pcr_plane_count_f64 over all `max_iteration` hypotheses: the points are read
@@ -34,24 +36,53 @@ def estimate_plane_params(selected_points: np.ndarray) -> np.ndarray:
     return np.array([a / n, b / n, c / n, d / n])
 
 
-def extract_initial_seeds(pcd_points: np.ndarray, LPR_size: int, threshold_seeds: float) -> np.ndarray:
-    """ground_detection_SVD.py:46-69: points below z_high, lowest-point-representative mean of the LPR_size
-    lowest z, then everything below LPR.z + threshold_seeds.  (np.argpartition instead of bottleneck's.)"""
-    z_high = -1.73 + 0.5
-    possible = pcd_points[pcd_points[:, 2] < z_high, :]
-    if LPR_size > possible.shape[0]:
-        lpr_idx = np.arange(possible.shape[0])
-    else:
-        lpr_idx = np.argpartition(possible[:, 2], LPR_size - 1)[:LPR_size]
-    lpr = np.mean(possible[lpr_idx, :], axis=0)
-    return possible[possible[:, 2] < lpr[2] + threshold_seeds, :]
+def extract_initial_seeds(ctx, pcd_points: np.ndarray, LPR_size: int, threshold_seeds: float) -> np.ndarray:
+    """ground_detection_SVD.py:46-71: the points below z_high whose z is below LPR.z + threshold_seeds (input order kept).
+    The selection of the LPR_size lowest z runs on the GPU (pcr_ground_seeds_f64)."""
+    if pcd_points.shape[0] == 0:
+        return pcd_points[:0]
+    cloud = ctx.cloud(np.ascontiguousarray(pcd_points[:, :3], np.float32), 1)
+    try:
+        mask, _ = ctx.ground_seeds(cloud, LPR_size, threshold_seeds)
+    finally:
+        cloud.free()
+    return pcd_points[mask, :]
+
+
+def ground_detection(ctx, pcd_points: np.ndarray, pcd_indices: np.ndarray, max_iter: int, LPR_size: int, threshold_dist: float):
+    """ground_detection_SVD.py:88-101 -> (seeds, ground indices, foreground indices); also returns the plane as 4th value
+    (the reference prints it, :100)."""
+    cloud = ctx.cloud(np.ascontiguousarray(pcd_points[:, :3], np.float32), 1)
+    try:
+        params, inliers_filter = ctx.ground_detection(cloud, max_iter, LPR_size, threshold_dist)
+    finally:
+        cloud.free()
+    return pcd_points[inliers_filter], pcd_indices[inliers_filter], pcd_indices[np.logical_not(inliers_filter)], params
+
+
+def ground_detection_on3segs(ctx, pcd_points: np.ndarray, main_dist=20, max_iter=6, threshold_dist=0.18):
+    """ground_detection_SVD.py:104-126: three x-segments [x_min, -main_dist, main_dist, x_max], open intervals as written."""
+    x_min, x_max = np.min(pcd_points[:, 0]), np.max(pcd_points[:, 0])
+    segments_x = [x_min, -main_dist, main_dist, x_max]
+    total_indices = np.array(range(pcd_points.shape[0]))
+    stacked_ground_idx = np.empty(0, dtype=int)
+    stacked_foregr_idx = np.empty(0, dtype=int)
+    for i in range(len(segments_x) - 1):
+        range_filter = np.logical_and(pcd_points[:, 0] < segments_x[i + 1], pcd_points[:, 0] > segments_x[i])
+        if not range_filter.any():
+            continue                                                    # the reference would fail on an empty segment
+        _, ground, foreground, _ = ground_detection(ctx, pcd_points[range_filter], total_indices[range_filter], max_iter,
+                                                    LPR_size=10000, threshold_dist=threshold_dist)
+        stacked_ground_idx = np.r_[stacked_ground_idx, ground]
+        stacked_foregr_idx = np.r_[stacked_foregr_idx, foreground]
+    return stacked_ground_idx, stacked_foregr_idx
 
 
 def my_ransac(ctx, data: np.ndarray, indices: np.ndarray, max_iteration: int, threshold: float, rng=None):
     """ground_detection_ransac.py:104-155 -> (inliers_idx, best_model_params).  `ctx` is a pcr Context."""
     assert data.shape[0] == indices.shape[0]
     rng = np.random.default_rng() if rng is None else rng
-    filtered_data = extract_initial_seeds(data, 40000, 1)                       # :125
+    filtered_data = extract_initial_seeds(ctx, data, 40000, 1)                  # :125
     if filtered_data.shape[0] < 3:
         return indices[:0], []
     hyps = np.zeros((max_iteration, 4), np.float64)

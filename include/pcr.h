@@ -172,6 +172,21 @@ typedef struct {
 int pcr_iss_keypoints_f32(pcr_ctx* ctx, const pcr_cloud* cloud, const pcr_iss_params* prm, uint8_t* is_key, float* lambda3,
                           uint32_t* neighbor_counts, uint64_t* n_keypoints);
 
+/* ---- next row N2: PCA ground fit around the inlier count, Homework4/ground_detection_SVD.py:46-101 --------------
+ * f64 arithmetic on the f32 points of the cloud (the reference's points are f64 after pcd_preprocessing, :35).
+ * pcr_fast_eigen3x3 (host logic, no GPU) = mylib.FastEigen3x3 (Homework1/.../my_pybind11/src/mylib.cpp:105-189): unit
+ * eigenvector of the smallest eigenvalue of the symmetric row-major A; (0,0,0) when the signed maximum of A is 0. */
+int pcr_fast_eigen3x3(const double A[9], double normal[3]);
+/* extract_initial_seeds (:46-71): seed_mask[i] = z_i < -1.73 + 0.5 && z_i < LPR_z + threshold_seeds, LPR_z = mean z of
+ * the lpr_size lowest candidates (all of them when fewer).  upper_bound / n_seeds optional. */
+int pcr_ground_seeds_f64(pcr_ctx* ctx, const pcr_cloud* cloud, size_t lpr_size, double threshold_seeds, uint8_t* seed_mask,
+                         double* upper_bound, uint64_t* n_seeds);
+/* ground_detection (:88-101): seeds, then max_iter (>= 1) x { estimate_plane (:74-85); inliers = |[p 1].params| <
+ * threshold_dist }.  params = the last plane (normal, d); ground_mask = the last inliers_filter; PCR_ERR_EMPTY when a
+ * fit has no point (the reference would propagate NaN). */
+int pcr_ground_detection_f64(pcr_ctx* ctx, const pcr_cloud* cloud, int max_iter, size_t lpr_size, double threshold_dist,
+                             double params[4], uint8_t* ground_mask, uint64_t* n_ground);
+
 /* ---- next row N4: global-registration front half, Homework9/hw9/src/registration.cpp:288-434, :535-615 -----------
  * N4a: exhaustive 1-NN between two descriptor sets (row-major n x dim / m x dim f32, host memory; dim 33 = FPFH),
  * nanoflann's evalMetric arithmetic for any dim (nanoflann.hpp:382-405: groups of four + tail, f32, unfused), canonical

@@ -1,6 +1,7 @@
 // registration.hpp — the ICP end of Homework9/hw9 (include/registration.hpp, src/registration.cpp) on the MI355X.
 //
 // Two layers:
+//  (0) pcr::GlobalRegistration — descriptor matching + feature RANSAC (the initial pose ICP starts from), arrays only
 //  (1) pcr::IcpPoint2Point — dependency-free core with the reference's parameter set
 //      (Registration::setICPparams, registration.hpp:126-137) and the semantics of
 //      Registration::ICPpoint2point (registration.hpp:204-211, registration.cpp:862-1011): R and t are
@@ -16,6 +17,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include "pcr_host.hpp"
 
@@ -69,6 +71,63 @@ public:
         pcr_cloud_destroy(ctx, cs);
         pcr_cloud_destroy(ctx, ct);
         return rc;
+    }
+};
+
+// The global-registration front half (next row N4): Registration::setRANSACparams (registration.hpp:115-124),
+// findRANSACCorrespondencesUnion (:191-193, registration.cpp:535-615) and RANSAC (:179-185, registration.cpp:288-434)
+// with plain arrays in place of pcl::PointCloud<FPFHSignature33> / PointCloud.
+class GlobalRegistration
+{
+    // defaults = reg.setRANSACparams(80000, voxel_size * 4, 10, 0.5) with voxel_size 0.3 (Homework9/hw9/main.cpp:30,86)
+    uint32_t m_RANSAC_max_iter = 80000;
+    float m_RANSAC_dist_threshold = 1.2f;
+    float m_RANSAC_angle_threshold = 10.0f;      // unused by the reference too (:419, commented out)
+    float m_RANSAC_corres_rejection_rate = 0.5f;
+
+public:
+    uint64_t seed = 5489u;                        // the reference seeds std::mt19937 from std::random_device (:298-299)
+    uint32_t max_consensus_set_size = 0;          // what the reference prints with DEBUG (:433)
+
+    void setRANSACparams(const uint32_t max_iter, const float dist_threshold, const float angle_threshold, const float corres_rejection_rate)
+    {
+        m_RANSAC_max_iter = max_iter;
+        m_RANSAC_dist_threshold = dist_threshold;
+        m_RANSAC_angle_threshold = angle_threshold;
+        m_RANSAC_corres_rejection_rate = corres_rejection_rate;
+    }
+
+    // descriptors: row-major n x dim (pcl::FPFHSignature33::histogram rows, dim 33).  correspondences[i] = {idx_src, idx_tar}
+    void findRANSACCorrespondencesUnion(const float* fpfh_source, size_t N_source, const float* fpfh_target, size_t N_target, int dim,
+                                        std::vector<std::vector<size_t>>& correspondences)
+    {
+        std::vector<uint32_t> pairs(2 * (N_source + N_target) + 2);
+        std::vector<float> dist(N_source + N_target + 1);
+        size_t kept = 0;
+        check(pcr_match_union_f32(default_ctx(), fpfh_source, N_source, fpfh_target, N_target, dim, m_RANSAC_corres_rejection_rate, pairs.data(),
+                                  dist.data(), &kept),
+              "pcr_match_union_f32");
+        correspondences.resize(kept);
+        for (size_t i = 0; i < kept; i++) correspondences[i] = std::vector<size_t>{ pairs[2 * i], pairs[2 * i + 1] };
+    }
+
+    // keypoints: AoS xyz (n x 3).  R (row-major) and t are written only when a non-empty consensus set exists, as in the
+    // reference (:423-428).  Returns the C-ABI status.
+    int RANSAC(const std::vector<std::vector<size_t>>& correspondences, const float* kp_source_xyz, size_t n_source, const float* kp_target_xyz,
+               size_t n_target, float R[9], float t[3])
+    {
+        const size_t M = correspondences.size();
+        std::vector<uint32_t> pairs(2 * M + 2);
+        for (size_t i = 0; i < M; i++) {
+            pairs[2 * i] = (uint32_t)correspondences[i][0];
+            pairs[2 * i + 1] = (uint32_t)correspondences[i][1];
+        }
+        std::vector<uint32_t> quads(4 * (size_t)m_RANSAC_max_iter + 4);
+        int rc = pcr_ransac_sample_quads(kp_source_xyz, n_source, pairs.data(), M, m_RANSAC_max_iter, seed, quads.data());
+        if (rc != PCR_OK) return rc;
+        int64_t winner = -1;
+        return pcr_ransac_global_f32(default_ctx(), kp_source_xyz, n_source, kp_target_xyz, n_target, pairs.data(), M, quads.data(), m_RANSAC_max_iter,
+                                     m_RANSAC_dist_threshold, R, t, &max_consensus_set_size, &winner, nullptr);
     }
 };
 

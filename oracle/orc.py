@@ -79,6 +79,13 @@ def lib():
         L.orc_consensus_count_f32.restype = C.c_uint32
         L.orc_ransac_global_f32.argtypes = [f32p, f32p, u32p, sz, u32p, sz, C.c_float, f32p, f32p, u32p, C.c_void_p]
         L.orc_ransac_global_f32.restype = C.c_int64
+        L.orc_fast_eigen3x3.argtypes = [f64p, f64p]
+        L.orc_ground_seeds_f64.argtypes = [f32p, f32p, f32p, sz, sz, C.c_double, u8p, f64p]
+        L.orc_ground_seeds_f64.restype = sz
+        L.orc_estimate_plane_f64.argtypes = [f32p, f32p, f32p, sz, u8p, f64p]
+        L.orc_estimate_plane_f64.restype = sz
+        L.orc_ground_detection_f64.argtypes = [f32p, f32p, f32p, sz, C.c_int, sz, C.c_double, f64p, u8p]
+        L.orc_ground_detection_f64.restype = sz
         L.orc_iss_f32.argtypes = [f32p, f32p, f32p, sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, u8p, f32p]
         L.orc_hw2_knn_add.argtypes = [f64p, i32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                       C.c_double, C.c_int]
@@ -305,6 +312,38 @@ def ransac_global_f32(src_xyz, tgt_xyz, pairs, quads, thr):
     w = lib().orc_ransac_global_f32(np.ascontiguousarray(src_xyz, np.float32).reshape(-1), np.ascontiguousarray(tgt_xyz, np.float32).reshape(-1),
                                     p.reshape(-1), p.shape[0], qd.reshape(-1), qd.shape[0], thr, R, t, best, counts.ctypes.data)
     return int(w), R.reshape(3, 3), t, int(best[0]), counts[: qd.shape[0]]
+
+
+def fast_eigen3x3(A):
+    """mylib.FastEigen3x3: unit eigenvector of the smallest eigenvalue of a symmetric 3x3."""
+    out = np.zeros(3, np.float64)
+    lib().orc_fast_eigen3x3(np.ascontiguousarray(A, np.float64).reshape(9), out)
+    return out
+
+
+def ground_seeds_f64(soa, lpr_size, threshold_seeds):
+    """extract_initial_seeds -> (seed mask u8[n], upper bound)."""
+    x, y, z = _soa(soa)
+    mask = np.zeros(max(x.size, 1), np.uint8)
+    ub = np.zeros(1, np.float64)
+    lib().orc_ground_seeds_f64(x, y, z, x.size, lpr_size, threshold_seeds, mask, ub)
+    return mask[: x.size], float(ub[0])
+
+
+def estimate_plane_f64(soa, mask):
+    x, y, z = _soa(soa)
+    params = np.zeros(4, np.float64)
+    m = lib().orc_estimate_plane_f64(x, y, z, x.size, np.ascontiguousarray(mask, np.uint8), params)
+    return params, int(m)
+
+
+def ground_detection_f64(soa, max_iter, lpr_size, threshold_dist):
+    """ground_detection -> (params f64[4], ground mask u8[n], count or -1)."""
+    x, y, z = _soa(soa)
+    params = np.zeros(4, np.float64)
+    mask = np.zeros(max(x.size, 1), np.uint8)
+    c = lib().orc_ground_detection_f64(x, y, z, x.size, max_iter, lpr_size, threshold_dist, params, mask)
+    return params, mask[: x.size], (-1 if c == C.c_size_t(-1).value else int(c))
 
 
 def iss_f32(soa, local_radius, non_max_radius, gamma21=0.9, gamma32=0.9, min_neighbors=5, weighted=True):

@@ -705,3 +705,178 @@ int64_t orc_ransac_global_f32(const float* src_xyz, const float* tgt_xyz, const 
     if (best_count) *best_count = max_consensus;
     return winner;
 }
+
+/* ------------------------------------------------------------------ N2 */
+typedef struct { double v[3]; } vec3d;
+static vec3d v3(double a, double b, double c) { vec3d r = { { a, b, c } }; return r; }
+static vec3d v3_cross(vec3d a, vec3d b)
+{
+    return v3(a.v[1] * b.v[2] - a.v[2] * b.v[1], a.v[2] * b.v[0] - a.v[0] * b.v[2], a.v[0] * b.v[1] - a.v[1] * b.v[0]);
+}
+static double v3_dot(vec3d a, vec3d b) { return a.v[0] * b.v[0] + a.v[1] * b.v[1] + a.v[2] * b.v[2]; }
+static vec3d v3_scale(vec3d a, double s) { return v3(a.v[0] * s, a.v[1] * s, a.v[2] * s); }
+static vec3d v3_div(vec3d a, double s) { return v3(a.v[0] / s, a.v[1] / s, a.v[2] / s); }
+static vec3d v3_sub(vec3d a, vec3d b) { return v3(a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2]); }
+
+/* mylib.cpp:9-38: null vector of (A - eval I) as the largest of the three row cross products */
+static vec3d fe_evec0(const double A[9], double eval)
+{
+    const vec3d r0 = v3(A[0] - eval, A[1], A[2]), r1 = v3(A[1], A[4] - eval, A[5]), r2 = v3(A[2], A[5], A[8] - eval);
+    const vec3d c01 = v3_cross(r0, r1), c02 = v3_cross(r0, r2), c12 = v3_cross(r1, r2);
+    const double d0 = v3_dot(c01, c01), d1 = v3_dot(c02, c02), d2 = v3_dot(c12, c12);
+    double dmax = d0;
+    int imax = 0;
+    if (d1 > dmax) { dmax = d1; imax = 1; }
+    if (d2 > dmax) imax = 2;
+    if (imax == 0) return v3_div(c01, sqrt(d0));
+    if (imax == 1) return v3_div(c02, sqrt(d1));
+    return v3_div(c12, sqrt(d2));
+}
+
+/* mylib.cpp:40-102: second eigenvector inside the plane orthogonal to evec0 (2x2 problem in the basis U, V) */
+static vec3d fe_evec1(const double A[9], vec3d e0, double eval1)
+{
+    vec3d U;
+    if (fabs(e0.v[0]) > fabs(e0.v[1])) {
+        const double inv = 1 / sqrt(e0.v[0] * e0.v[0] + e0.v[2] * e0.v[2]);
+        U = v3(-e0.v[2] * inv, 0, e0.v[0] * inv);
+    } else {
+        const double inv = 1 / sqrt(e0.v[1] * e0.v[1] + e0.v[2] * e0.v[2]);
+        U = v3(0, e0.v[2] * inv, -e0.v[1] * inv);
+    }
+    const vec3d V = v3_cross(e0, U);
+    const vec3d AU = v3(A[0] * U.v[0] + A[1] * U.v[1] + A[2] * U.v[2], A[1] * U.v[0] + A[4] * U.v[1] + A[5] * U.v[2],
+                        A[2] * U.v[0] + A[5] * U.v[1] + A[8] * U.v[2]);
+    const vec3d AV = v3(A[0] * V.v[0] + A[1] * V.v[1] + A[2] * V.v[2], A[1] * V.v[0] + A[4] * V.v[1] + A[5] * V.v[2],
+                        A[2] * V.v[0] + A[5] * V.v[1] + A[8] * V.v[2]);
+    double m00 = U.v[0] * AU.v[0] + U.v[1] * AU.v[1] + U.v[2] * AU.v[2] - eval1;
+    double m01 = U.v[0] * AV.v[0] + U.v[1] * AV.v[1] + U.v[2] * AV.v[2];
+    double m11 = V.v[0] * AV.v[0] + V.v[1] * AV.v[1] + V.v[2] * AV.v[2] - eval1;
+    const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+    if (a00 >= a11) {
+        if (!(fmax(a00, a01) > 0)) return U;
+        if (a00 >= a01) { m01 /= m00; m00 = 1 / sqrt(1 + m01 * m01); m01 *= m00; }
+        else { m00 /= m01; m01 = 1 / sqrt(1 + m00 * m00); m00 *= m01; }
+        return v3_sub(v3_scale(U, m01), v3_scale(V, m00));
+    }
+    if (!(fmax(a11, a01) > 0)) return U;
+    if (a11 >= a01) { m01 /= m11; m11 = 1 / sqrt(1 + m01 * m01); m01 *= m11; }
+    else { m11 /= m01; m01 = 1 / sqrt(1 + m11 * m11); m11 *= m01; }
+    return v3_sub(v3_scale(U, m11), v3_scale(V, m01));
+}
+
+void orc_fast_eigen3x3(const double Ain[9], double normal[3])
+{
+    double A[9];
+    memcpy(A, Ain, sizeof A);
+    double max_coeff = A[0];                                             /* mylib.cpp:112 maxCoeff(): signed maximum */
+    for (int k = 1; k < 9; k++) if (A[k] > max_coeff) max_coeff = A[k];
+    vec3d out = v3(0, 0, 0);
+    if (max_coeff == 0) { memcpy(normal, out.v, sizeof out.v); return; }
+    for (int k = 0; k < 9; k++) A[k] /= max_coeff;                        /* :116 */
+    const double norm = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (norm > 0) {
+        const double q = (A[0] + A[4] + A[8]) / 3;
+        const double b00 = A[0] - q, b11 = A[4] - q, b22 = A[8] - q;
+        const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2) / 6);
+        const double c00 = b11 * b22 - A[5] * A[5], c01 = A[1] * b22 - A[5] * A[2], c02 = A[1] * A[5] - b11 * A[2];
+        const double det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
+        double half_det = det * 0.5;
+        half_det = fmin(fmax(half_det, -1.0), 1.0);
+        const double angle = acos(half_det) / (double)3;
+        const double two_thirds_pi = 2.09439510239319549;
+        const double beta2 = cos(angle) * 2, beta0 = cos(angle + two_thirds_pi) * 2, beta1 = -(beta0 + beta2);
+        const double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
+        if (half_det >= 0) {                                              /* :152-163 */
+            const vec3d v2 = fe_evec0(A, e2);
+            if (e2 < e0 && e2 < e1) out = v2;
+            else {
+                const vec3d v1 = fe_evec1(A, v2, e1);
+                out = (e1 < e0 && e1 < e2) ? v1 : v3_cross(v1, v2);
+            }
+        } else {                                                          /* :164-176 */
+            const vec3d v0 = fe_evec0(A, e0);
+            if (e0 < e1 && e0 < e2) out = v0;
+            else {
+                const vec3d v1 = fe_evec1(A, v0, e1);
+                out = (e1 < e0 && e1 < e2) ? v1 : v3_cross(v0, v1);
+            }
+        }
+    } else {                                                              /* :177-187 diagonal matrix (scaled back) */
+        const double a0 = A[0] * max_coeff, a1 = A[4] * max_coeff, a2 = A[8] * max_coeff;
+        if (a0 < a1 && a0 < a2) out = v3(1, 0, 0);
+        else if (a1 < a0 && a1 < a2) out = v3(0, 1, 0);
+        else out = v3(0, 0, 1);
+    }
+    memcpy(normal, out.v, sizeof out.v);
+}
+
+static int cmp_f32(const void* a, const void* b)
+{
+    const float x = *(const float*)a, y = *(const float*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+size_t orc_ground_seeds_f64(const float* x, const float* y, const float* z, size_t n, size_t lpr_size,
+                            double threshold_seeds, uint8_t* seed_mask, double* upper_bound)
+{
+    (void)x; (void)y;
+    const double z_high = -1.73 + 0.5;                                    /* :47 */
+    float* cand = (float*)malloc(sizeof(float) * (n ? n : 1));
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) if ((double)z[i] < z_high) cand[m++] = z[i];     /* :50-52 */
+    qsort(cand, m, sizeof(float), cmp_f32);
+    const size_t k = lpr_size > m ? m : lpr_size;                         /* :54-60 */
+    double sum = 0.0;
+    for (size_t i = 0; i < k; i++) sum += (double)cand[i];                /* np.mean(axis=0), z column (:62) */
+    const double lpr_z = sum / (double)k;                                 /* 0/0 = NaN without candidates */
+    const double ub = lpr_z + threshold_seeds;                            /* :65 */
+    size_t count = 0;
+    for (size_t i = 0; i < n; i++) {
+        seed_mask[i] = ((double)z[i] < z_high) && ((double)z[i] < ub);    /* :67-68 */
+        count += seed_mask[i];
+    }
+    if (upper_bound) *upper_bound = ub;
+    free(cand);
+    return count;
+}
+
+size_t orc_estimate_plane_f64(const float* x, const float* y, const float* z, size_t n, const uint8_t* mask, double params[4])
+{
+    double s[3] = { 0, 0, 0 };
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) if (mask[i]) { s[0] += x[i]; s[1] += y[i]; s[2] += z[i]; m++; }
+    const double c[3] = { s[0] / (double)m, s[1] / (double)m, s[2] / (double)m };   /* :75 */
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!mask[i]) continue;
+        const double dx = x[i] - c[0], dy = y[i] - c[1], dz = z[i] - c[2];           /* :76 */
+        xx += dx * dx; xy += dx * dy; xz += dx * dz; yy += dy * dy; yz += dy * dz; zz += dz * dz;   /* :77 */
+    }
+    const double XTX[9] = { xx, xy, xz, xy, yy, yz, xz, yz, zz };
+    double nrm[3];
+    orc_fast_eigen3x3(XTX, nrm);                                          /* :83 */
+    params[0] = nrm[0]; params[1] = nrm[1]; params[2] = nrm[2];
+    params[3] = -(nrm[0] * c[0] + nrm[1] * c[1] + nrm[2] * c[2]);          /* :84 */
+    return m;
+}
+
+size_t orc_ground_detection_f64(const float* x, const float* y, const float* z, size_t n, int max_iter, size_t lpr_size,
+                                double threshold_dist, double params[4], uint8_t* ground_mask)
+{
+    uint8_t* seeds = (uint8_t*)malloc(n ? n : 1);
+    size_t count = orc_ground_seeds_f64(x, y, z, n, lpr_size, threshold_dist, seeds, NULL);   /* :90, threshold_seeds = threshold_dist */
+    for (size_t i = 0; i < n; i++) ground_mask[i] = 0;
+    for (int it = 0; it < max_iter; it++) {
+        if (count == 0) { free(seeds); return (size_t)-1; }
+        orc_estimate_plane_f64(x, y, z, n, seeds, params);                 /* :94 */
+        count = 0;
+        for (size_t i = 0; i < n; i++) {
+            seeds[i] = fabs(plane_dist((double)x[i], (double)y[i], (double)z[i], params)) < threshold_dist;   /* :96-97 */
+            count += seeds[i];
+        }
+        memcpy(ground_mask, seeds, n);
+    }
+    free(seeds);
+    return count;
+}

@@ -186,6 +186,27 @@ int64_t orc_ransac_global_f32(const float* src_xyz, const float* tgt_xyz, const 
                               const uint32_t* quads, size_t n_hyp, float thr, float R[9], float t[3],
                               uint32_t* best_count, uint32_t* counts);
 
+/* ---- N2: PCA ground fit around the inlier count (Homework4/ground_detection_SVD.py:46-92), f64 on f32-valued points
+ * (the reference's points are f64 after pcd_preprocessing, :35).
+ * FastEigen3x3 (Homework1/.../my_pybind11/src/mylib.cpp:9-189, the closed-form symmetric 3x3 solver the reference took
+ * from open3d): unit eigenvector of the SMALLEST eigenvalue of symmetric A (row-major), (0,0,0) when max(A) == 0.
+ * UNPINNED (pybind11 + Eigen are absent); cross-checked against numpy.linalg.eigh in the tests. */
+void orc_fast_eigen3x3(const double A[9], double normal[3]);
+/* extract_initial_seeds (:46-71): candidates z < -1.73 + 0.5; LPR = mean of the lpr_size lowest candidates (all of them
+ * when there are fewer); seed iff candidate && z < LPR_z + threshold_seeds.  Only LPR_z is used by the reference.
+ * seed_mask: n bytes.  Returns the number of seeds; *upper_bound = LPR_z + threshold_seeds (NaN without candidates).
+ * PINNED through the reference function itself (tests/golden/ground_hw4.npz). */
+size_t orc_ground_seeds_f64(const float* x, const float* y, const float* z, size_t n, size_t lpr_size,
+                            double threshold_seeds, uint8_t* seed_mask, double* upper_bound);
+/* estimate_plane (:74-85) over the points with mask != 0: centre = mean, XTX of the centred points (sequential f64 sums in
+ * index order; numpy/BLAS order is unspecified), normal = FastEigen3x3(XTX), d = -normal . centre.  Returns the count. */
+size_t orc_estimate_plane_f64(const float* x, const float* y, const float* z, size_t n, const uint8_t* mask, double params[4]);
+/* ground_detection (:88-101): seeds, then max_iter x { estimate_plane(seeds); inliers = |[p 1] . params| < threshold_dist;
+ * seeds = inliers }.  ground_mask: n bytes (the final inliers_filter).  Returns the number of inliers, or (size_t)-1 when
+ * a fit had no point (the reference would propagate NaN). */
+size_t orc_ground_detection_f64(const float* x, const float* y, const float* z, size_t n, int max_iter, size_t lpr_size,
+                                double threshold_dist, double params[4], uint8_t* ground_mask);
+
 #ifdef __cplusplus
 }
 #endif

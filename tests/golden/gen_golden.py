@@ -305,6 +305,36 @@ def f9():
     save("desc_match_hw9.npz", desc_src=src, desc_tgt=tgt, nn_src_of_tgt=i_ts, d2_src_of_tgt=d_ts, nn_tgt_of_src=i_st, d2_tgt_of_src=d_st)
 
 
+# ------------------------------------------------------------------ F10 (next row N2)
+def f10():
+    """Homework4/ground_detection_SVD.py:46-71 extract_initial_seeds, executed from the reference source.  The module
+    imports bottleneck (absent): `bn.argpartition` is bound to `np.argpartition` — the same contract (indices of the kth+1
+    smallest first); the function's result depends only on WHICH z values are selected, not on their order.  A 4th
+    column carrying the point index rides along (the function only touches column 2 and whole rows), so the returned
+    seed rows identify themselves."""
+    import types
+    pyfile = f"{REF}/Homework4/ground_detection_SVD.py"
+    tree = ast.parse(open(pyfile).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "extract_initial_seeds"][0]
+    ns = {"np": np, "bn": types.SimpleNamespace(argpartition=np.argpartition)}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), pyfile, "exec"), ns)
+    extract_initial_seeds = ns["extract_initial_seeds"]
+    raw = read_kitti_bin(f"{REF}/Homework4/test/000111.bin")
+    pts = np.ascontiguousarray(raw[:: raw.shape[0] // 30000][:30000]).astype(np.float32)
+    aug = np.c_[pts.astype(np.float64), np.arange(pts.shape[0], dtype=np.float64)]
+    out = {"pts_f32": pts}
+    for tag, lpr, thr in (("lpr10000", 10000, 0.18), ("lpr500", 500, 0.4), ("lpr_all", 10 ** 6, 0.1)):   # :116 ships 10000 / 0.18
+        seeds = extract_initial_seeds(aug, lpr, thr)
+        mask = np.zeros(pts.shape[0], np.uint8)
+        mask[seeds[:, 3].astype(np.int64)] = 1
+        om, ub = orc.ground_seeds_f64(np.ascontiguousarray(pts.T), lpr, thr)
+        assert np.array_equal(om, mask), tag
+        out[f"mask_{tag}"] = np.packbits(mask)
+        out[f"args_{tag}"] = np.array([lpr, thr], np.float64)
+        print(tag, int(mask.sum()), "seeds of", pts.shape[0])
+    save("ground_hw4.npz", **out)
+
+
 def lib_d2(a, b):
     return orc.lib().orc_d2_dim_f32(np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32), a.size)
 
@@ -312,4 +342,4 @@ def lib_d2(a, b):
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not present"
     orc.build(ref=True)
-    f1(); f2_f3_f4(); f5(); f6(); f7(); f8(); f9()
+    f1(); f2_f3_f4(); f5(); f6(); f7(); f8(); f9(); f10()

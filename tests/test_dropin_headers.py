@@ -218,3 +218,46 @@ def test_iss_dropin_class_gives_the_oracle_keypoints(tmp_path, orc, golden):
     okey, ol3 = orc.iss_f32(np.ascontiguousarray(xyz.T), float(g["local_r"]), float(g["nms_r"]), 0.9, 0.9, 5, True)
     assert np.allclose(l3, ol3, rtol=1e-6, atol=0)
     assert len(set(idx.tolist()) ^ set(np.flatnonzero(okey).tolist())) <= 2
+
+
+def build_greg_check(tmp_path):
+    need_lib()
+    exe = tmp_path / "greg_check"
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-I" + INC, os.path.join(ROOT, "tests", "cpp", "greg_check.cpp"),
+                        "-o", str(exe)] + LINK, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_global_registration_driver_compiles(tmp_path):
+    build_greg_check(tmp_path)
+
+
+@pytest.mark.gpu
+def test_global_registration_core_then_icp(tmp_path, orc, pcr):
+    """pcr::GlobalRegistration (setRANSACparams / findRANSACCorrespondencesUnion / RANSAC) followed by ICP, as
+    Registration::compute chains them (registration.cpp:1082,1138,1141-1145); checked against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_global_registration import scene
+    exe = build_greg_check(tmp_path)
+    src, tgt, dsrc, dtgt, R, t = scene(51, 900, 800, 400)
+    max_iter, thr, rate, seed = 5000, 0.3, 0.5, 77
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<qqqqffQ", src.shape[0], tgt.shape[0], 33, max_iter, thr, rate, seed))
+        for a in (src, tgt, dsrc, dtgt):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+    r = subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    buf = open(tmp_path / "out.bin", "rb").read()
+    nc, best = struct.unpack_from("<qI", buf, 0)
+    vals = np.frombuffer(buf, np.float32, 24, 12)
+    Rr, tr, Ri, ti = vals[:9].reshape(3, 3), vals[9:12], vals[12:21].reshape(3, 3), vals[21:24]
+    pairs, _ = orc.match_union_f32(dsrc, dtgt, rate)
+    assert nc == pairs.shape[0]
+    quads = pcr.ransac_sample_quads(src, pairs, max_iter, seed)
+    ow, oR, ot, obest, _ = orc.ransac_global_f32(src, tgt, pairs, quads, thr)
+    assert best == obest and f"max_consensus_set_size = {best}" in r.stdout
+    assert np.array_equal(Rr.view(np.uint32), oR.view(np.uint32)) and np.array_equal(tr.view(np.uint32), ot.view(np.uint32))
+    # ICP from that pose on the keypoints tightens it
+    assert np.linalg.norm(Ri - R) <= np.linalg.norm(Rr - R) + 1e-3 and np.linalg.norm(Ri - R) < 0.01
+    assert np.linalg.norm(ti - t) < 0.1

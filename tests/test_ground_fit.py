@@ -1,0 +1,138 @@
+"""Next row N2: seed extraction + PCA ground refit, Homework4/ground_detection_SVD.py:46-126 and
+FastEigen3x3 (Homework1/.../my_pybind11/src/mylib.cpp:9-189).
+
+Pinning: extract_initial_seeds is PINNED (tests/golden/ground_hw4.npz comes from the reference function itself).
+FastEigen3x3 / estimate_plane need pybind11 + Eigen (absent): UNPINNED, cross-checked against numpy.linalg.eigh and a
+numpy restatement of estimate_plane; GPU vs oracle: plane within 1e-9, masks equal away from the threshold."""
+import importlib
+
+import numpy as np
+import pytest
+
+PKG = "hands-on-point-cloud-processing_amd"
+CASES = ["lpr10000", "lpr500", "lpr_all"]
+
+
+def rand_sym(rng, k):
+    M = rng.normal(size=(rng.integers(3, 60), 3)) * rng.uniform(0.01, 10, 3)
+    if k % 5 == 0:
+        M[:, rng.integers(0, 3)] = 0
+    return M.T @ M
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_seeds_match_reference_function(orc, golden, case):
+    g = golden("ground_hw4.npz")
+    lpr, thr = g[f"args_{case}"]
+    mask, ub = orc.ground_seeds_f64(np.ascontiguousarray(g["pts_f32"].T), int(lpr), float(thr))
+    assert np.array_equal(np.packbits(mask), g[f"mask_{case}"])
+
+
+def test_fast_eigen3x3_oracle_product_and_numpy_agree(orc, pcr):
+    rng = np.random.default_rng(0)
+    for k in range(1500):
+        A = rand_sym(rng, k)
+        n_o, n_p = orc.fast_eigen3x3(A), pcr.fast_eigen3x3(A)
+        assert np.array_equal(n_o, n_p)                                 # same operations, same libm: bit-identical
+        w, v = np.linalg.eigh(A)
+        assert abs(np.linalg.norm(n_o) - 1) < 1e-9 and abs(n_o @ v[:, 0]) > 1 - 1e-6
+    # documented edge cases of the reference: diagonal input, all-zero input, signed maxCoeff() == 0
+    assert np.array_equal(pcr.fast_eigen3x3(np.diag([3.0, 1.0, 2.0])), [0, 1, 0])
+    assert np.array_equal(pcr.fast_eigen3x3(np.diag([1.0, 1.0, 2.0])), [0, 0, 1])      # no strict minimum -> z
+    assert np.array_equal(pcr.fast_eigen3x3(np.zeros((3, 3))), [0, 0, 0])
+    assert np.array_equal(pcr.fast_eigen3x3(-np.eye(3)), [0, 0, 0])
+
+
+def test_oracle_estimate_plane_matches_numpy_restatement(orc, synth):
+    scan = synth.kitti_like_scan(20000)
+    mask = (np.abs(scan[2] + 1.73) < 0.2).astype(np.uint8)
+    params, m = orc.estimate_plane_f64(scan, mask)
+    pts = scan.T[mask.astype(bool)].astype(np.float64)
+    c = np.mean(pts, axis=0)                                            # ground_detection_SVD.py:75-84 in numpy
+    cd = np.subtract(pts, c)
+    XTX = cd.transpose().dot(cd)
+    nrm = orc.fast_eigen3x3(XTX)
+    want = np.r_[nrm, -nrm.dot(c)]
+    assert m == pts.shape[0]
+    assert np.allclose(params, want, rtol=0, atol=1e-10)
+    assert abs(abs(params[2]) - 1) < 1e-3 and abs(abs(params[3]) - 1.73) < 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_seeds_match_reference_function(pcr, orc, golden, case):
+    g = golden("ground_hw4.npz")
+    lpr, thr = g[f"args_{case}"]
+    ctx = pcr.Context(0)
+    try:
+        soa = np.ascontiguousarray(g["pts_f32"].T)
+        mask, ub = ctx.ground_seeds(ctx.cloud(soa), int(lpr), float(thr))
+        assert np.array_equal(np.packbits(mask), g[f"mask_{case}"])
+        omask, oub = orc.ground_seeds_f64(soa, int(lpr), float(thr))
+        assert ub == oub                                                # ascending-z f64 sum on both sides: bit-identical
+    finally:
+        ctx.close()
+
+
+def masks_agree(params, pts, m1, m2, thr, slack=1e-9):
+    d = np.abs(np.c_[pts.astype(np.float64), np.ones(pts.shape[0])].dot(params))
+    diff = m1.astype(bool) != m2.astype(bool)
+    return (np.abs(d[diff] - thr) < slack).all(), int(diff.sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,max_iter,lpr,thr", [(120000, 6, 10000, 0.18), (30000, 1, 500, 0.3), (5000, 10, 10 ** 6, 0.1)])
+def test_gpu_ground_detection_matches_oracle(pcr, orc, synth, n, max_iter, lpr, thr):
+    scan = synth.kitti_like_scan(n)
+    ctx = pcr.Context(0)
+    try:
+        params, mask = ctx.ground_detection(ctx.cloud(scan), max_iter, lpr, thr)
+        oparams, omask, ocount = orc.ground_detection_f64(scan, max_iter, lpr, thr)
+        assert np.allclose(params, oparams, rtol=0, atol=1e-9)          # block-order vs sequential f64 sums
+        ok, ndiff = masks_agree(oparams, scan.T, mask, omask, thr)
+        assert ok and ndiff <= 2
+        assert abs(abs(params[2]) - 1) < 1e-3 and abs(abs(params[3]) - 1.73) < 0.02 and mask.sum() > 0.2 * n
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_ground_detection_reference_scan_and_segments(pcr, orc, golden):
+    hw4 = importlib.import_module(PKG + ".hw4")
+    pts = golden("ground_hw4.npz")["pts_f32"]                            # Homework4/test/000111.bin, every 4th point
+    ctx = pcr.Context(0)
+    try:
+        seeds, ground, foreground, params = hw4.ground_detection(ctx, pts, np.arange(pts.shape[0]), 6, 10000, 0.18)
+        oparams, omask, _ = orc.ground_detection_f64(np.ascontiguousarray(pts.T), 6, 10000, 0.18)
+        assert np.allclose(params, oparams, rtol=0, atol=1e-9)
+        assert len(set(ground.tolist()) ^ set(np.flatnonzero(omask).tolist())) <= 2
+        assert np.array_equal(seeds, pts[ground]) and ground.size + foreground.size == pts.shape[0]
+        g_idx, f_idx = hw4.ground_detection_on3segs(ctx, pts)
+        assert np.unique(np.r_[g_idx, f_idx]).size == g_idx.size + f_idx.size <= pts.shape[0]
+        assert g_idx.size > 0.2 * pts.shape[0]
+        sub = hw4.extract_initial_seeds(ctx, pts, 10000, 0.18)
+        omask, _ = orc.ground_seeds_f64(np.ascontiguousarray(pts.T), 10000, 0.18)
+        assert np.array_equal(sub, pts[omask.astype(bool)])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_ground_edges(pcr, synth):
+    ctx = pcr.Context(0)
+    try:
+        high = synth.kitti_like_scan(2000).copy()
+        high[2] = np.abs(high[2]) + 1.0                                  # nothing below z_high: no seed at all
+        mask, ub = ctx.ground_seeds(ctx.cloud(high), 100, 0.2)
+        assert not mask.any() and np.isnan(ub)
+        with pytest.raises(pcr.PcrError):
+            ctx.ground_detection(ctx.cloud(high), 3, 100, 0.2)           # the reference would propagate NaN
+        with pytest.raises(pcr.PcrError):
+            ctx.ground_detection(ctx.cloud(high), 0, 100, 0.2)
+        pts = synth.kitti_like_scan(3000).copy()
+        pts[2, 5] = np.nan; pts[0, 6] = np.inf                           # NaN z is never a candidate; inf x poisons nothing
+        pts[2, 6] = 5.0
+        params, mask = ctx.ground_detection(ctx.cloud(pts), 4, 500, 0.2)
+        assert np.isfinite(params).all() and not mask[5] and not mask[6]
+    finally:
+        ctx.close()
