@@ -87,7 +87,7 @@ def my_ransac(ctx, data: np.ndarray, indices: np.ndarray, max_iteration: int, th
         return indices[:0], []
     hyps = np.zeros((max_iteration, 4), np.float64)
     for it in range(max_iteration):                                             # :131-135
-        sel = rng.choice(range(filtered_data.shape[0]), 3, replace=False)
+        sel = rng.choice(filtered_data.shape[0], 3, replace=False)          # same draw as choice(range(n), ...) without building the list
         hyps[it] = estimate_plane_params(filtered_data[sel, :].astype(np.float64))
     valid = np.isfinite(hyps).all(axis=1)       # collinear samples give n = 0 -> NaN params; NaN < thr is False (:139)
     seeds = ctx.cloud(np.ascontiguousarray(filtered_data[:, :3], np.float32), 1)

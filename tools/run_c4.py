@@ -44,3 +44,18 @@ t0 = time.perf_counter(); row, ridx, rdist = h.radius(db[:m], 1.0); t1 = time.pe
 kc, msc = ctx.prof_get("radius_count"); kf, msf = ctx.prof_get("radius_fill")
 print(f"radius-NN r=1.0: {m} queries x {n} pts: {row[-1]} neighbours, count kernel {msc/max(kc,1):.2f} ms + fill kernel {msf/max(kf,1):.2f} ms, "
       f"call {t1*1e3:.1f} ms -> {m*n/((msc/max(kc,1)+msf/max(kf,1))*1e-3)/1e9:.1f} G pair-evals/s over both passes")
+
+# --- next row N2: PCA ground fit (ground_detection_SVD.py:88-101), 6 iterations, LPR 10000, 0.18 (the shipped values, :104,116)
+ctx.ground_detection(c, 6, 10000, 0.18); ctx.prof_reset()
+t0 = time.perf_counter()
+for _ in range(reps):
+    gp, gmask = ctx.ground_detection(c, 6, 10000, 0.18)
+dt = (time.perf_counter() - t0) / reps
+ks, mss = ctx.prof_get("ground_seed_select"); km, msm = ctx.prof_get("ground_moments")
+print(f"ground_detection (6 PCA refits, {n} pts): call {dt*1e3:.2f} ms; seed select (keys + radix sort) {mss/max(ks,1)*1e3:.0f} us, "
+      f"moment pass {msm/max(km,1)*1e3:.1f} us x {km//reps} ({12*n/(msm/max(km,1)*1e-3)/1e9:.0f} GB/s of 12 B/pt); plane {np.round(gp, 4)}, {int(gmask.sum())} ground points")
+try:
+    t0 = time.perf_counter(); op, om, oc = orc.ground_detection_f64(scan, 6, 10000, 0.18); tc = time.perf_counter() - t0
+    print(f"  CPU oracle (1 thread, f64): {tc*1e3:.1f} ms; plane max |diff| {np.abs(op-gp).max():.1e}; masks differ at {int((om.astype(bool) != gmask).sum())} points")
+except Exception as e:  # noqa: BLE001
+    print("  oracle unavailable:", e)
