@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
+    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
@@ -112,6 +112,8 @@ def lib():
     L.pcr_grid_stats.argtypes = [vp, vp]
     L.pcr_voxel_filter_f32.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
     L.pcr_iss_keypoints_f32.argtypes = [vp, vp, C.POINTER(IssParams), vp, vp, vp, C.POINTER(C.c_uint64)]
+    L.pcr_cloud_knn_f64.argtypes = [vp, vp, vp, C.c_int, C.c_double, C.c_int, vp, vp, vp]
+    L.pcr_normals_knn_f64.argtypes = [vp, vp, C.c_int, C.c_double, vp]
     L.pcr_fast_eigen3x3.argtypes = [vp, vp]
     L.pcr_ground_seeds_f64.argtypes = [vp, vp, sz, C.c_double, vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.pcr_ground_detection_f64.argtypes = [vp, vp, C.c_int, sz, C.c_double, vp, vp, C.POINTER(C.c_uint64)]
@@ -328,6 +330,23 @@ class Context:
         idx = np.flatnonzero(key[:n])
         assert idx.size == cnt.value
         return idx, l3[:n], cn[:n]
+
+    def cloud_knn(self, db: Cloud, queries: Cloud, k: int, radius: float = -1.0, squared: bool = True):
+        """Exact grid k-NN between resident clouds -> (idx i32 [m,k], dist f64 [m,k], found u32 [m]); see pcr_cloud_knn_f64."""
+        m = len(queries)
+        idx = np.zeros((max(m, 1), k), np.int32)
+        dist = np.zeros((max(m, 1), k), np.float64)
+        found = np.zeros(max(m, 1), np.uint32)
+        self._ck(lib().pcr_cloud_knn_f64(self.h, db.h, queries.h, int(k), float(radius), int(bool(squared)), idx.ctypes.data, dist.ctypes.data,
+                                         found.ctypes.data))
+        return idx[:m], dist[:m], found[:m]
+
+    def normals(self, cloud: Cloud, k: int = 10, radius: float = 5.0):
+        """pca_normal.py:89-103 -> normals f64 [n,3] (hybrid search radius / max_nn = k, FastEigen3x3 eigenvector)."""
+        n = len(cloud)
+        out = np.zeros((max(n, 1), 3), np.float64)
+        self._ck(lib().pcr_normals_knn_f64(self.h, cloud.h, int(k), float(radius), out.ctypes.data))
+        return out[:n]
 
     # ---- N2
     def ground_seeds(self, cloud: Cloud, lpr_size: int, threshold_seeds: float):

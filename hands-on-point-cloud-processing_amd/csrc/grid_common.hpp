@@ -46,5 +46,7 @@ __device__ __forceinline__ uint32_t clamped_cell_id(const GridParams& g, float x
 
 // builds the index over `c`; cell_edge > 0 forces the cell size (otherwise the heuristic of grid.hip is used)
 int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge);
+// builds (and caches on tgt) the 1-NN grid if needed, then groups the queries `src` by coarse cell -> ctx->qperm
+int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
 
 }  // namespace pcr

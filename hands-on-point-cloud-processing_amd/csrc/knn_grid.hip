@@ -1,0 +1,328 @@
+// knn_grid.hip — exact batched k-NN over the uniform grid (next row N1: "k-NN as a service"), and its first consumer,
+// per-point PCA normals (Homework1/YuF_KIT-第1章作业/pca_normal.py:89-103).
+//
+// Arithmetic = the hw2 / FLANN / nanoflann leaf arithmetic at dim 3 in f64:  s = ((dx*dx) + dy*dy) + dz*dz on the f32
+// coordinates of the cloud widened to f64 (exactly what the reference does with KITTI / PLY floats, test.hpp:28).
+//   SQ = true : order and report s   (FLANN / open3d / nanoflann contract; optional strict cap s < cap_s = hybrid search)
+//   SQ = false: order and report d = sqrt(s)   (hw2 contract, kdtree.hpp:341-346)
+// Canonical order everywhere: value ascending, then index ascending — the top-k lives in registers with a
+// branch-free lexicographic insertion, so the result does not depend on the order in which cells are visited.
+//
+// One lane per query.  Queries are taken in cell order (the grid records themselves for a self-query, a cell-sorted
+// permutation otherwise), so the lanes of a wave walk the same x-rows and their loads coalesce into broadcasts.
+// Search = growing cubes of cells around the query; cube r proves the current k-th value v when every point outside it
+// is farther: v < ((r - slack) h)^2.  The next radius is the smallest one that can prove the current k-th value
+// (or 2 r while fewer than k points have been seen); only the new shell is scanned, rows beyond the k-th ball are
+// skipped.  Every loop has an unconditional bound.
+#include "grid_common.hpp"
+#include "eig3.hpp"
+
+#include <cmath>
+#include <vector>
+
+namespace pcr {
+
+namespace {
+
+constexpr int KG_BLOCK = 256;
+
+template <int K>
+struct TopK {
+    double v[K];
+    int32_t i[K];
+};
+
+__device__ __forceinline__ bool lex_less(double va, int32_t ia, double vb, int32_t ib) { return va < vb || (va == vb && ia < ib); }
+
+// precondition: (val, idx) < (t.v[K-1], t.i[K-1]).  Slots are rewritten from the back: slot s keeps its entry when the
+// candidate is not better than it, takes its left neighbour when the candidate beats that one too, else the candidate.
+template <int K>
+__device__ __forceinline__ void topk_insert(TopK<K>& t, double val, int32_t idx)
+{
+#pragma unroll
+    for (int s = K - 1; s >= 0; s--) {
+        const bool beats_s = lex_less(val, idx, t.v[s], t.i[s]);
+        const bool beats_l = s > 0 ? lex_less(val, idx, t.v[s > 0 ? s - 1 : 0], t.i[s > 0 ? s - 1 : 0]) : false;
+        const double nv = !beats_s ? t.v[s] : (beats_l ? t.v[s > 0 ? s - 1 : 0] : val);
+        const int32_t ni = !beats_s ? t.i[s] : (beats_l ? t.i[s > 0 ? s - 1 : 0] : idx);
+        t.v[s] = nv;
+        t.i[s] = ni;
+    }
+}
+
+template <int K, bool SQ>
+__device__ __forceinline__ void scan_cells(const float4* __restrict__ records, uint32_t b, uint32_t e, double qx, double qy, double qz, double cap_s,
+                                           TopK<K>& t, double& kth_s)
+{
+#pragma clang fp contract(off)
+    for (uint32_t p = b; p < e; p++) {
+        const float4 rec = records[p];
+        const double dx = (double)rec.x - qx, dy = (double)rec.y - qy, dz = (double)rec.z - qz;   // t - q, kdtree.hpp:343
+        const double s = (dx * dx + dy * dy) + dz * dz;
+        if (!(s < cap_s) || !(s <= kth_s)) continue;             // kth_s: conservative s-domain bound of the k-th entry
+        const int32_t j = (int32_t)__float_as_uint(rec.w);
+        const double val = SQ ? s : sqrt(s);
+        if (lex_less(val, j, t.v[K - 1], t.i[K - 1])) {
+            topk_insert<K>(t, val, j);
+            const double w = t.v[K - 1];
+            kth_s = SQ ? w : w * w * (1.0 + 1e-12);               // sqrt(s) <= w  =>  s <= w*w*(1 + 2^-52 ...)
+        }
+    }
+}
+
+// perm == nullptr: query p is grid record p (self-query), row = its original index; else query = perm[t] of (qx, qy, qz)
+template <int K, bool SQ>
+__global__ __launch_bounds__(KG_BLOCK) void knn_grid_kernel(const float4* __restrict__ records, const uint32_t* __restrict__ cell_start, GridParams g,
+                                                            const float* __restrict__ qxs, const float* __restrict__ qys, const float* __restrict__ qzs,
+                                                            const uint32_t* __restrict__ perm, uint32_t m, int k_out, double cap_s, double empty_val,
+                                                            int32_t empty_idx, int32_t* __restrict__ idx_out, double* __restrict__ val_out,
+                                                            uint32_t* __restrict__ found_out)
+{
+    const uint32_t tq = blockIdx.x * KG_BLOCK + threadIdx.x;
+    if (tq >= m) return;
+    uint32_t row;
+    float fx, fy, fz;
+    if (perm) {
+        row = perm[tq];
+        fx = qxs[row]; fy = qys[row]; fz = qzs[row];
+    } else {
+        const float4 rec = records[tq];
+        row = __float_as_uint(rec.w);
+        fx = rec.x; fy = rec.y; fz = rec.z;
+    }
+    TopK<K> t;
+#pragma unroll
+    for (int s = 0; s < K; s++) { t.v[s] = INFINITY; t.i[s] = 0x7FFFFFFF; }
+    double kth_s = INFINITY;
+    if (finite3(fx, fy, fz)) {
+        const double qx = fx, qy = fy, qz = fz;
+        const int ux = cell_coord(fx, g.lo[0], g.inv_h), uy = cell_coord(fy, g.lo[1], g.inv_h), uz = cell_coord(fz, g.lo[2], g.inv_h);
+        const int r0 = max(max(max(-ux, ux - (g.n[0] - 1)), max(-uy, uy - (g.n[1] - 1))), max(max(-uz, uz - (g.n[2] - 1)), 0));
+        int r = max(r0, 1), rp = -1;
+        const double h = g.h, slack = g.slack;
+        for (int step = 0; step < 40; step++) {
+            const int xlo = max(ux - r, 0), xhi = min(ux + r, g.n[0] - 1);
+            const int ylo = max(uy - r, 0), yhi = min(uy + r, g.n[1] - 1);
+            const int zlo = max(uz - r, 0), zhi = min(uz + r, g.n[2] - 1);
+            if (xlo <= xhi && ylo <= yhi && zlo <= zhi) {
+                for (int cz = zlo; cz <= zhi; cz++) {
+                    const int adz = abs(cz - uz);
+                    const double fz2 = fmax((double)adz - 1.0 - slack, 0.0) * h;
+                    for (int cy = ylo; cy <= yhi; cy++) {
+                        const int ady = abs(cy - uy);
+                        const double fy2 = fmax((double)ady - 1.0 - slack, 0.0) * h;
+                        const double lim = fmin(kth_s, cap_s);
+                        if (fy2 * fy2 + fz2 * fz2 > lim * 1.0001) continue;          // the whole row is outside the k-th ball
+                        const uint32_t rowbase = (uint32_t)((cz * g.n[1] + cy) * g.n[0]);
+                        if (ady <= rp && adz <= rp) {                                  // crosses the old cube: two end pieces
+                            const int lb = min(xhi, ux - rp - 1), ra = max(xlo, ux + rp + 1);
+                            if (xlo <= lb) scan_cells<K, SQ>(records, cell_start[rowbase + xlo], cell_start[rowbase + lb + 1], qx, qy, qz, cap_s, t, kth_s);
+                            if (ra <= xhi) scan_cells<K, SQ>(records, cell_start[rowbase + ra], cell_start[rowbase + xhi + 1], qx, qy, qz, cap_s, t, kth_s);
+                        } else {
+                            scan_cells<K, SQ>(records, cell_start[rowbase + xlo], cell_start[rowbase + xhi + 1], qx, qy, qz, cap_s, t, kth_s);
+                        }
+                    }
+                }
+            }
+            const bool covers = (ux - r <= 0) && (ux + r >= g.n[0] - 1) && (uy - r <= 0) && (uy + r >= g.n[1] - 1) && (uz - r <= 0) && (uz + r >= g.n[2] - 1);
+            const double reach = ((double)r - slack) * h;
+            const double lim = fmin(kth_s, cap_s);                                     // nothing at or beyond `lim` can enter
+            if (covers || lim < reach * reach * 0.99999) break;
+            rp = r;
+            if (lim < INFINITY) {
+                const double need = fmin(sqrt(lim * 1.00002) * (double)g.inv_h + slack + 1.0, 16777216.0);
+                r = max((int)need, rp + 1);
+            } else {
+                r = min(r * 2, 1 << 24);
+            }
+        }
+    }
+    uint32_t found = 0;
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        if (s < k_out) {
+            const bool have = t.i[s] != 0x7FFFFFFF;
+            found += have;
+            idx_out[(size_t)row * k_out + s] = have ? t.i[s] : empty_idx;
+            val_out[(size_t)row * k_out + s] = have ? t.v[s] : empty_val;
+        }
+    }
+    if (found_out) found_out[row] = found;
+}
+
+// normals[i] = eigenvector of the smallest eigenvalue of the scatter matrix of point i's neighbours (pca_normal.py:17-36,
+// :96-103): centre = sum / n, XTX = sum (p - c)(p - c)^T in neighbour order (ascending distance); zeros when fewer than 3
+__global__ __launch_bounds__(KG_BLOCK) void normals_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
+                                                           const int32_t* __restrict__ nbr, const uint32_t* __restrict__ found, int k,
+                                                           double* __restrict__ normals)
+{
+#pragma clang fp contract(off)
+    const uint32_t i = blockIdx.x * KG_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t cnt = found[i];
+    double out[3] = { 0.0, 0.0, 0.0 };
+    if (cnt >= 3) {                                                                    // pca_normal.py:97
+        double sx = 0, sy = 0, sz = 0;
+        for (uint32_t s = 0; s < cnt; s++) {
+            const int32_t j = nbr[(size_t)i * k + s];
+            sx += (double)x[j]; sy += (double)y[j]; sz += (double)z[j];
+        }
+        const double cx = sx / (double)cnt, cy = sy / (double)cnt, cz = sz / (double)cnt;   // :20
+        double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+        for (uint32_t s = 0; s < cnt; s++) {
+            const int32_t j = nbr[(size_t)i * k + s];
+            const double dx = (double)x[j] - cx, dy = (double)y[j] - cy, dz = (double)z[j] - cz;
+            xx += dx * dx; xy += dx * dy; xz += dx * dz; yy += dy * dy; yz += dy * dz; zz += dz * dz;   // :22
+        }
+        const double A[9] = { xx, xy, xz, xy, yy, yz, xz, yz, zz };
+        eig3::smallest_eigenvector(A, out);
+    }
+    normals[3 * (size_t)i] = out[0]; normals[3 * (size_t)i + 1] = out[1]; normals[3 * (size_t)i + 2] = out[2];
+}
+
+// a grid for k-NN: the cached 1-NN grid's cell (occupancy ~2) widened by sqrt(k / 4) so that the first cube usually
+// holds the k neighbours (points per cell grow with h^2 on surfaces)
+int knn_grid_for(pcr_ctx* ctx, const pcr_cloud* db, int k, Grid** out, bool* owned)
+{
+    *owned = false;
+    if (!db->grid) {
+        Grid* g = nullptr;
+        ProfScope p(ctx, "grid_build");
+        int rc = grid_build(ctx, db, &g, 0.0);
+        if (rc) return rc;
+        const_cast<pcr_cloud*>(db)->grid = g;
+    }
+    const double scale = (double)tune_get(ctx, "knn_cell_scale_x100", 0) / 100.0;
+    const double f = scale > 0 ? scale : std::min(2.0, std::sqrt(std::max(1.0, (double)k / 4.0)));   // measured: profiles/r01_knn_grid.txt
+    if (f <= 1.05) { *out = db->grid; return PCR_OK; }
+    ProfScope p(ctx, "grid_build");
+    int rc = grid_build(ctx, db, out, (double)db->grid->p.h * f);
+    if (rc) return rc;
+    *owned = true;
+    return PCR_OK;
+}
+
+// device results: idx [m x k], val [m x k], found [m] at the head of a fresh allocation (caller frees)
+int knn_grid_device(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k, double cap_s, bool squared, double empty_val, int32_t empty_idx,
+                    void** result, int32_t** idx_dev, double** val_dev, uint32_t** found_dev)
+{
+    const size_t m = q->n;
+    Grid* g = nullptr;
+    bool owned = false;
+    int rc = knn_grid_for(ctx, db, k, &g, &owned);
+    if (rc) return rc;
+    const uint32_t* perm = nullptr;
+    if (q != db) {
+        // cell-sorted permutation of the queries (coarse cells of db's cached grid; any spatial grouping will do)
+        ProfScope p(ctx, "grid_sort_queries");
+        rc = grid_prepare_queries(ctx, db, q);
+        if (rc) { if (owned) grid_free(g); return rc; }
+        perm = ctx->qperm;
+    }
+    const size_t vb = (m * (size_t)k * 8 + 255) & ~(size_t)255, ib = (m * (size_t)k * 4 + 255) & ~(size_t)255, fb = (m * 4 + 255) & ~(size_t)255;
+    char* res = nullptr;
+    hipError_t e = hipMalloc((void**)&res, vb + ib + fb);
+    if (e != hipSuccess) { if (owned) grid_free(g); return fail(ctx, PCR_ERR_HIP, "hipMalloc(knn)", e); }
+    *result = res;
+    *val_dev = (double*)res;
+    *idx_dev = (int32_t*)(res + vb);
+    *found_dev = (uint32_t*)(res + vb + ib);
+    {
+        ProfScope p(ctx, "knn_grid", 1);
+        const dim3 grid((unsigned)((m + KG_BLOCK - 1) / KG_BLOCK));
+#define PCR_KG(KK)                                                                                                                          \
+    do {                                                                                                                                    \
+        if (squared)                                                                                                                        \
+            hipLaunchKernelGGL((knn_grid_kernel<KK, true>), grid, dim3(KG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, q->x(), q->y(), q->z(), \
+                               perm, (uint32_t)m, k, cap_s, empty_val, empty_idx, *idx_dev, *val_dev, *found_dev);                             \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((knn_grid_kernel<KK, false>), grid, dim3(KG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, q->x(), q->y(), q->z(), \
+                               perm, (uint32_t)m, k, cap_s, empty_val, empty_idx, *idx_dev, *val_dev, *found_dev);                             \
+    } while (0)
+        if (k <= 1) PCR_KG(1);
+        else if (k <= 4) PCR_KG(4);
+        else if (k <= 8) PCR_KG(8);
+        else if (k <= 16) PCR_KG(16);
+        else PCR_KG(32);
+#undef PCR_KG
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess && owned) e = hipStreamSynchronize(ctx->stream);      // the private grid must outlive the kernel
+    if (owned) grid_free(g);
+    if (e != hipSuccess) { hipFree(res); *result = nullptr; return fail(ctx, PCR_ERR_HIP, "knn_grid", e); }
+    return PCR_OK;
+}
+
+}  // namespace
+
+int cloud_knn_host(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k, double cap_s, bool squared, double empty_val, int32_t empty_idx,
+                   int32_t* idx, double* val, uint32_t* found)
+{
+    const size_t m = q->n;
+    if (m == 0) return PCR_OK;
+    void* res = nullptr;
+    int32_t* idx_dev = nullptr;
+    double* val_dev = nullptr;
+    uint32_t* found_dev = nullptr;
+    int rc = knn_grid_device(ctx, db, q, k, cap_s, squared, empty_val, empty_idx, &res, &idx_dev, &val_dev, &found_dev);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(idx, idx_dev, m * (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(val, val_dev, m * (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && found) e = hipMemcpyAsync(found, found_dev, m * 4, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    hipFree(res);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(ctx, PCR_ERR_HIP, "knn_grid read-back", e != hipSuccess ? e : e2);
+    return PCR_OK;
+}
+
+}  // namespace pcr
+
+using namespace pcr;
+
+extern "C" {
+
+int pcr_cloud_knn_f64(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* queries, int k, double radius, int squared, int32_t* idx, double* dist,
+                      uint32_t* found)
+{
+    if (!ctx || !db || !queries || k < 1 || k > 32 || (queries->n && (!idx || !dist))) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_knn_f64");
+    if (db->n > 0x7FFFFFF0ull || queries->n > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_knn_f64: cloud too large");
+    if (std::isnan(radius)) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_knn_f64: radius is NaN");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    // hybrid search: strict cap on the squared distance (FLANN KNNRadiusResultSet semantics); radius < 0 = no cap
+    const double cap_s = radius < 0 ? INFINITY : radius * radius;
+    const int rc = cloud_knn_host(ctx, db, queries, k, cap_s, squared != 0, squared ? 1.7976931348623157e308 : 1e10, squared ? -1 : 0, idx, dist, found);
+    prof_flush(ctx);
+    return rc;
+}
+
+int pcr_normals_knn_f64(pcr_ctx* ctx, const pcr_cloud* cloud, int k, double radius, double* normals)
+{
+    if (!ctx || !cloud || k < 1 || k > 32 || (cloud->n && !normals) || std::isnan(radius)) return fail(ctx, PCR_ERR_ARG, "pcr_normals_knn_f64");
+    if (cloud->n > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_normals_knn_f64: cloud too large");
+    const size_t n = cloud->n;
+    if (n == 0) return PCR_OK;
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    void* res = nullptr;
+    int32_t* idx_dev = nullptr;
+    double* val_dev = nullptr;
+    uint32_t* found_dev = nullptr;
+    int rc = knn_grid_device(ctx, cloud, cloud, k, radius < 0 ? INFINITY : radius * radius, true, 1.7976931348623157e308, -1, &res, &idx_dev, &val_dev, &found_dev);
+    if (rc) return rc;
+    double* nrm_dev = nullptr;
+    hipError_t e = hipMalloc((void**)&nrm_dev, n * 3 * sizeof(double));
+    if (e == hipSuccess) {
+        ProfScope p(ctx, "normals_pca", 1);
+        hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((n + KG_BLOCK - 1) / KG_BLOCK)), dim3(KG_BLOCK), 0, ctx->stream, cloud->x(), cloud->y(), cloud->z(),
+                           (uint32_t)n, idx_dev, found_dev, k, nrm_dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(normals, nrm_dev, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    hipFree(res);
+    if (nrm_dev) hipFree(nrm_dev);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(ctx, PCR_ERR_HIP, "pcr_normals_knn_f64", e != hipSuccess ? e : e2);
+    prof_flush(ctx);
+    return PCR_OK;
+}
+
+}  // extern "C"

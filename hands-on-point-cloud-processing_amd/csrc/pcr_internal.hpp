@@ -127,6 +127,9 @@ void prof_flush(pcr_ctx* ctx);
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
 int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm);
+// exact grid k-NN between resident clouds (knn_grid.hip); host outputs idx/val [m x k], found [m] (optional)
+int cloud_knn_host(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k, double cap_s, bool squared, double empty_val, int32_t empty_idx,
+                   int32_t* idx, double* val, uint32_t* found);
 // device-wide exclusive scan of u32 (grid.hip): totals needs ceil(n / SCAN_TILE) + 1 words
 constexpr int SCAN_TILE = 2048;
 int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* totals, uint32_t* grand);

@@ -13,6 +13,7 @@
 #include "pcr_internal.hpp"
 
 #include <cmath>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -212,6 +213,18 @@ static int upload_soa_f64(pcr_ctx* ctx, const double* aos, size_t n, size_t cap,
     return PCR_OK;
 }
 
+// true when every value survives the round trip through f32 (then f32 -> f64 widening reproduces the input exactly)
+static bool f32_exact(const double* aos, size_t n, std::vector<float>& out)
+{
+    out.resize(3 * n);
+    for (size_t i = 0; i < 3 * n; i++) {
+        const float f = (float)aos[i];
+        if (!((double)f == aos[i])) return false;          // also false for NaN
+        out[i] = f;
+    }
+    return true;
+}
+
 static size_t tile_cap(size_t n) { return ((n + SF_TILE - 1) / SF_TILE) * SF_TILE + SF_TILE; }
 
 }  // namespace pcr
@@ -221,6 +234,8 @@ struct pcr_db64 {
     size_t n = 0;
     size_t cap = 0;
     double* dev = nullptr;
+    pcr_cloud* twin = nullptr;   // the same points as an f32 cloud when every coordinate is f32-representable (KITTI / PLY data
+                                 // widened to f64, test.hpp:28): large k-NN batches then take the exact grid search
 };
 
 using namespace pcr;
@@ -238,6 +253,13 @@ extern "C" int pcr_db64_create(pcr_ctx* ctx, const double* db, size_t n, pcr_db6
     if (e != hipSuccess) { delete h; return fail(ctx, PCR_ERR_HIP, "hipMalloc(db64)", e); }
     int rc = upload_soa_f64(ctx, db, n, h->cap, h->dev);
     if (rc) { hipFree(h->dev); delete h; return rc; }
+    if (n >= 4096) {
+        std::vector<float> f32;
+        if (f32_exact(db, n, f32)) {
+            rc = pcr_cloud_create(ctx, f32.data(), n, PCR_AOS3, &h->twin);
+            if (rc) { hipFree(h->dev); delete h; return rc; }
+        }
+    }
     *out = h;
     return PCR_OK;
 }
@@ -247,6 +269,7 @@ extern "C" int pcr_db64_destroy(pcr_ctx* ctx, pcr_db64* db)
     if (!db) return PCR_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (db->dev) hipFree(db->dev);
+    if (db->twin) pcr_cloud_destroy(ctx, db->twin);
     delete db;
     return PCR_OK;
 }
@@ -260,6 +283,20 @@ extern "C" int pcr_db64_knn(pcr_ctx* ctx, const pcr_db64* db, const double* q, s
     if (m == 0) return PCR_OK;
     if (m > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_db64_knn: too many queries");
     PCR_HIP(ctx, hipSetDevice(ctx->device));
+    // large batches on f32-representable data: the exact grid search returns the same answers (same arithmetic, same
+    // canonical order) without touching all n x m pairs; knn_method 1 forces the exhaustive scan, 2 the grid
+    const int64_t method = tune_get(ctx, "knn_method", 0);
+    if (db->twin && method != 1 && (method == 2 || (double)db->n * (double)m >= 6.7e7)) {
+        std::vector<float> qf;
+        if (f32_exact(q, m, qf)) {
+            pcr_cloud* qc = nullptr;
+            int rcq = pcr_cloud_create(ctx, qf.data(), m, PCR_AOS3, &qc);
+            if (rcq) return rcq;
+            rcq = cloud_knn_host(ctx, db->twin, qc, k, INFINITY, squared != 0, squared ? 1.7976931348623157e308 : 1e10, squared ? -1 : 0, idx, dist, nullptr);
+            pcr_cloud_destroy(ctx, qc);
+            return rcq;
+        }
+    }
     const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
     const size_t bytes_q = 3 * m_cap * 8, bytes_i = m * (size_t)k * 4, bytes_d = m * (size_t)k * 8;
     const size_t off_d = bytes_q, off_i = off_d + ((bytes_d + 63) & ~(size_t)63);

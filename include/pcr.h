@@ -172,6 +172,21 @@ typedef struct {
 int pcr_iss_keypoints_f32(pcr_ctx* ctx, const pcr_cloud* cloud, const pcr_iss_params* prm, uint8_t* is_key, float* lambda3,
                           uint32_t* neighbor_counts, uint64_t* n_keypoints);
 
+/* ---- next row N1 (second consumer): batched exact k-NN on resident clouds + per-point PCA normals ------------------
+ * k-NN of every point of `queries` (may be `db` itself) in `db`, k <= 32, over a uniform grid; f64 leaf arithmetic of
+ * hw2 / FLANN / nanoflann at dim 3 on the f32 coordinates widened to f64: s = ((dx*dx) + dy*dy) + dz*dz.
+ * squared != 0: order and report s (FLANN / open3d / nanoflann contract), empty slots (DBL_MAX, -1); radius >= 0 adds the
+ * hybrid-search cap s < radius^2 (strict, FLANN's KNNRadiusResultSet); radius < 0: none.
+ * squared == 0: order and report d = sqrt(s) (hw2, kdtree.hpp:341-346), empty slots (1e10, 0) (resultSet.hpp:35-42).
+ * Canonical order: value ascending, then index ascending.  idx, dist: m x k row-major; found (optional): m. */
+int pcr_cloud_knn_f64(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* queries, int k, double radius, int squared,
+                      int32_t* idx, double* dist, uint32_t* found);
+/* pca_normal.py:89-103: normals[i] = eigenvector of the smallest eigenvalue of the scatter matrix of the <= k nearest
+ * points within `radius` of point i (itself included; the reference: search_hybrid_vector_3d(radius = 5, max_nn = 10) +
+ * PCA, :17-36), zeros when fewer than 3.  Sign and eigen-solver follow FastEigen3x3 (the reference's PCA_faster, :39-45;
+ * np.linalg.eig leaves the sign unspecified).  normals: n x 3 f64. */
+int pcr_normals_knn_f64(pcr_ctx* ctx, const pcr_cloud* cloud, int k, double radius, double* normals);
+
 /* ---- next row N2: PCA ground fit around the inlier count, Homework4/ground_detection_SVD.py:46-101 --------------
  * f64 arithmetic on the f32 points of the cloud (the reference's points are f64 after pcd_preprocessing, :35).
  * pcr_fast_eigen3x3 (host logic, no GPU) = mylib.FastEigen3x3 (Homework1/.../my_pybind11/src/mylib.cpp:105-189): unit

@@ -86,6 +86,8 @@ def lib():
         L.orc_estimate_plane_f64.restype = sz
         L.orc_ground_detection_f64.argtypes = [f32p, f32p, f32p, sz, C.c_int, sz, C.c_double, f64p, u8p]
         L.orc_ground_detection_f64.restype = sz
+        L.orc_knn_sq_f32pts.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, C.c_int, C.c_double, i32p, f64p, u32p]
+        L.orc_normals_knn_f64.argtypes = [f32p, f32p, f32p, sz, C.c_int, C.c_double, f64p]
         L.orc_iss_f32.argtypes = [f32p, f32p, f32p, sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, u8p, f32p]
         L.orc_hw2_knn_add.argtypes = [f64p, i32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                       C.c_double, C.c_int]
@@ -344,6 +346,26 @@ def ground_detection_f64(soa, max_iter, lpr_size, threshold_dist):
     mask = np.zeros(max(x.size, 1), np.uint8)
     c = lib().orc_ground_detection_f64(x, y, z, x.size, max_iter, lpr_size, threshold_dist, params, mask)
     return params, mask[: x.size], (-1 if c == C.c_size_t(-1).value else int(c))
+
+
+def knn_sq_f32pts(db_soa, q_soa, k, radius=-1.0):
+    """squared-distance k-NN (FLANN / open3d contract), optional hybrid cap s < radius^2 -> (idx [m,k], s [m,k], found [m])."""
+    x, y, z = _soa(db_soa)
+    qx, qy, qz = _soa(q_soa)
+    m = qx.size
+    idx = np.zeros((max(m, 1), k), np.int32)
+    s = np.zeros((max(m, 1), k), np.float64)
+    found = np.zeros(max(m, 1), np.uint32)
+    cap = float("inf") if radius < 0 else float(radius) * float(radius)
+    lib().orc_knn_sq_f32pts(x, y, z, x.size, qx, qy, qz, m, k, cap, idx.reshape(-1), s.reshape(-1), found)
+    return idx[:m], s[:m], found[:m]
+
+
+def normals_knn_f64(soa, k, radius):
+    x, y, z = _soa(soa)
+    out = np.zeros((max(x.size, 1), 3), np.float64)
+    lib().orc_normals_knn_f64(x, y, z, x.size, k, radius, out.reshape(-1))
+    return out[: x.size]
 
 
 def iss_f32(soa, local_radius, non_max_radius, gamma21=0.9, gamma32=0.9, min_neighbors=5, weighted=True):

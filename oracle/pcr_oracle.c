@@ -880,3 +880,51 @@ size_t orc_ground_detection_f64(const float* x, const float* y, const float* z, 
     free(seeds);
     return count;
 }
+
+/* ------------------------------------------------------------------ N1, second consumer */
+void orc_knn_sq_f32pts(const float* x, const float* y, const float* z, size_t n, const float* qx, const float* qy,
+                       const float* qz, size_t m, int k, double cap_s, int32_t* idx, double* s_out, uint32_t* found)
+{
+    for (size_t i = 0; i < m; i++) {
+        int32_t* bi = idx + i * (size_t)k;
+        double* bs = s_out + i * (size_t)k;
+        int cnt = 0;
+        for (int c = 0; c < k; c++) { bi[c] = -1; bs[c] = DBL_MAX; }
+        for (size_t j = 0; j < n; j++) {
+            const double dx = (double)x[j] - (double)qx[i], dy = (double)y[j] - (double)qy[i], dz = (double)z[j] - (double)qz[i];
+            const double s = (dx * dx + dy * dy) + dz * dz;
+            if (!(s < cap_s)) continue;
+            if (cnt == k && !(s < bs[k - 1])) continue;            /* ascending j: an equal s never displaces a lower index */
+            int pos = cnt < k ? cnt : k - 1;
+            while (pos > 0 && bs[pos - 1] > s) { bs[pos] = bs[pos - 1]; bi[pos] = bi[pos - 1]; pos--; }
+            bs[pos] = s; bi[pos] = (int32_t)j;
+            if (cnt < k) cnt++;
+        }
+        if (found) found[i] = (uint32_t)cnt;
+    }
+}
+
+void orc_normals_knn_f64(const float* x, const float* y, const float* z, size_t n, int k, double radius, double* normals)
+{
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)k);
+    double* ss = (double*)malloc(sizeof(double) * (size_t)k);
+    const double cap_s = radius < 0 ? INFINITY : radius * radius;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t cnt = 0;
+        orc_knn_sq_f32pts(x, y, z, n, x + i, y + i, z + i, 1, k, cap_s, idx, ss, &cnt);
+        double* out = normals + 3 * i;
+        out[0] = out[1] = out[2] = 0.0;
+        if (cnt < 3) continue;                                       /* pca_normal.py:97 */
+        double s[3] = { 0, 0, 0 };
+        for (uint32_t c = 0; c < cnt; c++) { s[0] += x[idx[c]]; s[1] += y[idx[c]]; s[2] += z[idx[c]]; }
+        const double ctr[3] = { s[0] / (double)cnt, s[1] / (double)cnt, s[2] / (double)cnt };   /* :20 */
+        double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+        for (uint32_t c = 0; c < cnt; c++) {
+            const double dx = x[idx[c]] - ctr[0], dy = y[idx[c]] - ctr[1], dz = z[idx[c]] - ctr[2];
+            xx += dx * dx; xy += dx * dy; xz += dx * dz; yy += dy * dy; yz += dy * dz; zz += dz * dz;   /* :22 */
+        }
+        const double XTX[9] = { xx, xy, xz, xy, yy, yz, xz, yz, zz };
+        orc_fast_eigen3x3(XTX, out);                                 /* PCA_faster :39-45 */
+    }
+    free(idx); free(ss);
+}

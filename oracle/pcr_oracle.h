@@ -207,6 +207,16 @@ size_t orc_estimate_plane_f64(const float* x, const float* y, const float* z, si
 size_t orc_ground_detection_f64(const float* x, const float* y, const float* z, size_t n, int max_iter, size_t lpr_size,
                                 double threshold_dist, double params[4], uint8_t* ground_mask);
 
+/* ---- N1 (second consumer): squared-distance k-NN with the optional hybrid cap, and per-point PCA normals
+ * (Homework1/.../pca_normal.py:89-103; search = open3d KDTreeFlann.search_hybrid_vector_3d -> FLANN, absent: UNPINNED).
+ * s = ((dx*dx) + dy*dy) + dz*dz in f64 on f32 points (A2 without the sqrt = FLANN / nanoflann L2 at dim 3); canonical
+ * order (s, then index); candidates need s < cap_s (strict; +inf = no cap); empty slots (DBL_MAX, -1). */
+void orc_knn_sq_f32pts(const float* x, const float* y, const float* z, size_t n, const float* qx, const float* qy,
+                       const float* qz, size_t m, int k, double cap_s, int32_t* idx, double* s_out, uint32_t* found);
+/* normals[i] = FastEigen3x3 of the scatter matrix (centre = sum / cnt, pca_normal.py:20-22) of point i's <= k nearest
+ * points with s < radius^2, in ascending (s, index) order; zeros when fewer than 3 (:97). */
+void orc_normals_knn_f64(const float* x, const float* y, const float* z, size_t n, int k, double radius, double* normals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,165 @@
+"""Next row N1, second consumer: batched exact k-NN over the uniform grid on resident clouds, and the
+per-point PCA normals of Homework1 pca_normal.py:89-103.
+
+Pinning: the k-NN arithmetic is the hw2 leaf arithmetic (A2, pinned) — in the non-squared mode the grid search must
+reproduce the pinned brute-force contract (orc.knn_f64) bit for bit.  The reference's own search here is open3d's
+KDTreeFlann (FLANN; absent) and its PCA is np.linalg.eig (sign unspecified): UNPINNED; normals are compared up to the
+tolerance of device libm (acos / cos) against the oracle's FastEigen3x3 and, sign-free, against numpy.linalg.eigh."""
+import numpy as np
+import pytest
+
+
+def test_oracle_knn_sq_matches_pinned_hw2_contract(orc, synth):
+    scan = synth.kitti_like_scan(3000)
+    q = scan[:, ::7]
+    idx, s, found = orc.knn_sq_f32pts(scan, q, 8)
+    db64 = np.ascontiguousarray(scan.T.astype(np.float64))
+    hi, hd = orc.knn_f64(db64, np.ascontiguousarray(q.T.astype(np.float64)), 8)
+    assert np.array_equal(idx, hi) and np.array_equal(np.sqrt(s), hd) and (found == 8).all()
+    # hybrid cap: strict s < r^2, fewer than k found -> (-1, DBL_MAX) padding
+    idx2, s2, f2 = orc.knn_sq_f32pts(scan, q, 8, radius=0.3)
+    assert ((s2 < 0.09) | (idx2 == -1)).all() and (f2 == (idx2 >= 0).sum(1)).all() and (f2 < 8).any()
+    keep = s < 0.09
+    assert np.array_equal(np.where(keep, idx, -1), idx2)
+
+
+def test_oracle_normals_match_numpy_eigh(orc, synth):
+    scan = synth.kitti_like_scan(1500)
+    nrm = orc.normals_knn_f64(scan, 10, 5.0)
+    idx, s, found = orc.knn_sq_f32pts(scan, scan, 10, 5.0)
+    pts = scan.T.astype(np.float64)
+    checked = 0
+    for i in range(0, 1500, 3):
+        if found[i] < 3:
+            assert (nrm[i] == 0).all()
+            continue
+        nb = pts[idx[i, : found[i]]]
+        c = nb.sum(0) / nb.shape[0]
+        w, v = np.linalg.eigh((nb - c).T @ (nb - c))
+        if w[1] - w[0] > 1e-6 * w[2]:                                # a well-separated smallest eigenvalue
+            assert abs(nrm[i] @ v[:, 0]) > 1 - 1e-6
+            checked += 1
+    assert checked > 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 3, 8, 10, 16, 32])
+def test_gpu_cloud_knn_self_query_both_contracts(pcr, orc, synth, k):
+    scan = synth.kitti_like_scan(6000)
+    ctx = pcr.Context(0)
+    try:
+        c = ctx.cloud(scan)
+        idx, s, found = ctx.cloud_knn(c, c, k)
+        oi, os_, of = orc.knn_sq_f32pts(scan, scan, k)
+        assert np.array_equal(idx, oi) and np.array_equal(s.view(np.uint64), os_.view(np.uint64)) and np.array_equal(found, of)
+        assert (idx[:, 0] == np.arange(6000)).mean() > 0.99          # a point is its own nearest neighbour (s = 0) barring duplicates
+        # hw2 contract (sqrt'd distance, (1e10, 0) placeholders) == the pinned brute-force oracle
+        idx2, d2, _ = ctx.cloud_knn(c, c, k, squared=False)
+        db64 = np.ascontiguousarray(scan.T.astype(np.float64))
+        hi, hd = orc.knn_f64(db64, db64, k)
+        assert np.array_equal(idx2, hi) and np.array_equal(d2.view(np.uint64), hd.view(np.uint64))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_cloud_knn_external_queries_ties_cap_and_edges(pcr, orc, synth):
+    ctx = pcr.Context(0)
+    try:
+        rng = np.random.default_rng(4)
+        db = synth.kitti_like_scan(8000).copy()
+        db[:, 100:140] = db[:, 60:100]                               # duplicates: tie sets of size 2 (lowest index first)
+        lat = np.ascontiguousarray(synth.lattice_cloud(3000, 3, 10.0, seed=5, levels=12).T.astype(np.float32))
+        q = np.concatenate([db[:, ::5] + rng.normal(0, 0.05, (3, 1600)).astype(np.float32), db[:, 60:140],
+                            np.array([[500.0, -500.0, 80.0], [0, 0, 0], [1e6, 1e6, 1e6]], np.float32).T], axis=1)
+        q = np.ascontiguousarray(q)
+        for base, qq in ((db, q), (lat, lat[:, ::3].copy())):
+            cdb, cq = ctx.cloud(base), ctx.cloud(qq)
+            for k, radius in ((8, -1.0), (10, 1.0), (4, 0.0), (16, 0.25), (32, 3.0)):
+                idx, s, found = ctx.cloud_knn(cdb, cq, k, radius)
+                oi, os_, of = orc.knn_sq_f32pts(base, qq, k, radius)
+                assert np.array_equal(idx, oi), (k, radius)
+                assert np.array_equal(s.view(np.uint64), os_.view(np.uint64)) and np.array_equal(found, of)
+        # k larger than the cloud; non-finite query and database points; empty query set
+        small = ctx.cloud(db[:, :5].copy())
+        idx, s, found = ctx.cloud_knn(small, small, 8)
+        assert (found == 5).all() and (idx[:, 5:] == -1).all() and (s[:, 5:] == np.finfo(np.float64).max).all()
+        bad = db[:, :2000].copy(); bad[0, 7] = np.nan; bad[1, 9] = np.inf
+        qb = bad[:, :50].copy()
+        idx, s, found = ctx.cloud_knn(ctx.cloud(bad), ctx.cloud(qb), 4)
+        oi, os_, of = orc.knn_sq_f32pts(bad, qb, 4)
+        assert np.array_equal(idx, oi) and np.array_equal(found, of) and found[7] == 0 and found[9] == 0
+        idx, s, found = ctx.cloud_knn(small, ctx.cloud(np.zeros((3, 0), np.float32)), 4)
+        assert idx.shape == (0, 4)
+        with pytest.raises(pcr.PcrError):
+            ctx.cloud_knn(small, small, 33)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_cloud_knn_full_scan_properties(pcr, orc, synth):
+    """120 k x 120 k, k = 10 (no O(n^2) oracle pass over everything): a sampled exact check + order/symmetry properties."""
+    scan = synth.kitti_like_scan(120000)
+    ctx = pcr.Context(0)
+    try:
+        c = ctx.cloud(scan)
+        idx, s, found = ctx.cloud_knn(c, c, 10)
+        assert (found == 10).all() and (np.diff(s, axis=1) >= 0).all() and (s[:, 0] == 0).all()
+        pick = np.arange(0, 120000, 997)
+        oi, os_, _ = orc.knn_sq_f32pts(scan, np.ascontiguousarray(scan[:, pick]), 10)
+        assert np.array_equal(idx[pick], oi) and np.array_equal(s[pick].view(np.uint64), os_.view(np.uint64))
+        # reported distances are the arithmetic's value for the reported pair
+        j = idx[:, 9]
+        d = scan.astype(np.float64)[:, j] - scan.astype(np.float64)
+        assert np.array_equal((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2], s[:, 9])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_normals_match_oracle(pcr, orc, synth, golden):
+    ctx = pcr.Context(0)
+    try:
+        for soa, k, radius in ((synth.kitti_like_scan(5000), 10, 5.0), (np.ascontiguousarray(golden("iss_hw7.npz")["xyz_airplane_0001"].T), 10, 0.05),
+                               (synth.kitti_like_scan(3000), 20, 0.4)):
+            got = ctx.normals(ctx.cloud(soa), k, radius)
+            want = orc.normals_knn_f64(soa, k, radius)
+            zero = (want == 0).all(1)
+            assert np.array_equal(zero, (got == 0).all(1))
+            # same operations; device acos / cos differ from glibc in the last bits -> compare with a tolerance that
+            # widens where the two smallest eigenvalues are close (the eigenvector is then ill-conditioned)
+            err = np.linalg.norm(got - want, axis=1)
+            assert np.median(err) < 1e-12 and (err < 1e-6).mean() > 0.99
+            assert np.allclose(np.linalg.norm(got[~zero], axis=1), 1.0, atol=1e-9)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("squared", [False, True])
+def test_gpu_db64_knn_grid_route_equals_exhaustive_scan(pcr, synth, squared):
+    """pcr_db64_knn (the hw2 / nanoflann drop-in path) takes the grid search for large f32-representable batches:
+    same indices, same distance bits as the exhaustive kernel; inputs that are not f32-representable keep the scan."""
+    scan = synth.kitti_like_scan(20000)
+    db = np.ascontiguousarray(scan.T.astype(np.float64))
+    rng = np.random.default_rng(8)
+    q = np.ascontiguousarray((scan[:, ::4] + rng.normal(0, 0.1, (3, 5000)).astype(np.float32)).T.astype(np.float64))
+    ctx = pcr.Context(0)
+    try:
+        h = ctx.db64(db)
+        for k in (1, 8, 20):
+            ctx.tune("knn_method", 1)
+            bi, bd = h.knn(q, k, squared=squared)
+            ctx.tune("knn_method", 2)
+            gi, gd = h.knn(q, k, squared=squared)
+            assert np.array_equal(bi, gi) and np.array_equal(bd.view(np.uint64), gd.view(np.uint64))
+        q2 = q + 1e-9                                                  # no longer f32-representable -> exhaustive scan, still exact
+        ctx.tune("knn_method", 2)
+        gi, gd = h.knn(q2, 8, squared=squared)
+        ctx.tune("knn_method", 1)
+        bi, bd = h.knn(q2, 8, squared=squared)
+        assert np.array_equal(bi, gi) and np.array_equal(bd.view(np.uint64), gd.view(np.uint64))
+        ctx.tune("knn_method", 0)
+    finally:
+        ctx.close()
