@@ -43,7 +43,8 @@ def _newer(a: str, b: str) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
-    headers = [os.path.join(CSRC, "pcr_internal.hpp"), os.path.join(ROOT, "include", "pcr.h"), __file__]
+    # every object depends on every internal header (a handful of small files: precise tracking is not worth a stale object)
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(ROOT, "include", "pcr.h"), __file__]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
