@@ -203,8 +203,9 @@ __global__ __launch_bounds__(256) void consensus_kernel(const PairXyz* __restric
     for (int k = 0; k < 3; k++) t[k] = Rt[12 * (size_t)hs + 9 + k];
     const uint32_t p0 = blockIdx.y * chunk, p1 = min(n_pairs, p0 + chunk);
     uint32_t c = 0;
+#pragma unroll 4
     for (uint32_t i = p0; i < p1; i++) {
-        const PairXyz pr = pairs[i];                                       // wave-uniform: scalar loads
+        const PairXyz pr = pairs[i];                                       // wave-uniform: scalar loads, 4 in flight
         const float ex = pr.t[0] - (((R[0] * pr.s[0] + R[1] * pr.s[1]) + R[2] * pr.s[2]) + t[0]);
         const float ey = pr.t[1] - (((R[3] * pr.s[0] + R[4] * pr.s[1]) + R[5] * pr.s[2]) + t[1]);
         const float ez = pr.t[2] - (((R[6] * pr.s[0] + R[7] * pr.s[1]) + R[8] * pr.s[2]) + t[2]);
