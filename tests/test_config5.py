@@ -1,0 +1,54 @@
+"""BASELINE config 5 at its full size on ONE GPU: a 10 M x 10 M synthetic pair (the 8-GPU run shards exactly this pair's
+sources).  No O(n^2) oracle pass is possible: the exact grid search is checked on a sample against the brute-force oracle
+and through size-independent properties; the sharded reduction through linearity of the moments."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N = 10_000_000
+
+
+def test_c5_10M_pair_exact_search_shard_linearity_and_pose(pcr, orc, synth):
+    src, tgt = synth.kitti_like_pair(N)
+    ctx = pcr.Context(0)
+    try:
+        ctx.tune("nn_method", 2)
+        cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+        idx, d2 = ctx.nn1(ct, cs)
+        # (1) a sample against the exhaustive oracle: indices and d2 bits
+        sel = np.arange(0, N, N // 96)[:96]
+        oi, od = orc.nn1_f32(tgt, np.ascontiguousarray(src[:, sel]))
+        assert np.array_equal(idx[sel], oi) and np.array_equal(d2[sel].view(np.uint32), od.view(np.uint32))
+        # (2) every reported d2 is the A1 arithmetic of its reported pair; no query is left without an answer
+        assert idx.max() < N and np.isfinite(d2).all()
+        some = np.random.default_rng(0).integers(0, N, 200000)
+        dx, dy, dz = (src[c, some] - tgt[c, idx[some]] for c in range(3))
+        assert np.array_equal(((dx * dx + dy * dy) + dz * dz).astype(np.float32).view(np.uint32), d2[some].view(np.uint32))
+        # (3) optimality on a second sample: no target of a random 2 000-point subset is strictly closer
+        probe = np.random.default_rng(1).integers(0, N, 2000)
+        qs = np.random.default_rng(2).integers(0, N, 500)
+        for q in qs[:50]:
+            ex, ey, ez = (src[c, q] - tgt[c, probe] for c in range(3))
+            assert (((ex * ex + ey * ey) + ez * ez).astype(np.float32) >= d2[q]).all()
+        # (4) sharding: the moments of two half-shards add up to the moments of the whole (what the all-reduce relies on)
+        full, _, _ = ctx.kabsch_sums(ct, cs, 1.0)
+        b, e = pcr.shard_range(N, 2, 0)
+        h0 = ctx.cloud(np.ascontiguousarray(src[:, b:e]))
+        ctx.nn1_async(ct, h0); s0, _, _ = ctx.kabsch_sums(ct, h0, 1.0)
+        h0.free()
+        b1, e1 = pcr.shard_range(N, 2, 1)
+        h1 = ctx.cloud(np.ascontiguousarray(src[:, b1:e1]))
+        ctx.nn1_async(ct, h1); s1, _, _ = ctx.kabsch_sums(ct, h1, 1.0)
+        h1.free()
+        assert e == b1 and e1 == N
+        assert s0[15] + s1[15] == full[15]                           # kept-pair counts: exact
+        assert np.allclose(s0 + s1, full, rtol=1e-11, atol=1e-6)
+        # (5) ICP from the identity walks towards the planted pose (dense clouds: small steps; 20 iterations reach 4e-2)
+        e0 = np.linalg.norm(np.eye(4) - synth.gt_pose())
+        T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=4, eps=0.0)
+        e4 = np.linalg.norm(T - synth.gt_pose())
+        assert st["iters_run"] == 4 and st["last_pairs"] > 0.99 * N and e4 < 0.6 * e0
+        T2, st2 = ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=4, eps=0.0)
+        assert np.linalg.norm(T2 - synth.gt_pose()) < 0.7 * e4
+    finally:
+        ctx.close()
