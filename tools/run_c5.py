@@ -13,7 +13,8 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 t0 = time.time(); src, tgt = synth.kitti_like_pair(n); print(f"generated {n} x {n} pair in {time.time()-t0:.1f} s", flush=True)
 ctx = pcr.Context(0)
 ctx.tune("nn_method", 2)
-for k, v in (("grid_occupancy_x10", os.environ.get("OCC")), ("grid_lanes", os.environ.get("LANES")), ("grid_max_cells", os.environ.get("MAXCELLS"))):
+for k, v in (("grid_occupancy_x10", os.environ.get("OCC")), ("grid_lanes", os.environ.get("LANES")), ("grid_max_cells", os.environ.get("MAXCELLS")),
+             ("grid_query_bins_log2", os.environ.get("BINS")), ("grid_query_bin_min", os.environ.get("BINMIN"))):
     if v: ctx.tune(k, int(v))
 t0 = time.time(); cs, ct = ctx.cloud(src), ctx.cloud(tgt); print(f"upload {time.time()-t0:.2f} s", flush=True)
 ctx.tune("prof", 2)
