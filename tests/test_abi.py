@@ -52,3 +52,20 @@ def test_no_gpu_means_loud_failure(pcr):
         pytest.skip("GPU present")
     with pytest.raises(pcr.PcrError):
         pcr.Context(0)
+
+
+def test_header_is_plain_c_and_links_from_c(pcr, tmp_path):
+    """The boundary is a C ABI: include/pcr.h must compile as strict C11 (no C++-isms) and link from a C program."""
+    import subprocess
+    src = tmp_path / "abi_c.c"
+    src.write_text('#include "pcr.h"\n#include <stdio.h>\n'
+                   'int main(void) { pcr_iss_params p = {0}; pcr_icp_params q = {0}; (void)p; (void)q;\n'
+                   '  double A[9] = {2,0,0, 0,1,0, 0,0,3}, n[3]; if (pcr_fast_eigen3x3(A, n) != PCR_OK) return 1;\n'
+                   '  printf("%s %.0f %.0f %.0f\\n", pcr_version(), n[0], n[1], n[2]); return 0; }\n')
+    libdir = os.path.dirname(pcr.LIB_PATH)
+    exe = tmp_path / "abi_c"
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L" + libdir, "-lpcr_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("0 1 0"), r.stdout + r.stderr    # host logic only: runs without a GPU
