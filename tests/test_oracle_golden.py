@@ -283,3 +283,55 @@ def test_live_reference_agrees_with_oracle_when_present(orc, synth):
     assert np.array_equal(i1, i2) and np.array_equal(bits32(d1), bits32(d2))
     i3, d3, _, _ = orc.ref_nano_nn1_f32(tgt, src, leaf=2, threads=4)
     assert np.array_equal(i1, i3)
+
+
+def random_cloud(rng, n, kind):
+    """continuous / lattice (ties, duplicates) / clustered / huge and tiny magnitudes"""
+    if kind == 0:
+        return rng.normal(0, 10, (n, 3))
+    if kind == 1:
+        return rng.integers(0, 6, (n, 3)).astype(np.float64) * 0.5
+    if kind == 2:
+        c = rng.normal(0, 30, (max(n // 8, 1), 3))
+        return c[rng.integers(0, c.shape[0], n)] + rng.normal(0, 0.01, (n, 3))
+    s = 10.0 ** rng.integers(-12, 12)
+    return rng.normal(0, 1, (n, 3)) * s
+
+
+def test_live_reference_randomised_sweep(orc):
+    """200 random small problems against the compiled reference: nanoflann f32 1-NN (d2 bits; index equal or inside the
+    tie set), hw2 kd-tree k-NN distances and radius sets — continuous, lattice, clustered and extreme-magnitude clouds."""
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref not built (reference absent)")
+    rng = np.random.default_rng(20240607)
+    ties_seen = 0
+    for trial in range(200):
+        kind = trial % 4
+        n, m = int(rng.integers(1, 300)), int(rng.integers(1, 40))
+        db, q = random_cloud(rng, n, kind), random_cloud(rng, m, kind)
+        if trial % 3 == 0:
+            q[: min(m, n) // 2] = db[: min(m, n) // 2]                        # exact hits
+        # --- A1/A3/A6: nanoflann f32, leaf 2
+        t32, s32 = np.ascontiguousarray(db.T.astype(np.float32)), np.ascontiguousarray(q.T.astype(np.float32))
+        ri, rd, _, _ = orc.ref_nano_nn1_f32(t32, s32, leaf=2)
+        oi, od = orc.nn1_f32(t32, s32)
+        assert np.array_equal(bits32(rd), bits32(od)), trial
+        for k in np.flatnonzero(ri != oi):
+            assert oi[k] < ri[k] and orc.lib().orc_d2_f32(*map(float, s32[:, k]), *map(float, t32[:, ri[k]])) == od[k]
+            ties_seen += 1
+        # --- A2/A4: hw2 kd-tree k-NN (lattice clouds can make its median split recurse forever: leaf >= 32 there, see DESIGN)
+        if np.unique(db, axis=0).shape[0] == n or kind != 1:
+            k = int(rng.integers(1, 9))
+            leaf = 32 if kind == 1 else 1
+            hi, hd = orc.ref_hw2_kd_knn(db, q, k, leaf=leaf)
+            ki, kd = orc.knn_f64(db, q, k)
+            assert np.array_equal(hd.view(np.uint64), kd.view(np.uint64)), trial
+            # --- A11: radius sets
+            r = float(np.median(kd[:, -1])) if n >= k else 1.0
+            row, ridx, rdist = orc.ref_hw2_kd_radius(db, q, r, leaf=leaf)
+            orow, oidx, odist = orc.radius_f64(db, q, r)
+            assert np.array_equal(row, orow)
+            for i in range(m):
+                o = np.argsort(ridx[row[i]:row[i + 1]], kind="stable")
+                assert np.array_equal(ridx[row[i]:row[i + 1]][o], oidx[row[i]:row[i + 1]])
+    assert ties_seen > 0
