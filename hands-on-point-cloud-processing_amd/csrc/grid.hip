@@ -181,6 +181,11 @@ __global__ __launch_bounds__(GR_BLOCK) void scatter_perm_kernel(uint32_t n, cons
 
 // ---------------------------------------------------------------------------------------- query
 constexpr unsigned long long KEY_NONE = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;   // (FLT_MAX, no index)
+// Geometry proves "every point outside the scanned cube is farther than the best" for TRUE distances; the computed f32 d2
+// follows the true one only above the underflow range (squares below 2^-126 lose their bits, below 2^-149 they are 0:
+// a cloud of 1e-25-sized coordinates has d2 == 0 for EVERY pair, and the lowest index must win among all of them).
+// So a bound is only used when it is at least TRUST (1e-15, squared 1e-30 >> 2^-126): smaller clouds are scanned whole.
+constexpr float TRUST = 1e-15f, TRUST2 = 1e-30f;
 
 // candidates [b, e) of one x-row, strided over the G lanes of the query's sub-group: 16 B per lane, G*16 B contiguous
 template <int G>
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
                                 (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
             const float reach = (1.0f - g.slack) * g.h;
-            done = covers || (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f);
+            done = covers || (best != KEY_NONE && reach > TRUST && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f);
             r = 2;
         }
         // ---- later stages.  rp = radius of the cube already scanned (0: none).  The next radius is the smallest one
@@ -275,10 +280,10 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
         int rp = (r == 2) ? 1 : 0;
         for (int step = 0; step < 28 && !done; step++) {
             const bool have = best != KEY_NONE;
-            const float bestf = __uint_as_float((uint32_t)(best >> 32));
+            const float bestf = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2);   // never reason below the trusted range
             if (have) {
                 // smallest r with ((r - slack) h)^2 * 0.99999 > best
-                const int need = (int)(sqrtf(bestf * 1.00002f) * g.inv_h + g.slack) + 1;
+                const int need = (int)fminf(sqrtf(bestf * 1.00002f) * g.inv_h + g.slack, 16777215.0f) + 1;
                 r = max(min(need, 1 << 24), rp + 1);
             }
             const int xlo = max(ux - r, 0), xhi = min(ux + r, g.n[0] - 1);
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                             if (rem2 < 0.0f) {
                                 open = false;                                  // the whole row is outside the ball
                             } else {
-                                const int wx = (int)(sqrtf(rem2) * g.inv_h + g.slack) + 2;
+                                const int wx = (int)fminf(sqrtf(rem2) * g.inv_h + g.slack, 16777215.0f) + 2;   // clamp BEFORE the conversion: far queries x tiny cells overflow int
                                 xa = max(xa, ux - wx);
                                 xb = min(xb, ux + wx);
                             }
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                                 (uz - r <= 0) && (uz + r >= g.n[2] - 1);
             // every target outside the cube is farther than (r - slack) * h in some axis
             const float reach = ((float)r - g.slack) * g.h;
-            done = covers || (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f);
+            done = covers || (best != KEY_NONE && reach > TRUST && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f);
             rp = r;
             r = min(r * 2, 1 << 24);
         }

@@ -260,7 +260,9 @@ extern "C" int pcr_iss_keypoints_f32(pcr_ctx* ctx, const pcr_cloud* cloud, const
     Grid* g = nullptr;
     {
         ProfScope ps(ctx, "iss_grid_build");
-        int rc = grid_build(ctx, cloud, &g, std::max(rmax * 1.01, 1e-30));
+        // >= 2e-15: below that, squared f32 distances underflow and a point outside the 27-cell block could still compute
+        // s == 0 <= s_max; with h >= 2e-15 every outside point has s >= ~4e-30 (normal range) > s_max
+        int rc = grid_build(ctx, cloud, &g, std::max(rmax * 1.01, 2e-15));
         if (rc) return rc;
     }
     if ((double)g->p.h < rmax * 1.005) { grid_free(g); return fail(ctx, PCR_ERR_STATE, "pcr_iss_keypoints_f32: grid cell smaller than the radius"); }

@@ -23,6 +23,41 @@ def ctx(pcr):
     c.close()
 
 
+def random_cloud32(rng, n, kind):
+    """continuous / lattice (ties, duplicates) / clustered / extreme magnitudes — SoA f32"""
+    if kind == 0:
+        a = rng.normal(0, 10, (3, n))
+    elif kind == 1:
+        a = rng.integers(0, 6, (3, n)).astype(np.float64) * 0.5
+    elif kind == 2:
+        c = rng.normal(0, 30, (3, max(n // 8, 1)))
+        a = c[:, rng.integers(0, c.shape[1], n)] + rng.normal(0, 0.01, (3, n))
+    else:
+        a = rng.normal(0, 1, (3, n)) * 10.0 ** rng.integers(-12, 12)
+    return np.ascontiguousarray(a.astype(np.float32))
+
+
+def test_nn1_randomised_sweep_every_kernel(ctx, orc):
+    """120 random problems x {FTRACK, TRACK scalar, TRACK LDS, exact grid}: indices and d2 bits equal to the oracle."""
+    rng = np.random.default_rng(77)
+    for trial in range(120):
+        kind = trial % 4
+        nt, ns = int(rng.integers(1, 5000)), int(rng.integers(1, 700))
+        tgt, src = random_cloud32(rng, nt, kind), random_cloud32(rng, ns, kind)
+        if trial % 3 == 0:
+            src[:, : min(ns, nt) // 2] = tgt[:, : min(ns, nt) // 2]
+        oi, od = orc.nn1_f32(tgt, src)
+        ct, cs = ctx.cloud(tgt), ctx.cloud(src)
+        for method, variant in ((1, 1), (1, 2), (1, 3), (2, 1)):
+            ctx.tune("nn_method", method)
+            ctx.tune("nn1_variant", variant)
+            idx, d2 = ctx.nn1(ct, cs)
+            assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (trial, kind, nt, ns, method, variant)
+        cs.free(); ct.free()
+    ctx.tune("nn_method", 0)
+    ctx.tune("nn1_variant", 0)
+
+
 # ------------------------------------------------------------------ 1-NN (A1/A3/A6) vs reference goldens
 @pytest.mark.parametrize("method", [1, 2])            # 1 = brute force, 2 = exact grid
 @pytest.mark.parametrize("case", ["synth1000", "synth4096", "kitti4096", "lattice1000"])
