@@ -128,6 +128,9 @@ def main():
         src, tgt = synth.kitti_like_pair(n, n_src=n, shard=rank)
         scaling, total_src = "weak", world * n
     ctx = pcr.Context(device_index)
+    for kv in filter(None, os.environ.get("PCR_TUNE", "").split(",")):     # experiments: PCR_TUNE="key=value,key=value"
+        k, v = kv.split("=")
+        ctx.tune(k.strip(), int(v))
     if args.qpl:
         ctx.tune("nn1_qpl", args.qpl)
     if args.tiles_per_slice:
@@ -273,11 +276,22 @@ def main():
             ctx.tune("grid_stats", 1); ctx.nn1_async(ct, ca); ctx.sync(); gs = ctx.grid_stats(); ctx.tune("grid_stats", 0)
             ca.free()
             steady_s = gms / 1e3 / max(gl, 1)
+            gpmc = None
+            try:
+                gpmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_grid.json")))
+                if gpmc.get("n") != n_t or n_q != n_t:
+                    gpmc = None
+            except Exception:   # noqa: BLE001
+                gpmc = None
             alg_bytes = n_q * (12.0 + 4.0 + 8.0) + 8.0 * gs["fine_rows"] + 16.0 * gs["candidates"]
             L2_PEAK_GBS = 34500.0    # aggregate L2 bandwidth measured on MI355X (MI355X_MICROARCH.md, L2 section)
             roofline = {
                 "bound": "l2-gather", "achieved": alg_bytes / steady_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
-                "frac": alg_bytes / steady_s / 1e9 / L2_PEAK_GBS, "traffic": None, "traffic_note": "not collected for this kernel yet",
+                "frac": alg_bytes / steady_s / 1e9 / L2_PEAK_GBS,
+                "traffic": (gpmc["fetch_bytes_per_launch_corrected_x2"] + gpmc["write_bytes_per_launch"]) if gpmc else None,
+                "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
+                                 f"kernel at {gpmc['n']} x {gpmc['n']}, {gpmc['source']}: the candidate records come out of L2, not HBM") if gpmc
+                                else "collected at 10M x 10M only (profiles/latest_pmc_grid.json)",
                 "vs_hbm_stream_peak": alg_bytes / steady_s / 1e9 / HBM_PEAK_GBS,
                 "kernel": "pcr::nn1_grid_kernel<16, false> (exact uniform-grid 1-NN) at the converged pose",
                 "launches": int(gl), "avg_launch_ms": steady_s * 1e3, "kernel_M_corr_per_s": n_q / steady_s / 1e6,

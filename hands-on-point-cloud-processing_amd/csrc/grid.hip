@@ -20,6 +20,8 @@
 // Traffic (algorithmic): 12 B query + 8 B key + 16 B per visited candidate + 8 B per visited cell row.
 #include "grid_common.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <cmath>
 
 #pragma clang fp contract(off)
@@ -76,13 +78,36 @@ __global__ __launch_bounds__(GR_BLOCK) void bbox_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------- counting sort
 __global__ __launch_bounds__(GR_BLOCK) void cell_count_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ z, uint32_t n, GridParams g,
-                                                              uint32_t* __restrict__ cell_of, uint32_t* __restrict__ count)
+                                                              uint32_t* __restrict__ cell_of, uint32_t* __restrict__ count,
+                                                              uint32_t nonfinite_cell)
 {
     const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const uint32_t c = clamped_cell_id(g, x[i], y[i], z[i]);
+    const uint32_t c = clamped_cell_id(g, x[i], y[i], z[i], nonfinite_cell);
     cell_of[i] = c;
     atomicAdd(&count[c], 1u);
+}
+
+// key = (cell, order-preserving bits of x): one radix sort gives the records cell by cell and x-ascending inside a cell —
+// a deterministic layout (no atomics decide a position); x-sorted rows are what the CLIP variant of the search kernel needs (rows cut to the best-distance window).
+__global__ __launch_bounds__(GR_BLOCK) void record_keys_kernel(const float* __restrict__ x, uint32_t n, const uint32_t* __restrict__ cell_of,
+                                                               unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t u = __float_as_uint(x[i]);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    keys[i] = ((unsigned long long)cell_of[i] << 32) | u;
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(GR_BLOCK) void gather_records_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                                  uint32_t n, const uint32_t* __restrict__ order, float4* __restrict__ records)
+{
+    const uint32_t p = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t i = order[p];
+    records[p] = make_float4(x[i], y[i], z[i], __uint_as_float(i));
 }
 
 
@@ -154,20 +179,6 @@ __global__ __launch_bounds__(GR_BLOCK) void scan_add_kernel(uint32_t* __restrict
         if (base + k < n) out[base + k] += off;
 }
 
-// records[cell_start[c] + cursor[c]++] = {x, y, z, index}
-__global__ __launch_bounds__(GR_BLOCK) void scatter_records_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                                   const float* __restrict__ z, uint32_t n,
-                                                                   const uint32_t* __restrict__ cell_of,
-                                                                   const uint32_t* __restrict__ cell_start,
-                                                                   uint32_t* __restrict__ cursor, float4* __restrict__ records)
-{
-    const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t c = cell_of[i];
-    const uint32_t pos = cell_start[c] + atomicAdd(&cursor[c], 1u);
-    records[pos] = make_float4(x[i], y[i], z[i], __uint_as_float(i));
-}
-
 // perm[cell_start[c] + cursor[c]++] = i   (queries grouped by cell)
 __global__ __launch_bounds__(GR_BLOCK) void scatter_perm_kernel(uint32_t n, const uint32_t* __restrict__ cell_of,
                                                                 const uint32_t* __restrict__ cell_start,
@@ -202,6 +213,39 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ records, u
     }
 }
 
+// Every x-row of the records is sorted by x (grid_build), so a long range can be cut down to the records whose x lies
+// within the current best distance of the query before any distance is evaluated: the candidates of a dense row (a LiDAR
+// ring packs hundreds of points into one 3-cell row at 10 M points) shrink to the few that can still win or tie.
+// [lo, hi] must contain every x with |x - qx| <= sqrt(best d2) in REAL arithmetic (the caller widens for rounding).
+// Both searches are bounded (32 halvings); predicates are false for NaN, which cannot occur inside a row (non-finite
+// points live in the extra cell).
+__device__ __forceinline__ void clip_range_x(const float4* __restrict__ records, uint32_t& b, uint32_t& e, float lo, float hi)
+{
+    if (e - b <= 48u) return;                                   // short rows: the searches would cost more than they save
+    uint32_t l = b, h = e;                                      // first p with x >= lo
+    for (int it = 0; it < 32 && l < h; it++) {
+        const uint32_t mid = l + ((h - l) >> 1);
+        if (records[mid].x < lo) l = mid + 1; else h = mid;
+    }
+    const uint32_t nb = l;
+    h = e;                                                      // first p >= nb with x > hi
+    for (int it = 0; it < 32 && l < h; it++) {
+        const uint32_t mid = l + ((h - l) >> 1);
+        if (records[mid].x <= hi) l = mid + 1; else h = mid;
+    }
+    b = nb;
+    e = l;
+}
+
+// window for clip_range_x from a squared bound; widened by the rounding of qx -+ d (relative to |qx|, not to d)
+__device__ __forceinline__ void x_window(float qx, float bound2, float& lo, float& hi)
+{
+    const float d = sqrtf(bound2) * 1.00001f;
+    const float pad = (fabsf(qx) + d) * 2.4e-7f;
+    lo = qx - d - pad;
+    hi = qx + d + pad;
+}
+
 template <int G>
 __device__ __forceinline__ unsigned long long group_min(unsigned long long v)
 {
@@ -215,7 +259,8 @@ __device__ __forceinline__ unsigned long long group_min(unsigned long long v)
 
 // G lanes cooperate on one query (G divides 64).  Stage 1 scans the 3 x 3 x-rows of the radius-1 cube with all
 // row bounds fetched up front (18 independent loads in flight); later stages double the radius.
-template <int G, bool STATS>
+// CLIP: the variant for large / dense targets — long x-sorted rows are cut to the best-distance window first.
+template <int G, bool STATS, bool CLIP>
 __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     const float4* __restrict__ records, const uint32_t* __restrict__ cell_start,
     GridParams g, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
@@ -260,6 +305,36 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                 rb[k] = ok ? cell_start[row + xlo] : 0u;
                 re[k] = ok ? cell_start[row + xhi + 1] : 0u;
             }
+            if (CLIP) {
+                uint32_t total = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) total += re[k] - rb[k];
+                // dense neighbourhood without a warm-start candidate: the query's own row first, its best distance then
+                // cuts the other rows
+                if (best == KEY_NONE && total > 512u) {
+                    scan_range<G>(records, rb[4], re[4], l, qx, qy, qz, best);
+                    if (STATS && l == 0) st_cand += re[4] - rb[4];
+                    rb[4] = re[4] = 0;
+                    best = group_min<G>(best);
+                }
+                if (best != KEY_NONE && total > 48u) {
+                    float lo, hi;
+                    x_window(qx, fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f, lo, hi);
+                    if (G >= 9) {
+                        // one row per lane: the nine binary searches run side by side (one chain of ~12 dependent loads
+                        // instead of nine), the results travel back through shuffles
+                        uint32_t cb = 0, ce = 0;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) if (l == k) { cb = rb[k]; ce = re[k]; }
+                        if (l < 9) clip_range_x(records, cb, ce, lo, hi);
+#pragma unroll
+                        for (int k = 0; k < 9; k++) { rb[k] = __shfl(cb, k, G); re[k] = __shfl(ce, k, G); }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) clip_range_x(records, rb[k], re[k], lo, hi);
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 9; k++) scan_range<G>(records, rb[k], re[k], l, qx, qy, qz, best);
             if (STATS && l == 0) { for (int k = 0; k < 9; k++) st_cand += re[k] - rb[k]; st_rows += 9; }
@@ -290,6 +365,8 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             const int ylo = max(uy - r, 0), yhi = min(uy + r, g.n[1] - 1);
             const int zlo = max(uz - r, 0), zhi = min(uz + r, g.n[2] - 1);
             const float clip2 = bestf * 1.0001f;
+            float wlo = 0.0f, whi = 0.0f;
+            if (CLIP && have) x_window(qx, clip2, wlo, whi);
             if (xlo <= xhi && ylo <= yhi && zlo <= zhi) {
                 // Far searches open many x-rows, most of them short.  Rows are taken G at a time: every lane resolves
                 // ONE row (clipping + its cell_start bounds: G independent loads in flight per query), then the whole
@@ -326,6 +403,10 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                                 if (ra <= rb2) { b2 = cell_start[row + ra]; e2 = cell_start[row + rb2 + 1]; }
                             } else {
                                 b1 = cell_start[row + xa]; e1 = cell_start[row + xb + 1];
+                            }
+                            if (CLIP && have) {                            // x-sorted rows: keep only |x - qx| <= best
+                                clip_range_x(records, b1, e1, wlo, whi);
+                                clip_range_x(records, b2, e2, wlo, whi);
                             }
                             if (STATS) { st_rows++; st_cand += (e1 - b1) + (e2 - b2); }
                         }
@@ -461,7 +542,7 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge)
         hipError_t e0 = hipMemsetAsync(count0, 0, (cells0 + 2) * 4, ctx->stream);
         if (e0 != hipSuccess) { delete g; return fail(ctx, PCR_ERR_HIP, "memset(grid)", e0); }
         hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream,
-                           c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of0, count0);
+                           c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of0, count0, 0u);
         hipLaunchKernelGGL(count_nonzero_kernel, dim3(256), dim3(GR_BLOCK), 0, ctx->stream, count0, (uint32_t)cells0, nz);
         uint32_t occupied = 0;
         e0 = hipMemcpyAsync(&occupied, nz, 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -475,31 +556,42 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge)
         }
     }
     const size_t cells = g->n_cells;
-    // 3. counting sort
-    const size_t nb = (cells + 1 + SC_TILE - 1) / SC_TILE;
-    const size_t off_count = ((n * 4 + 255) & ~(size_t)255);
-    const size_t off_tot = off_count + (((cells + 1) * 4 + 255) & ~(size_t)255);
-    rc = ensure_scratch(ctx, off_tot + (nb + 2) * 4 + 256);
+    // 3. sort by (cell, x).  Histogram + scan give cell_start; one radix sort of (cell << 32 | x bits, index) gives the
+    //    order (deterministic: no atomics decide a position).  Non-finite points go to the extra cell `cells`.
+    const size_t ncell = cells + 2;                                  // real cells, the non-finite cell, the end sentinel
+    const size_t nb = (ncell + SC_TILE - 1) / SC_TILE;
+    int key_bits = 1;
+    while (((size_t)1 << key_bits) < cells + 1) key_bits++;
+    size_t temp_bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr,
+                                       (uint32_t*)nullptr, (int)n, 0, 32 + key_bits, ctx->stream);
+    const size_t a4 = (n * 4 + 255) & ~(size_t)255, a8 = (n * 8 + 255) & ~(size_t)255;
+    const size_t off_count = a4, off_tot = off_count + ((ncell * 4 + 255) & ~(size_t)255), off_kin = off_tot + (((nb + 2) * 4 + 255) & ~(size_t)255),
+                 off_kout = off_kin + a8, off_vin = off_kout + a8, off_vout = off_vin + a4, off_temp = off_vout + a4;
+    rc = ensure_scratch(ctx, off_temp + temp_bytes + 256);
     if (rc) { delete g; return rc; }
-    uint32_t* cell_of = (uint32_t*)ctx->scratch;
-    uint32_t* count = (uint32_t*)((char*)ctx->scratch + off_count);
-    uint32_t* totals = (uint32_t*)((char*)ctx->scratch + off_tot);
-    hipError_t e = hipMalloc((void**)&g->cell_start, (cells + 1) * sizeof(uint32_t));
+    char* sc = (char*)ctx->scratch;
+    uint32_t* cell_of = (uint32_t*)sc;
+    uint32_t* count = (uint32_t*)(sc + off_count);
+    uint32_t* totals = (uint32_t*)(sc + off_tot);
+    unsigned long long* k_in = (unsigned long long*)(sc + off_kin);
+    unsigned long long* k_out = (unsigned long long*)(sc + off_kout);
+    uint32_t* v_in = (uint32_t*)(sc + off_vin);
+    uint32_t* v_out = (uint32_t*)(sc + off_vout);
+    hipError_t e = hipMalloc((void**)&g->cell_start, ncell * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&g->records, std::max<size_t>(n, 1) * sizeof(float4));
     if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "hipMalloc(grid)", e); }
-    e = hipMemsetAsync(count, 0, (cells + 1) * 4, ctx->stream);
+    e = hipMemsetAsync(count, 0, ncell * 4, ctx->stream);
     if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "memset(grid)", e); }
-    if (n) {
-        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream,
-                           c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of, count);
-    }
-    rc = exclusive_scan_u32(ctx, count, g->cell_start, cells + 1, totals, totals + nb);
+    const dim3 gridn((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK));
+    if (n) hipLaunchKernelGGL(cell_count_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of, count, (uint32_t)cells);
+    rc = exclusive_scan_u32(ctx, count, g->cell_start, ncell, totals, totals + nb);
     if (rc) { grid_free(g); return rc; }
-    e = hipMemsetAsync(count, 0, (cells + 1) * 4, ctx->stream);   // reuse as the scatter cursor
-    if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "memset(grid)", e); }
     if (n) {
-        hipLaunchKernelGGL(scatter_records_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream,
-                           c->x(), c->y(), c->z(), (uint32_t)n, cell_of, g->cell_start, count, g->records);
+        hipLaunchKernelGGL(record_keys_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), (uint32_t)n, cell_of, k_in, v_in);
+        e = hipcub::DeviceRadixSort::SortPairs(sc + off_temp, temp_bytes, k_in, k_out, v_in, v_out, (int)n, 0, 32 + key_bits, ctx->stream);
+        if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "radix sort(grid)", e); }
+        hipLaunchKernelGGL(gather_records_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)n, v_out, g->records);
     }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the scratch is reused by the caller right away
@@ -544,7 +636,7 @@ static int sort_queries(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
     uint32_t* totals = (uint32_t*)((char*)ctx->scratch + off_tot);
     PCR_HIP(ctx, hipMemsetAsync(count, 0, (cells + 1) * 4, ctx->stream));
     const dim3 gridn((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK));
-    hipLaunchKernelGGL(cell_count_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), (uint32_t)n, cp, cell_of, count);
+    hipLaunchKernelGGL(cell_count_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), (uint32_t)n, cp, cell_of, count, 0u);
     rc = exclusive_scan_u32(ctx, count, start, cells + 1, totals, totals + nb);
     if (rc) return rc;
     PCR_HIP(ctx, hipMemsetAsync(count, 0, (cells + 1) * 4, ctx->stream));
@@ -593,16 +685,24 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     // warm start: only inside an ICP loop (reuse_perm), from its second search on, when keys[] belongs to this source
     const int warm = (reuse_perm && have_perm && ctx->keys_warm && tune_get(ctx, "grid_warm_start", 1) > 0) ? 1 : 0;
     ctx->keys_warm = reuse_perm;
+    // x-window clipping of long rows: 14.1 -> 8.1 ms per search at 10 M x 10 M and 20.9 -> 15.9 ms per ICP iteration there
+    // (1 277 -> 462 candidates per query); on sparse clouds the extra phase costs ~25 % (38 -> 48 us at 120 k), so the
+    // plain kernel serves small targets.  Same box, same call: profiles/r01_c5_10M_single_gpu.txt.
+    // grid_clip_x: 1 = always, 2 = never (0 / unset = by target size)
+    const int64_t clip_tune = tune_get(ctx, "grid_clip_x", 0);
+    const bool clip = clip_tune == 1 || (clip_tune != 2 && tgt->n >= 500000);
     const int G = (int)tune_get(ctx, "grid_lanes", 16);   // measured: profiles/r01_tune_grid.txt
     {
         ProfScope p(ctx, "nn1_grid", 1);
+#define PCR_GRID2(GG, ST, CL)                                                                                          \
+    hipLaunchKernelGGL((nn1_grid_kernel<GG, ST, CL>), dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records, \
+                       g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(), tgt->y(),   \
+                       tgt->z(), (uint32_t)tgt->n, warm)
 #define PCR_GRID(GG)                                                                                                   \
-    if (stats_dev)                                                                                                     \
-        hipLaunchKernelGGL((nn1_grid_kernel<GG, true>), dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0,  \
-                           ctx->stream, g->records, g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(), tgt->y(), tgt->z(), (uint32_t)tgt->n, warm); \
-    else                                                                                                               \
-        hipLaunchKernelGGL((nn1_grid_kernel<GG, false>), dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0,  \
-                       ctx->stream, g->records, g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(), tgt->y(), tgt->z(), (uint32_t)tgt->n, warm)
+    do {                                                                                                               \
+        if (stats_dev) { if (clip) PCR_GRID2(GG, true, true); else PCR_GRID2(GG, true, false); }                       \
+        else { if (clip) PCR_GRID2(GG, false, true); else PCR_GRID2(GG, false, false); }                               \
+    } while (0)
         switch (G) {
         case 1: PCR_GRID(1); break;
         case 2: PCR_GRID(2); break;
@@ -612,6 +712,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         case 64: PCR_GRID(64); break;
         default: PCR_GRID(16); break;
         }
+#undef PCR_GRID2
 #undef PCR_GRID
     }
     PCR_HIP(ctx, hipGetLastError());

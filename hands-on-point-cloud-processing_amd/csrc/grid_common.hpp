@@ -19,8 +19,8 @@ struct Grid {
     GridParams p;
     size_t n_points = 0;
     size_t n_cells = 0;
-    float4* records = nullptr;        // n_points, sorted by cell
-    uint32_t* cell_start = nullptr;   // n_cells + 1
+    float4* records = nullptr;        // n_points, sorted by (cell, x): every x-row of cells is one x-sorted range
+    uint32_t* cell_start = nullptr;   // n_cells + 2 (cell n_cells holds the non-finite points, never visited)
 };
 
 __device__ __forceinline__ int cell_coord(float v, float lo, float inv_h)
@@ -35,9 +35,11 @@ __device__ __forceinline__ bool finite3(float x, float y, float z)
     return (fabsf(x) <= FLT_MAX) && (fabsf(y) <= FLT_MAX) && (fabsf(z) <= FLT_MAX);   // false for NaN / inf
 }
 
-__device__ __forceinline__ uint32_t clamped_cell_id(const GridParams& g, float x, float y, float z)
+// nonfinite_cell: where NaN / inf points go.  They never win a comparison (d2 = inf / NaN); the index build parks them in
+// an extra cell behind the last real one so that every x-row of the records stays sorted by x.
+__device__ __forceinline__ uint32_t clamped_cell_id(const GridParams& g, float x, float y, float z, uint32_t nonfinite_cell = 0)
 {
-    if (!finite3(x, y, z)) return 0;   // never wins a comparison (d2 = inf / NaN), any cell will do
+    if (!finite3(x, y, z)) return nonfinite_cell;
     const int cx = min(max(cell_coord(x, g.lo[0], g.inv_h), 0), g.n[0] - 1);
     const int cy = min(max(cell_coord(y, g.lo[1], g.inv_h), 0), g.n[1] - 1);
     const int cz = min(max(cell_coord(z, g.lo[2], g.inv_h), 0), g.n[2] - 1);

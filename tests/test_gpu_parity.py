@@ -48,14 +48,16 @@ def test_nn1_randomised_sweep_every_kernel(ctx, orc):
             src[:, : min(ns, nt) // 2] = tgt[:, : min(ns, nt) // 2]
         oi, od = orc.nn1_f32(tgt, src)
         ct, cs = ctx.cloud(tgt), ctx.cloud(src)
-        for method, variant in ((1, 1), (1, 2), (1, 3), (2, 1)):
+        for method, variant, clip in ((1, 1, 0), (1, 2, 0), (1, 3, 0), (2, 1, 2), (2, 1, 1)):
             ctx.tune("nn_method", method)
             ctx.tune("nn1_variant", variant)
+            ctx.tune("grid_clip_x", clip)              # 1: the x-window kernel of large targets forced; 2: the plain kernel
             idx, d2 = ctx.nn1(ct, cs)
-            assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (trial, kind, nt, ns, method, variant)
+            assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (trial, kind, nt, ns, method, variant, clip)
         cs.free(); ct.free()
     ctx.tune("nn_method", 0)
     ctx.tune("nn1_variant", 0)
+    ctx.tune("grid_clip_x", 0)
 
 
 # ------------------------------------------------------------------ 1-NN (A1/A3/A6) vs reference goldens
@@ -253,15 +255,15 @@ def test_grid_equals_brute_force_at_120k(ctx, synth):
     src, tgt = synth.kitti_like_pair(120000)
     cs, ct = ctx.cloud(src), ctx.cloud(tgt)
     ctx.tune("nn_method", 1); bi, bd = ctx.nn1(ct, cs)
-    for m in (2,):
-        ctx.tune("nn_method", m); gi, gd = ctx.nn1(ct, cs)
+    for clip in (2, 1):                                  # both grid kernels: plain, and the x-window variant of large targets
+        ctx.tune("nn_method", 2); ctx.tune("grid_clip_x", clip); gi, gd = ctx.nn1(ct, cs)
         assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd))
     ctx.transform(cs, synth.gt_pose().astype(np.float32))
     ctx.tune("nn_method", 1); bi, bd = ctx.nn1(ct, cs)
-    for m in (2,):
-        ctx.tune("nn_method", m); gi, gd = ctx.nn1(ct, cs)
+    for clip in (2, 1):
+        ctx.tune("nn_method", 2); ctx.tune("grid_clip_x", clip); gi, gd = ctx.nn1(ct, cs)
         assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd))
-    ctx.tune("nn_method", 0)
+    ctx.tune("nn_method", 0); ctx.tune("grid_clip_x", 0)
     assert np.median(bd) < 1e-3
     cs.free(); ct.free()
 

@@ -25,6 +25,8 @@ ctx.tune("nn1_qpl", qpl)
 ctx.tune("nn1_tiles_per_slice", tps)
 method = int(os.environ.get("NN_METHOD", "1"))     # 1 = brute force, 2 = exact grid
 ctx.tune("nn_method", method)
+if os.environ.get("GRID_CLIP_X"):     # 1 = x-window kernel, 2 = plain kernel (0 / unset: by target size)
+    ctx.tune("grid_clip_x", int(os.environ["GRID_CLIP_X"]))
 if os.environ.get("GRID_CELL_UM"):
     ctx.tune("grid_cell_um", int(os.environ["GRID_CELL_UM"]))
 aligned = os.environ.get("ALIGNED", "0") == "1"

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condense the --pmc passes of tools/gpu_pmc_grid.sh into profiles/<tag>_grid_pmc.md + profiles/latest_pmc_grid.json
+(read by bench.py --nn grid / --workload c5 for roofline.traffic).  usage: python tools/summarize_grid_pmc.py r01 10000000"""
+import collections, csv, glob, json, os, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+go, out = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+vals, durs = {}, {}
+for d in ("pmc_grid_fetch", "pmc_grid_write", "pmc_grid_sq"):
+    files = glob.glob(os.path.join(go, d, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    f = max(files, key=os.path.getmtime)
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "nn1_grid_kernel" in r["Kernel_Name"]:
+            agg[(r["Counter_Name"], r["Dispatch_Id"])].append(float(r["Counter_Value"]))
+    per = collections.defaultdict(list)
+    for (c, _), v in agg.items():
+        per[c].append(sum(v))
+    for c, v in per.items():
+        vals[c] = sum(v[1:]) / max(len(v) - 1, 1) if len(v) > 1 else v[0]      # skip the first (cold) launch
+    kt = max(glob.glob(os.path.join(go, d, "*", "*_kernel_trace.csv")), key=os.path.getmtime)
+    dd = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt)) if "nn1_grid_kernel" in r["Kernel_Name"]]
+    durs[d] = sum(dd[1:]) / max(len(dd) - 1, 1) if len(dd) > 1 else dd[0]
+lines = [f"# {tag}: PMC passes of pcr::nn1_grid_kernel at the converged pose, {n} x {n} (tools/gpu_pmc_grid.sh)\n",
+         "| counter | mean / launch (warm launches) |", "|---|---|"]
+for c, v in vals.items():
+    lines.append(f"| {c} | {v:.5g} |")
+lines.append("")
+for d, ms in durs.items():
+    lines.append(f"launch duration in pass {d}: {ms:.3f} ms")
+if "FETCH_SIZE" in vals:
+    fetch = vals["FETCH_SIZE"] * 2 * 1024
+    write = vals.get("WRITE_SIZE", 0.0) * 1024
+    ms = durs.get("pmc_grid_fetch")
+    lines.append(f"\nHBM-side traffic per launch: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB x 2 (gfx950 correction, MI355X_MICROARCH.md §HBM) = {fetch/1e6:.1f} MB"
+                 f" + WRITE_SIZE {write/1e6:.1f} MB -> {(fetch+write)/ (ms*1e-3)/1e9:.0f} GB/s over the {ms:.2f} ms launch; compulsory: "
+                 f"{n*(12+16+4+8)/1e6:.0f} MB (queries 12 B, records 16 B once, order 4 B, key 8 B)")
+    json.dump({"kernel": "pcr::nn1_grid_kernel", "n": n, "source": f"profiles/{tag}_grid_pmc.md", "fetch_bytes_per_launch_corrected_x2": fetch,
+               "write_bytes_per_launch": write, "launch_ms_in_pass": ms}, open(os.path.join(out, "latest_pmc_grid.json"), "w"), indent=1)
+open(os.path.join(out, f"{tag}_grid_pmc.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
