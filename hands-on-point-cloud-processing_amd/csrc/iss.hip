@@ -53,6 +53,36 @@ __device__ __forceinline__ void row_range(const GridParams& g, const uint32_t* _
     e = cell_start[row + x1 + 1];
 }
 
+// The records of a row are sorted by x (grid_build): cut [b, e) to the records with lo <= x <= hi, the only ones that can
+// lie within the radius.  Two bounded binary searches, worth it on long rows only; uniform over the lanes of a group.
+__device__ __forceinline__ void clip_row_x(const float4* __restrict__ records, uint32_t& b, uint32_t& e, float lo, float hi)
+{
+    if (e - b <= 384u) return;
+    uint32_t l = b, h = e;
+    for (int it = 0; it < 32 && l < h; it++) {
+        const uint32_t mid = l + ((h - l) >> 1);
+        if (records[mid].x < lo) l = mid + 1; else h = mid;
+    }
+    const uint32_t nb = l;
+    h = e;
+    for (int it = 0; it < 32 && l < h; it++) {
+        const uint32_t mid = l + ((h - l) >> 1);
+        if (records[mid].x <= hi) l = mid + 1; else h = mid;
+    }
+    b = nb;
+    e = l;
+}
+
+// [lo, hi] around qx that contains every x whose hw7 sum can still be <= s_max: |dx|^2 <= s_max (1 + 3 * 2^-24); the floor
+// 1e-18 covers differences whose squares vanish in f32 (|e| < 3.7e-23 gives s == 0), the pad the rounding of qx -+ d
+__device__ __forceinline__ void radius_window(float qx, float s_max, float& lo, float& hi)
+{
+    const float d = sqrtf(fmaxf(s_max, 0.0f)) * 1.00001f + 1e-18f;
+    const float pad = (fabsf(qx) + d) * 2.4e-7f;
+    lo = qx - d - pad;
+    hi = qx + d + pad;
+}
+
 template <int G>
 __device__ __forceinline__ unsigned group_sum_u32(unsigned v)
 {
@@ -90,9 +120,12 @@ __global__ __launch_bounds__(ISS_BLOCK) void iss_count_kernel(const float4* __re
     if (finite3(q.x, q.y, q.z)) {
         int cx, cy, cz;
         query_cell(g, q, cx, cy, cz);
+        float wlo, whi;
+        radius_window(q.x, s_max, wlo, whi);
         for (int k = 0; k < 9; k++) {
             uint32_t b, e;
             row_range(g, cell_start, cx, cy, cz, k, b, e);
+            clip_row_x(records, b, e, wlo, whi);
             for (uint32_t j = b + sub; j < e; j += G) {
                 const float4 t = records[j];
                 c += hw7_s(t.x, t.y, t.z, q.x, q.y, q.z) <= s_max;
@@ -148,9 +181,12 @@ __global__ __launch_bounds__(ISS_BLOCK) void iss_cov_kernel(const float4* __rest
     if (cnt_sorted[p] >= 3) {                               // uniform over the group
         int cx, cy, cz;
         query_cell(g, q, cx, cy, cz);
+        float wlo, whi;
+        radius_window(q.x, prm.s_local, wlo, whi);
         for (int k = 0; k < 9; k++) {
             uint32_t b, e;
             row_range(g, cell_start, cx, cy, cz, k, b, e);
+            clip_row_x(records, b, e, wlo, whi);
             for (uint32_t j = b + sub; j < e; j += G) {
                 const float4 t = records[j];
                 if (!(hw7_s(t.x, t.y, t.z, q.x, q.y, q.z) <= prm.s_local)) continue;
@@ -209,9 +245,12 @@ __global__ __launch_bounds__(ISS_BLOCK) void iss_nms_kernel(const float4* __rest
     if (mine != -1.0f) {                                    // :88, uniform over the group
         int cx, cy, cz;
         query_cell(g, q, cx, cy, cz);
+        float wlo, whi;
+        radius_window(q.x, prm.s_nms, wlo, whi);
         for (int k = 0; k < 9; k++) {
             uint32_t b, e;
             row_range(g, cell_start, cx, cy, cz, k, b, e);
+            clip_row_x(records, b, e, wlo, whi);
             for (uint32_t j = b + sub; j < e; j += G) {
                 const float4 t = records[j];
                 if (!(hw7_s(t.x, t.y, t.z, q.x, q.y, q.z) <= prm.s_nms)) continue;

@@ -1,4 +1,4 @@
 set -o pipefail
 mkdir -p gpurun_out
-( timeout -k 10 300 python tools/run_c5.py 10000000 20 > gpurun_out/run_c5.log 2>&1; echo "rc=$?"; cat gpurun_out/run_c5.log ) && \
-( timeout -k 10 300 python bench.py --workload c5 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_c5.json 2> gpurun_out/bench.err; echo "bench c5 rc=$?"; cat gpurun_out/bench_c5.json )
+L=$GRAFT_REPO_ROOT/hands-on-point-cloud-processing_amd
+for rep in 1 2; do for lib in a hip; do ( echo "== $lib"; PCR_LIB_PATH=$L/libpcr_$lib.so timeout -k 10 300 python tools/run_iss.py 32 2>&1 | grep -E "lanes 32" | sed 's/, [0-9]* keypoints.*//' ) || exit 1; done; done
