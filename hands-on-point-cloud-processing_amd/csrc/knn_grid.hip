@@ -55,6 +55,26 @@ __device__ __forceinline__ void scan_cells(const float4* __restrict__ records, u
                                            TopK<K>& t, double& kth_s)
 {
 #pragma clang fp contract(off)
+    // rows of the index are sorted by x: once a bound is known, a long row shrinks to |x - qx| <= sqrt(bound) by two bounded
+    // binary searches (a candidate outside cannot pass `s < cap_s && s <= kth_s`: s >= dx*dx up to rounding, margin 1e-5)
+    const double lim = fmin(kth_s, cap_s);
+    if (e - b > 32u && lim < 1e300) {
+        const double d = sqrt(lim) * 1.00001 + 1e-30;
+        const float lo = (float)((qx - d) - (fabs(qx) + d) * 2.4e-7), hi = (float)((qx + d) + (fabs(qx) + d) * 2.4e-7);
+        uint32_t l = b, h = e;
+        for (int it = 0; it < 32 && l < h; it++) {
+            const uint32_t mid = l + ((h - l) >> 1);
+            if (records[mid].x < lo) l = mid + 1; else h = mid;
+        }
+        const uint32_t nb = l;
+        h = e;
+        for (int it = 0; it < 32 && l < h; it++) {
+            const uint32_t mid = l + ((h - l) >> 1);
+            if (records[mid].x <= hi) l = mid + 1; else h = mid;
+        }
+        b = nb;
+        e = l;
+    }
     for (uint32_t p = b; p < e; p++) {
         const float4 rec = records[p];
         const double dx = (double)rec.x - qx, dy = (double)rec.y - qy, dz = (double)rec.z - qz;   // t - q, kdtree.hpp:343
