@@ -1,4 +1,4 @@
 set -o pipefail
 mkdir -p gpurun_out
-L=$GRAFT_REPO_ROOT/hands-on-point-cloud-processing_amd
-for n in 120000 2000000; do for lib in a hip a hip; do ( echo "== $lib n=$n"; PCR_LIB_PATH=$L/libpcr_$lib.so timeout -k 10 300 python tools/run_knn.py $n 2>&1 | grep -E "^grid k-NN" | sed 's/ (cell scale auto), [0-9]* x [0-9]*: kernel/:/; s/ -> .*//' | tr '\n' ' '; echo ) || exit 1; done; done
+( timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -6 gpurun_out/pytest_gpu.log; [ $rc -eq 0 ] ) && \
+( timeout -k 10 300 python tools/run_iss.py 32 > gpurun_out/run_iss.log 2>&1; echo "run_iss rc=$?"; cat gpurun_out/run_iss.log )
