@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
+    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
@@ -114,6 +114,7 @@ def lib():
     L.pcr_iss_keypoints_f32.argtypes = [vp, vp, C.POINTER(IssParams), vp, vp, vp, C.POINTER(C.c_uint64)]
     L.pcr_cloud_knn_f64.argtypes = [vp, vp, vp, C.c_int, C.c_double, C.c_int, vp, vp, vp]
     L.pcr_normals_knn_f64.argtypes = [vp, vp, C.c_int, C.c_double, vp]
+    L.pcr_cloud_pca_f64.argtypes = [vp, vp, vp, vp, vp]
     L.pcr_fast_eigen3x3.argtypes = [vp, vp]
     L.pcr_ground_seeds_f64.argtypes = [vp, vp, sz, C.c_double, vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.pcr_ground_detection_f64.argtypes = [vp, vp, C.c_int, sz, C.c_double, vp, vp, C.POINTER(C.c_uint64)]
@@ -347,6 +348,12 @@ class Context:
         out = np.zeros((max(n, 1), 3), np.float64)
         self._ck(lib().pcr_normals_knn_f64(self.h, cloud.h, int(k), float(radius), out.ctypes.data))
         return out[:n]
+
+    def pca(self, cloud: Cloud):
+        """pca_normal.py PCA(data) -> (eigenvalues descending f64[3], eigenvectors in columns f64[3,3], centre f64[3])."""
+        w = np.zeros(3, np.float64); v = np.zeros(9, np.float64); c = np.zeros(3, np.float64)
+        self._ck(lib().pcr_cloud_pca_f64(self.h, cloud.h, w.ctypes.data, v.ctypes.data, c.ctypes.data))
+        return w, v.reshape(3, 3), c
 
     # ---- N2
     def ground_seeds(self, cloud: Cloud, lpr_size: int, threshold_seeds: float):

@@ -28,7 +28,7 @@ constexpr int GD_MAX_BLOCKS = 1024;
 constexpr double GD_Z_HIGH = -1.73 + 0.5;   // ground_detection_SVD.py:47
 
 struct Pred {
-    int mode;          // 0: seed test, 1: plane test
+    int mode;          // 0: seed test, 1: plane test, 2: every finite point
     double ub;         // mode 0: LPR_z + threshold_seeds
     double p[4];       // mode 1: plane
     double thr;
@@ -38,6 +38,7 @@ __device__ __forceinline__ bool gd_test(const Pred& pr, float xf, float yf, floa
 {
 #pragma clang fp contract(off)
     const double x = xf, y = yf, z = zf;
+    if (pr.mode == 2) return fabs(x) <= 1.7976931348623157e308 && fabs(y) <= 1.7976931348623157e308 && fabs(z) <= 1.7976931348623157e308;   // every finite point
     if (pr.mode == 0) return z < GD_Z_HIGH && z < pr.ub;
     return fabs(((x * pr.p[0] + y * pr.p[1]) + z * pr.p[2]) + 1.0 * pr.p[3]) < pr.thr;   // np.c_[p, 1].dot(params), k = 0..3
 }
@@ -158,8 +159,23 @@ int seed_upper_bound(pcr_ctx* ctx, const pcr_cloud* c, size_t lpr_size, double t
     return PCR_OK;
 }
 
+// centre and scatter matrix (row-major, symmetric) of the points passing `pr`; *count = number of such points
+int moments(pcr_ctx* ctx, const pcr_cloud* c, const Pred& pr, double centre[3], double XTX[9], uint64_t* count);
+
 // estimate_plane over the points passing `pr` (:74-85); *count = number of such points
 int fit_plane(pcr_ctx* ctx, const pcr_cloud* c, const Pred& pr, double params[4], uint64_t* count)
+{
+    double ctr[3], XTX[9];
+    int rc = moments(ctx, c, pr, ctr, XTX, count);
+    if (rc || *count == 0) return rc;
+    double nrm[3];
+    pcr_fast_eigen3x3(XTX, nrm);                                                     // :83
+    params[0] = nrm[0]; params[1] = nrm[1]; params[2] = nrm[2];
+    params[3] = -(nrm[0] * ctr[0] + nrm[1] * ctr[1] + nrm[2] * ctr[2]);               // :84
+    return PCR_OK;
+}
+
+int moments(pcr_ctx* ctx, const pcr_cloud* c, const Pred& pr, double centre[3], double XTX_out[9], uint64_t* count)
 {
     const size_t n = c->n;
     const unsigned blocks = gd_blocks(n);
@@ -190,10 +206,8 @@ int fit_plane(pcr_ctx* ctx, const pcr_cloud* c, const Pred& pr, double params[4]
     for (unsigned b = 0; b < blocks; b++)
         for (int k = 0; k < 6; k++) m[k] += h[(size_t)b * 6 + k];
     const double XTX[9] = { m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5] };  // :77
-    double nrm[3];
-    pcr_fast_eigen3x3(XTX, nrm);                                                     // :83
-    params[0] = nrm[0]; params[1] = nrm[1]; params[2] = nrm[2];
-    params[3] = -(nrm[0] * cx + nrm[1] * cy + nrm[2] * cz);                           // :84
+    for (int k = 0; k < 9; k++) XTX_out[k] = XTX[k];
+    centre[0] = cx; centre[1] = cy; centre[2] = cz;
     return PCR_OK;
 }
 
@@ -223,6 +237,31 @@ int pcr_fast_eigen3x3(const double A[9], double normal[3])
 {
     if (!A || !normal) return PCR_ERR_ARG;
     eig3::smallest_eigenvector(A, normal);
+    return PCR_OK;
+}
+
+// pca_normal.py:17-36 PCA(data, sort = True): centre = sum / n, XTX = centred^T centred (streamed on the GPU, f64), then the
+// eigen-decomposition on the host (one-sided Jacobi; np.linalg.eig there — eigenvector signs are unspecified in both).
+int pcr_cloud_pca_f64(pcr_ctx* ctx, const pcr_cloud* cloud, double eigenvalues[3], double eigenvectors[9], double centre[3])
+{
+    if (!ctx || !cloud || !eigenvalues || !eigenvectors) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_pca_f64");
+    if (cloud->n > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_pca_f64: cloud too large");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    Pred pr{};
+    pr.mode = 2;
+    double ctr[3] = { 0, 0, 0 }, XTX[9];
+    uint64_t count = 0;
+    if (cloud->n) {
+        int rc = moments(ctx, cloud, pr, ctr, XTX, &count);
+        if (rc) return rc;
+    }
+    if (count == 0) return fail(ctx, PCR_ERR_EMPTY, "pcr_cloud_pca_f64: no finite point");
+    double U[9], S[3], V[9];
+    svd3(XTX, U, S, V);                                      // symmetric PSD: singular values = eigenvalues, descending (:31-34)
+    for (int k = 0; k < 3; k++) eigenvalues[k] = S[k];
+    for (int k = 0; k < 9; k++) eigenvectors[k] = V[k];      // row-major, eigenvectors in the COLUMNS like numpy's
+    if (centre) for (int k = 0; k < 3; k++) centre[k] = ctr[k];
+    prof_flush(ctx);
     return PCR_OK;
 }
 

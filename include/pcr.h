@@ -187,6 +187,11 @@ int pcr_cloud_knn_f64(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* querie
  * np.linalg.eig leaves the sign unspecified).  normals: n x 3 f64. */
 int pcr_normals_knn_f64(pcr_ctx* ctx, const pcr_cloud* cloud, int k, double radius, double* normals);
 
+/* pca_normal.py:17-36 PCA(data, correlation = False, sort = True) of the whole cloud: eigenvalues descending, eigenvectors in
+ * the columns of the row-major 3x3 (signs unspecified, as with np.linalg.eig); centre (optional) = sum / n.  Non-finite
+ * points are skipped; PCR_ERR_EMPTY without a finite point. */
+int pcr_cloud_pca_f64(pcr_ctx* ctx, const pcr_cloud* cloud, double eigenvalues[3], double eigenvectors[9], double centre[3]);
+
 /* ---- next row N2: PCA ground fit around the inlier count, Homework4/ground_detection_SVD.py:46-101 --------------
  * f64 arithmetic on the f32 points of the cloud (the reference's points are f64 after pcd_preprocessing, :35).
  * pcr_fast_eigen3x3 (host logic, no GPU) = mylib.FastEigen3x3 (Homework1/.../my_pybind11/src/mylib.cpp:105-189): unit

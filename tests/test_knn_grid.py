@@ -163,3 +163,30 @@ def test_gpu_db64_knn_grid_route_equals_exhaustive_scan(pcr, synth, squared):
         ctx.tune("knn_method", 0)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_cloud_pca_matches_numpy(pcr, synth, golden):
+    """pca_normal.py PCA(data): eigenvalues descending, eigenvectors up to sign (np.linalg.eig leaves it open)."""
+    ctx = pcr.Context(0)
+    try:
+        for soa in (synth.kitti_like_scan(50000), np.ascontiguousarray(golden("iss_hw7.npz")["xyz_chair_0001"].T)):
+            w, v, c = ctx.pca(ctx.cloud(soa))
+            data = soa.T.astype(np.float64)
+            centre = np.sum(data, axis=0) / data.shape[0]                       # pca_normal.py:20-22
+            cd = np.subtract(data, centre)
+            XTX = cd.transpose().dot(cd)
+            ew, ev = np.linalg.eigh(XTX)
+            assert np.allclose(c, centre, rtol=1e-12, atol=1e-12)
+            assert np.allclose(w, ew[::-1], rtol=1e-10)
+            for k in range(3):
+                assert abs(v[:, k] @ ev[:, 2 - k]) > 1 - 1e-8
+            assert np.allclose(v.T @ v, np.eye(3), atol=1e-12)
+        bad = synth.kitti_like_scan(1000).copy(); bad[0, 3] = np.nan                # non-finite points are skipped
+        w2, _, _ = ctx.pca(ctx.cloud(bad))
+        w3, _, _ = ctx.pca(ctx.cloud(np.ascontiguousarray(np.delete(bad, 3, axis=1))))
+        assert np.allclose(w2, w3, rtol=1e-12)
+        with pytest.raises(pcr.PcrError):
+            ctx.pca(ctx.cloud(np.zeros((3, 0), np.float32)))
+    finally:
+        ctx.close()
