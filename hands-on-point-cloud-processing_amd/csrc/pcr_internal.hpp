@@ -127,6 +127,9 @@ void prof_flush(pcr_ctx* ctx);
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
 int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm);
+// grid radius search with the hw2 contract (radius_grid.hip); *used = false -> the caller runs the exhaustive kernels
+int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r, double r2max, int64_t* row_ptr_host, int32_t* idx_host, double* dist_host,
+                bool* used);
 // exact grid k-NN between resident clouds (knn_grid.hip); host outputs idx/val [m x k], found [m] (optional)
 int cloud_knn_host(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k, double cap_s, bool squared, double empty_val, int32_t empty_idx,
                    int32_t* idx, double* val, uint32_t* found);

@@ -1,0 +1,231 @@
+// radius_grid.hip — A11 at scale: radius search with the hw2 contract (d = sqrt(((dx^2) + dy^2) + dz^2) in f64, member iff
+// d <= r, CSR rows in ascending index order; kdtree.hpp:367-402, resultSet.hpp:96-142) over the uniform grid instead of the
+// exhaustive n x m scan.  Used by pcr_db64_radius when database and queries are f32-representable (KITTI / PLY floats
+// widened to f64, test.hpp:28 — then the f32 twin cloud widened back gives the very same doubles).
+//
+//   cell edge = 1.01 r  ->  every neighbour lies in the 27-cell block = 9 x-sorted record ranges, each cut to |x - qx| <= r
+//   pass 1  count    32 lanes per query (cell-sorted queries), membership s <= r2max (the sqrt hoisted, search_f64.hip)
+//   scan             row_ptr
+//   pass 2  fill     same walk, members compacted with a ballot prefix -> indices in grid order
+//   sort             hipCUB segmented radix sort of every row (log2(n) bits) -> ascending index, the canonical order
+//   pass 3  dist     d = sqrt(s) recomputed per reported pair
+#include "grid_common.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace pcr {
+
+namespace {
+
+constexpr int RG_BLOCK = 256;
+constexpr int RG_G = 32;           // lanes per query
+
+__device__ __forceinline__ double s_f64(float tx, float ty, float tz, double qx, double qy, double qz)
+{
+    const double e0 = (double)tx - qx, e1 = (double)ty - qy, e2 = (double)tz - qz;   // t - q, kdtree.hpp:343
+    return (e0 * e0 + e1 * e1) + e2 * e2;
+}
+
+__device__ __forceinline__ void clip_x(const float4* __restrict__ records, uint32_t& b, uint32_t& e, float lo, float hi)
+{
+    if (e - b <= 256u) return;
+    uint32_t l = b, h = e;
+    for (int it = 0; it < 32 && l < h; it++) {
+        const uint32_t mid = l + ((h - l) >> 1);
+        if (records[mid].x < lo) l = mid + 1; else h = mid;
+    }
+    const uint32_t nb = l;
+    h = e;
+    for (int it = 0; it < 32 && l < h; it++) {
+        const uint32_t mid = l + ((h - l) >> 1);
+        if (records[mid].x <= hi) l = mid + 1; else h = mid;
+    }
+    b = nb;
+    e = l;
+}
+
+// the k-th of the 9 rows around the query's (unclamped) cell, cut to the x window; empty when outside the grid
+__device__ __forceinline__ void row_k(const GridParams& g, const uint32_t* __restrict__ cell_start, const float4* __restrict__ records, int cx, int cy, int cz,
+                                      int k, float lo, float hi, uint32_t& b, uint32_t& e)
+{
+    const int yy = cy + (k % 3) - 1, zz = cz + (k / 3) - 1;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.n[0] - 1);
+    if (yy < 0 || yy >= g.n[1] || zz < 0 || zz >= g.n[2] || x0 > x1) { b = e = 0; return; }
+    const uint32_t row = (uint32_t)((zz * g.n[1] + yy) * g.n[0]);
+    b = cell_start[row + x0];
+    e = cell_start[row + x1 + 1];
+    clip_x(records, b, e, lo, hi);
+}
+
+// FILL = false: counts[q] = |N(q)|;  FILL = true: idx_out[row_ptr[q] ...] = members in grid order
+template <bool FILL>
+__global__ __launch_bounds__(RG_BLOCK) void radius_grid_kernel(const float4* __restrict__ records, const uint32_t* __restrict__ cell_start, GridParams g,
+                                                               const float* __restrict__ qxs, const float* __restrict__ qys, const float* __restrict__ qzs,
+                                                               const uint32_t* __restrict__ perm, uint32_t m, double r2max, float win,
+                                                               uint32_t* __restrict__ counts, const uint32_t* __restrict__ row_ptr, int32_t* __restrict__ idx_out)
+{
+    const uint32_t tq = (blockIdx.x * RG_BLOCK + threadIdx.x) / RG_G;
+    const int sub = threadIdx.x % RG_G;
+    if (tq >= m) return;                                   // whole groups leave together
+    const uint32_t qi = perm[tq];
+    const float fx = qxs[qi], fy = qys[qi], fz = qzs[qi];
+    uint32_t c = 0;
+    uint32_t w = FILL ? row_ptr[qi] : 0u;
+    if (finite3(fx, fy, fz)) {
+        const double qx = fx, qy = fy, qz = fz;
+        const int cx = cell_coord(fx, g.lo[0], g.inv_h), cy = cell_coord(fy, g.lo[1], g.inv_h), cz = cell_coord(fz, g.lo[2], g.inv_h);
+        const float pad = (fabsf(fx) + win) * 2.4e-7f;
+        const float lo = fx - win - pad, hi = fx + win + pad;
+        for (int k = 0; k < 9; k++) {
+            uint32_t b, e;
+            row_k(g, cell_start, records, cx, cy, cz, k, lo, hi, b, e);
+            for (uint32_t j0 = b; j0 < e; j0 += RG_G) {    // uniform trip count over the group (ballot below)
+                const uint32_t j = j0 + sub;
+                bool in = false;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < e) {
+                    t = records[j];
+                    in = s_f64(t.x, t.y, t.z, qx, qy, qz) <= r2max;
+                }
+                if (FILL) {
+                    const unsigned long long all = __ballot(in);
+                    const uint32_t mine = (uint32_t)(all >> ((threadIdx.x & 63) / RG_G * RG_G));      // this group's 32 lanes
+                    if (in) idx_out[w + __popc(mine & ((1u << sub) - 1u))] = (int32_t)__float_as_uint(t.w);
+                    w += __popc(mine);
+                } else {
+                    c += in;
+                }
+            }
+        }
+    }
+    if (!FILL) {
+#pragma unroll
+        for (int o = RG_G / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, RG_G);
+        if (sub == 0) counts[qi] = c;
+    }
+}
+
+// one group per query: distances of its (now index-sorted) neighbours
+__global__ __launch_bounds__(RG_BLOCK) void radius_dist_kernel(const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
+                                                               const float* __restrict__ qxs, const float* __restrict__ qys, const float* __restrict__ qzs, uint32_t m,
+                                                               const uint32_t* __restrict__ row_ptr, const int32_t* __restrict__ idx, double* __restrict__ dist)
+{
+    const uint32_t qi = (blockIdx.x * RG_BLOCK + threadIdx.x) / RG_G;
+    const int sub = threadIdx.x % RG_G;
+    if (qi >= m) return;
+    const double qx = qxs[qi], qy = qys[qi], qz = qzs[qi];
+    for (uint32_t p = row_ptr[qi] + sub; p < row_ptr[qi + 1]; p += RG_G) {
+        const int32_t j = idx[p];
+        dist[p] = sqrt(s_f64(tx[j], ty[j], tz[j], qx, qy, qz));
+    }
+}
+
+// self-query: the records' order IS the cell order of the points -> perm[t] = original index of record t
+__global__ __launch_bounds__(RG_BLOCK) void record_index_kernel(const float4* __restrict__ rec, uint32_t n, uint32_t* __restrict__ perm)
+{
+    const uint32_t i = blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (i < n) perm[i] = __float_as_uint(rec[i].w);
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+};
+
+}  // namespace
+
+// *used = false: the caller falls back to the exhaustive kernels (radius too large for a useful grid, 2^31 neighbours, ...)
+int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r, double r2max, int64_t* row_ptr_host, int32_t* idx_host, double* dist_host,
+                bool* used)
+{
+    *used = false;
+    const size_t n = db->n, m = q->n;
+    if (n == 0 || m == 0 || !(r > 0.0) || !std::isfinite(r) || r2max < 0.0) return PCR_OK;
+    Grid* g = nullptr;
+    {
+        ProfScope ps(ctx, "radius_grid_build");
+        int rc = grid_build(ctx, db, &g, std::max(r * 1.01, 2e-15));
+        if (rc) return rc;
+    }
+    struct GridGuard { Grid* g; ~GridGuard() { grid_free(g); } } guard{ g };
+    // the cell budget may have enlarged the cells: fine.  A cell much SMALLER than asked cannot happen; a grid of a few
+    // cells only (radius ~ extent) is the exhaustive scan in disguise: leave that to the tiled kernels
+    if ((double)g->p.h < r * 1.005) return fail(ctx, PCR_ERR_STATE, "radius_grid: cell smaller than the radius");
+    if ((size_t)g->p.n[0] * g->p.n[1] * g->p.n[2] < 64) return PCR_OK;
+    // cell-sorted query order
+    const uint32_t* perm = nullptr;
+    DevBuf permbuf;
+    if (q == db) {
+        PCR_HIP(ctx, hipMalloc(&permbuf.p, std::max<size_t>(m, 1) * 4));
+        hipLaunchKernelGGL(record_index_kernel, dim3((unsigned)((m + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, ctx->stream, g->records, (uint32_t)m,
+                           (uint32_t*)permbuf.p);
+        perm = (const uint32_t*)permbuf.p;
+    } else {
+        ProfScope ps(ctx, "grid_sort_queries");
+        int rc = grid_prepare_queries(ctx, db, q);           // coarse cells of db's cached 1-NN grid: any spatial grouping will do
+        if (rc) return rc;
+        perm = ctx->qperm;
+    }
+    const float win = (float)(r * 1.00001) + 1e-30f;
+    DevBuf cnt, rows;
+    PCR_HIP(ctx, hipMalloc(&cnt.p, (m + 1) * 4));
+    PCR_HIP(ctx, hipMalloc(&rows.p, (m + 2) * 4));
+    const dim3 grid((unsigned)((m * RG_G + RG_BLOCK - 1) / RG_BLOCK));
+    {
+        ProfScope ps(ctx, "radius_count", 1);
+        hipLaunchKernelGGL(radius_grid_kernel<false>, grid, dim3(RG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, q->x(), q->y(), q->z(), perm, (uint32_t)m,
+                           r2max, win, (uint32_t*)cnt.p, (const uint32_t*)nullptr, (int32_t*)nullptr);
+    }
+    PCR_HIP(ctx, hipGetLastError());
+    std::vector<uint32_t> hc(m);
+    PCR_HIP(ctx, hipMemcpyAsync(hc.data(), cnt.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t acc = 0;
+    for (size_t i = 0; i < m; i++) { row_ptr_host[i] = (int64_t)acc; acc += hc[i]; }
+    row_ptr_host[m] = (int64_t)acc;
+    if (acc >= 0x7FFFFFF0ull) return PCR_OK;                   // 32-bit offsets / hipCUB item counts: exhaustive path (which redoes the counts)
+    *used = true;
+    if (!idx_host || acc == 0) return PCR_OK;
+    const size_t total = (size_t)acc;
+    std::vector<uint32_t> hr(m + 1);
+    for (size_t i = 0; i <= m; i++) hr[i] = (uint32_t)row_ptr_host[i];
+    PCR_HIP(ctx, hipMemcpyAsync(rows.p, hr.data(), (m + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    DevBuf idx_a, idx_b, dist;
+    PCR_HIP(ctx, hipMalloc(&idx_a.p, total * 4));
+    PCR_HIP(ctx, hipMalloc(&idx_b.p, total * 4));
+    PCR_HIP(ctx, hipMalloc(&dist.p, total * 8));
+    {
+        ProfScope ps(ctx, "radius_fill", 1);
+        hipLaunchKernelGGL(radius_grid_kernel<true>, grid, dim3(RG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, q->x(), q->y(), q->z(), perm, (uint32_t)m,
+                           r2max, win, (uint32_t*)nullptr, (const uint32_t*)rows.p, (int32_t*)idx_a.p);
+    }
+    int bits = 1;
+    while (((size_t)1 << bits) < n) bits++;
+    size_t temp_bytes = 0;
+    PCR_HIP(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, temp_bytes, (const uint32_t*)idx_a.p, (uint32_t*)idx_b.p, (int)total, (int)m,
+                                                          (const uint32_t*)rows.p, (const uint32_t*)rows.p + 1, 0, bits, ctx->stream));
+    DevBuf temp;
+    PCR_HIP(ctx, hipMalloc(&temp.p, std::max<size_t>(temp_bytes, 16)));
+    {
+        ProfScope ps(ctx, "radius_sort", 1);
+        PCR_HIP(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(temp.p, temp_bytes, (const uint32_t*)idx_a.p, (uint32_t*)idx_b.p, (int)total, (int)m,
+                                                              (const uint32_t*)rows.p, (const uint32_t*)rows.p + 1, 0, bits, ctx->stream));
+    }
+    {
+        ProfScope ps(ctx, "radius_dist", 1);
+        hipLaunchKernelGGL(radius_dist_kernel, grid, dim3(RG_BLOCK), 0, ctx->stream, db->x(), db->y(), db->z(), q->x(), q->y(), q->z(), (uint32_t)m,
+                           (const uint32_t*)rows.p, (const int32_t*)idx_b.p, (double*)dist.p);
+    }
+    PCR_HIP(ctx, hipGetLastError());
+    PCR_HIP(ctx, hipMemcpyAsync(idx_host, idx_b.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipMemcpyAsync(dist_host, dist.p, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+}  // namespace pcr

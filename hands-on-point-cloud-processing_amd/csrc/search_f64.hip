@@ -321,6 +321,23 @@ extern "C" int pcr_db64_radius(pcr_ctx* ctx, const pcr_db64* db, const double* q
     if (m > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_db64_radius: too many queries");
     PCR_HIP(ctx, hipSetDevice(ctx->device));
     const double r2max = radius_sq_bound(r);
+    // large batches on f32-representable data: the grid walk (27 cells of edge 1.01 r, rows cut to |x - qx| <= r) returns the
+    // same CSR rows without touching all n x m pairs; radius_method 1 forces the exhaustive scan, 2 the grid
+    const int64_t rmethod = tune_get(ctx, "radius_method", 0);
+    if (db->twin && rmethod != 1 && (rmethod == 2 || (double)db->n * (double)m >= 6.7e7)) {
+        std::vector<float> qf;
+        if (f32_exact(q, m, qf)) {
+            pcr_cloud* qc = nullptr;
+            int rcq = pcr_cloud_create(ctx, qf.data(), m, PCR_AOS3, &qc);
+            if (rcq) return rcq;
+            bool used = false;
+            rcq = radius_grid(ctx, db->twin, qc, r, r2max, row_ptr, idx, dist, &used);
+            pcr_cloud_destroy(ctx, qc);
+            if (rcq) return rcq;
+            prof_flush(ctx);
+            if (used) return PCR_OK;
+        }
+    }
     const size_t n = db->n, n_cap = db->cap;
     const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
     const size_t bytes_q = 3 * m_cap * 8, bytes_c = (m + 1) * 8;

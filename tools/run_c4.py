@@ -40,10 +40,19 @@ print(f"my_ransac (40 iterations, one segment): {t1*1e3:.2f} ms, {idx.size} grou
 db = pts.astype(np.float64)
 h = ctx.db64(db)
 m = int(os.environ.get("RADIUS_QUERIES", n))
+h.radius(db[:2000], 1.0); ctx.prof_reset()                          # first launches load code objects: keep them out of the numbers
 t0 = time.perf_counter(); row, ridx, rdist = h.radius(db[:m], 1.0); t1 = time.perf_counter() - t0
-kc, msc = ctx.prof_get("radius_count"); kf, msf = ctx.prof_get("radius_fill")
-print(f"radius-NN r=1.0: {m} queries x {n} pts: {row[-1]} neighbours, count kernel {msc/max(kc,1):.2f} ms + fill kernel {msf/max(kf,1):.2f} ms, "
-      f"call {t1*1e3:.1f} ms -> {m*n/((msc/max(kc,1)+msf/max(kf,1))*1e-3)/1e9:.1f} G pair-evals/s over both passes")
+parts = {k: ctx.prof_get(k) for k in ("radius_grid_build", "radius_count", "radius_fill", "radius_sort", "radius_dist")}
+desc = ", ".join(f"{k[7:]} {v[1]/v[0]:.2f} ms x{v[0]}" for k, v in parts.items() if v[0])
+kern = sum(v[1] for v in parts.values())
+print(f"radius-NN r=1.0: {m} queries x {n} pts: {row[-1]} neighbours ({row[-1]*12/1e9:.2f} GB of results); kernels: {desc} = {kern:.1f} ms in the two calls "
+      f"(count-only, then fill); whole exchange incl. D2H {t1*1e3:.1f} ms")
+ctx.tune("radius_method", 1); ctx.prof_reset()
+t0 = time.perf_counter(); row_b, ridx_b, rdist_b = h.radius(db[:m], 1.0); t2 = time.perf_counter() - t0
+pb = {k: ctx.prof_get(k) for k in ("radius_count", "radius_fill")}
+print(f"  exhaustive f64 kernels (radius_method 1): " + ", ".join(f"{k[7:]} {v[1]/max(v[0],1):.2f} ms x{v[0]}" for k, v in pb.items()) + f", exchange {t2*1e3:.1f} ms; "
+      f"rows / indices / distance bits equal: {np.array_equal(row, row_b)} {np.array_equal(ridx, ridx_b)} {np.array_equal(rdist.view(np.uint64), rdist_b.view(np.uint64))}")
+ctx.tune("radius_method", 0)
 
 # --- next row N2: PCA ground fit (ground_detection_SVD.py:88-101), 6 iterations, LPR 10000, 0.18 (the shipped values, :104,116)
 ctx.ground_detection(c, 6, 10000, 0.18); ctx.prof_reset()
