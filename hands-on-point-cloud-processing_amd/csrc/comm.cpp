@@ -9,6 +9,8 @@
 
 #include <dlfcn.h>
 
+#include <mutex>
+
 namespace pcr {
 
 namespace {
@@ -27,16 +29,24 @@ struct Rccl {
     std::string err;
 };
 
+void rccl_load(Rccl& r);
+
 Rccl& rccl()
 {
     static Rccl r;
-    if (r.handle || !r.err.empty()) return r;
+    static std::once_flag once;                     // several contexts (threads) may attach communicators concurrently
+    std::call_once(once, [] { rccl_load(r); });
+    return r;
+}
+
+void rccl_load(Rccl& r)
+{
     const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
     for (const char* n : names) {
         r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
     }
-    if (!r.handle) { r.err = std::string("dlopen(librccl): ") + dlerror(); return r; }
+    if (!r.handle) { r.err = std::string("dlopen(librccl): ") + dlerror(); return; }
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
@@ -46,7 +56,6 @@ Rccl& rccl()
         r.err = "librccl: missing symbols";
         r.handle = nullptr;
     }
-    return r;
 }
 
 constexpr int kNcclFloat64 = 8;   // rccl.h: ncclFloat64 = 8
