@@ -73,7 +73,7 @@ def main():
             P = orc.transform_f32(P, R, t)
         print(f"rank {rank}: protocol ok")
     elif mode == "gpu":
-        n = 20000
+        n = 20003                                   # not divisible by 2, 3 or 5: the shards differ in size
         src, tgt = synth.kitti_like_pair(n, seed_target=61, seed_pair=62)
         ctx = pcr.Context(0)
         ct = ctx.cloud(tgt)

@@ -45,6 +45,14 @@ def test_sharded_icp_two_ranks_one_gpu():
 
 
 @pytest.mark.gpu
+def test_sharded_icp_five_ranks_one_gpu():
+    """uneven shards (20 000 / 5 is even, the empty-shard leg is not): five ranks share the one GPU over gloo — still within
+    the 6-process limit of the GPU box; the pose must be identical on every rank and equal to the single-rank pose."""
+    out = run_workers("gpu", 5, timeout=600)
+    assert out.count("gpu sharded icp ok") == 5
+
+
+@pytest.mark.gpu
 def test_native_rccl_communicator_single_rank(pcr, synth):
     """RCCL is bound with dlopen (ncclGetUniqueId / ncclCommInitRank with a by-value 128-byte id / ncclAllReduce):
     a one-rank communicator exercises that ABI end to end, and ICP runs unchanged with it attached."""
