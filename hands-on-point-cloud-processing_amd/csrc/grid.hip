@@ -480,6 +480,7 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge)
 {
     *out = nullptr;
     const size_t n = c->n;
+    if (n > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "grid index: more than 2^31 points (hipCUB item counts are int)");
     Grid* g = new (std::nothrow) Grid();
     if (!g) return fail(ctx, PCR_ERR_NOMEM, "grid");
     g->n_points = n;
