@@ -242,3 +242,27 @@ def test_gpu_db64_radius_grid_route_equals_exhaustive_scan(pcr, orc, synth):
         ctx.tune("radius_method", 0)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_kat_query5_open3d_squared_distances(pcr, golden):
+    """Homework2/hw2/result_py.txt:34-35: open3d's 8-NN of point #5 of 000000.bin, squared distances — through the grid k-NN
+    service on the resident cloud and through the db64 drop-in path (squared = 1)."""
+    g = golden("kat_kitti_q5.npz")
+    pts = np.ascontiguousarray(g["db_f32"].T)
+    printed = [0, 0.347574, 1.50463, 1.95563, 2.14362, 2.48257, 2.67194, 2.75159]
+    ctx = pcr.Context(0)
+    try:
+        c = ctx.cloud(pts)
+        idx, s, found = ctx.cloud_knn(c, ctx.cloud(np.ascontiguousarray(pts[:, 5:6])), 8)
+        assert idx[0].tolist() == [5, 1972, 6, 1971, 1970, 3946, 8, 3945] and np.allclose(s[0], printed, rtol=2e-6, atol=0)
+        idx_all, s_all, _ = ctx.cloud_knn(c, c, 8)                                     # self-query path, all 100 000 points
+        assert idx_all[5].tolist() == idx[0].tolist() and np.array_equal(s_all[5], s[0])
+        h = ctx.db64(np.ascontiguousarray(g["db_f32"].astype(np.float64)))
+        for method in (1, 2):
+            ctx.tune("knn_method", method)
+            bi, bd = h.knn(g["db_f32"][5:6].astype(np.float64), 8, squared=True)
+            assert bi[0].tolist() == idx[0].tolist() and np.array_equal(bd[0], s[0])
+        ctx.tune("knn_method", 0)
+    finally:
+        ctx.close()

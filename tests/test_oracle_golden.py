@@ -335,3 +335,15 @@ def test_live_reference_randomised_sweep(orc):
                 o = np.argsort(ridx[row[i]:row[i + 1]], kind="stable")
                 assert np.array_equal(ridx[row[i]:row[i + 1]][o], oidx[row[i]:row[i + 1]])
     assert ties_seen > 0
+
+
+def test_kat_query5_open3d_squared_distances(orc, golden):
+    """The reference's second known answer: open3d (FLANN) on the same query prints SQUARED distances
+    (Homework2/hw2/result_py.txt:34-35, result_cpp.txt:46-53) — the contract of the `squared` k-NN entry points."""
+    g = golden("kat_kitti_q5.npz")
+    pts = np.ascontiguousarray(g["db_f32"].T)
+    q = np.ascontiguousarray(pts[:, 5:6])
+    idx, s, found = orc.knn_sq_f32pts(pts, q, 8)
+    assert idx[0].tolist() == [5, 1972, 6, 1971, 1970, 3946, 8, 3945]
+    printed = [0, 0.347574, 1.50463, 1.95563, 2.14362, 2.48257, 2.67194, 2.75159]
+    assert np.allclose(s[0], printed, rtol=2e-6, atol=0) and found[0] == 8
