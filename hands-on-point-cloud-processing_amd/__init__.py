@@ -53,8 +53,8 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
-    "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
+    "pcr_grid_stats", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
+    "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_match_inter_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
 
@@ -112,6 +112,7 @@ def lib():
     L.pcr_grid_stats.argtypes = [vp, vp]
     L.pcr_voxel_filter_f32.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
     L.pcr_iss_keypoints_f32.argtypes = [vp, vp, C.POINTER(IssParams), vp, vp, vp, C.POINTER(C.c_uint64)]
+    L.pcr_icp_p2plane_f32.argtypes = [vp, vp, vp, vp, vp, C.POINTER(IcpParams), vp, C.POINTER(IcpStats)]
     L.pcr_cloud_knn_f64.argtypes = [vp, vp, vp, C.c_int, C.c_double, C.c_int, vp, vp, vp]
     L.pcr_normals_knn_f64.argtypes = [vp, vp, C.c_int, C.c_double, vp]
     L.pcr_cloud_pca_f64.argtypes = [vp, vp, vp, vp, vp]
@@ -120,6 +121,7 @@ def lib():
     L.pcr_ground_detection_f64.argtypes = [vp, vp, C.c_int, sz, C.c_double, vp, vp, C.POINTER(C.c_uint64)]
     L.pcr_nn1_desc_f32.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, vp]
     L.pcr_match_union_f32.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.c_float, vp, vp, C.POINTER(sz)]
+    L.pcr_match_inter_f32.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.c_float, vp, vp, C.POINTER(sz)]
     L.pcr_ransac_sample_quads.argtypes = [vp, sz, vp, sz, sz, C.c_uint64, vp]
     L.pcr_consensus_count_f32.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, C.c_float, vp]
     L.pcr_ransac_global_f32.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, C.c_float, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int64), vp]
@@ -318,6 +320,15 @@ class Context:
         self._ck(lib().pcr_voxel_filter_f32(self.h, cloud.h, float(leaf_size), C.byref(h)))
         return Cloud(self, h)
 
+    def icp_point2plane(self, src: Cloud, tgt: Cloud, tgt_normals: Cloud, init_T=None, max_corr=1.0, max_iter=20, eps=1e-8):
+        """Registration::ICPpoint2plane (registration.cpp:710-860) on already-sampled clouds -> (T 4x4, stats)."""
+        T0 = np.eye(4, dtype=np.float32) if init_T is None else np.ascontiguousarray(init_T, np.float32)
+        out = np.zeros(16, np.float32)
+        prm = IcpParams(max_corr, max_iter, eps)
+        st = IcpStats()
+        self._ck(lib().pcr_icp_p2plane_f32(self.h, src.h, tgt.h, tgt_normals.h, T0.ctypes.data, C.byref(prm), out.ctypes.data, C.byref(st)))
+        return out.reshape(4, 4), {k: getattr(st, k) for k, _ in IcpStats._fields_}
+
     # ---- N1
     def iss_keypoints(self, cloud: Cloud, local_radius, non_max_radius, gamma21=0.9, gamma32=0.9, min_neighbors=5, weighted=True):
         """ISSKeypoint::compute (hw7 iss_detector.cpp:38-110) -> (keypoint indices ascending, lambda3 f32[n], |N_local| u32[n])."""
@@ -394,6 +405,17 @@ class Context:
         dist = np.zeros(max(total, 1), np.float32)
         k = C.c_size_t()
         self._ck(lib().pcr_match_union_f32(self.h, a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], a.shape[1], rejection_rate,
+                                           pairs.ctypes.data, dist.ctypes.data, C.byref(k)))
+        return pairs[: k.value], dist[: k.value]
+
+    def match_inter(self, desc_src, desc_tgt, rejection_rate):
+        """findRANSACCorrespondencesInter (registration.cpp:437-533) -> (pairs [K, 2] (src, tgt), dist [K])."""
+        a = np.ascontiguousarray(desc_src, np.float32)
+        b = np.ascontiguousarray(desc_tgt, np.float32)
+        pairs = np.zeros((max(a.shape[0], 1), 2), np.uint32)
+        dist = np.zeros(max(a.shape[0], 1), np.float32)
+        k = C.c_size_t()
+        self._ck(lib().pcr_match_inter_f32(self.h, a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], a.shape[1], rejection_rate,
                                            pairs.ctypes.data, dist.ctypes.data, C.byref(k)))
         return pairs[: k.value], dist[: k.value]
 

@@ -322,6 +322,38 @@ int pcr_match_union_f32(pcr_ctx* ctx, const float* desc_src, size_t n_src, const
     return PCR_OK;
 }
 
+int pcr_match_inter_f32(pcr_ctx* ctx, const float* desc_src, size_t n_src, const float* desc_tgt, size_t n_tgt, int dim, float rejection_rate,
+                        uint32_t* pairs, float* dist, size_t* n_pairs)
+{
+    if (!ctx || !n_pairs || (n_src && !desc_src) || (n_tgt && !desc_tgt) || dim < 1 || dim > DS_MAX_DIM) return fail(ctx, PCR_ERR_ARG, "pcr_match_inter_f32");
+    *n_pairs = 0;
+    if (n_src == 0 || n_tgt == 0) return PCR_OK;
+    if (!pairs || !dist) return fail(ctx, PCR_ERR_ARG, "pcr_match_inter_f32: null output");
+    if (n_src + n_tgt > 0xFFFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_match_inter_f32: too many descriptors");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> t2s(n_tgt), s2t(n_src);
+    std::vector<float> dt(n_tgt), ds(n_src);
+    int rc = nn1_dim(ctx, desc_src, n_src, desc_tgt, n_tgt, dim, t2s.data(), dt.data());           // :455-473
+    if (rc) return rc;
+    rc = nn1_dim(ctx, desc_tgt, n_tgt, desc_src, n_src, dim, s2t.data(), ds.data());               // :475-494
+    if (rc) return rc;
+    prof_flush(ctx);
+    struct Rec { uint32_t s, t; float d; };
+    std::vector<Rec> rec;
+    for (size_t s = 0; s < n_src; s++) {                                                            // :497-508: mutual pairs, ascending s
+        const uint32_t t = s2t[s];
+        if (t == 0xFFFFFFFFu) continue;
+        if (t2s[t] == (uint32_t)s) rec.push_back(Rec{ (uint32_t)s, t, ds[s] });
+    }
+    std::stable_sort(rec.begin(), rec.end(), [](const Rec& a, const Rec& b) { return a.d < b.d; });   // :519-521
+    const float keep_f = std::floor((1 - rejection_rate) * (float)rec.size());                      // :523
+    size_t keep = keep_f > 0 ? (size_t)keep_f : 0;
+    keep = std::min(keep, rec.size());
+    for (size_t i = 0; i < keep; i++) { pairs[2 * i] = rec[i].s; pairs[2 * i + 1] = rec[i].t; dist[i] = rec[i].d; }
+    *n_pairs = keep;
+    return PCR_OK;
+}
+
 // Host logic (no GPU): the sampling loop of Registration::RANSAC (:318-352) with an explicit seed instead of
 // std::random_device: four distinct-as-the-reference-checks correspondences whose SOURCE keypoints are not coplanar
 // (signed distance of the 4th from the plane of the first three > 0.15, f32 as written).

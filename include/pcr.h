@@ -147,6 +147,14 @@ int pcr_db64_knn(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, in
 int pcr_db64_radius(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, double r,
                     int64_t* row_ptr, int32_t* idx, double* dist);
 
+/* Registration::ICPpoint2plane (registration.hpp:195-202, registration.cpp:710-860): the point-to-plane variant on the same
+ * 1-NN loop.  tgt_normals: one normal per target point (a cloud whose x/y/z are normal_x/y/z; e.g. floats 3..5 of hw9's .bin
+ * rows).  Rows A = [n x p, n], b = n.q - n.p in f32 as written (:807-814); normal equations in f64; update R_delta = I + [x]_x,
+ * NOT re-orthonormalised (:843).  Same parameters, stop rules and stats as pcr_icp_p2p_f32; `empty_pairs` is also set when
+ * the 6x6 system is singular.  Sources shard like the point-to-point loop: one all-reduce of 29 f64 per iteration. */
+int pcr_icp_p2plane_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, const pcr_cloud* tgt_normals, const float init_T[16],
+                        const pcr_icp_params* prm, float out_T[16], pcr_icp_stats* stats);
+
 /* ---- next row N3: voxel-grid down-sampling, Homework1 voxel_filter.py:17-52 (centroid mode) -----------------
  * One centroid per occupied voxel of edge leaf_size, in ascending voxel-index order; f32 arithmetic and summation
  * order of the reference (bit-exact), including its quirk that the last voxel of the sorted order is never emitted
@@ -216,6 +224,10 @@ int pcr_nn1_desc_f32(pcr_ctx* ctx, const float* db, size_t n, const float* q, si
  * dist: n_src + n_tgt floats (squared descriptor distance of each kept pair); *n_pairs = floor((1 - rate) * total) as
  * the reference computes it (f32).  Sorted by distance; ties in input order (the reference: std::sort, unspecified). */
 int pcr_match_union_f32(pcr_ctx* ctx, const float* desc_src, size_t n_src, const float* desc_tgt, size_t n_tgt, int dim,
+                        float rejection_rate, uint32_t* pairs, float* dist, size_t* n_pairs);
+/* findRANSACCorrespondencesInter (:437-533): the mutual-nearest-neighbour variant — (s, nn_tgt(s)) kept iff nn_src(nn_tgt(s)) == s,
+ * ascending s, then sorted by the source->target distance and cut to floor((1 - rate) * count).  pairs: room for 2 * n_src. */
+int pcr_match_inter_f32(pcr_ctx* ctx, const float* desc_src, size_t n_src, const float* desc_tgt, size_t n_tgt, int dim,
                         float rejection_rate, uint32_t* pairs, float* dist, size_t* n_pairs);
 /* N4c: Registration::RANSAC (:288-434).  Sampling (host logic, no GPU): n_hyp quads of correspondence indices drawn as
  * :318-352 draws them (std::mt19937 + uniform_int_distribution, non-coplanar SOURCE keypoints), seeded explicitly

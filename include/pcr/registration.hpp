@@ -111,6 +111,20 @@ public:
         for (size_t i = 0; i < kept; i++) correspondences[i] = std::vector<size_t>{ pairs[2 * i], pairs[2 * i + 1] };
     }
 
+    // the mutual-nearest-neighbour variant (registration.hpp:187-189, registration.cpp:437-533)
+    void findRANSACCorrespondencesInter(const float* fpfh_source, size_t N_source, const float* fpfh_target, size_t N_target, int dim,
+                                        std::vector<std::vector<size_t>>& correspondences)
+    {
+        std::vector<uint32_t> pairs(2 * N_source + 2);
+        std::vector<float> dist(N_source + 1);
+        size_t kept = 0;
+        check(pcr_match_inter_f32(default_ctx(), fpfh_source, N_source, fpfh_target, N_target, dim, m_RANSAC_corres_rejection_rate, pairs.data(),
+                                  dist.data(), &kept),
+              "pcr_match_inter_f32");
+        correspondences.resize(kept);
+        for (size_t i = 0; i < kept; i++) correspondences[i] = std::vector<size_t>{ pairs[2 * i], pairs[2 * i + 1] };
+    }
+
     // keypoints: AoS xyz (n x 3).  R (row-major) and t are written only when a non-empty consensus set exists, as in the
     // reference (:423-428).  Returns the C-ABI status.
     int RANSAC(const std::vector<std::vector<size_t>>& correspondences, const float* kp_source_xyz, size_t n_source, const float* kp_target_xyz,

@@ -74,6 +74,8 @@ def lib():
         L.orc_nn1_dim_f32.argtypes = [f32p, sz, f32p, sz, C.c_int, u32p, f32p]
         L.orc_match_union_f32.argtypes = [f32p, sz, f32p, sz, C.c_int, C.c_float, u32p, f32p]
         L.orc_match_union_f32.restype = sz
+        L.orc_match_inter_f32.argtypes = [f32p, sz, f32p, sz, C.c_int, C.c_float, u32p, f32p]
+        L.orc_match_inter_f32.restype = sz
         L.orc_ransac_hypothesis.argtypes = [f32p, f32p, u32p, u32p, f32p, f32p]
         L.orc_consensus_count_f32.argtypes = [f32p, f32p, u32p, sz, f32p, f32p, C.c_float]
         L.orc_consensus_count_f32.restype = C.c_uint32
@@ -88,6 +90,8 @@ def lib():
         L.orc_ground_detection_f64.restype = sz
         L.orc_knn_sq_f32pts.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, C.c_int, C.c_double, i32p, f64p, u32p]
         L.orc_normals_knn_f64.argtypes = [f32p, f32p, f32p, sz, C.c_int, C.c_double, f64p]
+        L.orc_icp_p2plane_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, f32p, f32p, f32p, f32p, C.POINTER(IcpParams), f32p, C.POINTER(IcpStats)]
+        L.orc_solve6.argtypes = [f64p, f64p, f64p]
         L.orc_iss_f32.argtypes = [f32p, f32p, f32p, sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, u8p, f32p]
         L.orc_hw2_knn_add.argtypes = [f64p, i32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                       C.c_double, C.c_int]
@@ -234,6 +238,19 @@ def icp_p2p_f32(src_soa, tgt_soa, init_T=None, max_corr=1.0, max_iter=20, eps=1e
     return out.reshape(4, 4), stats
 
 
+def icp_p2plane_f32(src_soa, tgt_soa, tgt_normals_soa, init_T=None, max_corr=1.0, max_iter=20, eps=1e-8):
+    sx, sy, sz = _soa(src_soa)
+    tx, ty, tz = _soa(tgt_soa)
+    nx, ny, nz = _soa(tgt_normals_soa)
+    T0 = np.eye(4, dtype=np.float32) if init_T is None else np.ascontiguousarray(init_T, np.float32)
+    prm = IcpParams(max_corr, max_iter, eps)
+    st = IcpStats()
+    out = np.zeros(16, np.float32)
+    lib().orc_icp_p2plane_f32(sx, sy, sz, sx.size, tx, ty, tz, tx.size, nx, ny, nz, T0.reshape(16), C.byref(prm), out, C.byref(st))
+    return out.reshape(4, 4), dict(iters_run=int(st.iters_run), converged=int(st.converged), empty_pairs=int(st.empty_pairs),
+                                   last_pairs=int(st.last_pairs), last_loss=float(st.last_loss))
+
+
 def plane_count(soa, planes4, thr):
     planes4 = np.ascontiguousarray(planes4, np.float64).reshape(-1, 4)
     counts = np.zeros(planes4.shape[0], np.int64)
@@ -285,6 +302,16 @@ def match_union_f32(desc_src, desc_tgt, rejection_rate):
     pairs = np.zeros((max(total, 1), 2), np.uint32)
     dist = np.zeros(max(total, 1), np.float32)
     k = lib().orc_match_union_f32(a, a.shape[0], b, b.shape[0], a.shape[1], rejection_rate, pairs.reshape(-1), dist)
+    return pairs[:k], dist[:k]
+
+
+def match_inter_f32(desc_src, desc_tgt, rejection_rate):
+    """findRANSACCorrespondencesInter -> (pairs [K, 2] u32 (src, tgt), dist f32[K])."""
+    a = np.ascontiguousarray(desc_src, np.float32)
+    b = np.ascontiguousarray(desc_tgt, np.float32)
+    pairs = np.zeros((max(a.shape[0], 1), 2), np.uint32)
+    dist = np.zeros(max(a.shape[0], 1), np.float32)
+    k = lib().orc_match_inter_f32(a, a.shape[0], b, b.shape[0], a.shape[1], rejection_rate, pairs.reshape(-1), dist)
     return pairs[:k], dist[:k]
 
 

@@ -652,6 +652,31 @@ size_t orc_match_union_f32(const float* desc_src, size_t n_src, const float* des
     return keep;
 }
 
+size_t orc_match_inter_f32(const float* desc_src, size_t n_src, const float* desc_tgt, size_t n_tgt, int dim,
+                           float rejection_rate, uint32_t* pairs, float* dist)
+{
+    uint32_t* t2s = (uint32_t*)malloc(sizeof(uint32_t) * (n_tgt ? n_tgt : 1));
+    uint32_t* s2t = (uint32_t*)malloc(sizeof(uint32_t) * (n_src ? n_src : 1));
+    float* dt = (float*)malloc(sizeof(float) * (n_tgt ? n_tgt : 1));
+    float* ds = (float*)malloc(sizeof(float) * (n_src ? n_src : 1));
+    match_rec* rec = (match_rec*)malloc(sizeof(match_rec) * (n_src ? n_src : 1));
+    orc_nn1_dim_f32(desc_src, n_src, desc_tgt, n_tgt, dim, t2s, dt);               /* :455-473 */
+    orc_nn1_dim_f32(desc_tgt, n_tgt, desc_src, n_src, dim, s2t, ds);               /* :475-494 */
+    size_t m = 0;
+    for (size_t s = 0; s < n_src; s++) {                                           /* :497-508 */
+        const uint32_t t = s2t[s];
+        if (t == UINT32_MAX) continue;
+        if (t2s[t] == (uint32_t)s) { rec[m].s = (uint32_t)s; rec[m].t = t; rec[m].d = ds[s]; rec[m].pos = m; m++; }
+    }
+    qsort(rec, m, sizeof(match_rec), match_cmp);                                   /* :519-521 */
+    const float keep_f = floorf((1 - rejection_rate) * (float)m);                  /* :523 */
+    size_t keep = keep_f > 0 ? (size_t)keep_f : 0;
+    if (keep > m) keep = m;
+    for (size_t i = 0; i < keep; i++) { pairs[2 * i] = rec[i].s; pairs[2 * i + 1] = rec[i].t; dist[i] = rec[i].d; }
+    free(t2s); free(s2t); free(dt); free(ds); free(rec);
+    return keep;
+}
+
 int orc_ransac_hypothesis(const float* src_xyz, const float* tgt_xyz, const uint32_t* pairs, const uint32_t quad[4],
                           float R[9], float t[3])
 {
@@ -927,4 +952,89 @@ void orc_normals_knn_f64(const float* x, const float* y, const float* z, size_t 
         orc_fast_eigen3x3(XTX, out);                                 /* PCA_faster :39-45 */
     }
     free(idx); free(ss);
+}
+
+/* ------------------------------------------------------------------ ICPpoint2plane */
+int orc_solve6(const double M[36], const double v[6], double x[6])
+{
+    double a[6][7];
+    for (int r = 0; r < 6; r++) { for (int c = 0; c < 6; c++) a[r][c] = M[6 * r + c]; a[r][6] = v[r]; }
+    for (int col = 0; col < 6; col++) {
+        int piv = col;
+        for (int r = col + 1; r < 6; r++) if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+        if (!(fabs(a[piv][col]) > 1e-300)) return -1;
+        if (piv != col) for (int c = 0; c < 7; c++) { const double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
+        for (int r = col + 1; r < 6; r++) {
+            const double f = a[r][col] / a[col][col];
+            for (int c = col; c < 7; c++) a[r][c] -= f * a[col][c];
+        }
+    }
+    for (int r = 5; r >= 0; r--) {
+        double s = a[r][6];
+        for (int c = r + 1; c < 6; c++) s -= a[r][c] * x[c];
+        x[r] = s / a[r][r];
+    }
+    for (int r = 0; r < 6; r++) if (!(fabs(x[r]) <= DBL_MAX)) return -1;
+    return 0;
+}
+
+void orc_icp_p2plane_f32(const float* sx, const float* sy, const float* sz, size_t ns,
+                         const float* tx, const float* ty, const float* tz, size_t nt,
+                         const float* tnx, const float* tny, const float* tnz,
+                         const float init_T[16], const orc_icp_params* prm, float out_T[16], orc_icp_stats* stats)
+{
+    float* px = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+    float* py = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+    float* pz = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+    uint32_t* idx = (uint32_t*)malloc(sizeof(uint32_t) * (ns ? ns : 1));
+    float* d2 = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+    memcpy(px, sx, sizeof(float) * ns); memcpy(py, sy, sizeof(float) * ns); memcpy(pz, sz, sizeof(float) * ns);
+    const float R0[9] = { init_T[0], init_T[1], init_T[2], init_T[4], init_T[5], init_T[6], init_T[8], init_T[9], init_T[10] };
+    const float t0[3] = { init_T[3], init_T[7], init_T[11] };
+    orc_transform_f32(px, py, pz, ns, R0, t0);                                      /* :722 */
+    float T_total[16] = { R0[0], R0[1], R0[2], t0[0], R0[3], R0[4], R0[5], t0[1], R0[6], R0[7], R0[8], t0[2], 0, 0, 0, 1 };   /* :759-760 */
+    orc_icp_stats st;
+    memset(&st, 0, sizeof st);
+    float last_loss = 0.0f;
+    uint64_t unchanged = 0;
+    for (uint64_t iter = 0; iter < prm->max_iter; iter++) {
+        orc_nn1_f32(tx, ty, tz, nt, px, py, pz, ns, idx, d2);                        /* :771-781 */
+        double M[36], v[6], btb = 0.0, cnt = 0.0;
+        memset(M, 0, sizeof M); memset(v, 0, sizeof v);
+        for (size_t i = 0; i < ns; i++) {
+            if (!(d2[i] < prm->max_corr)) continue;                                  /* :778 */
+            const uint32_t j = idx[i];
+            const float p[3] = { px[i], py[i], pz[i] }, q[3] = { tx[j], ty[j], tz[j] }, n[3] = { tnx[j], tny[j], tnz[j] };
+            const float A[6] = { n[2] * p[1] - n[1] * p[2], n[0] * p[2] - n[2] * p[0], n[1] * p[0] - n[0] * p[1], n[0], n[1], n[2] };   /* :807-812 */
+            const float b = n[0] * q[0] + n[1] * q[1] + n[2] * q[2] - n[0] * p[0] - n[1] * p[1] - n[2] * p[2];                         /* :814 */
+            for (int r = 0; r < 6; r++) {
+                for (int c = r; c < 6; c++) M[6 * r + c] += (double)A[r] * (double)A[c];
+                v[r] += (double)A[r] * (double)b;
+            }
+            btb += (double)b * (double)b;
+            cnt += 1.0;
+        }
+        for (int r = 0; r < 6; r++) for (int c = 0; c < r; c++) M[6 * r + c] = M[6 * c + r];
+        st.last_pairs = (uint64_t)cnt;
+        double x64[6];
+        if (cnt == 0.0 || orc_solve6(M, v, x64) != 0) { st.empty_pairs = 1; break; }   /* :818 (the reference: NaN) */
+        float x[6];
+        for (int k = 0; k < 6; k++) x[k] = (float)x64[k];
+        double xMx = 0.0, xv = 0.0;
+        for (int r = 0; r < 6; r++) { for (int c = 0; c < 6; c++) xMx += (double)x[r] * M[6 * r + c] * (double)x[c]; xv += (double)x[r] * v[r]; }
+        const float loss = (float)(xMx - 2.0 * xv + btb);                            /* :820 */
+        st.last_loss = loss;
+        if (fabsf(last_loss - loss) < prm->eps) unchanged++;                         /* :828-831 */
+        if (unchanged > 15) { st.converged = 1; break; }                             /* :834-838 */
+        last_loss = loss;
+        const float Rd[9] = { 1, -x[2], x[1], x[2], 1, -x[0], -x[1], x[0], 1 };      /* :843 */
+        const float td[3] = { x[3], x[4], x[5] };
+        const float T_delta[16] = { Rd[0], Rd[1], Rd[2], td[0], Rd[3], Rd[4], Rd[5], td[1], Rd[6], Rd[7], Rd[8], td[2], 0, 0, 0, 1 };
+        orc_mat4_mul_f32(T_delta, T_total, T_total);                                 /* :849 */
+        orc_transform_f32(px, py, pz, ns, Rd, td);                                   /* :851 */
+        st.iters_run++;
+    }
+    memcpy(out_T, T_total, sizeof T_total);
+    if (stats) *stats = st;
+    free(px); free(py); free(pz); free(idx); free(d2);
 }

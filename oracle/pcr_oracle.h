@@ -172,6 +172,10 @@ void orc_nn1_dim_f32(const float* db, size_t n, const float* q, size_t m, int di
  * (src, tgt interleaved), dist likewise; returns the number kept. */
 size_t orc_match_union_f32(const float* desc_src, size_t n_src, const float* desc_tgt, size_t n_tgt, int dim,
                            float rejection_rate, uint32_t* pairs, float* dist);
+/* findRANSACCorrespondencesInter (:437-533): mutual nearest neighbours only — (s, nn_tgt(s)) is kept iff nn_src(nn_tgt(s)) == s —
+ * in ascending s, then sorted by the source->target distance (std::sort there; stable here) and cut like the union. */
+size_t orc_match_inter_f32(const float* desc_src, size_t n_src, const float* desc_tgt, size_t n_tgt, int dim,
+                           float rejection_rate, uint32_t* pairs, float* dist);
 /* N4c: one RANSAC hypothesis (:366-392): Kabsch over the 4 sampled correspondences `quad` (indices into pairs), f64
  * moments + orc_kabsch_solve (the reference: f32 Eigen, JacobiSVD — unpinned, as A7). src/tgt: AoS xyz. */
 int orc_ransac_hypothesis(const float* src_xyz, const float* tgt_xyz, const uint32_t* pairs, const uint32_t quad[4],
@@ -216,6 +220,20 @@ void orc_knn_sq_f32pts(const float* x, const float* y, const float* z, size_t n,
 /* normals[i] = FastEigen3x3 of the scatter matrix (centre = sum / cnt, pca_normal.py:20-22) of point i's <= k nearest
  * points with s < radius^2, in ascending (s, index) order; zeros when fewer than 3 (:97). */
 void orc_normals_knn_f64(const float* x, const float* y, const float* z, size_t n, int k, double radius, double* normals);
+
+/* ---- ICPpoint2plane (Homework9/hw9/src/registration.cpp:710-860), the point-to-plane sibling of A9 on the same 1-NN loop.
+ * Per kept pair (d2 < max_corr, :778): row A = [n x p (as written :807-812), n], b = n.q - n.p in f32 as written (:814);
+ * normal equations accumulated in f64 (the reference: f32 Eigen, (A^T A).inverse() * A^T * b, :818 — UNPINNED), 6x6 solve by
+ * Gaussian elimination with partial pivoting, x rounded to f32; loss = |A x - b|^2 (:820) from the moments; the same
+ * never-reset `unchanged` counter (:828-838); update R_delta = I + [x0..2]_x (NOT re-orthonormalised, :843), t_delta = x3..5,
+ * T_total = T_delta T_total, source moved by (R_delta, t_delta).  tn*: target normals.  Other arguments as orc_icp_p2p_f32;
+ * empty_pairs is also set when the 6x6 system is singular. */
+void orc_icp_p2plane_f32(const float* sx, const float* sy, const float* sz, size_t ns,
+                         const float* tx, const float* ty, const float* tz, size_t nt,
+                         const float* tnx, const float* tny, const float* tnz,
+                         const float init_T[16], const orc_icp_params* prm, float out_T[16], orc_icp_stats* stats);
+/* the 6x6 solve used above: M symmetric (row-major 36), returns 0 or -1 when singular */
+int orc_solve6(const double M[36], const double v[6], double x[6]);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,20 @@ def test_oracle_match_union_structure(orc, golden):
     assert orc.match_union_f32(a, b, 0.0)[0].shape[0] == 1300
 
 
+def test_oracle_match_inter_structure(orc, golden):
+    g = golden("desc_match_hw9.npz")
+    a, b = g["desc_src"], g["desc_tgt"]
+    pairs, dist = orc.match_inter_f32(a, b, 0.0)
+    s2t, ds = orc.nn1_dim_f32(b, a)
+    t2s, _ = orc.nn1_dim_f32(a, b)
+    mutual = [(s, int(s2t[s])) for s in range(a.shape[0]) if t2s[s2t[s]] == s]
+    assert sorted(map(tuple, pairs.tolist())) == sorted(mutual) and (np.diff(dist) >= 0).all()
+    assert np.array_equal(dist, ds[pairs[:, 0]])
+    half, _ = orc.match_inter_f32(a, b, 0.5)
+    assert half.shape[0] == int(np.floor(np.float32(0.5) * np.float32(len(mutual)))) and np.array_equal(half, pairs[: half.shape[0]])
+    assert len(mutual) > 300                                          # the planted noisy copies find each other
+
+
 def test_sample_quads_host_logic(pcr):
     src, tgt, dsrc, dtgt, R, t = scene(3, 300, 300, 150)
     rng = np.random.default_rng(0)
@@ -183,6 +197,21 @@ def test_gpu_match_union_equals_oracle(pcr, orc, golden, rate):
             pairs, dist = ctx.match_union(a, b, rate)
             op, od = orc.match_union_f32(a, b, rate)
             assert np.array_equal(pairs, op) and np.array_equal(dist.view(np.uint32), od.view(np.uint32))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate", [0.5, 0.0, 0.9])
+def test_gpu_match_inter_equals_oracle(pcr, orc, golden, rate):
+    g = golden("desc_match_hw9.npz")
+    ctx = pcr.Context(0)
+    try:
+        for a, b in ((g["desc_src"], g["desc_tgt"]), scene(6)[2:4]):
+            pairs, dist = ctx.match_inter(a, b, rate)
+            op, od = orc.match_inter_f32(a, b, rate)
+            assert np.array_equal(pairs, op) and np.array_equal(dist.view(np.uint32), od.view(np.uint32))
+        assert ctx.match_inter(g["desc_src"], np.zeros((0, 33), np.float32), 0.5)[0].shape[0] == 0
     finally:
         ctx.close()
 

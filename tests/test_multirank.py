@@ -45,11 +45,12 @@ def test_sharded_icp_two_ranks_one_gpu():
 
 
 @pytest.mark.gpu
-def test_sharded_icp_five_ranks_one_gpu():
-    """uneven shards (20 000 / 5 is even, the empty-shard leg is not): five ranks share the one GPU over gloo — still within
-    the 6-process limit of the GPU box; the pose must be identical on every rank and equal to the single-rank pose."""
-    out = run_workers("gpu", 5, timeout=600)
-    assert out.count("gpu sharded icp ok") == 5
+def test_sharded_icp_four_ranks_one_gpu():
+    """uneven shards (20 003 points over 4 ranks): four ranks share the one GPU over gloo.  The GPU box allows 6 processes
+    on the card and the pytest process itself holds it too, so 4 workers is the safe maximum here.  The pose must be
+    identical on every rank and equal to the single-rank pose."""
+    out = run_workers("gpu", 4, timeout=600)
+    assert out.count("gpu sharded icp ok") == 4
 
 
 @pytest.mark.gpu
