@@ -98,6 +98,15 @@ def main():
         ctx.comm_destroy()
         T4, st4 = ctx.icp_point2point(full, ct, max_corr=1.0, max_iter=3, eps=1e-8)
         assert np.linalg.norm(T3.astype(np.float64) - T4.astype(np.float64)) <= 1e-6 and st3["last_pairs"] == st4["last_pairs"]
+        # the point-to-plane sibling shards the same way (one all-reduce of 29 f64 per iteration); any normal field will do
+        nrm = tgt / np.maximum(np.linalg.norm(tgt, axis=0, keepdims=True), 1e-6)
+        cn = ctx.cloud(np.ascontiguousarray(nrm.astype(np.float32)))
+        P1, ps1 = ctx.icp_point2plane(full, ct, cn, max_corr=1.0, max_iter=5, eps=0.0)
+        ctx.comm_init_callback(world, rank, allreduce)
+        P2, ps2 = ctx.icp_point2plane(cs, ct, cn, max_corr=1.0, max_iter=5, eps=0.0)
+        ctx.comm_destroy()
+        assert ps1["iters_run"] == ps2["iters_run"] == 5 and ps1["last_pairs"] == ps2["last_pairs"], (ps1, ps2)
+        assert np.linalg.norm(P1.astype(np.float64) - P2.astype(np.float64)) <= 1e-6
         ctx.close()
         print(f"rank {rank}: gpu sharded icp ok")
     dist.barrier()
