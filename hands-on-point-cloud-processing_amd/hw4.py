@@ -4,6 +4,7 @@ Mirrors (same names, argument meaning and return values):
   estimate_plane_params   Homework4/ground_detection_ransac.py:158-169   (host, f64; 3 points)
   my_ransac               Homework4/ground_detection_ransac.py:104-155
   ransac_on_segments      Homework4/ground_detection_ransac.py:54-73
+  ransac_on_segments_v2   Homework4/ground_detection_ransac.py:76-101
   extract_initial_seeds   Homework4/ground_detection_SVD.py:46-71        (GPU: radix-select of the lowest z, pcr_ground_seeds_f64)
   ground_detection        Homework4/ground_detection_SVD.py:88-101       (GPU: pcr_ground_detection_f64, PCA refit loop)
   ground_detection_on3segs  Homework4/ground_detection_SVD.py:104-126
@@ -119,3 +120,20 @@ def ransac_on_segments(ctx, data: np.ndarray, segment_x=0, max_iteration=40, thr
     idx1, _ = my_ransac(ctx, data[fwd], total[fwd], max_iteration, threshold, rng)
     idx2, _ = my_ransac(ctx, data[np.logical_not(fwd)], total[np.logical_not(fwd)], max_iteration, threshold, rng)
     return np.r_[idx1, idx2]
+
+
+def ransac_on_segments_v2(ctx, data: np.ndarray, segments_num=5, max_iteration=40, threshold=0.15, rng=None):
+    """ground_detection_ransac.py:76-101: RANSAC on `segments_num` uniform x-segments (open intervals, as written)."""
+    total = np.array(range(data.shape[0]))
+    x_min, x_max = np.min(data[:, 0]), np.max(data[:, 0])
+    seg_bound = x_min + np.array(range(segments_num + 1)) * ((x_max - x_min) / segments_num)
+    stacked = np.empty(0, dtype=int)
+    for i in range(segments_num):
+        flt = np.logical_and(data[:, 0] < seg_bound[i + 1], data[:, 0] > seg_bound[i])
+        if not flt.any():
+            continue
+        idx, _ = my_ransac(ctx, data[flt], total[flt], max_iteration, threshold, rng)
+        if idx is None:
+            continue
+        stacked = np.r_[stacked, idx]
+    return stacked

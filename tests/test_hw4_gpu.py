@@ -38,6 +38,8 @@ def test_my_ransac_matches_oracle_procedure(pcr, orc, synth):
         assert got_idx.size > 30000
         both = hw4.ransac_on_segments(ctx, scan, rng=np.random.default_rng(3))
         assert both.size > 30000 and np.unique(both).size == both.size
+        five = hw4.ransac_on_segments_v2(ctx, scan, rng=np.random.default_rng(4))
+        assert five.size > 30000 and np.unique(five).size == five.size and (np.abs(scan[five, 2] + 1.73) < 0.6).mean() > 0.97
     finally:
         ctx.close()
 
