@@ -42,7 +42,7 @@ def build(ref: bool = True) -> None:
 def lib():
     global _ORC
     if _ORC is None:
-        path = os.path.join(_HERE, "liborc.so")
+        path = os.environ.get("ORC_LIB_PATH") or os.path.join(_HERE, "liborc.so")   # override: the sanitizer build (make sanitize)
         if not os.path.exists(path):
             build(ref=False)
         L = C.CDLL(path)
