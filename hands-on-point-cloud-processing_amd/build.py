@@ -73,5 +73,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+def build_host_sanitized(out_dir: str) -> str:
+    """ASan + UBSan on the HOST side only (-Xarch_host; GPU sanitizers are not available on the pool): a second library
+    for running the host-logic tests on the CPU:
+        PCR_LIB_PATH=<out>/libpcr_hip_san.so ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 \
+        LD_PRELOAD=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so) \
+        python -m pytest tests -m "not gpu" --deselect tests/test_abi.py::test_header_is_plain_c_and_links_from_c"""
+    os.makedirs(out_dir, exist_ok=True)
+    cc = hipcc()
+    san = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-sanitize-recover=undefined"]
+    flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g"] + san
+    objs = []
+    for s in SOURCES:
+        obj = os.path.join(out_dir, s + ".o")
+        r = subprocess.run([cc, *flags, "-c", os.path.join(CSRC, s), "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")
+        objs.append(obj)
+    out = os.path.join(out_dir, "libpcr_hip_san.so")
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-o", out, *objs, "-ldl"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
+    if "--sanitize-host" in sys.argv:
+        print(build_host_sanitized(sys.argv[sys.argv.index("--sanitize-host") + 1]))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
