@@ -111,3 +111,84 @@ def test_plane_count_and_ground_seeds_randomised(pcr, orc):
             assert np.array_equal(mask, omask.astype(bool)) and (ub == oub or (np.isnan(ub) and np.isnan(oub))), (trial, "seeds", n, lpr)
     finally:
         ctx.close()
+
+
+def test_db64_radius_and_knn_grid_routes_randomised(pcr, orc):
+    """the drop-in f64 entry points with the grid routes forced, on random f32-representable clouds (far queries, ties,
+    clusters): CSR rows / neighbour lists and distance bits must equal the exhaustive kernels'."""
+    rng = np.random.default_rng(505)
+    ctx = pcr.Context(0)
+    try:
+        for trial in range(30):
+            kind = trial % 3
+            n, m = int(rng.integers(4096, 9000)), int(rng.integers(1, 400))     # >= 4096: the f32 twin exists
+            db32 = random_cloud32(rng, n, kind)
+            q32 = random_cloud32(rng, m, kind if trial % 4 else (kind + 1) % 3)
+            if trial % 3 == 0:
+                q32[:, : m // 2] = db32[:, : m // 2]
+            db, q = np.ascontiguousarray(db32.T.astype(np.float64)), np.ascontiguousarray(q32.T.astype(np.float64))
+            h = ctx.db64(db)
+            ext = float(np.ptp(db, axis=0).max()) + 1e-12
+            r = float(rng.uniform(0.005, 0.2) * ext)
+            k = int(rng.integers(1, 33))
+            res = {}
+            for meth in (1, 2):
+                ctx.tune("radius_method", meth); ctx.tune("knn_method", meth)
+                res[meth] = (h.radius(q, r), h.knn(q, k), h.knn(q, k, squared=True))
+            for a, b in zip(res[1], res[2]):
+                for x, y in zip(a, b):
+                    assert np.array_equal(x.view(np.uint64) if x.dtype == np.float64 else x, y.view(np.uint64) if y.dtype == np.float64 else y), (trial, kind, n, m, r, k)
+            h.free()
+        ctx.tune("radius_method", 0); ctx.tune("knn_method", 0)
+    finally:
+        ctx.close()
+
+
+def test_descriptor_matching_randomised(pcr, orc):
+    rng = np.random.default_rng(606)
+    ctx = pcr.Context(0)
+    try:
+        for trial in range(30):
+            dim = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 33, 34, 64, 100]))
+            ns, nt = int(rng.integers(1, 900)), int(rng.integers(1, 900))
+            a = rng.gamma(0.7, 1.0, (ns, dim)).astype(np.float32)
+            b = rng.gamma(0.7, 1.0, (nt, dim)).astype(np.float32)
+            if trial % 2 == 0:
+                kk = min(ns, nt) // 2
+                b[:kk] = a[:kk]                                                 # exact matches and, below, duplicates
+                a[-(kk // 2 + 1):] = a[: kk // 2 + 1]
+            rate = float(rng.choice([0.0, 0.3, 0.5, 0.95]))
+            for fn_g, fn_o in ((ctx.match_union, orc.match_union_f32), (ctx.match_inter, orc.match_inter_f32)):
+                pg, dg = fn_g(a, b, rate)
+                po, do = fn_o(a, b, rate)
+                assert np.array_equal(pg, po) and np.array_equal(dg.view(np.uint32), do.view(np.uint32)), (trial, dim, ns, nt, rate, fn_o.__name__)
+    finally:
+        ctx.close()
+
+
+def test_icp_variants_randomised(pcr, orc, synth):
+    """point-to-point and point-to-plane loops on small random pairs: pose within 1e-5 of the oracle, identical statistics."""
+    rng = np.random.default_rng(707)
+    ctx = pcr.Context(0)
+    try:
+        for trial in range(12):
+            n = int(rng.integers(200, 2500))
+            src, tgt = synth.kitti_like_pair(n, seed_target=int(rng.integers(1, 1 << 30)), seed_pair=int(rng.integers(1, 1 << 30)))
+            nrm = tgt / np.maximum(np.linalg.norm(tgt, axis=0, keepdims=True), 1e-6)
+            nrm = np.ascontiguousarray(nrm.astype(np.float32))
+            mc = float(rng.choice([0.05, 0.5, 1.0, 4.0]))
+            it = int(rng.integers(1, 25))
+            eps = float(rng.choice([0.0, 1e-8, 1e-3]))
+            cs, ct, cn = ctx.cloud(src), ctx.cloud(tgt), ctx.cloud(nrm)
+            ctx.tune("nn_method", 1 + trial % 2)
+            T, st = ctx.icp_point2point(cs, ct, max_corr=mc, max_iter=it, eps=eps)
+            oT, ost = orc.icp_p2p_f32(src, tgt, max_corr=mc, max_iter=it, eps=eps)
+            assert np.linalg.norm(T.astype(np.float64) - oT.astype(np.float64)) <= 1e-5, (trial, n, mc, it, eps)
+            assert (st["iters_run"], st["converged"], st["empty_pairs"], st["last_pairs"]) == (ost["iters_run"], ost["converged"], ost["empty_pairs"], ost["last_pairs"])
+            P, ps = ctx.icp_point2plane(cs, ct, cn, max_corr=mc, max_iter=it, eps=eps)
+            oP, ops = orc.icp_p2plane_f32(src, tgt, nrm, max_corr=mc, max_iter=it, eps=eps)
+            assert np.linalg.norm(P.astype(np.float64) - oP.astype(np.float64)) <= 1e-5, (trial, n, mc, it, eps, "p2plane")
+            assert (ps["iters_run"], ps["converged"], ps["empty_pairs"], ps["last_pairs"]) == (ops["iters_run"], ops["converged"], ops["empty_pairs"], ops["last_pairs"])
+        ctx.tune("nn_method", 0)
+    finally:
+        ctx.close()

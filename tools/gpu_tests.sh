@@ -1,3 +1,3 @@
 set -o pipefail
 mkdir -p gpurun_out
-( timeout -k 10 900 python -m pytest tests/test_hw4_gpu.py -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -12 gpurun_out/pytest_gpu.log; [ $rc -eq 0 ] )
+( timeout -k 10 900 python -m pytest tests/test_random_sweeps.py -m gpu -q -x --durations=5 > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -25 gpurun_out/pytest_gpu.log; [ $rc -eq 0 ] )
