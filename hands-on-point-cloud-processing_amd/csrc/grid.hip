@@ -246,6 +246,30 @@ __device__ __forceinline__ void x_window(float qx, float bound2, float& lo, floa
     hi = qx + d + pad;
 }
 
+// The nine row ranges of stage 1 as ONE flattened index space: lane l takes candidates l, l + G, ... of the concatenation.
+// Rows are short (1-4 trips of G lanes each), so scanning them one after the other leaves a single load in flight per
+// lane; flattened, consecutive trips are independent and the unrolled loop keeps four loads in flight.
+template <int G>
+__device__ __forceinline__ void scan_flat9(const float4* __restrict__ records, const uint32_t (&rb)[9], const uint32_t (&re)[9], int l,
+                                           float qx, float qy, float qz, unsigned long long& best)
+{
+    uint32_t off[10], delta[9];
+    off[0] = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { off[k + 1] = off[k] + (re[k] - rb[k]); delta[k] = rb[k] - off[k]; }
+#pragma unroll 4
+    for (uint32_t f = (uint32_t)l; f < off[9]; f += G) {
+        uint32_t p = f + delta[0];
+#pragma unroll
+        for (int k = 1; k < 9; k++) p = f >= off[k] ? f + delta[k] : p;
+        const float4 rec = records[p];
+        const float dx = qx - rec.x, dy = qy - rec.y, dz = qz - rec.z;
+        const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);   // A1, unfused
+        const unsigned long long key = ((unsigned long long)d << 32) | __float_as_uint(rec.w);
+        if (d < 0x7F7FFFFFu && key < best) best = key;
+    }
+}
+
 template <int G>
 __device__ __forceinline__ unsigned long long group_min(unsigned long long v)
 {
@@ -335,8 +359,12 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                     }
                 }
             }
+            if (CLIP) {
+                scan_flat9<G>(records, rb, re, l, qx, qy, qz, best);      // dense rows: 8.1 -> 6.9 ms at 10 M (costs 15 % at 120 k)
+            } else {
 #pragma unroll
-            for (int k = 0; k < 9; k++) scan_range<G>(records, rb[k], re[k], l, qx, qy, qz, best);
+                for (int k = 0; k < 9; k++) scan_range<G>(records, rb[k], re[k], l, qx, qy, qz, best);
+            }
             if (STATS && l == 0) { for (int k = 0; k < 9; k++) st_cand += re[k] - rb[k]; st_rows += 9; }
             best = group_min<G>(best);
             const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
