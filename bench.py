@@ -111,7 +111,8 @@ def main():
     # path on a box with fewer GPUs (ranks then share devices and the collective runs over gloo / torch.distributed)
     backend = os.environ.get("PCR_BENCH_BACKEND", "nccl")
     n_dev = max(torch.cuda.device_count(), 1)
-    if backend == "nccl" and world > n_dev:
+    masked = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"))
+    if backend == "nccl" and world > n_dev and not masked:     # a launcher that masks one GPU per rank shows 1 device to each rank: fine
         raise SystemExit(f"{world} ranks but {n_dev} GPU(s): RCCL needs one GPU per rank (PCR_BENCH_BACKEND=gloo rehearses)")
     device_index = local_rank % n_dev
     dist = None
