@@ -101,7 +101,7 @@ int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool re
     // nn_method: 0 auto (grid for targets >= 2048 points), 1 brute force, 2 uniform grid
     const int64_t method = tune_get(ctx, "nn_method", 0);
     const bool grid = method == 2 || (method != 1 && tgt->n >= 2048);
-    return grid ? launch_nn1_grid(ctx, tgt, src, reuse_perm) : launch_nn1_brute(ctx, tgt, src);
+    return grid ? launch_nn1_grid(ctx, tgt, src, reuse_perm) : launch_nn1_brute(ctx, tgt, src, reuse_perm);
 }
 
 static int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out)
@@ -287,6 +287,7 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
     if (!c) return PCR_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (ctx && ctx->qperm_src == c) ctx->qperm_src = nullptr;
+    if (ctx && ctx->keys_src == c) { ctx->keys_src = nullptr; ctx->keys_warm = false; }
     cloud_modified(c);
     if (c->base) hipFree(c->base);
     delete c;

@@ -101,6 +101,40 @@ __global__ __launch_bounds__(GR_BLOCK) void record_keys_kernel(const float* __re
     vals[i] = i;
 }
 
+// one thread per chunk of GRID_CHUNK consecutive records: centre = mean of the finite ones, then the shifted copy (Grid::chunks)
+__global__ __launch_bounds__(GR_BLOCK) void build_chunks_kernel(const float4* __restrict__ records, uint32_t n, uint32_t n_chunks, float* __restrict__ chunks,
+                                                                int* __restrict__ unsafe)
+{
+    const uint32_t c = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (c >= n_chunks) return;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    int cnt = 0;
+    for (int j = 0; j < GRID_CHUNK; j++) {
+        const uint32_t p = c * GRID_CHUNK + j;
+        if (p >= n) break;
+        const float4 r = records[p];
+        if (finite3(r.x, r.y, r.z)) { cx += r.x; cy += r.y; cz += r.z; cnt++; }
+    }
+    if (cnt) { cx /= (float)cnt; cy /= (float)cnt; cz /= (float)cnt; }
+    bool bad = !finite3(cx, cy, cz) || fabsf(cx) > 1e18f || fabsf(cy) > 1e18f || fabsf(cz) > 1e18f;
+    float* out = chunks + (size_t)c * GRID_CHUNK_FLOATS;
+    out[0] = cx; out[1] = cy; out[2] = cz; out[3] = 0.f;
+    for (int j = 0; j < GRID_CHUNK; j++) {
+        const uint32_t p = c * GRID_CHUNK + j;
+        float tx = 0.f, ty = 0.f, tz = 0.f, w = INFINITY;                  // padding / non-finite: never the minimum
+        if (p < n) {
+            const float4 r = records[p];
+            if (finite3(r.x, r.y, r.z)) {
+                tx = r.x - cx; ty = r.y - cy; tz = r.z - cz;
+                w = ((tx * tx + ty * ty) + tz * tz) * 0.999996185302734375f;   // (1 - 2^-18): see the error analysis in nn1_brute.hip
+                if (!(fabsf(tx) < 1e18f && fabsf(ty) < 1e18f && fabsf(tz) < 1e18f) || !(w < 3e38f)) bad = true;
+            }
+        }
+        out[4 + 4 * j] = tx; out[5 + 4 * j] = ty; out[6 + 4 * j] = tz; out[7 + 4 * j] = w;
+    }
+    if (bad) atomicOr(unsafe, 1);
+}
+
 __global__ __launch_bounds__(GR_BLOCK) void gather_records_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                                   uint32_t n, const uint32_t* __restrict__ order, float4* __restrict__ records)
 {
@@ -498,6 +532,7 @@ int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n
 void grid_free(Grid* g)
 {
     if (!g) return;
+    if (g->chunks) hipFree(g->chunks);
     if (g->records) hipFree(g->records);
     if (g->cell_start) hipFree(g->cell_start);
     delete g;
@@ -622,9 +657,24 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge)
         if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "radix sort(grid)", e); }
         hipLaunchKernelGGL(gather_records_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)n, v_out, g->records);
     }
+    // chunked, centred copy for the expanded-form brute-force filter (17 B per point)
+    g->n_chunks = (n + GRID_CHUNK - 1) / GRID_CHUNK;
+    int* unsafe_dev = (int*)count;                                  // the histogram is no longer needed
+    int unsafe_host = 1;
+    if (g->n_chunks) {
+        e = hipMalloc((void**)&g->chunks, g->n_chunks * GRID_CHUNK_FLOATS * sizeof(float));
+        if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "hipMalloc(grid chunks)", e); }
+        e = hipMemsetAsync(unsafe_dev, 0, 4, ctx->stream);
+        if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "memset(grid)", e); }
+        hipLaunchKernelGGL(build_chunks_kernel, dim3((unsigned)((g->n_chunks + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records, (uint32_t)n,
+                           (uint32_t)g->n_chunks, g->chunks, unsafe_dev);
+        e = hipMemcpyAsync(&unsafe_host, unsafe_dev, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "grid chunks", e); }
+    }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the scratch is reused by the caller right away
     if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "grid build", e); }
+    g->chunk_safe = g->n_chunks != 0 && unsafe_host == 0;
     *out = g;
     return PCR_OK;
 }
@@ -712,8 +762,9 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         stats_dev = ctx->grid_stats_dev;
     }
     // warm start: only inside an ICP loop (reuse_perm), from its second search on, when keys[] belongs to this source
-    const int warm = (reuse_perm && have_perm && ctx->keys_warm && tune_get(ctx, "grid_warm_start", 1) > 0) ? 1 : 0;
+    const int warm = (reuse_perm && have_perm && ctx->keys_warm && ctx->keys_src == src && tune_get(ctx, "grid_warm_start", 1) > 0) ? 1 : 0;
     ctx->keys_warm = reuse_perm;
+    ctx->keys_src = src;
     // x-window clipping of long rows: 14.1 -> 8.1 ms per search at 10 M x 10 M and 20.9 -> 15.9 ms per ICP iteration there
     // (1 277 -> 462 candidates per query); on sparse clouds the extra phase costs ~25 % (38 -> 48 us at 120 k), so the
     // plain kernel serves small targets.  Same box, same call: profiles/r01_c5_10M_single_gpu.txt.

@@ -25,8 +25,9 @@
 //    slices merge through one 64-bit atomicMin per query on key = d2_bits << 32 | idx, which implements
 //    "min d2, then lowest index" exactly and independently of arrival order.
 // The kernel is VALU-bound: 9 algorithmic lane-ops per (query, target) pair.
-#include "pcr_internal.hpp"
+#include "grid_common.hpp"
 
+#include <algorithm>
 #include <cfloat>
 
 #pragma clang fp contract(off)
@@ -273,6 +274,139 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ftrack_kernel(
     }
 }
 
+// ---- ETRACK: the filter in EXPANDED form on chunk-centred targets: 3 FMAs per pair instead of 3 subtractions + 3 (mul / fma).
+// The target is taken in the cell-sorted order of its grid index (grid.hip), 16 consecutive = spatially neighbouring points
+// per chunk, stored relative to the chunk centre C:  t'' = fl(t - C),  w = fl(|t''|^2) (1 - 2^-18)   (Grid::chunks).
+// Per (query, chunk):  r = fl(q - C),  a = -2 r,  R = fl(|r|^2);  per pair  g = fma(ax, t''x, fma(ay, t''y, fma(az, t''z, w))).
+// In real arithmetic |q - t|^2 = |r|^2 + |t''|^2 - 2 r.t''.  With u = 2^-24, Q = |r|^2, W = |t''|^2 (of the float vectors):
+//   rounding of g                      <= 3.1 u (2 W + Q)        (three nested FMAs, partial results <= W + 2 |r||t''| <= 2 W + Q)
+//   w vs W                             <= 3 u W
+//   r, t'' vs the true q - C, t - C    |D - |r - t''|^2| <= 4 u (Q + W)         (D = true squared distance)
+//   exact A1 value d2 vs D             d2 >= D (1 - 5 u),  D <= 2 (Q + W)
+//   R vs Q, the final fma              <= 3 u Q,  <= 2 u (Q + W)
+// Sum: d2 >= Q (1 - 22.1 u) + g_real - 25.2 u W.  The stored w carries (1 - 2^-18) = 1 - 64 u and R is scaled by
+// KAPPA = 1 - 2^-19 = 1 - 32 u, so   L = fma(R, KAPPA, g)  <=  d2   for EVERY target (absolute slack 1e-30 for underflow).
+// Per query the loop tracks, branch-free, m1 = smallest chunk value min_j L, c1 = the first chunk attaining it, m2 = the smallest
+// over all other chunks.  After the scan the 16 targets of c1 are evaluated with the exact A1 arithmetic (original coordinates
+// from the grid records) -> (e, index);  m2 - 1e-30 > e  proves that every target outside c1 is strictly farther: the answer is
+// exact and canonical.  Otherwise the wave rescans its slice exactly.  Chunk radius ~ 0.2 m keeps the absolute error of L
+// around 1e-7 m^2, far below the gap between the nearest and the next candidates of a LiDAR scan.
+// Cost: 3 FMAs + (3 sub + 3 mul + 3 (mul/fma) + 1 fma) / 16 + min tree + tracking ~ 4.4 lane-ops per pair (FTRACK: 7.1).
+template <int QPL>
+__global__ __launch_bounds__(NN_BLOCK) void nn1_etrack_kernel(
+    const float* __restrict__ chunks, const float4* __restrict__ records, uint32_t nt, uint32_t n_chunks, uint32_t chunks_per_slice,
+    const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
+    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop, unsigned long long* __restrict__ stats)
+{
+    if (stop && (stop[0] | stop[1])) return;
+    constexpr int CH = 16;
+    constexpr float KAPPA = 0.99999809265136718750f;          // 1 - 2^-19
+    const uint32_t tid = threadIdx.x;
+    const uint32_t qbase = blockIdx.x * (NN_BLOCK * QPL);
+    float qx[QPL], qy[QPL], qz[QPL], m1[QPL], m2[QPL];
+    uint32_t c1[QPL];
+    bool okq[QPL];
+#pragma unroll
+    for (int k = 0; k < QPL; k++) {
+        const uint32_t i = min(qbase + k * NN_BLOCK + tid, ns - 1);
+        qx[k] = sx[i]; qy[k] = sy[i]; qz[k] = sz[i];
+        okq[k] = fabsf(qx[k]) < 1e18f && fabsf(qy[k]) < 1e18f && fabsf(qz[k]) < 1e18f;      // false for NaN / inf
+        m1[k] = INFINITY; m2[k] = INFINITY; c1[k] = 0xFFFFFFFFu;
+    }
+    const uint32_t cb = blockIdx.y * chunks_per_slice, ce = min(cb + chunks_per_slice, n_chunks);
+    for (uint32_t c = cb; c < ce; c++) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(chunks + (size_t)c * (4 + 4 * CH));   // wave-uniform: scalar loads
+        const float4 C = p[0];
+        float4 T[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) T[j] = p[1 + j];
+#pragma unroll
+        for (int k = 0; k < QPL; k++) {
+            const float rx = qx[k] - C.x, ry = qy[k] - C.y, rz = qz[k] - C.z;
+            const float ax = -2.0f * rx, ay = -2.0f * ry, az = -2.0f * rz;
+            const float R = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
+            float g[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) g[j] = __builtin_fmaf(ax, T[j].x, __builtin_fmaf(ay, T[j].y, __builtin_fmaf(az, T[j].z, T[j].w)));
+            float m = fminf(fminf(g[0], g[1]), g[2]);
+#pragma unroll
+            for (int j = 3; j + 1 < CH; j += 2) m = fminf(fminf(m, g[j]), g[j + 1]);
+            m = fminf(m, g[CH - 1]);
+            const float L = __builtin_fmaf(R, KAPPA, m);
+            m2[k] = fminf(m2[k], fmaxf(m1[k], L));             // smallest chunk value among the chunks that are not c1
+            const bool better = L < m1[k];
+            m1[k] = fminf(m1[k], L);
+            c1[k] = better ? c : c1[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < QPL; k++) {
+        uint32_t best = 0x7F7FFFFFu, bidx = 0xFFFFFFFFu;      // FLT_MAX gate, nanoflann.hpp:163,1360
+        bool proven = false;
+        // The other slices of this query publish their results through keys[] as they finish.  Whatever is there now is an upper
+        // bound of the final answer (the key only ever decreases; a stale read is merely less helpful): a slice whose every
+        // target is provably farther than that bound (m1 = min L <= every d2 of the slice) cannot win or tie and is done;
+        // likewise "every chunk but c1 is farther than the bound" (m2) settles the slice with c1's exact result alone.
+        float cur = INFINITY;
+        {
+            const uint32_t iq = min(qbase + k * NN_BLOCK + tid, ns - 1);
+            if (merge_atomic) cur = __uint_as_float((uint32_t)(__atomic_load_n(&keys[iq], __ATOMIC_RELAXED) >> 32));   // read NOW, not hoisted; 0xFFFFFFFF (nothing yet) = NaN: no claim
+        }
+        const bool slice_out = okq[k] && (m1[k] - 1e-30f) > cur;
+        if (!slice_out && okq[k] && c1[k] != 0xFFFFFFFFu) {
+            const uint32_t j0 = c1[k] * CH;
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                if (j0 + j < nt) {
+                    const float4 rec = records[j0 + j];                                  // original coordinates + original index
+                    const uint32_t e = d2_exact_bits(qx[k], qy[k], qz[k], rec.x, rec.y, rec.z);
+                    const uint32_t oi = __float_as_uint(rec.w);
+                    if (e < best || (e == best && e < 0x7F7FFFFFu && oi < bidx)) { best = e; bidx = oi; }
+                }
+            }
+            proven = (bidx != 0xFFFFFFFFu && (m2[k] - 1e-30f) > __uint_as_float(best)) || (m2[k] - 1e-30f) > cur;
+        }
+        if (!__all(proven || slice_out || cb >= ce)) {
+            if (stats && (tid & 63) == 0) atomicAdd(&stats[2], 1ull);          // diagnostics: (wave, query slot) pairs that had to rescan
+            // exact rescan of the slice (the whole wave: lanes that were proven get the same answer); the records are not in index
+            // order, so the canonical rule needs the lexicographic (d2, index) minimum
+            unsigned long long kbest = ~0ull;
+            for (uint32_t j = cb * CH; j < min(ce * CH, nt); j++) {
+                const float4 rec = records[j];
+                const uint32_t e = d2_exact_bits(qx[k], qy[k], qz[k], rec.x, rec.y, rec.z);
+                const unsigned long long key = ((unsigned long long)e << 32) | __float_as_uint(rec.w);
+                if (e < 0x7F7FFFFFu && key < kbest) kbest = key;
+            }
+            best = (uint32_t)(kbest >> 32);
+            bidx = kbest == ~0ull ? 0xFFFFFFFFu : (uint32_t)(kbest & 0xFFFFFFFFull);
+        }
+        const uint32_t i = qbase + k * NN_BLOCK + tid;
+        if (i < ns) {
+            const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : best;
+            const unsigned long long key = ((unsigned long long)bits << 32) | bidx;
+            if (merge_atomic) atomicMin(&keys[i], key);
+            else keys[i] = key;
+        }
+    }
+}
+
+// ICP iterations after the first: the previous correspondence, re-evaluated exactly against the moved query, is a genuine
+// candidate and therefore an upper bound of the new answer from the first instruction on (ETRACK settles every far slice with it).
+__global__ __launch_bounds__(NN_BLOCK) void nn1_seed_kernel(const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, uint32_t nt,
+                                                            const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
+                                                            unsigned long long* __restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * NN_BLOCK + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t j = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+    unsigned long long key = ~0ull;
+    if (j < nt) {
+        const uint32_t e = d2_exact_bits(sx[i], sy[i], sz[i], tx[j], ty[j], tz[j]);
+        if (e < 0x7F7FFFFFu) key = ((unsigned long long)e << 32) | j;                   // FLT_MAX gate, nanoflann.hpp:163,1360
+    }
+    keys[i] = key;
+}
+
 // keys -> (idx, d2) split for the host-facing API
 __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, uint32_t n,
                                   uint32_t* __restrict__ idx, float* __restrict__ d2)
@@ -315,21 +449,82 @@ static void launch_ftrack(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt
 #undef PCR_FTRACK
 }
 
-int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
+int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool in_loop)
 {
     const size_t ns = src->n;
     if (ns == 0) { ctx->keys_n = 0; return PCR_OK; }
     if (ns > 0xFFFFFFF0ull || tgt->n > 0xFFFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "cloud too large for u32 indices");
+    // keys[] still holds this source's correspondences of the previous ICP iteration?
+    const bool warm = in_loop && ctx->keys_warm && ctx->keys_src == src && ctx->keys_n == ns && tune_get(ctx, "nn1_warm_start", 1) == 1;
     int rc = ensure_keys(ctx, ns);
     if (rc) return rc;
     ctx->keys_n = ns;
-    ctx->keys_warm = false;
+    ctx->keys_warm = in_loop;
+    ctx->keys_src = src;
 
     int qpl = (int)tune_get(ctx, "nn1_qpl", 2);
     if (qpl != 1 && qpl != 4) qpl = 2;
+    // variant 4 = ETRACK: needs the target's grid index (cell-sorted records + the chunked, centred copy)
+    // nn1_variant unset: FTRACK for a cold search, ETRACK when a warm-start bound exists (measured: ETRACK needs the bound to
+    // settle the far slices, profiles/r01_tune_nn1_etrack.txt); 4 forces ETRACK, 1-3 the kernels below
+    const int64_t variant_tune = tune_get(ctx, "nn1_variant", 0);
+    if (variant_tune == 4 || (variant_tune == 0 && warm && tgt->n >= 2048)) {
+        if (!tgt->grid) {
+            Grid* g = nullptr;
+            ProfScope p(ctx, "grid_build");
+            rc = grid_build(ctx, tgt, &g, 0.0);
+            if (rc) return rc;
+            const_cast<pcr_cloud*>(tgt)->grid = g;
+        }
+        const Grid* g = tgt->grid;
+        if (g->chunk_safe && g->n_chunks) {
+            // queries per lane: the filter is bound by the scalar operand path (272 B per chunk per wave), more queries per lane
+            // amortise it — measured: profiles/r01_tune_nn1_etrack.txt
+            int eq = (int)tune_get(ctx, "nn1_etrack_qpl", 4);
+            if (eq != 1 && eq != 2 && eq != 8) eq = 4;
+            const uint32_t qblocks = (uint32_t)((ns + (size_t)NN_BLOCK * eq - 1) / ((size_t)NN_BLOCK * eq));
+            int64_t cps = tune_get(ctx, "nn1_chunks_per_slice", 0);
+            if (cps <= 0) {
+                const int64_t want_blocks = tune_get(ctx, "nn1_etrack_blocks", 32768);
+                const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
+                cps = std::max<int64_t>(1, ((int64_t)g->n_chunks + slices - 1) / slices);
+            }
+            uint32_t slices = (uint32_t)((g->n_chunks + cps - 1) / cps);
+            if (slices > 65535) { slices = 65535; cps = (g->n_chunks + slices - 1) / slices; slices = (uint32_t)((g->n_chunks + cps - 1) / cps); }
+            const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
+            if (warm)
+                hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
+                                   (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
+            else if (merge_atomic)
+                PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
+            const dim3 grid(qblocks, slices);
+            unsigned long long* stats_dev = nullptr;
+            if (tune_get(ctx, "grid_stats", 0) > 0) {          // diagnostics: slot 2 counts the exact rescans of this launch
+                if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
+                PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
+                stats_dev = ctx->grid_stats_dev;
+            }
+            {
+                ProfScope p(ctx, "nn1_brute", 1);
+#define PCR_ETRACK(Q)                                                                                                                   \
+    hipLaunchKernelGGL((nn1_etrack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->chunks, g->records, (uint32_t)tgt->n, (uint32_t)g->n_chunks, \
+                       (uint32_t)cps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev)
+                switch (eq) {
+                case 1: PCR_ETRACK(1); break;
+                case 2: PCR_ETRACK(2); break;
+                case 8: PCR_ETRACK(8); break;
+                default: PCR_ETRACK(4); break;
+                }
+#undef PCR_ETRACK
+            }
+            PCR_HIP(ctx, hipGetLastError());
+            return PCR_OK;
+        }
+        // non-finite or astronomically large coordinates: the exact-filter kernels below handle them
+    }
     // variant: 1 = FTRACK (default: fused-filter tracking + exact decision, targets through the scalar cache);
     //          2 = TRACK (exact arithmetic only, scalar cache); 3 (or any other value) = TRACK with targets through LDS tiles
-    const int variant = (int)tune_get(ctx, "nn1_variant", 1);   // default FTRACK: fastest measured (profiles/r01_tune_nn1_ftrack.txt)
+    const int variant = variant_tune == 0 ? 1 : (int)variant_tune;   // cold default FTRACK: fastest measured (profiles/r01_tune_nn1_ftrack.txt)
     const int chunk = (int)tune_get(ctx, "nn1_chunk", 16);
     const uint32_t n_tiles = (uint32_t)((tgt->n + NN_TILE - 1) / NN_TILE);
     const uint32_t qblocks = (uint32_t)((ns + (size_t)NN_BLOCK * qpl - 1) / ((size_t)NN_BLOCK * qpl));

@@ -76,6 +76,7 @@ struct pcr_ctx {
     size_t keys_cap = 0;
     size_t keys_n = 0;
     bool keys_warm = false;               // keys[] holds the previous ICP iteration's result for the same source cloud
+    const pcr_cloud* keys_src = nullptr;  // ... which is this one (identity only; reset when the cloud is destroyed)
     uint32_t* qperm = nullptr;            // queries grouped by target-grid cell (grid NN)
     size_t qperm_cap = 0;
     size_t qperm_n = 0;
@@ -125,7 +126,7 @@ struct ProfScope {
 void prof_flush(pcr_ctx* ctx);
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
-int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
+int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool in_loop);
 int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm);
 // grid radius search with the hw2 contract (radius_grid.hip); *used = false -> the caller runs the exhaustive kernels
 int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r, double r2max, int64_t* row_ptr_host, int32_t* idx_host, double* dist_host,

@@ -38,7 +38,7 @@ def random_cloud32(rng, n, kind):
 
 
 def test_nn1_randomised_sweep_every_kernel(ctx, orc):
-    """120 random problems x {FTRACK, TRACK scalar, TRACK LDS, exact grid}: indices and d2 bits equal to the oracle."""
+    """120 random problems x {FTRACK, TRACK scalar, TRACK LDS, ETRACK, exact grid (both kernels)}: indices and d2 bits equal to the oracle."""
     rng = np.random.default_rng(77)
     for trial in range(120):
         kind = trial % 4
@@ -48,7 +48,7 @@ def test_nn1_randomised_sweep_every_kernel(ctx, orc):
             src[:, : min(ns, nt) // 2] = tgt[:, : min(ns, nt) // 2]
         oi, od = orc.nn1_f32(tgt, src)
         ct, cs = ctx.cloud(tgt), ctx.cloud(src)
-        for method, variant, clip in ((1, 1, 0), (1, 2, 0), (1, 3, 0), (2, 1, 2), (2, 1, 1)):
+        for method, variant, clip in ((1, 1, 0), (1, 2, 0), (1, 3, 0), (1, 4, 0), (2, 1, 2), (2, 1, 1)):
             ctx.tune("nn_method", method)
             ctx.tune("nn1_variant", variant)
             ctx.tune("grid_clip_x", clip)              # 1: the x-window kernel of large targets forced; 2: the plain kernel
@@ -80,7 +80,7 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
 
 # variant 1: FTRACK (default: fused-filter tracking, exact decision); 2: TRACK (exact only), scalar-cache targets; 3: TRACK, LDS tiles
 # (4 exact, 5 fused filter, 6/7 the same with scalar-load targets); chunk = targets per min-tree
-VARIANTS = [(1, 8), (1, 16), (2, 8), (2, 16), (3, 8), (3, 16)]
+VARIANTS = [(1, 8), (1, 16), (2, 8), (2, 16), (3, 8), (3, 16), (4, 16)]   # 4 = ETRACK (expanded-form filter on the grid's chunked target copy)
 
 
 def set_variant(ctx, vc):
