@@ -251,7 +251,8 @@ def main():
             pairs = float(n_q) * float(n_t)
             achieved_tflops = OPS_PER_PAIR * pairs / kern_s / 1e12
             compulsory_bytes = 12.0 * n_t + 12.0 * n_q + 8.0 * n_q        # targets + sources + (idx, d2) key
-            have_pmc = pmc and pmc.get("valu_insts_per_launch") and "ftrack" in pmc.get("kernel", "") and n_q == 120000 == n_t
+            have_pmc = pmc and pmc.get("valu_insts_per_launch") and "etrack" in pmc.get("kernel", "") and n_q == 120000 == n_t
+            default_kernels = not (args.qpl or args.variant)
             roofline = {
                 "bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS_NOFMA, "unit": "TFLOP/s",
                 "frac": achieved_tflops / VALU_PEAK_TFLOPS_NOFMA,
@@ -259,23 +260,26 @@ def main():
                 "traffic_note": ("HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from a separate "
                                  "rocprofv3 --pmc pass of this kernel, " + pmc["source"]) if have_pmc else "not collected",
                 "clock_ghz_profiled": pmc.get("clock_ghz_profiled") if have_pmc else None,
-                "kernel": "pcr::nn1_ftrack_kernel<2, 16> (brute force; targets broadcast through the scalar cache; fused "
-                          "pre-filter tracked branch-free, winner decided with the exact unfused arithmetic)"
-                          if not (args.qpl or args.variant) else f"nn1 variant={args.variant} qpl={args.qpl}",
+                "kernel": ("pcr::nn1_etrack_kernel<4> in every ICP iteration but the first (exhaustive scan; chunk-centred targets "
+                           "broadcast through the scalar cache; expanded-form lower bound, 3 FMAs per pair, tracked branch-free; the "
+                           "winner decided with the exact unfused arithmetic; the previous correspondence seeds the bound), "
+                           "pcr::nn1_ftrack_kernel<2, 16> in the first (no bound yet); avg_launch_ms averages all launches")
+                          if default_kernels else f"nn1 variant={args.variant} qpl={args.qpl}",
                 "executed_lane_ops_per_pair": (pmc["valu_insts_per_launch"] * 64 / pairs) if have_pmc else None,
                 "issue_frac": (pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TFLOPS_NOFMA) if have_pmc else None,
                 "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
                 "algorithmic": f"{OPS_PER_PAIR} f32 lane-ops per (query,target) pair (SURVEY.md 8d) x {pairs:.3e} pairs/launch; "
                                "peak = 157.3 TF/s / 2: one op per lane per issue slot (the exact arithmetic has no FMA). "
-                               "frac can exceed 1 because the kernel needs fewer than 9 issue slots per pair: its hot loop "
-                               "evaluates a fused 6-op filter and only the winning chunk exactly; issue_frac = executed "
-                               "lane-ops (PMC) / time / peak is the share of VALU issue slots actually used",
+                               "frac can exceed 1 because the kernels need fewer than 9 issue slots per pair: the hot loop "
+                               "evaluates a cheaper filter (3 FMAs on chunk-centred targets; fused 6-op form in the cold "
+                               "kernel) and only the winning chunk exactly; issue_frac = executed lane-ops of the warm kernel "
+                               "(PMC) / time / peak is the share of VALU issue slots actually used",
                 "hbm_literal": {"bound": "hbm", "achieved": compulsory_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
                                 "note": "compulsory bytes (32 B/point); brute force is VALU-bound, see DESIGN.md"}}
             workload = ("point-to-point ICP iteration = exhaustive 1-NN correspondence 120k x 120k + Kabsch + transform; BASELINE.json "
-                        "configs[1]/[2] ('LDS-tiled brute force': the default kernel broadcasts the target tiles through the scalar "
-                        "cache, 3-4 % faster than the LDS-tiled variant, which --variant 3 selects; same results)")
+                        "configs[1]/[2] ('LDS-tiled brute force': the default kernels broadcast the target tiles through the scalar "
+                        "cache, faster than the LDS-tiled variant, which --variant 3 selects; same results)")
         else:
             # steady state of the exact grid search: the source at the final pose, a few launches timed with HIP events,
             # one more launch with the diagnostics counters for the algorithmic bytes (SURVEY.md 8d "1-NN exact grid")

@@ -42,6 +42,14 @@ __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
     return min(min(a, b), c);   // -> v_min3_u32
 }
 
+// slice merge: one 64-bit atomicMin implements "min d2, then lowest index" independently of arrival order.  The key only ever
+// decreases, so a slice whose result cannot lower what is already published skips the read-modify-write (device-scope atomics
+// go to the fabric: at ~60-280 slices per query they were 57-267 MB of write traffic per launch; now only improving slices write).
+__device__ __forceinline__ void merge_key(unsigned long long* slot, unsigned long long key)
+{
+    if (key < __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMin(slot, key);
+}
+
 // exact A1 distance as raw bits
 __device__ __forceinline__ uint32_t d2_exact_bits(float qx, float qy, float qz, float x, float y, float z)
 {
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_track_kernel(
         if (i < ns) {
             const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : L.best[k];
             const unsigned long long key = ((unsigned long long)bits << 32) | bidx;
-            if (merge_atomic) atomicMin(&keys[i], key);
+            if (merge_atomic) merge_key(&keys[i], key);
             else keys[i] = key;
         }
     }
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ftrack_kernel(
         if (i < ns) {
             const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : best;
             const unsigned long long key = ((unsigned long long)bits << 32) | bidx;
-            if (merge_atomic) atomicMin(&keys[i], key);
+            if (merge_atomic) merge_key(&keys[i], key);
             else keys[i] = key;
         }
     }
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_etrack_kernel(
         if (i < ns) {
             const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : best;
             const unsigned long long key = ((unsigned long long)bits << 32) | bidx;
-            if (merge_atomic) atomicMin(&keys[i], key);
+            if (merge_atomic) merge_key(&keys[i], key);
             else keys[i] = key;
         }
     }

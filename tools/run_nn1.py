@@ -35,8 +35,11 @@ if aligned:
     ctx.transform(cs, synth.gt_pose().astype(np.float32))
 ctx.tune("prof", 2)
 ctx.nn1_async(ct, cs); ctx.sync(); print("first call:", {nm: ctx.prof_get(nm) for nm in ("grid_build",) if ctx.prof_get(nm)[0]}); ctx.prof_reset()
-for _ in range(launches):
-    ctx.nn1_async(ct, cs)
+if os.environ.get("ICP_LOOP"):      # inside an ICP loop: iterations after the first run the warm-start kernel (ETRACK for brute force)
+    ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=launches, eps=0.0)
+else:
+    for _ in range(launches):
+        ctx.nn1_async(ct, cs)
 if os.environ.get("GRID_STATS"):
     ctx.tune("grid_stats", 1); ctx.nn1_async(ct, cs); ctx.sync(); gs = ctx.grid_stats(); ctx.tune("grid_stats", 0)
     print("grid stats per query:", {k: round(v / n, 2) for k, v in gs.items()})
