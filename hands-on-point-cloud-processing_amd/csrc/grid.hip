@@ -130,7 +130,7 @@ __global__ __launch_bounds__(GR_BLOCK) void build_chunks_kernel(const float4* __
                 if (!(fabsf(tx) < 1e18f && fabsf(ty) < 1e18f && fabsf(tz) < 1e18f) || !(w < 3e38f)) bad = true;
             }
         }
-        out[4 + 4 * j] = tx; out[5 + 4 * j] = ty; out[6 + 4 * j] = tz; out[7 + 4 * j] = w;
+        out[4 + j] = tx; out[4 + GRID_CHUNK + j] = ty; out[4 + 2 * GRID_CHUNK + j] = tz; out[4 + 3 * GRID_CHUNK + j] = w;   // SoA inside the chunk
     }
     if (bad) atomicOr(unsafe, 1);
 }
