@@ -25,9 +25,7 @@ SOURCES = ["api.cpp", "numerics.cpp", "icp.cpp", "comm.cpp", "nn1_brute.hip", "k
 # -fno-slp-vectorize: keeps the inner loop on plain v_sub/v_mul/v_add_f32; the SLP vectoriser otherwise packs
 #   pairs into v_pk_mul_f32 / v_pk_add_f32, which issue at half rate on gfx950 and need extra v_mov to form
 #   register pairs (measured: profiles/).
-# -mllvm -amdgpu-mfma-vgpr-form: the f32 MFMA of the matrix-core filter (nn1_brute.hip, MTRACK) writes its tile straight into
-#   VGPRs; without it the accumulators live in AGPRs and every value costs a v_accvgpr_read before the minimum tree.
-FLAGS = ["-O3", "-mllvm", "-amdgpu-mfma-vgpr-form", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 
 

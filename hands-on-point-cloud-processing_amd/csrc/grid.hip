@@ -101,8 +101,7 @@ __global__ __launch_bounds__(GR_BLOCK) void record_keys_kernel(const float* __re
     vals[i] = i;
 }
 
-// one thread per chunk of CHN consecutive records: centre = mean of the finite ones, then the shifted copy (Grid::chunks, chunks_m)
-template <int CHN>
+// one thread per chunk of GRID_CHUNK consecutive records: centre = mean of the finite ones, then the shifted copy (Grid::chunks)
 __global__ __launch_bounds__(GR_BLOCK) void build_chunks_kernel(const float4* __restrict__ records, uint32_t n, uint32_t n_chunks, float* __restrict__ chunks,
                                                                 int* __restrict__ unsafe)
 {
@@ -110,18 +109,18 @@ __global__ __launch_bounds__(GR_BLOCK) void build_chunks_kernel(const float4* __
     if (c >= n_chunks) return;
     float cx = 0.f, cy = 0.f, cz = 0.f;
     int cnt = 0;
-    for (int j = 0; j < CHN; j++) {
-        const uint32_t p = c * CHN + j;
+    for (int j = 0; j < GRID_CHUNK; j++) {
+        const uint32_t p = c * GRID_CHUNK + j;
         if (p >= n) break;
         const float4 r = records[p];
         if (finite3(r.x, r.y, r.z)) { cx += r.x; cy += r.y; cz += r.z; cnt++; }
     }
     if (cnt) { cx /= (float)cnt; cy /= (float)cnt; cz /= (float)cnt; }
     bool bad = !finite3(cx, cy, cz) || fabsf(cx) > 1e18f || fabsf(cy) > 1e18f || fabsf(cz) > 1e18f;
-    float* out = chunks + (size_t)c * (4 + 4 * CHN);
+    float* out = chunks + (size_t)c * GRID_CHUNK_FLOATS;
     out[0] = cx; out[1] = cy; out[2] = cz; out[3] = 0.f;
-    for (int j = 0; j < CHN; j++) {
-        const uint32_t p = c * CHN + j;
+    for (int j = 0; j < GRID_CHUNK; j++) {
+        const uint32_t p = c * GRID_CHUNK + j;
         float tx = 0.f, ty = 0.f, tz = 0.f, w = INFINITY;                  // padding / non-finite: never the minimum
         if (p < n) {
             const float4 r = records[p];
@@ -131,9 +130,7 @@ __global__ __launch_bounds__(GR_BLOCK) void build_chunks_kernel(const float4* __
                 if (!(fabsf(tx) < 1e18f && fabsf(ty) < 1e18f && fabsf(tz) < 1e18f) || !(w < 3e38f)) bad = true;
             }
         }
-        // SoA inside the chunk; the matrix-core copy carries the factor -2 of the cross term (exact) on the target side
-        const float sc = CHN == GRID_CHUNK_M ? -2.0f : 1.0f;
-        out[4 + j] = sc * tx; out[4 + CHN + j] = sc * ty; out[4 + 2 * CHN + j] = sc * tz; out[4 + 3 * CHN + j] = w;
+        out[4 + j] = tx; out[4 + GRID_CHUNK + j] = ty; out[4 + 2 * GRID_CHUNK + j] = tz; out[4 + 3 * GRID_CHUNK + j] = w;   // SoA inside the chunk
     }
     if (bad) atomicOr(unsafe, 1);
 }
@@ -536,7 +533,6 @@ void grid_free(Grid* g)
 {
     if (!g) return;
     if (g->chunks) hipFree(g->chunks);
-    if (g->chunks_m) hipFree(g->chunks_m);
     if (g->records) hipFree(g->records);
     if (g->cell_start) hipFree(g->cell_start);
     delete g;
@@ -670,13 +666,8 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge)
         if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "hipMalloc(grid chunks)", e); }
         e = hipMemsetAsync(unsafe_dev, 0, 4, ctx->stream);
         if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "memset(grid)", e); }
-        hipLaunchKernelGGL(build_chunks_kernel<GRID_CHUNK>, dim3((unsigned)((g->n_chunks + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records,
-                           (uint32_t)n, (uint32_t)g->n_chunks, g->chunks, unsafe_dev);
-        g->n_chunks_m = (n + GRID_CHUNK_M - 1) / GRID_CHUNK_M;
-        e = hipMalloc((void**)&g->chunks_m, g->n_chunks_m * GRID_CHUNK_M_FLOATS * sizeof(float));
-        if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "hipMalloc(grid chunks)", e); }
-        hipLaunchKernelGGL(build_chunks_kernel<GRID_CHUNK_M>, dim3((unsigned)((g->n_chunks_m + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records,
-                           (uint32_t)n, (uint32_t)g->n_chunks_m, g->chunks_m, unsafe_dev);
+        hipLaunchKernelGGL(build_chunks_kernel, dim3((unsigned)((g->n_chunks + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records, (uint32_t)n,
+                           (uint32_t)g->n_chunks, g->chunks, unsafe_dev);
         e = hipMemcpyAsync(&unsafe_host, unsafe_dev, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "grid chunks", e); }
     }

@@ -28,16 +28,11 @@ struct Grid {
     // enough (< 1e18) for the filter's error analysis.
     float* chunks = nullptr;
     size_t n_chunks = 0;
-    // the same in chunks of GRID_CHUNK_M records (one 32-row MFMA operand each) for the matrix-core filter (MTRACK)
-    float* chunks_m = nullptr;
-    size_t n_chunks_m = 0;
-    bool chunk_safe = false;          // covers both copies
+    bool chunk_safe = false;
 };
 
 constexpr int GRID_CHUNK = 16;
 constexpr int GRID_CHUNK_FLOATS = 4 + 4 * GRID_CHUNK;
-constexpr int GRID_CHUNK_M = 32;
-constexpr int GRID_CHUNK_M_FLOATS = 4 + 4 * GRID_CHUNK_M;
 
 __device__ __forceinline__ int cell_coord(float v, float lo, float inv_h)
 {

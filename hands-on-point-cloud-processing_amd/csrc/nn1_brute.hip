@@ -413,162 +413,6 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_etrack_kernel(
     }
 }
 
-// ---- MTRACK: ETRACK's filter with the pair products on the matrix cores.  g = (-2 r) . t'' + w is a K = 4 inner product
-// (x, y, z and w x 1), i.e. for 32 targets x 32 queries one 32 x 32 tile  G = A B  with A = [t''x t''y t''z w] (32 x 4, from
-// Grid::chunks_m: 32 consecutive cell-sorted records about their centre) and B = [-2rx; -2ry; -2rz; 1] (4 x 32), issued as two
-// v_mfma_f32_32x32x2_f32 (K = x,y then z,w).  The f32 MFMA rounds like an fma chain, so the error budget of ETRACK carries over:
-// the chain now has four roundings with partial sums <= Q + W (three) and <= Q + 2W (last), i.e. <= u (4.1 Q + 5.1 W) instead of
-// 3.1 u (Q + 2W); the totals become Q: 23.1 u, W: 24.1 u — and, if the unit rounded every product AND every sum (8 roundings),
-// Q: 27.2 u, W: 35.4 u — all inside KAPPA's 32 u and w's 64 u.  L = fma(R, KAPPA, min g) <= d2 for every target of the chunk.
-// Lane l of a wave serves query column j = l % 32 of each of its NG query groups and owns 16 of the 32 target rows (which 16
-// does not matter to a minimum); it tracks (m1, c1, m2) over its rows exactly as ETRACK does, and the two lanes of a column are
-// merged after the scan.  The VALU is left with the minimum tree, the tracking and the per-(query, chunk) operand (~23
-// instructions per 1024 pairs) which run in the shadow of the two MFMAs (128 cycles per SIMD); the tail is ETRACK's with
-// one query per lane again (lane l takes the groups of parity l / 32).
-typedef float f16v __attribute__((ext_vector_type(16)));
-template <int NG, int EXP = 0>
-__global__ __launch_bounds__(NN_BLOCK) void nn1_mtrack_kernel(
-    const float* __restrict__ chunks, const float4* __restrict__ records, uint32_t nt, uint32_t n_chunks, uint32_t chunks_per_slice,
-    const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
-    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop, unsigned long long* __restrict__ stats)
-{
-    if (stop && (stop[0] | stop[1])) return;
-    static_assert(NG % 2 == 0, "the tail pairs query groups");
-    constexpr int CH = GRID_CHUNK_M, STRIDE = GRID_CHUNK_M_FLOATS;
-    constexpr float KAPPA = 0.99999809265136718750f;          // 1 - 2^-19
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t col = lane & 31u;
-    const bool hi = lane >= 32u;
-    const uint32_t wbase = (blockIdx.x * (NN_BLOCK / 64) + (tid >> 6)) * (32u * NG);
-    float qx[NG], qy[NG], qz[NG], m1[NG], m2[NG];
-    uint32_t c1[NG];
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-        const uint32_t i = min(wbase + g * 32u + col, ns - 1);
-        qx[g] = sx[i]; qy[g] = sy[i]; qz[g] = sz[i];
-        m1[g] = INFINITY; m2[g] = INFINITY; c1[g] = 0xFFFFFFFFu;
-    }
-    // what is published for the tail's queries right now (seed of a warm ICP iteration / slices that already finished)
-    float cur0[NG / 2];
-#pragma unroll
-    for (int s = 0; s < NG / 2; s++) {
-        const uint32_t i = min(wbase + s * 64u + lane, ns - 1);
-        cur0[s] = merge_atomic ? __uint_as_float((uint32_t)(__atomic_load_n(&keys[i], __ATOMIC_RELAXED) >> 32)) : INFINITY;
-    }
-    const uint32_t cb = blockIdx.y * chunks_per_slice, ce = min(cb + chunks_per_slice, n_chunks);
-    if (cb < ce) {
-        // Software pipeline over the tiles (chunk, group): the two MFMAs of the NEXT tile are issued before the minimum tree and
-        // the tracking of the CURRENT one, so one wave keeps both the matrix pipe and the VALU busy (accumulators double-buffered);
-        // the A operands and the centre are requested two chunks ahead.  Chunk indices past the slice are clamped: the extra
-        // tile issued at the very end is never looked at.
-        const uint32_t last = ce - 1;
-        const bool same = (merge_atomic & 4) != 0;   // EXPERIMENT
-        auto hdr = [&](uint32_t c) { return *reinterpret_cast<const float4*>(chunks + (size_t)(same ? cb : min(c, last)) * STRIDE); };   // wave-uniform
-        auto opa = [&](uint32_t c, int half) { return chunks[(size_t)(same ? cb : min(c, last)) * STRIDE + 4 + 64 * half + lane]; };
-        float4 C0 = hdr(cb), C1 = hdr(cb + 1);
-        float a10 = opa(cb, 0), a20 = opa(cb, 1), a11 = opa(cb + 1, 0), a21 = opa(cb + 1, 1);
-        f16v acc[2];
-        float Rp[2];
-        const f16v zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-#define PCR_MTRACK_ISSUE(slot, g, CC, A1, A2)                                                                                  \
-    {                                                                                                                          \
-        const float rx = qx[g] - CC.x, ry = qy[g] - CC.y, rz = qz[g] - CC.z;                                                   \
-        Rp[slot] = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));                                                    \
-        const float b1 = hi ? ry : rx;                       /* B operands: lane l = (k = l / 32, column l % 32) */            \
-        const float b2 = hi ? 1.0f : rz;                                                                                       \
-        if (EXP == 2) { acc[slot] = zero; acc[slot][0] = A1 * b1; acc[slot][15] = A2 * b2; }                                    \
-        else {                                                                                                                 \
-        acc[slot] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, b1, zero, 0, 0, 0);                                               \
-        if (EXP != 3) acc[slot] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, b2, acc[slot], 0, 0, 0);                            \
-        }                                                                                                                      \
-    }
-        PCR_MTRACK_ISSUE(0, 0, C0, a10, a20)
-        for (uint32_t c = cb; c < ce; c++) {
-            const float4 C2 = hdr(c + 2);
-            const float a12 = opa(c + 2, 0), a22 = opa(c + 2, 1);
-#pragma unroll
-            for (int g = 0; g < NG; g++) {
-                if (g + 1 < NG) PCR_MTRACK_ISSUE((g + 1) & 1, g + 1, C0, a10, a20)
-                else PCR_MTRACK_ISSUE(0, 0, C1, a11, a21)
-                const f16v& t = acc[g & 1];
-                float m = fminf(fminf(t[0], t[1]), t[2]);
-                if (EXP == 1) m = fminf(t[0], t[15]);
-                else {
-                if (EXP == 4) {
-                    const float ma = fminf(fminf(t[3], t[4]), t[5]), mb = fminf(fminf(t[6], t[7]), t[8]), mc = fminf(fminf(t[9], t[10]), t[11]),
-                                md = fminf(fminf(t[12], t[13]), t[14]);
-                    m = fminf(fminf(fminf(m, ma), mb), fminf(fminf(mc, md), t[15]));
-                } else {
-#pragma unroll
-                for (int r = 3; r + 1 < 16; r += 2) m = fminf(fminf(m, t[r]), t[r + 1]);
-                m = fminf(m, t[15]);
-                }
-                }
-                const float L = __builtin_fmaf(Rp[g & 1], KAPPA, m);
-                m2[g] = fminf(m2[g], fmaxf(m1[g], L));
-                const bool better = L < m1[g];
-                m1[g] = fminf(m1[g], L);
-                c1[g] = better ? c : c1[g];
-            }
-            C0 = C1; C1 = C2; a10 = a11; a20 = a21; a11 = a12; a21 = a22;
-        }
-#undef PCR_MTRACK_ISSUE
-    }
-    // merge the two lanes of a query column: (m1, c1) = the smaller pair, m2 = smallest bound over all chunks but c1
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-        const float m1o = __shfl_xor(m1[g], 32), m2o = __shfl_xor(m2[g], 32);
-        const uint32_t c1o = (uint32_t)__shfl_xor((int)c1[g], 32);
-        const bool mine = m1[g] < m1o || (m1[g] == m1o && c1[g] <= c1o) || !(m1o == m1o);
-        const float m2a = fminf(m2[g], c1o == c1[g] ? m2o : m1o), m2b = fminf(m2o, c1o == c1[g] ? m2[g] : m1[g]);
-        m2[g] = mine ? m2a : m2b;
-        m1[g] = mine ? m1[g] : m1o;
-        c1[g] = mine ? c1[g] : c1o;
-    }
-#pragma unroll
-    for (int s = 0; s < NG / 2; s++) {
-        const float x = hi ? qx[2 * s + 1] : qx[2 * s], y = hi ? qy[2 * s + 1] : qy[2 * s], z = hi ? qz[2 * s + 1] : qz[2 * s];
-        const float M1 = hi ? m1[2 * s + 1] : m1[2 * s], M2 = hi ? m2[2 * s + 1] : m2[2 * s];
-        const uint32_t C1 = hi ? c1[2 * s + 1] : c1[2 * s];
-        const bool okq = fabsf(x) < 1e18f && fabsf(y) < 1e18f && fabsf(z) < 1e18f;      // false for NaN / inf
-        uint32_t best = 0x7F7FFFFFu, bidx = 0xFFFFFFFFu;      // FLT_MAX gate, nanoflann.hpp:163,1360
-        bool proven = false;
-        const float cur = cur0[s];                             // see ETRACK: an upper bound of the final answer (NaN = no claim)
-        const bool slice_out = okq && (M1 - 1e-30f) > cur;
-        if (!slice_out && okq && C1 != 0xFFFFFFFFu) {
-            const uint32_t j0 = C1 * CH;
-            for (int j = 0; j < CH; j++) {
-                if (j0 + j < nt) {
-                    const float4 rec = records[j0 + j];                                  // original coordinates + original index
-                    const uint32_t e = d2_exact_bits(x, y, z, rec.x, rec.y, rec.z);
-                    const uint32_t oi = __float_as_uint(rec.w);
-                    if (e < best || (e == best && e < 0x7F7FFFFFu && oi < bidx)) { best = e; bidx = oi; }
-                }
-            }
-            proven = (bidx != 0xFFFFFFFFu && (M2 - 1e-30f) > __uint_as_float(best)) || (M2 - 1e-30f) > cur;
-        }
-        if (!__all(proven || slice_out || cb >= ce)) {
-            if (stats && lane == 0) atomicAdd(&stats[2], 1ull);
-            unsigned long long kbest = ~0ull;                  // exact rescan of the slice, lexicographic (d2, index) minimum
-            for (uint32_t j = cb * CH; j < min(ce * CH, nt); j++) {
-                const float4 rec = records[j];
-                const uint32_t e = d2_exact_bits(x, y, z, rec.x, rec.y, rec.z);
-                const unsigned long long key = ((unsigned long long)e << 32) | __float_as_uint(rec.w);
-                if (e < 0x7F7FFFFFu && key < kbest) kbest = key;
-            }
-            best = (uint32_t)(kbest >> 32);
-            bidx = kbest == ~0ull ? 0xFFFFFFFFu : (uint32_t)(kbest & 0xFFFFFFFFull);
-        }
-        const uint32_t i = wbase + s * 64u + lane;
-        if (i < ns) {
-            const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : best;
-            const unsigned long long key = ((unsigned long long)bits << 32) | bidx;
-            if (merge_atomic) merge_key(&keys[i], key);
-            else keys[i] = key;
-        }
-    }
-}
-
 // ICP iterations after the first: the previous correspondence, re-evaluated exactly against the moved query, is a genuine
 // candidate and therefore an upper bound of the new answer from the first instruction on (ETRACK settles every far slice with it).
 __global__ __launch_bounds__(NN_BLOCK) void nn1_seed_kernel(const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, uint32_t nt,
@@ -647,7 +491,7 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     // nn1_variant unset: FTRACK for a cold search, ETRACK when a warm-start bound exists (measured: ETRACK needs the bound to
     // settle the far slices, profiles/r01_tune_nn1_etrack.txt); 4 forces ETRACK, 1-3 the kernels below
     const int64_t variant_tune = tune_get(ctx, "nn1_variant", 0);
-    if (variant_tune == 4 || variant_tune == 5 || (variant_tune == 0 && warm && tgt->n >= 2048)) {
+    if (variant_tune == 4 || (variant_tune == 0 && warm && tgt->n >= 2048)) {
         if (!tgt->grid) {
             Grid* g = nullptr;
             ProfScope p(ctx, "grid_build");
@@ -656,55 +500,6 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
             const_cast<pcr_cloud*>(tgt)->grid = g;
         }
         const Grid* g = tgt->grid;
-        const bool use_mfma = variant_tune == 5 || (variant_tune == 0 && tune_get(ctx, "nn1_warm_mfma", 2) == 1);
-        if (g->chunk_safe && g->n_chunks_m && use_mfma) {
-            // MTRACK: a wave owns NG groups of 32 queries, a block 4 waves
-            int ng = (int)tune_get(ctx, "nn1_mtrack_ng", 4);
-            if (ng != 2 && ng != 8) ng = 4;
-            const size_t per_block = (size_t)(NN_BLOCK / 64) * 32 * ng;
-            const uint32_t qblocks = (uint32_t)((ns + per_block - 1) / per_block);
-            int64_t cps = tune_get(ctx, "nn1_chunks_per_slice", 0);
-            if (cps <= 0) {
-                const int64_t want_blocks = tune_get(ctx, "nn1_mtrack_blocks", 16384);
-                const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
-                cps = std::max<int64_t>(1, ((int64_t)g->n_chunks_m + slices - 1) / slices);
-            }
-            uint32_t slices = (uint32_t)((g->n_chunks_m + cps - 1) / cps);
-            if (slices > 65535) { slices = 65535; cps = (g->n_chunks_m + slices - 1) / slices; slices = (uint32_t)((g->n_chunks_m + cps - 1) / cps); }
-            const int merge_atomic = ((slices > 1 || warm) ? 1 : 0) | (tune_get(ctx, "nn1_noload", 0) > 0 ? 4 : 0);
-            if (warm)
-                hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
-                                   (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
-            else if (merge_atomic)
-                PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
-            const dim3 grid(qblocks, slices);
-            unsigned long long* stats_dev = nullptr;
-            if (tune_get(ctx, "grid_stats", 0) > 0) {
-                if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
-                PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
-                stats_dev = ctx->grid_stats_dev;
-            }
-            {
-                ProfScope p(ctx, "nn1_brute", 1);
-#define PCR_MTRACK(Q)                                                                                                                       \
-    hipLaunchKernelGGL((nn1_mtrack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->chunks_m, g->records, (uint32_t)tgt->n, (uint32_t)g->n_chunks_m, \
-                       (uint32_t)cps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev)
-                const int64_t ex = tune_get(ctx, "nn1_exp", 0);
-                if (ex == 1) hipLaunchKernelGGL((nn1_mtrack_kernel<4, 1>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->chunks_m, g->records, (uint32_t)tgt->n, (uint32_t)g->n_chunks_m, (uint32_t)cps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev);
-                else if (ex == 2) hipLaunchKernelGGL((nn1_mtrack_kernel<4, 2>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->chunks_m, g->records, (uint32_t)tgt->n, (uint32_t)g->n_chunks_m, (uint32_t)cps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev);
-                else if (ex == 4) hipLaunchKernelGGL((nn1_mtrack_kernel<4, 4>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->chunks_m, g->records, (uint32_t)tgt->n, (uint32_t)g->n_chunks_m, (uint32_t)cps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev);
-                else if (ex == 3) hipLaunchKernelGGL((nn1_mtrack_kernel<4, 3>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->chunks_m, g->records, (uint32_t)tgt->n, (uint32_t)g->n_chunks_m, (uint32_t)cps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev);
-                else
-                switch (ng) {
-                case 2: PCR_MTRACK(2); break;
-                case 8: PCR_MTRACK(8); break;
-                default: PCR_MTRACK(4); break;
-                }
-#undef PCR_MTRACK
-            }
-            PCR_HIP(ctx, hipGetLastError());
-            return PCR_OK;
-        }
         if (g->chunk_safe && g->n_chunks) {
             // queries per lane: the filter is bound by the scalar operand path (272 B per chunk per wave), more queries per lane
             // amortise it — measured: profiles/r01_tune_nn1_etrack.txt
