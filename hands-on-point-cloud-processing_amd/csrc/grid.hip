@@ -130,7 +130,8 @@ __global__ __launch_bounds__(GR_BLOCK) void build_chunks_kernel(const float4* __
                 if (!(fabsf(tx) < 1e18f && fabsf(ty) < 1e18f && fabsf(tz) < 1e18f) || !(w < 3e38f)) bad = true;
             }
         }
-        out[4 + j] = tx; out[4 + GRID_CHUNK + j] = ty; out[4 + 2 * GRID_CHUNK + j] = tz; out[4 + 3 * GRID_CHUNK + j] = w;   // SoA inside the chunk
+        // SoA inside the chunk; the coordinates carry the factor -2 of the cross term (exact), so the filter multiplies by r itself
+        out[4 + j] = -2.0f * tx; out[4 + GRID_CHUNK + j] = -2.0f * ty; out[4 + 2 * GRID_CHUNK + j] = -2.0f * tz; out[4 + 3 * GRID_CHUNK + j] = w;
     }
     if (bad) atomicOr(unsafe, 1);
 }

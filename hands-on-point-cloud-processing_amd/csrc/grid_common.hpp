@@ -22,7 +22,7 @@ struct Grid {
     float4* records = nullptr;        // n_points, sorted by (cell, x): every x-row of cells is one x-sorted range
     uint32_t* cell_start = nullptr;   // n_cells + 2 (cell n_cells holds the non-finite points, never visited)
     // chunked, centred copy of the records for the expanded-form brute-force filter (nn1_brute.hip, ETRACK): per chunk of
-    // GRID_CHUNK consecutive records GRID_CHUNK_FLOATS floats = { Cx, Cy, Cz, 0 } + x''[GRID_CHUNK] + y''[..] + z''[..] + w_lb[..]
+    // GRID_CHUNK consecutive records GRID_CHUNK_FLOATS floats = { Cx, Cy, Cz, 0 } + -2x''[GRID_CHUNK] + -2y''[..] + -2z''[..] + w_lb[..]
     // (t'' = t - C, w_lb = |t''|^2 (1 - 2^-18); SoA inside the chunk so that two neighbouring targets sit in an aligned SGPR
     // pair for v_pk_fma_f32); padding / non-finite records are (0, 0, 0, +inf).  chunk_safe: every value finite and small
     // enough (< 1e18) for the filter's error analysis.

@@ -284,8 +284,8 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ftrack_kernel(
 
 // ---- ETRACK: the filter in EXPANDED form on chunk-centred targets: 3 FMAs per pair instead of 3 subtractions + 3 (mul / fma).
 // The target is taken in the cell-sorted order of its grid index (grid.hip), 16 consecutive = spatially neighbouring points
-// per chunk, stored relative to the chunk centre C:  t'' = fl(t - C),  w = fl(|t''|^2) (1 - 2^-18)   (Grid::chunks).
-// Per (query, chunk):  r = fl(q - C),  a = -2 r,  R = fl(|r|^2);  per pair  g = fma(ax, t''x, fma(ay, t''y, fma(az, t''z, w))).
+// per chunk, stored relative to the chunk centre C:  t'' = fl(t - C) (kept as -2 t'', exact),  w = fl(|t''|^2) (1 - 2^-18)   (Grid::chunks).
+// Per (query, chunk):  r = fl(q - C),  R = fl(|r|^2);  per pair  g = fma(rx, -2t''x, fma(ry, -2t''y, fma(rz, -2t''z, w))).
 // In real arithmetic |q - t|^2 = |r|^2 + |t''|^2 - 2 r.t''.  With u = 2^-24, Q = |r|^2, W = |t''|^2 (of the float vectors):
 //   rounding of g                      <= 3.1 u (2 W + Q)        (three nested FMAs, partial results <= W + 2 |r||t''| <= 2 W + Q)
 //   w vs W                             <= 3 u W
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_etrack_kernel(
 #pragma unroll
         for (int k = 0; k < QPL; k++) {
             const float rx = qx[k] - C.x, ry = qy[k] - C.y, rz = qz[k] - C.z;
-            const float ax = -2.0f * rx, ay = -2.0f * ry, az = -2.0f * rz;
+            const float ax = rx, ay = ry, az = rz;             // the -2 of the cross term is stored with the targets (exact)
             const float R = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
             // two neighbouring targets per instruction: a scalar f32 FMA issues at half the rate of add / mul / min on this chip
             // (measured: the all-FMA loop took 3.1 cycles per instruction instead of 2), v_pk_fma_f32 does two per lane in that time
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_etrack_kernel(
             for (int j = 3; j + 1 < CH; j += 2) m = fminf(fminf(m, g[j]), g[j + 1]);
             m = fminf(m, g[CH - 1]);
             const float L = __builtin_fmaf(R, KAPPA, m);
-            m2[k] = fminf(m2[k], fmaxf(m1[k], L));             // smallest chunk value among the chunks that are not c1
+            m2[k] = __builtin_amdgcn_fmed3f(m1[k], m2[k], L);  // second smallest of (m1 <= m2, L): the smallest chunk value outside c1
             const bool better = L < m1[k];
             m1[k] = fminf(m1[k], L);
             c1[k] = better ? c : c1[k];
