@@ -299,7 +299,8 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ftrack_kernel(
 // from the grid records) -> (e, index);  m2 - 1e-30 > e  proves that every target outside c1 is strictly farther: the answer is
 // exact and canonical.  Otherwise the wave rescans its slice exactly.  Chunk radius ~ 0.2 m keeps the absolute error of L
 // around 1e-7 m^2, far below the gap between the nearest and the next candidates of a LiDAR scan.
-// Cost: 3 FMAs + (3 sub + 3 mul + 3 (mul/fma) + 1 fma) / 16 + min tree + tracking ~ 4.4 lane-ops per pair (FTRACK: 7.1).
+// Cost per (query, chunk of 16): 3 sub + 3 (mul / fma) for R + 24 v_pk_fma_f32 + 8 v_min3 + fma + med3 + cmp + min + cndmask;
+// priced with tools/ubench/valu_rate.hip (min / max / med3 issue at ~0.6 of the add / fma rate): 80.6 ns per wave.
 template <int QPL>
 __global__ __launch_bounds__(NN_BLOCK) void nn1_etrack_kernel(
     const float* __restrict__ chunks, const float4* __restrict__ records, uint32_t nt, uint32_t n_chunks, uint32_t chunks_per_slice,
@@ -343,8 +344,8 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_etrack_kernel(
             const float rx = qx[k] - C.x, ry = qy[k] - C.y, rz = qz[k] - C.z;
             const float ax = rx, ay = ry, az = rz;             // the -2 of the cross term is stored with the targets (exact)
             const float R = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
-            // two neighbouring targets per instruction: a scalar f32 FMA issues at half the rate of add / mul / min on this chip
-            // (measured: the all-FMA loop took 3.1 cycles per instruction instead of 2), v_pk_fma_f32 does two per lane in that time
+            // two neighbouring targets per instruction: v_pk_fma_f32 with the SGPR pair costs 2.15 ns per wave-instruction against
+            // 2 x 1.18 ns for two scalar FMAs (profiles/r01_ubench_valu_rate.txt); the query operand is broadcast by op_sel_hi
             const f2 ax2 = { ax, ax }, ay2 = { ay, ay }, az2 = { az, az };
             float g[CH];
 #pragma unroll

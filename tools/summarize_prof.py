@@ -73,6 +73,8 @@ if pm:
                          f"**{pm['SQ_INSTS_VALU'][0]*2/cyc:.3f}**")
             lines.append(f"VALU wave-instructions per (query,target) pair x 64 lanes = {pm['SQ_INSTS_VALU'][0]*64/1.44e10:.3f} lane-ops/pair "
                          "(algorithmic convention: 9)")
+            lines.append("(the 2-cycle price undercounts this loop: v_pk_fma_f32 and the min / max / med3 class take about twice the slot of "
+                         "an add / fma — profiles/r01_ubench_valu_rate.txt; priced per form the loop needs 1.11 ms of the launch, DESIGN.md §5)")
     if "FETCH_SIZE" in pm:
         lines.append(f"HBM traffic per launch: FETCH_SIZE {pm['FETCH_SIZE'][0]:.0f} KiB x 2 (gfx950 correction for wide coalesced "
                      f"reads, MI355X_MICROARCH.md §HBM) = {pm['FETCH_SIZE'][0]*2*1024/1e6:.2f} MB; "
