@@ -267,13 +267,19 @@ def main():
                           if default_kernels else f"nn1 variant={args.variant} qpl={args.qpl}",
                 "executed_lane_ops_per_pair": (pmc["valu_insts_per_launch"] * 64 / pairs) if have_pmc else None,
                 "issue_frac": (pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TFLOPS_NOFMA) if have_pmc else None,
+                # the warm kernel's instruction mix per (query, chunk of 16 targets) priced with the measured issue costs of
+                # each instruction form (tools/ubench/valu_rate.hip -> profiles/r01_ubench_valu_rate.txt): 80.6 ns per wave
+                "mix_bound_ms": (pairs / 16 / 64 * 80.6e-9 / 1024 * 1e3) if default_kernels else None,
+                "mix_frac": (pairs / 16 / 64 * 80.6e-9 / 1024 / kern_s) if default_kernels else None,
                 "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
                 "algorithmic": f"{OPS_PER_PAIR} f32 lane-ops per (query,target) pair (SURVEY.md 8d) x {pairs:.3e} pairs/launch; "
                                "peak = 157.3 TF/s / 2: one op per lane per issue slot (the exact arithmetic has no FMA). "
                                "frac can exceed 1 because the kernels need fewer than 9 issue slots per pair: the hot loop "
                                "evaluates a cheaper filter (3 FMAs on chunk-centred targets; fused 6-op form in the cold "
                                "kernel) and only the winning chunk exactly; issue_frac = executed lane-ops of the warm kernel "
-                               "(PMC) / time / peak is the share of VALU issue slots actually used",
+                               "(PMC) / time / peak counts every wave-instruction as one slot; v_pk_fma_f32 and min/max/med3 "
+                               "take about two (microbenchmark), so mix_frac = mix_bound_ms / avg_launch_ms — the loop's "
+                               "instruction mix priced per form, 1 024 SIMDs — is the share of the VALU actually used",
                 "hbm_literal": {"bound": "hbm", "achieved": compulsory_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
                                 "note": "compulsory bytes (32 B/point); brute force is VALU-bound, see DESIGN.md"}}
