@@ -1,2 +1,2 @@
 set -o pipefail
-timeout -k 10 900 python tools/soak_etrack.py 3000 1000 | tail -5
+timeout -k 10 900 python tools/soak_etrack.py 3000 50000 | tail -6

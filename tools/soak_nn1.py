@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""One-off soak of the brute-force kernels on random inputs: the warm-start ETRACK path inside ICP loops and the cold
-ETRACK search must give the bits of the exact-only kernel (nn1_variant = 2) on every input.
-usage: soak_etrack.py [cases=60] [seed0=1]"""
+"""One-off soak of the correspondence kernels on random inputs: the warm-start ETRACK path inside ICP loops, the cold
+ETRACK search and the exact grid search must give the bits of the exact-only brute-force kernel (nn1_variant = 2) on every input.
+usage: soak_nn1.py [cases=60] [seed0=1]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -46,7 +46,7 @@ for case in range(cases):
     rng = np.random.default_rng(seed0 + case)
     kind, t, s, scale = make(rng)
     res = {}
-    for name, tunes in (("exact", {"nn1_variant": 2}), ("default", {}), ("etrack_cold", {"nn1_variant": 4})):
+    for name, tunes in (("exact", {"nn1_variant": 2}), ("default", {}), ("etrack_cold", {"nn1_variant": 4}), ("grid", {"nn_method": 2})):
         ctx = pcr.Context(0)
         ctx.tune("nn_method", 1)
         for k, v in tunes.items():
@@ -59,7 +59,7 @@ for case in range(cases):
             out.append(T.view(np.uint32).copy()); out.append(np.array([st["iters_run"], st["last_pairs"]]))
         res[name] = out
         del ctx
-    for name in ("default", "etrack_cold"):
+    for name in ("default", "etrack_cold", "grid"):
         ok = all(np.array_equal(a, b) for a, b in zip(res["exact"], res[name]))
         if not ok:
             bad += 1
