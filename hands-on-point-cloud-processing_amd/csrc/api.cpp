@@ -396,7 +396,7 @@ int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4])
 int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value)
 {
     if (!ctx || !key) return PCR_ERR_ARG;
-    if (!strcmp(key, "prof")) { ctx->prof_level = (int)value; return PCR_OK; }   // 0 off, 1 nn kernels, 2 all
+    if (!strcmp(key, "prof")) { ctx->prof_level = (int)value; return PCR_OK; }   // 0 off (default), 1 nn kernels, 2 all
     ctx->tune[key] = value;
     return PCR_OK;
 }

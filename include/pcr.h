@@ -103,7 +103,7 @@ typedef struct {
     float last_loss;
     float reserved;
     double ms_total;      /* wall time of the loop */
-    double ms_nn;         /* HIP-event time of the 1-NN kernel, summed over iterations */
+    double ms_nn;         /* HIP-event time of the 1-NN kernel, summed over iterations; 0 unless pcr_tune_set(ctx, "prof", >= 1) */
     uint64_t nn_launches;
 } pcr_icp_stats;
 
