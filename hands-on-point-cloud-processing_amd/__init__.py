@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -170,6 +171,13 @@ class Cloud:
     def __init__(self, ctx: "Context", handle):
         self.ctx = ctx
         self.h = handle
+        ctx._handles.add(self)        # freed with the context at the latest
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def __len__(self):
         return int(lib().pcr_cloud_size(self.h))
@@ -188,9 +196,9 @@ class Cloud:
         self.ctx._ck(lib().pcr_cloud_assign(self.ctx.h, self.h, other.h))
 
     def free(self):
-        if self.h:
+        if self.h and self.ctx.h:
             lib().pcr_cloud_destroy(self.ctx.h, self.h)
-            self.h = None
+        self.h = None
 
 
 class Db64:
@@ -199,6 +207,13 @@ class Db64:
     def __init__(self, ctx: "Context", handle):
         self.ctx = ctx
         self.h = handle
+        ctx._handles.add(self)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:   # noqa: BLE001
+            pass
 
     def __len__(self):
         return int(lib().pcr_db64_size(self.h))
@@ -224,9 +239,9 @@ class Db64:
         return row, idx[:total], dist[:total]
 
     def free(self):
-        if self.h:
+        if self.h and self.ctx.h:
             lib().pcr_db64_destroy(self.ctx.h, self.h)
-            self.h = None
+        self.h = None
 
 
 def read_kitti_bin(path: str, floats_per_point: int = 4) -> np.ndarray:
@@ -249,13 +264,29 @@ class Context:
                            "(no CPU fallback)")
         self.h = h
         self._cb_keepalive = None
+        self._handles = weakref.WeakSet()      # clouds / databases created on this context
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def _ck(self, rc: int):
         if rc != 0:
             raise PcrError(f"{ERRORS.get(rc, rc)}: {lib().pcr_ctx_last_error(self.h).decode()}")
 
     def close(self):
+        """Frees every cloud / database still alive on this context, then the context (stream, workspace, communicator)."""
         if self.h:
+            for obj in list(self._handles):
+                obj.free()
             lib().pcr_ctx_destroy(self.h)
             self.h = None
 

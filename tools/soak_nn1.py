@@ -58,7 +58,7 @@ for case in range(cases):
             T, st = ctx.icp_point2point(ctx.cloud(s), ct, max_corr=float(scale * scale), max_iter=iters, eps=0.0)
             out.append(T.view(np.uint32).copy()); out.append(np.array([st["iters_run"], st["last_pairs"]]))
         res[name] = out
-        del ctx
+        ctx.close()
     for name in ("default", "etrack_cold", "grid"):
         ok = all(np.array_equal(a, b) for a, b in zip(res["exact"], res[name]))
         if not ok:
