@@ -518,3 +518,20 @@ def test_radius_self_query_full_scan(ctx, synth):
     seg_start = np.zeros(idx.size, bool); seg_start[row[:-1]] = True
     assert (np.diff(idx)[~seg_start[1:]] > 0).all()
     assert (dist <= 1.0).all()
+
+
+def test_context_owns_its_handles(pcr, synth):
+    """close() (or leaving a with-block) frees the clouds / databases still alive; later free() calls are no-ops."""
+    src, tgt = synth.kitti_like_pair(500)
+    with pcr.Context(0) as ctx:
+        cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+        db = ctx.db64(np.ascontiguousarray(tgt.T.astype(np.float64)))
+        idx, _ = ctx.nn1(ct, cs)
+        assert idx.shape == (500,)
+    assert ctx.h is None and cs.h is None and ct.h is None and db.h is None
+    cs.free(); db.free(); ctx.close()          # idempotent
+    ctx2 = pcr.Context(0)
+    c = ctx2.cloud(src)
+    del ctx2                                     # the cloud keeps its context alive
+    assert len(c) == 500
+    c.free()
