@@ -11,12 +11,20 @@ for npts in (10000, 100000):
     db = np.unique(g["db_f32"][:npts].astype(np.float64), axis=0)   # the reference's build cannot take duplicates
     ctx = pcr.Context(0); ctx.tune("prof", 2)
     t0 = time.perf_counter(); h = ctx.db64(db); tb = time.perf_counter() - t0
-    h.knn(db[:256], 8)
-    t0 = time.perf_counter(); idx, dist = h.knn(db, 8); tq = time.perf_counter() - t0
-    k, ms = ctx.prof_get("knn_f64")
-    print(f"GPU  n={db.shape[0]}: upload {tb*1e3:.2f} ms, batched 8-NN of all points {tq*1e3:.2f} ms ({tq*1e3/db.shape[0]:.6f} ms/query; kernel {ms/k:.3f} ms avg)")
-    t0 = time.perf_counter(); row, ri, rd = h.radius(db, 1.0); tr = time.perf_counter() - t0
-    print(f"     radius r=1.0 of all points {tr*1e3:.2f} ms ({tr*1e3/db.shape[0]:.6f} ms/query), {row[-1]} neighbours")
+    # the first batched call pays one-time costs (code objects, sort workspace, the index over the database): reported apart
+    t0 = time.perf_counter(); idx, dist = h.knn(db, 8); tfirst = time.perf_counter() - t0
+    tq = 1e9
+    for _ in range(3):
+        ctx.prof_reset()
+        t0 = time.perf_counter(); idx, dist = h.knn(db, 8); tq = min(tq, time.perf_counter() - t0)
+    k, ms = ctx.prof_get("knn_grid")
+    print(f"GPU  n={db.shape[0]}: upload {tb*1e3:.2f} ms, first batched 8-NN call {tfirst*1e3:.2f} ms; steady state {tq*1e3:.2f} ms for all points "
+          f"({tq*1e3/db.shape[0]:.6f} ms/query; search kernel {ms/max(k,1):.3f} ms)")
+    h.radius(db, 1.0)
+    tr = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); row, ri, rd = h.radius(db, 1.0); tr = min(tr, time.perf_counter() - t0)
+    print(f"     radius r=1.0 of all points {tr*1e3:.2f} ms ({tr*1e3/db.shape[0]:.6f} ms/query), {row[-1]} neighbours ({row[-1]*12/1e6:.0f} MB of results over PCIe)")
     try:
         import orc
         if orc.have_ref():

@@ -1,2 +1,3 @@
 set -o pipefail
-timeout -k 10 900 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -3
+mkdir -p gpurun_out
+timeout -k 10 300 python tools/bench_hw2.py | tee gpurun_out/hw2.txt
