@@ -94,6 +94,7 @@ void prof_flush(pcr_ctx* ctx)
 void cloud_modified(pcr_cloud* c)
 {
     if (c && c->grid) { grid_free(c->grid); c->grid = nullptr; }
+    if (c && c->knn_grid) { grid_free(c->knn_grid); c->knn_grid = nullptr; c->knn_grid_factor = 0.0; }
 }
 
 int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm)

@@ -58,6 +58,8 @@ namespace pcr { struct Grid; void grid_free(Grid*); }
 
 struct pcr_cloud {
     pcr::Grid* grid = nullptr;   // exact-NN index over this cloud as a target; built lazily, dropped on modification
+    pcr::Grid* knn_grid = nullptr;   // the same index with the wider cell of the last k-NN batch (knn_grid.hip), same lifetime
+    double knn_grid_factor = 0.0;    // its cell edge / grid's cell edge
     size_t n = 0;
     size_t cap = 0;     // padded length of each of x, y, z
     float* base = nullptr;   // device; x = base, y = base + cap, z = base + 2*cap
