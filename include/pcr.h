@@ -260,13 +260,16 @@ int pcr_comm_selftest(pcr_ctx* ctx);
 /* contiguous shard [begin, end) of n items for `rank` of `nranks` (sizes differ by at most one) */
 void pcr_shard_range(size_t n, int nranks, int rank, size_t* begin, size_t* end);
 
-/* ---- profiling hooks for bench.py: HIP-event timing of the dominant kernel on the ctx stream ---------- */
+/* ---- profiling hooks for bench.py: HIP-event timing of the dominant kernel on the ctx stream ----------
+ * Off by default (an event pair costs ~6 us of stream time on each side of the kernel it brackets):
+ * pcr_tune_set(ctx, "prof", 1) times the correspondence kernels, 2 every kernel, 0 switches it off again. */
 int pcr_prof_reset(pcr_ctx* ctx);
 int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* total_ms);
 /* diagnostics of the last grid search launched with tune "grid_stats" = 1:
  * out = { candidates evaluated, fine x-rows opened, coarse rows tested, far stages run } summed over the queries */
 int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4]);
-/* tuning knobs of the 1-NN kernel (0 = default): target slices per query block */
+/* tuning / diagnostic knobs by name (value 0 = library default, except "prof"): "nn_method" 1 brute force / 2 exact grid,
+ * "nn1_variant", "knn_method", "radius_method", "icp_pipeline", "prof", ... — the names are listed where they are read (csrc/) */
 int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus
