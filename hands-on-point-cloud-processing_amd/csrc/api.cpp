@@ -288,7 +288,8 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
     if (!c) return PCR_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (ctx && ctx->qperm_src == c) ctx->qperm_src = nullptr;
-    if (ctx && ctx->keys_src == c) { ctx->keys_src = nullptr; ctx->keys_warm = false; }
+    if (ctx && ctx->keys_src == c) ctx->keys_src = nullptr;
+    if (ctx && ctx->keys_tgt == c) { ctx->keys_tgt = nullptr; ctx->keys_warm = false; }
     cloud_modified(c);
     if (c->base) hipFree(c->base);
     delete c;

@@ -763,9 +763,12 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         stats_dev = ctx->grid_stats_dev;
     }
     // warm start: only inside an ICP loop (reuse_perm), from its second search on, when keys[] belongs to this source
-    const int warm = (reuse_perm && have_perm && ctx->keys_warm && ctx->keys_src == src && tune_get(ctx, "grid_warm_start", 1) > 0) ? 1 : 0;
+    const int warm = (reuse_perm && ctx->keys_warm && (ctx->keys_src == src || ctx->keys_tgt == tgt) && ctx->keys_warm_n == ns &&
+                      tune_get(ctx, "grid_warm_start", 1) > 0) ? 1 : 0;
     ctx->keys_warm = reuse_perm;
+    ctx->keys_warm_n = ns;
     ctx->keys_src = src;
+    ctx->keys_tgt = tgt;
     // x-window clipping of long rows: 14.1 -> 8.1 ms per search at 10 M x 10 M and 20.9 -> 15.9 ms per ICP iteration there
     // (1 277 -> 462 candidates per query); on sparse clouds the extra phase costs ~25 % (38 -> 48 us at 120 k), so the
     // plain kernel serves small targets.  Same box, same call: profiles/r01_c5_10M_single_gpu.txt.

@@ -479,12 +479,15 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     if (ns == 0) { ctx->keys_n = 0; return PCR_OK; }
     if (ns > 0xFFFFFFF0ull || tgt->n > 0xFFFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "cloud too large for u32 indices");
     // keys[] still holds this source's correspondences of the previous ICP iteration?
-    const bool warm = in_loop && ctx->keys_warm && ctx->keys_src == src && ctx->keys_n == ns && tune_get(ctx, "nn1_warm_start", 1) == 1;
+    const bool warm = in_loop && ctx->keys_warm && (ctx->keys_src == src || ctx->keys_tgt == tgt) && ctx->keys_warm_n == ns &&
+                      tune_get(ctx, "nn1_warm_start", 1) == 1;
     int rc = ensure_keys(ctx, ns);
     if (rc) return rc;
     ctx->keys_n = ns;
     ctx->keys_warm = in_loop;
+    ctx->keys_warm_n = ns;
     ctx->keys_src = src;
+    ctx->keys_tgt = tgt;
 
     int qpl = (int)tune_get(ctx, "nn1_qpl", 2);
     if (qpl != 1 && qpl != 4) qpl = 2;

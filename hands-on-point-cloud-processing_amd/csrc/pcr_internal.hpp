@@ -77,8 +77,14 @@ struct pcr_ctx {
     unsigned long long* keys = nullptr;   // (d2_bits << 32 | idx) per query of the last nn1 pass
     size_t keys_cap = 0;
     size_t keys_n = 0;
-    bool keys_warm = false;               // keys[] holds the previous ICP iteration's result for the same source cloud
-    const pcr_cloud* keys_src = nullptr;  // ... which is this one (identity only; reset when the cloud is destroyed)
+    // Warm start of the searches inside ICP loops: keys[] still holds correspondences of an earlier search.  Any index < n_tgt
+    // is a genuine candidate once re-evaluated exactly against the query, so a stale entry can only make the seed worse, never
+    // the result wrong; the bookkeeping below only decides whether the seeds are likely to be GOOD: same source cloud (the
+    // previous iteration), or another same-sized source against the same target (the previous ICP run on this pair).
+    bool keys_warm = false;               // keys[] was written by a search of an ICP loop
+    const pcr_cloud* keys_src = nullptr;  // its source (identity only; reset when the cloud is destroyed)
+    const pcr_cloud* keys_tgt = nullptr;  // its target (identity only; reset when the cloud is destroyed)
+    size_t keys_warm_n = 0;               // number of queries of that search
     uint32_t* qperm = nullptr;            // queries grouped by target-grid cell (grid NN)
     size_t qperm_cap = 0;
     size_t qperm_n = 0;
