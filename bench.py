@@ -265,10 +265,12 @@ def main():
                 "traffic_note": ("HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from a separate "
                                  "rocprofv3 --pmc pass of this kernel, " + pmc["source"]) if have_pmc else "not collected",
                 "clock_ghz_profiled": pmc.get("clock_ghz_profiled") if have_pmc else None,
-                "kernel": ("pcr::nn1_etrack_kernel<4> in every ICP iteration but the first (exhaustive scan; chunk-centred targets "
-                           "broadcast through the scalar cache; expanded-form lower bound, 3 FMAs per pair, tracked branch-free; the "
-                           "winner decided with the exact unfused arithmetic; the previous correspondence seeds the bound), "
-                           "pcr::nn1_ftrack_kernel<2, 16> in the first (no bound yet); avg_launch_ms averages all launches")
+                "kernel": ("pcr::nn1_etrack_kernel<4> (exhaustive scan; chunk-centred targets broadcast through the scalar cache; "
+                           "expanded-form lower bound, 3 FMAs per pair, tracked branch-free; the winner decided with the exact unfused "
+                           "arithmetic; the previous correspondence of each query — of the previous iteration, or of the warm-up run for "
+                           "the first timed iteration — re-evaluated exactly, seeds the bound); a search without any earlier "
+                           "correspondences (the very first of the warm-up) runs pcr::nn1_ftrack_kernel<2, 16>; avg_launch_ms averages "
+                           "all launches of the timed region")
                           if default_kernels else f"nn1 variant={args.variant} qpl={args.qpl}",
                 "executed_lane_ops_per_pair": (pmc["valu_insts_per_launch"] * 64 / pairs) if have_pmc else None,
                 "issue_frac": (pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TFLOPS_NOFMA) if have_pmc else None,
