@@ -763,7 +763,10 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         stats_dev = ctx->grid_stats_dev;
     }
     // warm start: only inside an ICP loop (reuse_perm), from its second search on, when keys[] belongs to this source
-    const int warm = (reuse_perm && ctx->keys_warm && (ctx->keys_src == src || ctx->keys_tgt == tgt) && ctx->keys_warm_n == ns &&
+    // Unlike the exhaustive kernels (nn1_brute.hip), the grid walk TRUSTS its seed — the radius jumps to the one that proves it —
+    // so only the previous iteration of the same cloud object qualifies: correspondences left by another source cloud of the
+    // same size would be valid but arbitrarily bad candidates (measured: a 5-iteration ICP 0.93 -> 12.5 ms, profiles/r01_tune_grid.txt).
+    const int warm = (reuse_perm && ctx->keys_warm && ctx->keys_src == src && ctx->keys_warm_n == ns &&
                       tune_get(ctx, "grid_warm_start", 1) > 0) ? 1 : 0;
     ctx->keys_warm = reuse_perm;
     ctx->keys_warm_n = ns;
