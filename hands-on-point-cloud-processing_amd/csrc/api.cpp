@@ -97,12 +97,12 @@ void cloud_modified(pcr_cloud* c)
     if (c && c->knn_grid) { grid_free(c->knn_grid); c->knn_grid = nullptr; c->knn_grid_factor = 0.0; }
 }
 
-int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm)
+int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2)
 {
     // nn_method: 0 auto (grid for targets >= 2048 points), 1 brute force, 2 uniform grid
     const int64_t method = tune_get(ctx, "nn_method", 0);
     const bool grid = method == 2 || (method != 1 && tgt->n >= 2048);
-    return grid ? launch_nn1_grid(ctx, tgt, src, reuse_perm) : launch_nn1_brute(ctx, tgt, src, reuse_perm);
+    return grid ? launch_nn1_grid(ctx, tgt, src, reuse_perm, cap2) : launch_nn1_brute(ctx, tgt, src, reuse_perm);
 }
 
 static int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out)

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     GridParams g, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     const uint32_t* __restrict__ perm, uint32_t ns, unsigned long long* __restrict__ keys, const int* __restrict__ stop,
     unsigned long long* __restrict__ stats, const float* __restrict__ tx, const float* __restrict__ ty,
-    const float* __restrict__ tz, uint32_t nt, int warm_start)
+    const float* __restrict__ tz, uint32_t nt, int warm_start, float cap2)
 {
     if (stop && (stop[0] | stop[1])) return;      // pipelined ICP: the loop has ended, the enqueued tail is a no-op
     unsigned long long st_cand = 0, st_rows = 0, st_stages = 0;   // diagnostics (STATS builds only)
@@ -405,7 +405,9 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
                                 (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
             const float reach = (1.0f - g.slack) * g.h;
-            done = covers || (best != KEY_NONE && reach > TRUST && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f);
+            // (cap2: the caller discards neighbours with d2 >= cap2, so a cube that no closer target can lie outside of ends the search)
+            done = covers || (reach > TRUST && (reach * reach * 0.99999f >= cap2 ||
+                                                (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f)));
             r = 2;
         }
         // ---- later stages.  rp = radius of the cube already scanned (0: none).  The next radius is the smallest one
@@ -493,7 +495,9 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                                 (uz - r <= 0) && (uz + r >= g.n[2] - 1);
             // every target outside the cube is farther than (r - slack) * h in some axis
             const float reach = ((float)r - g.slack) * g.h;
-            done = covers || (best != KEY_NONE && reach > TRUST && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f);
+            // (cap2: the caller discards neighbours with d2 >= cap2, so a cube that no closer target can lie outside of ends the search)
+            done = covers || (reach > TRUST && (reach * reach * 0.99999f >= cap2 ||
+                                                (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f)));
             rp = r;
             r = min(r * 2, 1 << 24);
         }
@@ -741,7 +745,7 @@ int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     return sort_queries(ctx, tgt->grid, src);
 }
 
-int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm)
+int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2)
 {
     const size_t ns = src->n;
     if (ns == 0) { ctx->keys_n = 0; return PCR_OK; }
@@ -784,7 +788,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
 #define PCR_GRID2(GG, ST, CL)                                                                                          \
     hipLaunchKernelGGL((nn1_grid_kernel<GG, ST, CL>), dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records, \
                        g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(), tgt->y(),   \
-                       tgt->z(), (uint32_t)tgt->n, warm)
+                       tgt->z(), (uint32_t)tgt->n, warm, cap2)
 #define PCR_GRID(GG)                                                                                                   \
     do {                                                                                                               \
         if (stats_dev) { if (clip) PCR_GRID2(GG, true, true); else PCR_GRID2(GG, true, false); }                       \

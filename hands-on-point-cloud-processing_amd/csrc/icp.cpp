@@ -26,6 +26,8 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
     const uint64_t nn_l0 = ctx->prof["nn1_brute"].launches + ctx->prof["nn1_grid"].launches;
     const double nn_ms0 = ctx->prof["nn1_brute"].total_ms + ctx->prof["nn1_grid"].total_ms;
 
+    // pairs are kept only if d2 < max_corr (:936), so the grid search need not look farther (tune icp_bounded_search: 2 = off)
+    const float gate = tune_get(ctx, "icp_bounded_search", 1) == 1 ? prm->max_corr : __builtin_inff();
     pcr_cloud* work = nullptr;
     int rc = pcr_cloud_clone(ctx, src, &work);                                   // :872
     if (rc) return rc;
@@ -41,7 +43,7 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
     if (nred > 64) { pcr_cloud_destroy(ctx, work); return fail(ctx, PCR_ERR_ARG, "too many ranks"); }
 
     for (uint64_t iter = 0; rc == PCR_OK && iter < prm->max_iter; iter++) {      // :917
-        if ((rc = launch_nn1(ctx, tgt, work, true))) break;                      // :925-934
+        if ((rc = launch_nn1(ctx, tgt, work, true, gate))) break;                      // :925-934
         double* h = ctx->host_out;
         double last_kept, last_d2;
         hipError_t e = hipSuccess;
@@ -133,6 +135,8 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     IcpState* dev = ctx->icp_state_dev;
     IcpState* host = ctx->icp_state_host;      // [0..RING) ring of snapshots, [RING] upload / final download
 
+    // pairs are kept only if d2 < max_corr (:936), so the grid search need not look farther (tune icp_bounded_search: 2 = off)
+    const float gate = tune_get(ctx, "icp_bounded_search", 1) == 1 ? prm->max_corr : __builtin_inff();
     pcr_cloud* work = nullptr;
     int rc = pcr_cloud_clone(ctx, src, &work);                                   // :872
     if (rc) return rc;
@@ -158,7 +162,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     while (rc == PCR_OK && !stopped && enq < prm->max_iter) {
         for (int64_t c = 0; rc == PCR_OK && c < chunk && enq < prm->max_iter; c++, enq++) {   // :917
             ctx->stop_flag_dev = &dev->stop;     // correspondence kernels no-op once stop or stop_after_transform is set
-            if ((rc = launch_nn1(ctx, tgt, work, true))) break;                             // :925-934
+            if ((rc = launch_nn1(ctx, tgt, work, true, gate))) break;                             // :925-934
             uint32_t blocks = 0;
             if (work->n && (rc = launch_kabsch_partial(ctx, tgt, work, prm->max_corr, &blocks))) break;   // :936-940,:964-985
             if (nranks == 1 && work->n && tune_get(ctx, "icp_force_slots", 0) <= 0) {

@@ -137,7 +137,7 @@ extern "C" int pcr_icp_p2plane_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr
     }
     std::vector<double> hp((size_t)blocks * PP_NV);
     for (uint64_t iter = 0; rc == PCR_OK && iter < prm->max_iter; iter++) {
-        if ((rc = launch_nn1(ctx, tgt, work, true))) break;                              // :768-781
+        if ((rc = launch_nn1(ctx, tgt, work, true, tune_get(ctx, "icp_bounded_search", 1) == 1 ? prm->max_corr : __builtin_inff()))) break;                              // :768-781
         double s[64];
         for (int k = 0; k < 64; k++) s[k] = 0.0;
         if (ns) {

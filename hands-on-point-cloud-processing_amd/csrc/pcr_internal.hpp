@@ -136,7 +136,8 @@ void prof_flush(pcr_ctx* ctx);
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool in_loop);
-int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm);
+// cap2: the caller only uses neighbours with d2 < cap2 (ICP's max_corres_dist gate) — the walk may stop once no such target can exist
+int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2);
 // grid radius search with the hw2 contract (radius_grid.hip); *used = false -> the caller runs the exhaustive kernels
 int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r, double r2max, int64_t* row_ptr_host, int32_t* idx_host, double* dist_host,
                 bool* used);
@@ -147,7 +148,7 @@ int cloud_knn_host(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k,
 constexpr int SCAN_TILE = 2048;
 int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* totals, uint32_t* grand);
 // dispatcher: tune "nn_method" 0 = auto (grid for targets >= 2048 points), 1 = brute force, 2 = grid
-int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm);
+int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2 = __builtin_inff());
 void cloud_modified(pcr_cloud* c);
 int nn1_unpack(pcr_ctx* ctx, size_t n, uint32_t* idx_dev, float* d2_dev);
 int launch_transform(pcr_ctx* ctx, pcr_cloud* c, const float R[9], const float t[3]);

@@ -535,3 +535,26 @@ def test_context_owns_its_handles(pcr, synth):
     del ctx2                                     # the cloud keeps its context alive
     assert len(c) == 500
     c.free()
+
+
+def test_icp_bounded_search_with_outliers(pcr, synth):
+    """Partial overlap: 10 % of the source has no target within the max_corres_dist gate.  The grid search bounded by that gate
+    (default inside ICP loops), the unbounded exact search and brute force give the same pose bits and statistics."""
+    n = 20000
+    src, tgt = synth.kitti_like_pair(n)
+    rng = np.random.default_rng(11)
+    out = rng.choice(n, n // 10, replace=False)
+    src = src.copy()
+    src[:, out] += rng.uniform(15.0, 40.0, (1, out.size)).astype(np.float32) * np.array([[0.3], [0.2], [1.0]], np.float32)
+    res = []
+    for method, bounded in ((2, 1), (2, 2), (1, 1)):
+        with pcr.Context(0) as ctx:
+            ctx.tune("nn_method", method); ctx.tune("icp_bounded_search", bounded)
+            for mc, it in ((1.0, 6), (0.05, 4), (400.0, 3)):
+                T, st = ctx.icp_point2point(ctx.cloud(src), ctx.cloud(tgt), max_corr=mc, max_iter=it, eps=0.0)
+                res.append((method, bounded, mc, T.view(np.uint32).copy(), st["last_pairs"], st["iters_run"], st["empty_pairs"]))
+    ref = [r for r in res if r[0] == 1]
+    for r in res:
+        m = [x for x in ref if x[2] == r[2]][0]
+        assert np.array_equal(r[3], m[3]) and r[4:] == m[4:], (r[0], r[1], r[2])
+    assert ref[0][4] <= n - n // 10                      # the outliers were indeed rejected at max_corr = 1
