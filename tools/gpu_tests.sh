@@ -1,2 +1,3 @@
 set -o pipefail
-timeout -k 10 300 python tools/run_real_scan.py 20
+mkdir -p gpurun_out
+timeout -k 10 1000 python tools/soak_nn1.py 15000 8800000 > gpurun_out/soak.txt 2>&1; rc=$?; tail -2 gpurun_out/soak.txt; grep -c MISMATCH gpurun_out/soak.txt; exit $rc

@@ -37,6 +37,9 @@ def make(rng):
     s = (R @ t[:, rng.integers(0, nt, ns)].astype(np.float64) + tr[:, None] + rng.normal(0, 0.002 * scale, (3, ns))).astype(np.float32)
     if rng.integers(0, 4) == 0:
         s[:, :: max(1, ns // 5)] = t[:, : len(s[0, :: max(1, ns // 5)])]      # exact coincidences
+    if rng.integers(0, 3) == 0:                                              # partial overlap: sources with no target inside the gate
+        m = rng.random(ns) < 0.15
+        s[:, m] += (rng.uniform(3.0, 60.0, (1, int(m.sum()))) * scale * rng.choice([-1.0, 1.0], (3, 1))).astype(np.float32)
     return kind, np.ascontiguousarray(t), np.ascontiguousarray(s), scale
 
 
