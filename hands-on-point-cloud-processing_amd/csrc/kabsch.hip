@@ -132,7 +132,7 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_final_kernel(
 // a pure function of n: the order of the f64 additions (and so the bits of the sums) depends only on n
 static uint32_t kabsch_blocks(size_t ns)
 {
-    uint32_t blocks = (uint32_t)((ns + KB_BLOCK * 4 - 1) / (KB_BLOCK * 4));
+    uint32_t blocks = (uint32_t)((ns + KB_BLOCK - 1) / KB_BLOCK);          // one point per thread up to KB_MAX_BLOCKS: the pass is latency-bound
     if (blocks < 1) blocks = 1;
     if (blocks > KB_MAX_BLOCKS) blocks = KB_MAX_BLOCKS;
     return blocks;
