@@ -351,7 +351,9 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
         // Chebyshev distance (in cells) from the query's cell to the grid box: smaller cubes hold no cell
         const int r0 = max(max(max(-ux, ux - (g.n[0] - 1)), max(-uy, uy - (g.n[1] - 1))), max(max(-uz, uz - (g.n[2] - 1)), 0));
         int r = max(r0, 1);
-        bool done = false;
+        // a query farther from the grid box than the caller's gate (cap2) has no admissible neighbour at all
+        const float out_reach = ((float)r0 - 1.0f - g.slack) * g.h;
+        bool done = r0 > 1 && out_reach > TRUST && out_reach * out_reach * 0.99999f >= cap2;
         if (r == 1) {
             // ---- stage 1: static 3 x 3 rows, bounds first
             const int xlo = max(ux - 1, 0), xhi = min(ux + 1, g.n[0] - 1);
