@@ -1,6 +1,5 @@
 set -o pipefail
-mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -3 || exit 1
-timeout -k 10 600 python tools/soak_nn1.py 3000 4440000 > gpurun_out/soak.txt 2>&1; tail -1 gpurun_out/soak.txt
-for lib in old hip; do PCR_LIB_PATH=$R/hands-on-point-cloud-processing_amd/libpcr_$lib.so timeout -k 10 300 python tools/run_outliers.py 120000 0.1 10 | sed "s/^/$lib /" || exit 1; done
+for a in "--steps 1 --warmup 0" "--steps 3 --warmup 1 --no-grid-extra" "--steps 2 --warmup 0 --nn grid" "--steps 20 --warmup 3"; do
+  timeout -k 10 300 python bench.py $a --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$a ->', round(d['value'],1), d['steps'], d['warmup'], round(d['ms_per_step'],3))" || { echo "FAILED: $a"; exit 1; }
+done
+PCR_BENCH_BACKEND=gloo timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 3 --warmup 0 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('2 ranks gloo rehearsal ->', round(d['value'],1), d['n_gpus'])"
