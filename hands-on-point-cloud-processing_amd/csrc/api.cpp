@@ -163,6 +163,7 @@ int pcr_ctx_destroy(pcr_ctx* ctx)
     prof_flush(ctx);
     pcr_comm_destroy(ctx);
     if (ctx->keys) hipFree(ctx->keys);
+    if (ctx->far_list) hipFree(ctx->far_list);
     if (ctx->icp_state_dev) hipFree(ctx->icp_state_dev);
     if (ctx->icp_state_host) hipHostFree(ctx->icp_state_host);
     for (hipEvent_t ev : ctx->icp_events) if (ev) hipEventDestroy(ev);

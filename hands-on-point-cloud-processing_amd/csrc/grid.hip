@@ -232,6 +232,7 @@ constexpr unsigned long long KEY_NONE = ((unsigned long long)0x7F7FFFFFu << 32) 
 // a cloud of 1e-25-sized coordinates has d2 == 0 for EVERY pair, and the lowest index must win among all of them).
 // So a bound is only used when it is at least TRUST (1e-15, squared 1e-30 >> 2^-126): smaller clouds are scanned whole.
 constexpr float TRUST = 1e-15f, TRUST2 = 1e-30f;
+constexpr uint32_t FAR_DIV = 64;      // measured: profiles/r01_tune_grid.txt
 
 // candidates [b, e) of one x-row, strided over the G lanes of the query's sub-group: 16 B per lane, G*16 B contiguous
 template <int G>
@@ -325,7 +326,8 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     GridParams g, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     const uint32_t* __restrict__ perm, uint32_t ns, unsigned long long* __restrict__ keys, const int* __restrict__ stop,
     unsigned long long* __restrict__ stats, const float* __restrict__ tx, const float* __restrict__ ty,
-    const float* __restrict__ tz, uint32_t nt, int warm_start, float cap2)
+    const float* __restrict__ tz, uint32_t nt, int warm_start, float cap2,
+    uint32_t* __restrict__ far_list, uint32_t* __restrict__ far_count, uint32_t far_cap)
 {
     if (stop && (stop[0] | stop[1])) return;      // pipelined ICP: the loop has ended, the enqueued tail is a no-op
     unsigned long long st_cand = 0, st_rows = 0, st_stages = 0;   // diagnostics (STATS builds only)
@@ -440,6 +442,19 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                 // sub-group scans the G ranges one after the other with coalesced 16-byte loads.
                 const int ny_rows = yhi - ylo + 1;
                 const int n_rows = ny_rows * (zhi - zlo + 1);
+                // A far query (no target anywhere near: partial overlap in an unbounded search): once the next shell would open
+                // more rows than the target has points / FAR_DIV, the query is handed to the exhaustive kernel (one tiled pass over
+                // the target shared by hundreds of such queries) with what it has found so far; if the list is full it walks on.
+                if (far_list && (uint32_t)n_rows > nt / FAR_DIV + 256u) {
+                    int ok = 0;
+                    if (l == 0 && gt / G < ns) {
+                        const uint32_t pos = atomicAdd(far_count, 1u);
+                        if (pos < far_cap) { far_list[pos] = i; ok = 1; }
+                    }
+                    ok = __shfl(ok, 0, G);
+                    if (gt / G >= ns) ok = 1;               // surplus sub-groups of the last workgroup: nothing to do
+                    if (ok) { done = true; break; }
+                }
                 for (int k0 = 0; k0 < n_rows; k0 += G) {
                     const int k = k0 + l;
                     uint32_t b1 = 0, e1 = 0, b2 = 0, e2 = 0;       // up to two pieces per row
@@ -785,12 +800,24 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     const int64_t clip_tune = tune_get(ctx, "grid_clip_x", 0);
     const bool clip = clip_tune == 1 || (clip_tune != 2 && tgt->n >= 500000);
     const int G = (int)tune_get(ctx, "grid_lanes", 16);   // measured: profiles/r01_tune_grid.txt
+    // unbounded searches hand their far queries to the exhaustive kernel (grid_far_brute: 1 on (default), 2 off)
+    uint32_t* far_list = nullptr; uint32_t* far_count = nullptr; uint32_t far_cap = 0;
+    if (!(cap2 < __builtin_inff()) && tgt->n >= 4096 && tune_get(ctx, "grid_far_brute", 1) == 1) {
+        const size_t want = std::max<size_t>(ns / 8, 1024);
+        if (ctx->far_cap < want) {
+            if (ctx->far_list) { PCR_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->far_list); ctx->far_list = nullptr; ctx->far_cap = 0; }
+            PCR_HIP(ctx, hipMalloc((void**)&ctx->far_list, (want + 1) * sizeof(uint32_t)));
+            ctx->far_cap = want;
+        }
+        far_list = ctx->far_list; far_count = ctx->far_list + ctx->far_cap; far_cap = (uint32_t)std::min<size_t>(want, ctx->far_cap);
+        PCR_HIP(ctx, hipMemsetAsync(far_count, 0, sizeof(uint32_t), ctx->stream));
+    }
     {
         ProfScope p(ctx, "nn1_grid", 1);
 #define PCR_GRID2(GG, ST, CL)                                                                                          \
     hipLaunchKernelGGL((nn1_grid_kernel<GG, ST, CL>), dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records, \
                        g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(), tgt->y(),   \
-                       tgt->z(), (uint32_t)tgt->n, warm, cap2)
+                       tgt->z(), (uint32_t)tgt->n, warm, cap2, far_list, far_count, far_cap)
 #define PCR_GRID(GG)                                                                                                   \
     do {                                                                                                               \
         if (stats_dev) { if (clip) PCR_GRID2(GG, true, true); else PCR_GRID2(GG, true, false); }                       \
@@ -807,6 +834,10 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         }
 #undef PCR_GRID2
 #undef PCR_GRID
+        if (far_list) {
+            rc = launch_nn1_brute_list(ctx, tgt, src, far_list, far_count, far_cap);
+            if (rc) return rc;
+        }
     }
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;

@@ -197,16 +197,26 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ftrack_kernel(
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
     const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     uint32_t ns, uint32_t n_tiles, uint32_t tiles_per_slice,
-    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop)
+    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop,
+    const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qcount, uint32_t qcap)
 {
     if (stop && (stop[0] | stop[1])) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t qbase = blockIdx.x * (NN_BLOCK * QPL);
+    // qlist: only the listed queries (the far queries the grid walk handed over, grid.hip); their keys[] already hold a real
+    // candidate or "none", and the results are merged into them
+    uint32_t nq = ns;
+    if (qlist) {
+        nq = min(*qcount, qcap);
+        if (qbase >= nq) return;
+    }
     float qx[QPL], qy[QPL], qz[QPL];
-    uint32_t a1[QPL], a2[QPL], c1[QPL];
+    uint32_t a1[QPL], a2[QPL], c1[QPL], iq[QPL];
 #pragma unroll
     for (int k = 0; k < QPL; k++) {
-        uint32_t i = min(qbase + k * NN_BLOCK + tid, ns - 1);
+        const uint32_t slot = min(qbase + k * NN_BLOCK + tid, nq - 1);
+        const uint32_t i = qlist ? qlist[slot] : slot;
+        iq[k] = i;
         qx[k] = sx[i]; qy[k] = sy[i]; qz[k] = sz[i];
         a1[k] = 0x7F800000u; a2[k] = 0x7F800000u; c1[k] = 0xFFFFFFFFu;
     }
@@ -272,8 +282,8 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ftrack_kernel(
                 }
             }
         }
-        const uint32_t i = qbase + k * NN_BLOCK + tid;
-        if (i < ns) {
+        if (qbase + k * NN_BLOCK + tid < nq) {
+            const uint32_t i = iq[k];
             const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : best;
             const unsigned long long key = ((unsigned long long)bits << 32) | bidx;
             if (merge_atomic) merge_key(&keys[i], key);
@@ -464,7 +474,8 @@ static void launch_ftrack(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt
 {
 #define PCR_FTRACK(Q)                                                                                              \
     hipLaunchKernelGGL((nn1_ftrack_kernel<Q, CH>), grid, dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(),         \
-                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic, ctx->stop_flag_dev)
+                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic, ctx->stop_flag_dev, \
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u)
     switch (qpl) {
     case 1: PCR_FTRACK(1); break;
     case 4: PCR_FTRACK(4); break;
@@ -587,6 +598,24 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
             break;
         }
     }
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+// exhaustive search of the listed queries only (count on the device, at most qcap), merged into keys[] (grid.hip hands its far
+// queries over: one tiled pass over the target per ~512 of them instead of a cube walk to a neighbour tens of metres away)
+int launch_nn1_brute_list(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, const uint32_t* qlist, const uint32_t* qcount, uint32_t qcap)
+{
+    if (qcap == 0 || tgt->n == 0) return PCR_OK;
+    constexpr int Q = 2;
+    const uint32_t n_tiles = (uint32_t)((tgt->n + NN_TILE - 1) / NN_TILE);
+    const uint32_t qblocks = (qcap + NN_BLOCK * Q - 1) / (NN_BLOCK * Q);
+    // few query blocks: slice the target so that the listed queries still fill the chip
+    uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(n_tiles, 2048u / std::max<uint32_t>(1u, std::min<uint32_t>(qblocks, 2048u))));
+    uint32_t tps = (n_tiles + slices - 1) / slices;
+    slices = (n_tiles + tps - 1) / tps;
+    hipLaunchKernelGGL((nn1_ftrack_kernel<Q, 16>), dim3(qblocks, slices), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
+                       src->x(), src->y(), src->z(), (uint32_t)src->n, n_tiles, tps, ctx->keys, 1, ctx->stop_flag_dev, qlist, qcount, qcap);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }

@@ -102,6 +102,8 @@ struct pcr_ctx {
     hipEvent_t icp_events[4] = { nullptr, nullptr, nullptr, nullptr };
     unsigned long long* grid_stats_dev = nullptr;   // diagnostics of the grid search (tune grid_stats)
     const int* stop_flag_dev = nullptr;        // when set, the correspondence kernels exit early once *flag != 0
+    uint32_t* far_list = nullptr;              // far queries handed from the grid walk to the exhaustive kernel: [cap] indices + [1] count
+    size_t far_cap = 0;
     pcr::Comm comm;
     std::map<std::string, pcr::ProfEntry> prof;
     int prof_level = 0;                   // 0 off (default: an event pair costs ~6 us of stream time on each side of the kernel),
@@ -136,6 +138,7 @@ void prof_flush(pcr_ctx* ctx);
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool in_loop);
+int launch_nn1_brute_list(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, const uint32_t* qlist, const uint32_t* qcount, uint32_t qcap);
 // cap2: the caller only uses neighbours with d2 < cap2 (ICP's max_corres_dist gate) — the walk may stop once no such target can exist
 int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2);
 // grid radius search with the hw2 contract (radius_grid.hip); *used = false -> the caller runs the exhaustive kernels
