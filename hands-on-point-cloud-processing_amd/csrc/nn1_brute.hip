@@ -503,10 +503,12 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     int qpl = (int)tune_get(ctx, "nn1_qpl", 2);
     if (qpl != 1 && qpl != 4) qpl = 2;
     // variant 4 = ETRACK: needs the target's grid index (cell-sorted records + the chunked, centred copy)
-    // nn1_variant unset: FTRACK for a cold search, ETRACK when a warm-start bound exists (measured: ETRACK needs the bound to
-    // settle the far slices, profiles/r01_tune_nn1_etrack.txt); 4 forces ETRACK, 1-3 the kernels below
+    // nn1_variant unset: ETRACK when a warm-start bound exists or the target's index does (profiles/r01_tune_nn1_etrack.txt),
+    // FTRACK otherwise; 4 forces ETRACK, 1-3 the kernels below
     const int64_t variant_tune = tune_get(ctx, "nn1_variant", 0);
-    if (variant_tune == 4 || (variant_tune == 0 && warm && tgt->n >= 2048)) {
+    // cold searches take ETRACK too when its index exists or will be needed anyway (inside an ICP loop): 1.64 vs 1.82 ms at 120 k;
+    // a one-shot search on a fresh target stays on FTRACK, which needs no index (0.3 ms to build)
+    if (variant_tune == 4 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid))) {
         if (!tgt->grid) {
             Grid* g = nullptr;
             ProfScope p(ctx, "grid_build");
