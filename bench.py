@@ -275,8 +275,8 @@ def main():
                            "expanded-form lower bound, 3 FMAs per pair, tracked branch-free; the winner decided with the exact unfused "
                            "arithmetic; the previous correspondence of each query — of the previous iteration, or of the warm-up run for "
                            "the first timed iteration — re-evaluated exactly, seeds the bound); a search without any earlier "
-                           "correspondences (the very first of the warm-up) runs pcr::nn1_ftrack_kernel<2, 16>; avg_launch_ms averages "
-                           "all launches of the timed region")
+                           "correspondences (the very first of the preparation) runs the same kernel without a seed; avg_launch_ms "
+                           "averages all launches of the timed region")
                           if default_kernels else f"nn1 variant={args.variant} qpl={args.qpl}",
                 "executed_lane_ops_per_pair": (pmc["valu_insts_per_launch"] * 64 / pairs) if have_pmc else None,
                 "issue_frac": (pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TFLOPS_NOFMA) if have_pmc else None,
