@@ -22,7 +22,7 @@ if f:
     lines.append("| kernel | calls | total ms | avg us | % |")
     lines.append("|---|---|---|---|---|")
     for r in csv.DictReader(open(f)):
-        name = r["Name"].split("(")[0].replace("void ", "")
+        name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         lines.append(f"| {name} | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
     lines.append("")
 bj = os.path.join(go, "bench.json")
