@@ -1,7 +1,4 @@
 set -o pipefail
-mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-export TMPDIR=/tmp; cd /tmp
-for t in run_iss run_knn run_n3 run_n4 run_p2plane run_c4; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_rows/$t --output-format csv -- python3 $R/tools/$t.py > $R/gpurun_out/prof_rows_$t.log 2>&1; echo "$t rc=$?"
-done
+timeout -k 10 600 python -m pytest tests/test_voxel_filter.py tests/test_random_sweeps.py -m gpu -q -x --timeout 600 2>&1 | tail -3 || exit 1
+for lib in old hip; do PCR_LIB_PATH=$R/hands-on-point-cloud-processing_amd/libpcr_$lib.so timeout -k 10 300 python tools/run_n3.py 2>&1 | grep "voxel_filter" | cut -c1-150 | sed "s/^/$lib /" || exit 1; done
