@@ -29,6 +29,9 @@ if os.environ.get("GRID_CLIP_X"):     # 1 = x-window kernel, 2 = plain kernel (0
     ctx.tune("grid_clip_x", int(os.environ["GRID_CLIP_X"]))
 if os.environ.get("GRID_CELL_UM"):
     ctx.tune("grid_cell_um", int(os.environ["GRID_CELL_UM"]))
+for kv in os.environ.get("PCR_TUNE", "").split(","):      # any other knob: PCR_TUNE="key=value,..."
+    if "=" in kv:
+        k_, v_ = kv.split("="); ctx.tune(k_, int(v_))
 aligned = os.environ.get("ALIGNED", "0") == "1"
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
 if aligned:
