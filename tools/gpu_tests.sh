@@ -1,2 +1,4 @@
 set -o pipefail
-for t in "nn1_etrack_blocks=32768" "nn1_etrack_blocks=16384" "nn1_etrack_blocks=8192" "nn1_etrack_blocks=4096" "nn1_etrack_blocks=8192,nn1_etrack_qpl=2" "nn1_etrack_blocks=16384,nn1_etrack_qpl=2" "nn1_etrack_blocks=32768"; do PCR_TUNE=$t timeout -k 10 200 python tools/run_nn1.py 120000 10 4 | grep "n=120000" | cut -c60-140 | sed "s/^/$t /"; done
+mkdir -p gpurun_out
+timeout -k 10 1000 python tools/soak_nn1.py 15000 31000000 > gpurun_out/soak.txt 2>&1; rc=$?; tail -1 gpurun_out/soak.txt; [ $rc -eq 0 ] || exit 1
+PCR_SWEEP_SCALE=25 PCR_SWEEP_SEED=777001 timeout -k 10 700 python -m pytest tests/test_random_sweeps.py -m gpu -q -x --timeout 650 > gpurun_out/sweep.txt 2>&1; tail -2 gpurun_out/sweep.txt
