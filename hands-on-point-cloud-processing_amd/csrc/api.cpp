@@ -301,7 +301,9 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
 int pcr_nn1_f32_async(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
 {
     if (!ctx || !tgt || !src) return fail(ctx, PCR_ERR_ARG, "pcr_nn1_f32_async");
-    return launch_nn1(ctx, tgt, src, false);
+    // tune "nn1_async_in_loop" = 1: the caller iterates (its own ICP-style loop on the same pair) — the search may then be seeded by the
+    // correspondences of its previous call exactly as the searches inside pcr_icp_p2p_f32 are (same results, bit for bit)
+    return launch_nn1(ctx, tgt, src, tune_get(ctx, "nn1_async_in_loop", 0) > 0);
 }
 
 int pcr_nn1_fetch(pcr_ctx* ctx, size_t n, uint32_t* idx, float* d2)

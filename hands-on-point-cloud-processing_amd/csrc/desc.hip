@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void ransac_hyp_kernel(const PairXyz* __restri
         sums[15] += 1.0;
     }
     float R[9], t[3];
-    const int rc = num::kabsch_solve(sums, R, t);
+    const int rc = num::kabsch_solve_ransac(sums, R, t);   // t from U V^T, the reflection fix applies to R only (:382-392)
 #pragma unroll
     for (int k = 0; k < 9; k++) Rt[12 * (size_t)h + k] = R[k];
 #pragma unroll

@@ -106,34 +106,49 @@ PCR_HD void mul3(const double A[9], const double B[9], double C[9])
             C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
 }
 
-// registration.cpp:979-998; returns 0, or -1 when no pair was kept
-PCR_HD int kabsch_solve(const double sums[16], float R[9], float t[3])
+// The two Kabsch blocks of the reference differ in ONE statement order (both kept as written):
+//   ICPpoint2point (registration.cpp:979-998):  R = U V^T; if det R < 0: R = V B U^T;  t = qbar - R pbar      (t from the final R)
+//   RANSAC         (registration.cpp:373-392):  R = U V^T; t = qbar - R pbar;  if det R < 0: R = V B U^T      (t keeps the FIRST R)
+// T_FIRST selects the second.  Returns 0, or -1 when no pair was kept.
+template <bool T_FIRST>
+PCR_HD int kabsch_solve_as(const double sums[16], float R[9], float t[3])
 {
     const double M = sums[15];
     if (!(M > 0.0)) return -1;
     double pbar[3], qbar[3], H[9];
-    for (int c = 0; c < 3; c++) { pbar[c] = sums[c] / M; qbar[c] = sums[3 + c] / M; }        // :979-980
+    for (int c = 0; c < 3; c++) { pbar[c] = sums[c] / M; qbar[c] = sums[3 + c] / M; }        // :979-980 / :373-374
     for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) H[3 * r + c] = sums[6 + 3 * r + c] - M * qbar[r] * pbar[c];   // :982-985
+        for (int c = 0; c < 3; c++) H[3 * r + c] = sums[6 + 3 * r + c] - M * qbar[r] * pbar[c];   // :982-985 / :375-379
     double U[9], S[3], V[9], Vt[9], Ut[9], Rd[9];
     svd3(H, U, S, V);
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) { Vt[3 * r + c] = V[3 * c + r]; Ut[3 * r + c] = U[3 * c + r]; }
-    mul3(U, Vt, Rd);                                                                            // :988
+    mul3(U, Vt, Rd);                                                                            // :988 / :382
+    if (T_FIRST) {                                                                              // :383
+        for (int r = 0; r < 3; r++) {
+            const double Rp = ((double)(float)Rd[3 * r] * pbar[0] + (double)(float)Rd[3 * r + 1] * pbar[1]) + (double)(float)Rd[3 * r + 2] * pbar[2];
+            t[r] = (float)(qbar[r] - Rp);
+        }
+    }
     const double det = Rd[0] * (Rd[4] * Rd[8] - Rd[5] * Rd[7]) - Rd[1] * (Rd[3] * Rd[8] - Rd[5] * Rd[6])
                      + Rd[2] * (Rd[3] * Rd[7] - Rd[4] * Rd[6]);
-    if (det < 0) {                                                                              // :990-996
+    if (det < 0) {                                                                              // :990-996 / :386-392
         double VB[9];
         for (int r = 0; r < 3; r++) { VB[3 * r] = V[3 * r]; VB[3 * r + 1] = V[3 * r + 1]; VB[3 * r + 2] = V[3 * r + 2] * det; }
         mul3(VB, Ut, Rd);   // V * B * U^T, as the reference writes it
     }
     for (int k = 0; k < 9; k++) R[k] = (float)Rd[k];
-    for (int r = 0; r < 3; r++) {                                                               // :998
-        const double Rp = ((double)R[3 * r] * pbar[0] + (double)R[3 * r + 1] * pbar[1]) + (double)R[3 * r + 2] * pbar[2];
-        t[r] = (float)(qbar[r] - Rp);
+    if (!T_FIRST) {
+        for (int r = 0; r < 3; r++) {                                                           // :998
+            const double Rp = ((double)R[3 * r] * pbar[0] + (double)R[3 * r + 1] * pbar[1]) + (double)R[3 * r + 2] * pbar[2];
+            t[r] = (float)(qbar[r] - Rp);
+        }
     }
     return 0;
 }
+
+PCR_HD int kabsch_solve(const double sums[16], float R[9], float t[3]) { return kabsch_solve_as<false>(sums, R, t); }
+PCR_HD int kabsch_solve_ransac(const double sums[16], float R[9], float t[3]) { return kabsch_solve_as<true>(sums, R, t); }
 
 // out = A * B, 4x4 row-major f32, sequential k, unfused (registration.cpp:1002); out may alias A or B
 PCR_HD void mat4_mul_f32(const float A[16], const float B[16], float out[16])

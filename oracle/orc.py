@@ -50,6 +50,7 @@ def lib():
         L.orc_d2_f32.restype = C.c_float
         L.orc_d2_f32.argtypes = [C.c_float] * 6
         L.orc_nn1_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, u32p, f32p]
+        L.orc_nn1_f32_mt.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, u32p, f32p, C.c_int]
         L.orc_nn1_tiecount_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, u32p]
         L.orc_knn_f64.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_int, i32p, f64p]
         L.orc_radius_f64.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_double, i64p, C.c_void_p, C.c_void_p]
@@ -60,6 +61,8 @@ def lib():
         L.orc_svd3.argtypes = [f64p, f64p, f64p, f64p]
         L.orc_kabsch_solve.restype = C.c_int
         L.orc_kabsch_solve.argtypes = [f64p, f32p, f32p]
+        L.orc_kabsch_solve_ransac.restype = C.c_int
+        L.orc_kabsch_solve_ransac.argtypes = [f64p, f32p, f32p]
         L.orc_mat4_mul_f32.argtypes = [f32p, f32p, f32p]
         L.orc_icp_p2p_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, f32p,
                                       C.POINTER(IcpParams), f32p, C.POINTER(IcpStats), C.c_void_p, C.c_void_p]
@@ -147,6 +150,16 @@ def nn1_f32(tgt_soa, src_soa):
     return idx, d2
 
 
+def nn1_f32_mt(tgt_soa, src_soa, threads=8):
+    """orc_nn1_f32 with the queries split over host threads (identical results)."""
+    tx, ty, tz = _soa(tgt_soa)
+    sx, sy, sz = _soa(src_soa)
+    idx = np.empty(sx.size, np.uint32)
+    d2 = np.empty(sx.size, np.float32)
+    lib().orc_nn1_f32_mt(tx, ty, tz, tx.size, sx, sy, sz, sx.size, idx, d2, int(threads))
+    return idx, d2
+
+
 def nn1_tiecount_f32(tgt_soa, src_soa):
     tx, ty, tz = _soa(tgt_soa)
     sx, sy, sz = _soa(src_soa)
@@ -210,6 +223,14 @@ def kabsch_solve(sums):
     R = np.zeros(9, np.float32)
     t = np.zeros(3, np.float32)
     rc = lib().orc_kabsch_solve(np.ascontiguousarray(sums, np.float64), R, t)
+    return rc, R.reshape(3, 3), t
+
+
+def kabsch_solve_ransac(sums):
+    """registration.cpp:372-392: t from U V^T, the det < 0 repair replaces R only."""
+    R = np.zeros(9, np.float32)
+    t = np.zeros(3, np.float32)
+    rc = lib().orc_kabsch_solve_ransac(np.ascontiguousarray(sums, np.float64), R, t)
     return rc, R.reshape(3, 3), t
 
 

@@ -8,6 +8,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -40,6 +41,44 @@ void orc_nn1_f32(const float* tx, const float* ty, const float* tz, size_t nt,
         idx[i] = bi;
         d2[i] = (bi == UINT32_MAX) ? INFINITY : best;
     }
+}
+
+/* The same search with the queries split over `threads` host threads (contiguous blocks; every query is independent, so
+ * the result is identical to orc_nn1_f32).  Used by the full-size (120 k x 120 k) checks when oracle/_ref is absent. */
+typedef struct {
+    const float *tx, *ty, *tz, *sx, *sy, *sz;
+    size_t nt, begin, end;
+    uint32_t* idx;
+    float* d2;
+} orc_nn1_job;
+
+static void* orc_nn1_worker(void* arg)
+{
+    const orc_nn1_job* j = (const orc_nn1_job*)arg;
+    orc_nn1_f32(j->tx, j->ty, j->tz, j->nt, j->sx + j->begin, j->sy + j->begin, j->sz + j->begin, j->end - j->begin,
+                j->idx + j->begin, j->d2 + j->begin);
+    return NULL;
+}
+
+void orc_nn1_f32_mt(const float* tx, const float* ty, const float* tz, size_t nt,
+                    const float* sx, const float* sy, const float* sz, size_t ns,
+                    uint32_t* idx, float* d2, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if ((size_t)threads > ns) threads = ns ? (int)ns : 1;
+    pthread_t th[256];
+    orc_nn1_job job[256];
+    int live[256];
+    for (int t = 0; t < threads; t++) {
+        orc_nn1_job jb = { tx, ty, tz, sx, sy, sz, nt, ns * (size_t)t / (size_t)threads, ns * (size_t)(t + 1) / (size_t)threads, idx, d2 };
+        job[t] = jb;
+        live[t] = 0;
+        if (t + 1 < threads) live[t] = pthread_create(&th[t], NULL, orc_nn1_worker, &job[t]) == 0;
+        if (!live[t]) orc_nn1_worker(&job[t]);      /* the last block, or no thread available: run it here */
+    }
+    for (int t = 0; t < threads; t++)
+        if (live[t]) pthread_join(th[t], NULL);
 }
 
 void orc_nn1_tiecount_f32(const float* tx, const float* ty, const float* tz, size_t nt,
@@ -349,6 +388,40 @@ int orc_kabsch_solve(const double sums[16], float R[9], float t[3])
         double Rp = ((double)R[3 * r] * pbar[0] + (double)R[3 * r + 1] * pbar[1]) + (double)R[3 * r + 2] * pbar[2];
         t[r] = (float)(qbar[r] - Rp);
     }
+    return 0;
+}
+
+/* The Kabsch block of Registration::RANSAC, registration.cpp:372-392, statement by statement.  It is NOT the ICP block: here
+ *   R_ = U * V^T;  t_ = target_center - R_ * source_center;      (:382-383)
+ * come first, and the reflection repair `if (det R_ < 0) R_ = V * B * U^T` (:386-392) replaces R_ only — t_ is never
+ * recomputed, so a reflected quad carries the translation of the un-repaired rotation into its consensus count (:404). */
+int orc_kabsch_solve_ransac(const double sums[16], float R[9], float t[3])
+{
+    const double M = sums[15];
+    if (!(M > 0.0)) return -1;
+    double sc[3], tc[3], H[9];
+    for (int c = 0; c < 3; c++) { sc[c] = sums[c] / M; tc[c] = sums[3 + c] / M; }        /* :373-374 rowwise().mean() */
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) H[3 * r + c] = sums[6 + 3 * r + c] - M * tc[r] * sc[c];  /* :375-379 target_c * source_c^T */
+    double U[9], S[3], V[9], Vt[9], R0[9];
+    orc_svd3(H, U, S, V);                                                                /* :379-381 */
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Vt[3 * r + c] = V[3 * c + r];
+    mat3_mul(U, Vt, R0);                                                                 /* :382 */
+    float Rf[9];
+    for (int k = 0; k < 9; k++) Rf[k] = (float)R0[k];
+    for (int r = 0; r < 3; r++) {                                                        /* :383 — with the UN-repaired R_ */
+        const double Rs = ((double)Rf[3 * r] * sc[0] + (double)Rf[3 * r + 1] * sc[1]) + (double)Rf[3 * r + 2] * sc[2];
+        t[r] = (float)(tc[r] - Rs);
+    }
+    const double det = det3(R0);                                                         /* :386 */
+    if (det < 0) {                                                                       /* :387-392 */
+        double Ut[9], VB[9], R1[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ut[3 * r + c] = U[3 * c + r];
+        for (int r = 0; r < 3; r++) { VB[3 * r] = V[3 * r]; VB[3 * r + 1] = V[3 * r + 1]; VB[3 * r + 2] = V[3 * r + 2] * det; }
+        mat3_mul(VB, Ut, R1);
+        for (int k = 0; k < 9; k++) Rf[k] = (float)R1[k];
+    }
+    memcpy(R, Rf, sizeof Rf);
     return 0;
 }
 
@@ -690,7 +763,7 @@ int orc_ransac_hypothesis(const float* src_xyz, const float* tgt_xyz, const uint
         for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) sums[6 + 3 * r + c] += q[r] * p[c];
         sums[15] += 1.0;
     }
-    return orc_kabsch_solve(sums, R, t);                                           /* :368-392 */
+    return orc_kabsch_solve_ransac(sums, R, t);                                    /* :372-392 */
 }
 
 uint32_t orc_consensus_count_f32(const float* src_xyz, const float* tgt_xyz, const uint32_t* pairs, size_t n_pairs,

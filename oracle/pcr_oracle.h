@@ -42,6 +42,10 @@ float orc_d2_f32(float qx, float qy, float qz, float tx, float ty, float tz);
 void orc_nn1_f32(const float* tx, const float* ty, const float* tz, size_t nt,
                  const float* sx, const float* sy, const float* sz, size_t ns,
                  uint32_t* idx, float* d2);
+/* identical results, queries split over `threads` host threads */
+void orc_nn1_f32_mt(const float* tx, const float* ty, const float* tz, size_t nt,
+                    const float* sx, const float* sy, const float* sz, size_t ns,
+                    uint32_t* idx, float* d2, int threads);
 /* size of the tie set {j : d2_j == d2_min} per query (test helper for the tie-set rule). */
 void orc_nn1_tiecount_f32(const float* tx, const float* ty, const float* tz, size_t nt,
                           const float* sx, const float* sy, const float* sz, size_t ns,
@@ -94,6 +98,8 @@ void orc_svd3(const double A[9], double U[9], double S[3], double V[9]);
 /* ---- A7 solve: from the 16 sums to (R_delta, t_delta) as f32, registration.cpp:979-998 incl. the
  * det<0 branch `R = V*B*U^T` (:990-996, sic).  Returns 0, or -1 when count == 0. */
 int orc_kabsch_solve(const double sums[16], float R[9], float t[3]);
+/* the RANSAC twin (registration.cpp:372-392): t from U V^T BEFORE the det < 0 repair, which then replaces R only */
+int orc_kabsch_solve_ransac(const double sums[16], float R[9], float t[3]);
 
 /* 4x4 f32 compose T_out = A * B, row-major, sequential k, unfused (registration.cpp:1002). */
 void orc_mat4_mul_f32(const float A[16], const float B[16], float out[16]);
