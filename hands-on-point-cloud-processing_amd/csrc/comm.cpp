@@ -8,6 +8,7 @@
 #include "pcr_internal.hpp"
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>   // declarations only: the entry points are bound with dlopen below, their types come from here
 
 #include <mutex>
 
@@ -15,17 +16,18 @@ namespace pcr {
 
 namespace {
 
-struct UniqueId {
-    char internal[PCR_COMM_ID_BYTES];
-};
+// the ABI this file binds by name is the one rccl.h declares: the signatures are taken from the header (decltype), the
+// by-value id is the header's struct, and the id crosses the C ABI of pcr.h as PCR_COMM_ID_BYTES opaque bytes
+static_assert(sizeof(ncclUniqueId) == PCR_COMM_ID_BYTES, "pcr.h: PCR_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+static_assert(NCCL_UNIQUE_ID_BYTES == PCR_COMM_ID_BYTES, "pcr.h: PCR_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
 
 struct Rccl {
     void* handle = nullptr;
-    int (*GetUniqueId)(UniqueId*) = nullptr;
-    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
 };
 
@@ -58,8 +60,8 @@ void rccl_load(Rccl& r)
     }
 }
 
-constexpr int kNcclFloat64 = 8;   // rccl.h: ncclFloat64 = 8
-constexpr int kNcclSum = 0;       // rccl.h: ncclSum = 0
+constexpr ncclDataType_t kNcclFloat64 = ncclFloat64;
+constexpr ncclRedOp_t kNcclSum = ncclSum;
 
 }  // namespace
 
@@ -75,8 +77,8 @@ int comm_allreduce_f64(pcr_ctx* ctx, double* host_buf, double* dev_buf, int n)
     if (c.rccl) {
         Rccl& r = rccl();
         PCR_HIP(ctx, hipMemcpyAsync(dev_buf, host_buf, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        int rc = r.AllReduce(dev_buf, dev_buf, (size_t)n, kNcclFloat64, kNcclSum, c.rccl, ctx->stream);
-        if (rc != 0) {
+        ncclResult_t rc = r.AllReduce(dev_buf, dev_buf, (size_t)n, kNcclFloat64, kNcclSum, (ncclComm_t)c.rccl, ctx->stream);
+        if (rc != ncclSuccess) {
             ctx->err = std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
             return PCR_ERR_COMM;
         }
@@ -95,8 +97,8 @@ int comm_allreduce_f64_device(pcr_ctx* ctx, double* dev_buf, int n)
     if (c.nranks <= 1 && !(c.rccl && tune_get(ctx, "icp_force_slots", 0) > 0)) return PCR_OK;
     if (!c.rccl) return fail(ctx, PCR_ERR_STATE, "device all-reduce needs the RCCL transport");
     Rccl& r = rccl();
-    int rc = r.AllReduce(dev_buf, dev_buf, (size_t)n, kNcclFloat64, kNcclSum, c.rccl, ctx->stream);
-    if (rc != 0) {
+    ncclResult_t rc = r.AllReduce(dev_buf, dev_buf, (size_t)n, kNcclFloat64, kNcclSum, (ncclComm_t)c.rccl, ctx->stream);
+    if (rc != ncclSuccess) {
         ctx->err = std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
         return PCR_ERR_COMM;
     }
@@ -114,10 +116,10 @@ int pcr_comm_unique_id(char id[PCR_COMM_ID_BYTES])
     if (!id) return PCR_ERR_ARG;
     Rccl& r = rccl();
     if (!r.handle) { fprintf(stderr, "pcr_comm_unique_id: %s\n", r.err.c_str()); return PCR_ERR_COMM; }
-    UniqueId u;
+    ncclUniqueId u;
     memset(&u, 0, sizeof u);
-    int rc = r.GetUniqueId(&u);
-    if (rc != 0) return PCR_ERR_COMM;
+    ncclResult_t rc = r.GetUniqueId(&u);
+    if (rc != ncclSuccess) return PCR_ERR_COMM;
     memcpy(id, u.internal, PCR_COMM_ID_BYTES);
     return PCR_OK;
 }
@@ -125,15 +127,16 @@ int pcr_comm_unique_id(char id[PCR_COMM_ID_BYTES])
 int pcr_comm_init_rccl(pcr_ctx* ctx, int nranks, int rank, const char id[PCR_COMM_ID_BYTES])
 {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_rccl");
+    if (nranks > PCR_MAX_RANKS) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_rccl: more than PCR_MAX_RANKS ranks (the reduce buffer holds 16 + 2 * nranks <= 64 f64)");
     pcr_comm_destroy(ctx);
     Rccl& r = rccl();
     if (!r.handle) return fail(ctx, PCR_ERR_COMM, r.err.c_str());
     PCR_HIP(ctx, hipSetDevice(ctx->device));
-    UniqueId u;
+    ncclUniqueId u;
     memcpy(u.internal, id, PCR_COMM_ID_BYTES);
-    void* comm = nullptr;
-    int rc = r.CommInitRank(&comm, nranks, u, rank);
-    if (rc != 0) {
+    ncclComm_t comm = nullptr;
+    ncclResult_t rc = r.CommInitRank(&comm, nranks, u, rank);
+    if (rc != ncclSuccess) {
         ctx->err = std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
         return PCR_ERR_COMM;
     }
@@ -146,6 +149,7 @@ int pcr_comm_init_rccl(pcr_ctx* ctx, int nranks, int rank, const char id[PCR_COM
 int pcr_comm_init_callback(pcr_ctx* ctx, int nranks, int rank, pcr_allreduce_fn fn, void* user)
 {
     if (!ctx || !fn || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_callback");
+    if (nranks > PCR_MAX_RANKS) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_callback: more than PCR_MAX_RANKS ranks (the reduce buffer holds 16 + 2 * nranks <= 64 f64)");
     pcr_comm_destroy(ctx);
     ctx->comm.nranks = nranks;
     ctx->comm.rank = rank;
@@ -165,8 +169,8 @@ int pcr_comm_selftest(pcr_ctx* ctx)
     double h[8];
     for (int k = 0; k < 8; k++) h[k] = (double)(k + 1) * (c.rank + 1);
     PCR_HIP(ctx, hipMemcpyAsync(ctx->dev_out, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
-    int rc = r.AllReduce(ctx->dev_out, ctx->dev_out, 8, kNcclFloat64, kNcclSum, c.rccl, ctx->stream);
-    if (rc != 0) {
+    ncclResult_t rc = r.AllReduce(ctx->dev_out, ctx->dev_out, 8, kNcclFloat64, kNcclSum, (ncclComm_t)c.rccl, ctx->stream);
+    if (rc != ncclSuccess) {
         ctx->err = std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error");
         return PCR_ERR_COMM;
     }
@@ -183,7 +187,7 @@ int pcr_comm_destroy(pcr_ctx* ctx)
     if (!ctx) return PCR_ERR_ARG;
     if (ctx->comm.rccl) {
         Rccl& r = rccl();
-        if (r.handle) r.CommDestroy(ctx->comm.rccl);
+        if (r.handle) r.CommDestroy((ncclComm_t)ctx->comm.rccl);
     }
     ctx->comm = Comm();
     return PCR_OK;

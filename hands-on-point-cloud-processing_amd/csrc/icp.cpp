@@ -155,6 +155,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
 
     const int nranks = ctx->comm.nranks, rank = ctx->comm.rank;
     const int nred = 16 + 2 * nranks;
+    if (nred > 64) { pcr_cloud_destroy(ctx, work); return fail(ctx, PCR_ERR_ARG, "too many ranks"); }   // dev_out / host_out hold 64 f64
     int64_t chunk = tune_get(ctx, "icp_chunk", 4);
     if (chunk < 1) chunk = 1;
     uint64_t enq = 0, chunks = 0;

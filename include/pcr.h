@@ -248,6 +248,7 @@ int pcr_ransac_global_f32(pcr_ctx* ctx, const float* src_xyz, size_t n_src, cons
 /* ---- multi-GPU: one process per GPU, sources sharded, targets replicated ------------------------------
  * Exactly one collective per ICP iteration: all-reduce(sum) of 16 f64 (+2 bookkeeping words). */
 #define PCR_COMM_ID_BYTES 128
+#define PCR_MAX_RANKS 24      /* one node has 8 GPUs; the per-iteration reduce buffer is 16 + 2 * nranks <= 64 f64 */
 int pcr_comm_unique_id(char id[PCR_COMM_ID_BYTES]);                     /* rank 0; broadcast it out of band */
 int pcr_comm_init_rccl(pcr_ctx* ctx, int nranks, int rank, const char id[PCR_COMM_ID_BYTES]);
 /* alternative transport: a host callback that sums buf[0..n) over ranks in place and returns 0

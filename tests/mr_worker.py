@@ -5,6 +5,9 @@ mode "protocol" (CPU): each rank takes its contiguous shard of the source cloud 
   buffer exactly as icp.cpp lays it out ([16 moments][(kept flag, last d2) per rank]) over gloo and solves with
   the product's host code (pcr_kabsch_solve).  Checks: pose identical on all ranks and equal to the
   single-process pose; `loss` taken from the globally last kept pair.
+mode "rccl" (a box with >= world GPUs; one rank per GPU): the native transport — pcr_comm_init_rccl, one ncclAllReduce of
+  16 + 2 * world f64 per iteration ON THE CONTEXT STREAM (device-resident loop) — against the callback transport and the
+  single-rank pose; bit-identical across ranks.
 mode "gpu" (GPU box, 2 ranks sharing the one GPU): the real sharded pcr_icp_p2p_f32 with the callback
   transport over gloo; pose must equal the single-rank pose and be bit-identical across ranks.
 """
@@ -72,6 +75,40 @@ def main():
             assert torch.equal(lo, hi)
             P = orc.transform_f32(P, R, t)
         print(f"rank {rank}: protocol ok")
+    elif mode == "rccl":
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        n = 20003
+        src, tgt = synth.kitti_like_pair(n, seed_target=61, seed_pair=62)
+        ctx = pcr.Context(local)                     # one process per GPU
+        ct = ctx.cloud(tgt)
+        full = ctx.cloud(src)
+        T1, st1 = ctx.icp_point2point(full, ct, max_corr=1.0, max_iter=8, eps=1e-8)      # single rank
+        b, e = pcr.shard_range(n, world, rank)
+        cs = ctx.cloud(np.ascontiguousarray(src[:, b:e]))
+        ctx.comm_init_callback(world, rank, allreduce)
+        Tc, stc = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=8, eps=1e-8)        # sharded, host transport
+        ctx.comm_destroy()
+        uid = [pcr.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init_rccl(world, rank, uid[0])
+        ctx.comm_selftest()
+        for method in (1, 2):                        # brute force, exact grid
+            ctx.tune("nn_method", method)
+            for pipe in (1, -1):                     # device-resident loop (all-reduce on the stream), synchronous loop
+                ctx.tune("icp_pipeline", pipe)
+                T2, st2 = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=8, eps=1e-8)
+                assert st2["iters_run"] == 8 and st2["last_pairs"] == st1["last_pairs"] == stc["last_pairs"], (method, pipe, st1, st2)
+                assert np.linalg.norm(T1.astype(np.float64) - T2.astype(np.float64)) <= 1e-6, (method, pipe)
+                if world == 2:                       # a two-term f64 sum does not depend on the order
+                    assert np.array_equal(T2.view(np.uint32), Tc.view(np.uint32)), (method, pipe)
+                chk = torch.from_numpy(T2.astype(np.float64).reshape(-1).copy())
+                lo, hi = chk.clone(), chk.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                assert torch.equal(lo, hi), "pose differs between ranks"
+        ctx.tune("nn_method", 0); ctx.tune("icp_pipeline", 0)
+        ctx.comm_destroy()
+        ctx.close()
+        print(f"rank {rank}: rccl sharded icp ok")
     elif mode == "gpu":
         n = 20003                                   # not divisible by 2, 3 or 5: the shards differ in size
         src, tgt = synth.kitti_like_pair(n, seed_target=61, seed_pair=62)

@@ -132,7 +132,91 @@ def test_oracle_ransac_recovers_the_pose(pcr, orc):
     assert orc.consensus_count_f32(src, tgt, pairs, Rr, tr, 0.3) == best
 
 
+def reflected_quad_scene():
+    """four non-coplanar source keypoints whose targets are their MIRROR image (x -> -x) rotated and shifted: the optimal
+    orthogonal map is a reflection, det(U V^T) < 0, and the reference's repair branch (registration.cpp:386-392) runs;
+    plus 60 more correspondences scattered around both images so that consensus counts discriminate between poses."""
+    rng = np.random.default_rng(5)
+    src4 = np.array([[0.0, 0.0, 0.0], [2.0, 0.3, 0.1], [0.2, 1.7, -0.2], [0.4, 0.5, 1.9]])
+    a = np.deg2rad(20.0)
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    mirror = np.diag([-1.0, 1.0, 1.0])
+    tvec = np.array([1.5, -0.7, 0.3])
+    more = rng.uniform(-2, 2, (60, 3))
+    src = np.concatenate([src4 + [3.0, 2.0, 1.0], more]).astype(np.float32)        # centroid away from the origin: t matters
+    tgt = (src.astype(np.float64) @ (Rz @ mirror).T + tvec + rng.normal(0, 0.01, src.shape)).astype(np.float32)
+    pairs = np.stack([np.arange(64), np.arange(64)], 1).astype(np.uint32)
+    return src, tgt, pairs, np.array([0, 1, 2, 3], np.uint32)
+
+
+def numpy_ransac_block(src, tgt, quad_pairs):
+    """registration.cpp:372-392 with numpy's SVD (U V^T and V B U^T do not depend on the SVD's sign choices)."""
+    P = src[quad_pairs[:, 0]].astype(np.float64).T
+    Q = tgt[quad_pairs[:, 1]].astype(np.float64).T
+    sc, tc = P.mean(1), Q.mean(1)
+    U, S, Vt = np.linalg.svd((Q - tc[:, None]) @ (P - sc[:, None]).T)
+    R0 = U @ Vt
+    t = tc - R0 @ sc
+    det = np.linalg.det(R0)
+    R = R0
+    if det < 0:
+        R = Vt.T @ np.diag([1.0, 1.0, det]) @ U.T
+    return R0, R, t, det
+
+
+def test_ransac_kabsch_block_keeps_t_of_the_unrepaired_rotation(orc):
+    src, tgt, pairs, quad = reflected_quad_scene()
+    R0, R, t, det = numpy_ransac_block(src, tgt, pairs[quad])
+    assert det < -0.99
+    rc, oR, ot = orc.ransac_hypothesis(src, tgt, pairs, quad)
+    assert rc == 0
+    assert np.abs(oR - R).max() < 1e-5 and np.abs(ot - t).max() < 1e-4        # R repaired, t from U V^T (:383, never recomputed)
+    # the ICP block (registration.cpp:990-998) would recompute t from the repaired R: a different translation on this quad
+    sums = np.zeros(16)
+    P, Q = src[quad].astype(np.float64), tgt[quad].astype(np.float64)
+    sums[0:3], sums[3:6], sums[6:15], sums[15] = P.sum(0), Q.sum(0), (Q.T @ P).reshape(9), 4
+    rc2, iR, it = orc.kabsch_solve(sums)
+    rc3, rR, rt = orc.kabsch_solve_ransac(sums)
+    assert np.array_equal(iR, rR) and np.array_equal(rR, oR) and np.array_equal(rt, ot)
+    assert np.abs(it - ot).max() > 0.1
+    assert np.abs(it - (Q.mean(0) - R @ P.mean(0))).max() < 1e-4
+    # proper quads: both blocks agree bit for bit
+    Qp = (P @ np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]]).T + 1.0)
+    sums[3:6], sums[6:15] = Qp.sum(0), (Qp.T @ P).reshape(9)
+    a, b = orc.kabsch_solve(sums), orc.kabsch_solve_ransac(sums)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.linalg.det(a[1].astype(np.float64)) > 0.99
+
+
 # ----------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_gpu_ransac_reflected_quad_R_t_and_count(pcr, orc):
+    """a quad with det(U V^T) < 0 — R, t and the consensus count of the GPU hypothesis kernel against the oracle's
+    statement-by-statement restatement of registration.cpp:372-392 and against numpy."""
+    src, tgt, pairs, quad = reflected_quad_scene()
+    R0, R, t, det = numpy_ransac_block(src, tgt, pairs[quad])
+    ctx = pcr.Context(0)
+    try:
+        for thr in (50.0, 3.0, 0.5):
+            win, Rg, tg, best, counts = ctx.ransac_global(src, tgt, pairs, quad[None], thr)
+            rc, oR, ot = orc.ransac_hypothesis(src, tgt, pairs, quad)
+            want = orc.consensus_count_f32(src, tgt, pairs, oR, ot, thr)
+            assert counts[0] == want == best
+            if want:
+                assert win == 0
+                assert np.array_equal(Rg.view(np.uint32), oR.view(np.uint32)) and np.array_equal(tg.view(np.uint32), ot.view(np.uint32))
+                assert np.abs(Rg - R).max() < 1e-5 and np.abs(tg - t).max() < 1e-4
+        # mixed batch: reflected and proper quads side by side, every count bit-exact
+        rng = np.random.default_rng(3)
+        quads = np.stack([rng.permutation(64)[:4] for _ in range(500)]).astype(np.uint32)
+        quads[::7] = quad
+        win, Rg, tg, best, counts = ctx.ransac_global(src, tgt, pairs, quads, 0.5)
+        ow, oR, ot, obest, ocounts = orc.ransac_global_f32(src, tgt, pairs, quads, 0.5)
+        assert np.array_equal(counts, ocounts) and (win, best) == (ow, obest)
+        assert np.array_equal(Rg.view(np.uint32), oR.view(np.uint32)) and np.array_equal(tg.view(np.uint32), ot.view(np.uint32))
+    finally:
+        ctx.close()
+
+
 @pytest.mark.gpu
 def test_gpu_nn1_desc_matches_nanoflann_fixture_and_oracle(pcr, orc, golden):
     g = golden("desc_match_hw9.npz")

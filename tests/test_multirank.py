@@ -54,6 +54,18 @@ def test_sharded_icp_four_ranks_one_gpu():
 
 
 @pytest.mark.gpu
+def test_sharded_icp_two_ranks_two_gpus_rccl_device_path():
+    """The native transport with MORE than one rank: one process per GPU, ncclAllReduce enqueued on the context stream between
+    icp_reduce_slots and icp_update_from_sums (csrc/icp.cpp).  Needs two GPUs in this box; the single-GPU boxes skip it
+    (the driver's 8-GPU scaling run is then the first multi-rank RCCL execution)."""
+    import torch
+    if torch.cuda.device_count() < 2:        # counting devices does not initialise the GPU
+        pytest.skip("one GPU visible: the RCCL device path needs one GPU per rank")
+    out = run_workers("rccl", 2)
+    assert out.count("rccl sharded icp ok") == 2
+
+
+@pytest.mark.gpu
 def test_native_rccl_communicator_single_rank(pcr, synth):
     """RCCL is bound with dlopen (ncclGetUniqueId / ncclCommInitRank with a by-value 128-byte id / ncclAllReduce):
     a one-rank communicator exercises that ABI end to end, and ICP runs unchanged with it attached."""
@@ -62,6 +74,11 @@ def test_native_rccl_communicator_single_rank(pcr, synth):
     try:
         uid = pcr.comm_unique_id()
         assert len(uid) == 128
+        for bad in (25, 64, 1000):               # the reduce buffer holds 16 + 2 * nranks <= 64 f64 (PCR_MAX_RANKS = 24)
+            with pytest.raises(pcr.PcrError):
+                ctx.comm_init_rccl(bad, 0, uid)
+            with pytest.raises(pcr.PcrError):
+                ctx.comm_init_callback(bad, 0, lambda a: None)
         ctx.comm_init_rccl(1, 0, uid)
         ctx.comm_selftest()
         src, tgt = synth.kitti_like_pair(5000, seed_target=91, seed_pair=92)
