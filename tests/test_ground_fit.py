@@ -102,15 +102,15 @@ def test_gpu_ground_detection_reference_scan_and_segments(pcr, orc, golden):
     pts = golden("ground_hw4.npz")["pts_f32"]                            # Homework4/test/000111.bin, every 4th point
     ctx = pcr.Context(0)
     try:
-        seeds, ground, foreground, params = hw4.ground_detection(ctx, pts, np.arange(pts.shape[0]), 6, 10000, 0.18)
+        seeds, ground, foreground, params = hw4.ground_detection(pts, np.arange(pts.shape[0]), 6, 10000, 0.18, ctx=ctx, return_params=True)
         oparams, omask, _ = orc.ground_detection_f64(np.ascontiguousarray(pts.T), 6, 10000, 0.18)
         assert np.allclose(params, oparams, rtol=0, atol=1e-9)
         assert len(set(ground.tolist()) ^ set(np.flatnonzero(omask).tolist())) <= 2
         assert np.array_equal(seeds, pts[ground]) and ground.size + foreground.size == pts.shape[0]
-        g_idx, f_idx = hw4.ground_detection_on3segs(ctx, pts)
+        g_idx, f_idx = hw4.ground_detection_on3segs(pts, ctx=ctx)
         assert np.unique(np.r_[g_idx, f_idx]).size == g_idx.size + f_idx.size <= pts.shape[0]
         assert g_idx.size > 0.2 * pts.shape[0]
-        sub = hw4.extract_initial_seeds(ctx, pts, 10000, 0.18)
+        sub = hw4.extract_initial_seeds(pts, 10000, 0.18, ctx=ctx)
         omask, _ = orc.ground_seeds_f64(np.ascontiguousarray(pts.T), 10000, 0.18)
         assert np.array_equal(sub, pts[omask.astype(bool)])
     finally:

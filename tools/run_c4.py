@@ -34,7 +34,7 @@ try:
     print(f"  CPU oracle (1 thread, f64): {tc*1e3:.1f} ms -> x{tc/dt:.0f}; counts equal: {np.array_equal(oc, counts)}")
 except Exception as e:  # noqa: BLE001
     print("  oracle unavailable:", e)
-t0 = time.perf_counter(); idx, params = hw4.my_ransac(ctx, pts, np.arange(n), 40, 0.15, rng=np.random.default_rng(1)); t1 = time.perf_counter() - t0
+t0 = time.perf_counter(); idx, params = hw4.my_ransac(pts, np.arange(n), 40, 0.15, ctx=ctx, rng=np.random.default_rng(1)); t1 = time.perf_counter() - t0
 print(f"my_ransac (40 iterations, one segment): {t1*1e3:.2f} ms, {idx.size} ground points, plane {np.round(params, 4)}")
 # --- radius-NN r = 1.0 (the value benchmark.hpp:14 intended), every point queries its own scan
 db = pts.astype(np.float64)
