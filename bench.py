@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the k-NN correspondence + ICP hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
+        N = 1: runs in this process.  N > 1 without a launcher (WORLD_SIZE unset): starts its own ranks —
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a
+        CHILD process before anything touches the GPU, and exits with the child's code (rank 0's JSON line goes to stdout).
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W     (the driver's launch)
 
-A *step* is one point-to-point ICP iteration on the BASELINE.json configs[1]/[2] workload: 1-NN correspondence
-of 120 000 source points against a 120 000-point target (exhaustive / brute force) + Kabsch accumulation +
-(N > 1: one all-reduce of 16 f64 moments) + 3x3 SVD + in-place transform.  W untimed iterations, then
-exactly K iterations timed between barrier + torch.cuda.synchronize() on both sides; max over ranks.
-Weak scaling: every rank owns its own 120 000-point shard of the source cloud, the target is replicated.
+A *step* is one point-to-point ICP iteration on the BASELINE.json configs[1]/[2] workload: 1-NN correspondence of the source
+points against the 120 000-point target (exhaustive / brute force) + Kabsch accumulation + (N > 1: one RCCL all-reduce of
+16 + 2N f64) + 3x3 SVD + in-place transform.  W untimed iterations, then exactly K iterations timed between
+barrier + torch.cuda.synchronize() on both sides; max over ranks.
 
-value            = correspondences of the whole job per second (M corr/s) = N * n_src * K / t
-icp_iter_per_s   = K / t
-roofline         = the dominant kernel (nn1_brute): ALGORITHMIC work per launch / average launch duration
-                   measured live with HIP events on the kernel's own stream (inside libpcr_hip.so)
-cpu_baseline     = the reference's own nanoflann 1-NN (oracle/_ref, kind "reference") or, if that binary is
-                   absent, the oracle's scalar brute force (kind "port"), timed on this box's host cores.
+value            = correspondences of the whole job per second (M corr/s) on ONE 120 000 x 120 000 pair; with N > 1 ranks the
+                   120 000 sources are SHARDED N ways (contiguous blocks, target replicated): "scaling": "strong" — the reading of
+                   BASELINE.json.metric ("120k-pt KITTI pair, 1/2/4/8 MI355X").  "weak" (extra key, N > 1) is the other reading:
+                   every rank registers its own 120 000-point shard of a denser source scan.
+roofline         = the dominant kernel (nn1_etrack_kernel): FMA flops the kernel's algorithm needs per launch / average launch
+                   duration measured live with HIP events on the kernel's own stream (inside libpcr_hip.so) / 157.3 TFLOP/s.
+kernels          = the same for the exact-only kernel (9-op convention of SURVEY.md 8d) and the two HBM streaming kernels.
+one_shot         = the cold configs[1] search (no previous correspondences), fresh target and indexed target.
+c4 / c5          = BASELINE configs[3] (plane count + radius-NN on the 120k scan) and configs[4] (10 M x 10 M pair, exact grid,
+                   sources sharded) measured in the same invocation (--no-c4 / --no-c5 skip them; --workload c4|c5 makes one the
+                   headline instead).
+cpu_baseline     = the reference's own nanoflann 1-NN (oracle/_ref, kind "reference") or, if that binary is absent, the oracle's
+                   scalar brute force (kind "port"), timed on this box's host cores (rank 0, N = 1 only).
 Inputs are resident in HBM before the timed region starts; data = synthetic (no dataset ships, no network).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,23 +41,60 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "hands-on-point-cloud-processing_amd"
 
-VALU_PEAK_TFLOPS_NOFMA = 78.6   # MI355X: 157.3 TF/s vector f32 counts FMA as 2; the contract forbids FMA
+VALU_PEAK_TFLOPS = 157.3        # MI355X vector f32, FMA = 2 flop (MI355X_MICROARCH.md)
+VALU_PEAK_TOPS_NOFMA = 78.6     # the same issue rate counted one op per lane-slot: the bound of arithmetic without FMA (A1 is unfused)
 HBM_PEAK_GBS = 8000.0
-OPS_PER_PAIR = 9                # 3 sub + 3 mul + 2 add + 1 compare per (query, target) pair
+OPS_PER_PAIR = 9                # 3 sub + 3 mul + 2 add + 1 compare per (query, target) pair — the exact kernel's work
+ETRACK_FLOPS_PER_PAIR = 6       # the filter kernel's algorithm: 3 FMAs per (query, target) pair (csrc/nn1_brute.hip, ETRACK)
+METRIC = "M correspondences/sec + ICP iter/sec, 120k-pt KITTI pair, 1/2/4/8 MI355X"
+
+
+# ------------------------------------------------------------------------------------------------------------ self-launch
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """--gpus N > 1 without a launcher: one rank per GPU through torch.distributed.run, as a child (never exec: this process
+    may not replace itself once anything GPU-related is loaded, and a child keeps the rule trivially true)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode        # stdout / stderr inherited: rank 0's JSON line is the child's line
+
+
+# ------------------------------------------------------------------------------------------------------------ CPU baseline
+def host_threads():
+    """threads the CPU baseline may use: the cores this process is allowed on, capped by the cgroup CPU quota when there is one"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except Exception:   # noqa: BLE001
+        quota = None
+    return (min(n, quota) if quota else n), n, quota
 
 
 def cpu_baseline(src, tgt):
-    """Rank 0, N = 1 only.  Bounded: one kd-tree build + 120k queries (~0.1-0.3 s) x 3 repetitions."""
+    """Rank 0, N = 1 only.  Bounded: one kd-tree build + 120k queries (~0.1-0.3 s) x 3 repetitions, single- and multi-threaded."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
-    cores = os.cpu_count() or 1
+    nthr, affinity, quota = host_threads()
     n = src.shape[1]
     if orc.have_ref():
         best1, bestn = None, None
         for _ in range(3):
             _, _, b, q = orc.ref_nano_nn1_f32(tgt, src, leaf=2, threads=1)
             best1 = (b + q) if best1 is None else min(best1, b + q)
-        nthr = min(cores, 16)
         for _ in range(3):
             _, _, b, q = orc.ref_nano_nn1_f32(tgt, src, leaf=2, threads=nthr)
             bestn = (b + q) if bestn is None else min(bestn, b + q)
@@ -63,9 +112,10 @@ def cpu_baseline(src, tgt):
                                  f"{rest_ms:.1f} ms (oracle restatement), 1 thread",
                 "sample": f"vendored nanoflann 1.3.2 f32 leaf 2 (ICP's configuration), build + {n} queries, "
                           f"best of 3, 1 thread as the reference runs it",
-                "multi_thread": {"value": n / bestn / 1e3, "cores": nthr,
-                                 "note": "same tree, queries split over std::thread"},
-                "host_cpus": cores}
+                "all_cores": {"value": n / bestn / 1e3, "cores": nthr,
+                              "note": "same tree (built on one thread), queries split over std::thread; cores = every core this process may "
+                                      f"use (affinity {affinity}, cgroup quota {quota})"},
+                "host_cpus": os.cpu_count()}
     # port: scalar brute force of the oracle on a bounded sample
     m = 400
     t0 = time.perf_counter()
@@ -73,27 +123,52 @@ def cpu_baseline(src, tgt):
     dt = time.perf_counter() - t0
     return {"value": m / dt / 1e6, "unit": "M corr/s", "cores": 1, "kind": "port",
             "sample": f"oracle scalar brute force, {m} of {n} queries against {tgt.shape[1]} targets",
-            "host_cpus": cores}
+            "host_cpus": os.cpu_count()}
 
 
+def lib_sha16(pcr):
+    try:
+        return hashlib.sha256(open(pcr.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def load_pmc(name, sha):
+    """HBM-side traffic from the separate rocprofv3 --pmc passes of tools/gpu_check.sh (PMC counters cannot be read from inside
+    this process).  Only trusted when it was collected with the very library that is loaded now (sha of libpcr_hip.so)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return d if d.get("lib_sha16") == sha and sha else None
+    except Exception:   # noqa: BLE001
+        return None
+
+
+# ------------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=0, help="target points (and source points per GPU for c2); 0 = workload default")
-    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
-                    help="c2 (default, BASELINE configs[1]/[2]): 120k x 120k pair per GPU, weak scaling, brute force; "
-                         "c5 (BASELINE configs[4]): ONE 10M x 10M pair, sources sharded over the GPUs (strong scaling), exact grid")
+    ap.add_argument("--points", type=int, default=0, help="points of the pair (target, and source of the whole job); 0 = workload default")
+    ap.add_argument("--workload", choices=["c2", "c4", "c5"], default="c2",
+                    help="headline of the JSON line.  c2 (default, BASELINE configs[1]/[2]): ONE 120k x 120k pair, sources sharded over the "
+                         "GPUs (strong scaling), brute force; c5 (configs[4]): ONE 10M x 10M pair, sources sharded, exact grid; "
+                         "c4 (configs[3]): 80-hypothesis plane count + radius-NN r = 1 on the 120k scan (one GPU)")
     ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the configs[3] block of the default line")
+    ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] block of the default line")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed loop and its roofline (profiling runs)")
+    ap.add_argument("--c5-points", type=int, default=10_000_000)
     ap.add_argument("--qpl", type=int, default=0)
     ap.add_argument("--tiles-per-slice", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=0, help="nn1 kernel variant (0 = library default FTRACK; 2 = exact TRACK; 3 = exact TRACK through LDS tiles)")
-    ap.add_argument("--no-grid-extra", action="store_true", help="skip the additional exact-grid pass")
+    ap.add_argument("--variant", type=int, default=0, help="nn1 kernel variant (0 = library default; 2 = exact TRACK; 3 = exact TRACK through LDS tiles)")
     ap.add_argument("--nn", choices=["brute", "grid"], default="brute",
-                    help="correspondence search: brute = BASELINE configs[1] (LDS-tiled brute force), grid = exact grid index")
+                    help="correspondence search of the c2 headline: brute = BASELINE configs[1] (exhaustive), grid = exact grid index")
     args = ap.parse_args()
+
+    if args.gpus > 1 and not os.environ.get("WORLD_SIZE"):
+        sys.exit(self_launch(args.gpus))                # before torch / HIP are even imported
 
     import numpy as np
     import torch   # device sync + torch.distributed (RCCL) plumbing; loaded BEFORE libpcr_hip.so so that the
@@ -105,8 +180,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # one rank per GPU (the driver's launch); PCR_BENCH_BACKEND=gloo lets several ranks REHEARSE the multi-rank code
     # path on a box with fewer GPUs (ranks then share devices and the collective runs over gloo / torch.distributed)
     backend = os.environ.get("PCR_BENCH_BACKEND", "nccl")
@@ -126,20 +200,8 @@ def main():
             if args.collective == "rccl":
                 args.collective = "torch"
 
-    if args.workload == "c5":
-        # one pair for the whole job: every rank builds the same source cloud and keeps its contiguous shard
-        n = args.points or 10_000_000
-        args.nn = "grid"
-        full_src, tgt = synth.kitti_like_pair(n)
-        b, e = pcr.shard_range(n, world, rank)
-        src = np.ascontiguousarray(full_src[:, b:e])
-        del full_src
-        scaling, total_src = "strong", n
-    else:
-        n = args.points or 120000
-        src, tgt = synth.kitti_like_pair(n, n_src=n, shard=rank)
-        scaling, total_src = "weak", world * n
     ctx = pcr.Context(device_index)
+    sha = lib_sha16(pcr)
     for kv in filter(None, os.environ.get("PCR_TUNE", "").split(",")):     # experiments: PCR_TUNE="key=value,key=value"
         k, v = kv.split("=")
         ctx.tune(k.strip(), int(v))
@@ -149,13 +211,12 @@ def main():
         ctx.tune("nn1_tiles_per_slice", args.tiles_per_slice)
     if args.variant:
         ctx.tune("nn1_variant", args.variant)
-    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
 
     collective = "none"
     if world > 1:
         collective = args.collective
         if collective == "rccl":
-            # native transport: the library's own RCCL communicator (one ncclAllReduce of <= 32 f64 per iteration, enqueued
+            # native transport: the library's own RCCL communicator (one ncclAllReduce of 16 + 2N f64 per iteration, enqueued
             # on the context stream).  Every step below is collective-safe: rank 0 ALWAYS broadcasts (the id or None),
             # and the ranks agree on the outcome before anybody uses the communicator.
             uid = [None]
@@ -165,6 +226,7 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     print(f"[rank 0] pcr_comm_unique_id failed: {e}", file=sys.stderr)
             dist.broadcast_object_list(uid, src=0)
+
             def all_agree(ok):
                 flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -205,162 +267,386 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_icp(method, prof=1):
+    def max_over_ranks(dt):
+        if dist is None:
+            return dt
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def prepare(cs, ct, method, src_np):
+        """one-time preparation, whatever --warmup says: the index over the (replicated) target and the code objects of every kernel
+        of the loop — a 2-iteration ICP of a small slice of this rank's sources; initialisation, not a step"""
+        ctx.tune("nn_method", method)
+        n_prep = min(4096, src_np.shape[1])
+        c_prep = ctx.cloud(np.ascontiguousarray(src_np[:, :n_prep]))
+        ctx.icp_point2point(c_prep, ct, max_corr=1.0, max_iter=2, eps=0.0)
+        c_prep.free()
+
+    def timed_icp(cs, ct, method, src_np, prof=1, steps=None, warmup=None):
         """W untimed + exactly K timed ICP iterations with the given correspondence search; max over ranks.
         prof = 1: every correspondence launch of the timed region is bracketed by a HIP event pair on the library's stream
         (the kernel's average duration for the roofline); the pairs cost ~13 us of stream time per iteration."""
-        ctx.tune("nn_method", method)
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
         ctx.tune("prof", prof)
-        # one-time preparation, whatever --warmup says: the index over the (replicated) target and the code objects of every kernel
-        # of the loop — a 2-iteration ICP of a small slice of this rank's sources; initialisation, not a step
-        n_prep = min(4096, src.shape[1])
-        c_prep = ctx.cloud(np.ascontiguousarray(src[:, :n_prep]))
-        ctx.icp_point2point(c_prep, ct, max_corr=1.0, max_iter=2, eps=0.0)
-        c_prep.free()
-        if args.warmup > 0:
-            ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=args.warmup, eps=0.0)
+        prepare(cs, ct, method, src_np)
+        if warmup > 0:
+            ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=warmup, eps=0.0)
         ctx.prof_reset()
         barrier()
         t0 = time.perf_counter()
-        T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=args.steps, eps=0.0)   # eps = 0: never early-exits
+        T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=steps, eps=0.0)   # eps = 0: never early-exits
         barrier()
-        dt = time.perf_counter() - t0
-        assert st["iters_run"] == args.steps, st
-        if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        dt = max_over_ranks(time.perf_counter() - t0)
+        assert st["iters_run"] == steps, st
         return T, st, dt
 
-    main_method = 1 if args.nn == "brute" else 2
-    T, st, dt = timed_icp(main_method)
-    nn_name = "nn1_brute" if args.nn == "brute" else "nn1_grid"
-    nn_launches, nn_ms = ctx.prof_get(nn_name)
-    # second, separately timed pass with the exact grid index (same answers, different search): extra info only
-    grid_extra = None
-    if args.nn == "brute" and not args.no_grid_extra:
-        Tg, stg, dtg = timed_icp(2, prof=0)       # throughput without the event pairs (11 % of this much shorter step) ...
-        ctx.tune("prof", 1); ctx.prof_reset()       # ... and the kernel time from a second, profiled run of the same loop
-        ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=args.steps, eps=0.0)
-        gl, gms = ctx.prof_get("nn1_grid")
-        grid_extra = {"value": total_src * args.steps / dtg / 1e6, "unit": "M corr/s", "icp_iter_per_s": args.steps / dtg,
-                      "ms_per_step": dtg * 1e3 / args.steps, "avg_nn_kernel_ms": gms / max(gl, 1),
-                      "pose_bit_identical_to_brute_force": bool(np.array_equal(T.view(np.uint32), Tg.view(np.uint32))),
-                      "note": "same ICP with pcr nn_method = grid (exact uniform-grid index, csrc/grid.hip); NOT the "
-                              "BASELINE configs[1] workload, reported for information"}
-    if rank == 0:
-        pmc = None
-        try:   # HBM traffic of the same kernel from a separate rocprofv3 --pmc pass (tools/gpu_check.sh), committed
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-        except Exception:   # noqa: BLE001
-            pmc = None
-        total_corr = total_src * args.steps
+    def kernel_breakdown(cs, ct, method, steps):
+        """a second, fully profiled run of the same loop (an event pair around EVERY kernel): per-kernel average durations"""
+        ctx.tune("nn_method", method)
+        ctx.tune("prof", 2)
+        ctx.prof_reset()
+        ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=steps, eps=0.0)
+        out = {}
+        for name in ("nn1_brute", "nn1_grid", "kabsch_partial", "kabsch_final", "icp_update", "transform"):
+            k, ms = ctx.prof_get(name)
+            if k:
+                out[name] = (int(k), ms / k)
+        ctx.tune("prof", 0)
+        return out
+
+    def stream_kernels(bd, n_q, kept):
+        """the two HBM streaming kernels of an iteration against the 8 TB/s peak (28 B per kept pair, 24 B per point)"""
+        out = {}
+        if "kabsch_partial" in bd:
+            k, ms = bd["kabsch_partial"]
+            b = 28.0 * kept
+            out["kabsch_partial"] = {"bytes": b, "ms": ms, "GB/s": b / ms / 1e6, "frac_of_8TB/s": b / ms / 1e6 / HBM_PEAK_GBS, "launches": k,
+                                     "algorithmic": "28 B per kept pair: 12 B source + 8 B key + 12 B gathered target - 4 (the key carries the index)"}
+        if "transform" in bd:
+            k, ms = bd["transform"]
+            b = 24.0 * n_q
+            out["transform_state"] = {"bytes": b, "ms": ms, "GB/s": b / ms / 1e6, "frac_of_8TB/s": b / ms / 1e6 / HBM_PEAK_GBS, "launches": k,
+                                      "algorithmic": "24 B per point: 12 B read + 12 B written in place"}
+        for name in ("kabsch_final", "icp_update"):
+            if name in bd:
+                out[name] = {"ms": bd[name][1], "launches": bd[name][0], "note": "one workgroup: block partials -> 16 moments -> 3x3 SVD (latency-bound)"}
+        return out
+
+    out = None
+    # ==================================================================================================== c2 headline (+ extras)
+    if args.workload == "c2":
+        n = args.points or 120000
+        full_src, tgt = synth.kitti_like_pair(n)
+        b, e = pcr.shard_range(n, world, rank)
+        src = np.ascontiguousarray(full_src[:, b:e])
+        cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+        main_method = 1 if args.nn == "brute" else 2
+        T, st, dt = timed_icp(cs, ct, main_method, src)
+        nn_name = "nn1_brute" if args.nn == "brute" else "nn1_grid"
+        nn_launches, nn_ms = ctx.prof_get(nn_name)
         kern_s = nn_ms / 1e3 / max(nn_launches, 1)
         n_q, n_t = src.shape[1], tgt.shape[1]
-        gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
-        if args.nn == "brute":
-            pairs = float(n_q) * float(n_t)
-            achieved_tflops = OPS_PER_PAIR * pairs / kern_s / 1e12
-            compulsory_bytes = 12.0 * n_t + 12.0 * n_q + 8.0 * n_q        # targets + sources + (idx, d2) key
-            have_pmc = pmc and pmc.get("valu_insts_per_launch") and "etrack" in pmc.get("kernel", "") and n_q == 120000 == n_t
-            default_kernels = not (args.qpl or args.variant)
-            roofline = {
-                "bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS_NOFMA, "unit": "TFLOP/s",
-                "frac": achieved_tflops / VALU_PEAK_TFLOPS_NOFMA,
-                "traffic": (pmc["fetch_bytes_per_launch_corrected_x2"] + pmc["write_bytes_per_launch"]) if have_pmc else None,
-                "traffic_note": ("HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from a separate "
-                                 "rocprofv3 --pmc pass of this kernel, " + pmc["source"]) if have_pmc else "not collected",
-                "clock_ghz_profiled": pmc.get("clock_ghz_profiled") if have_pmc else None,
-                "kernel": ("pcr::nn1_etrack_kernel<4> (exhaustive scan; chunk-centred targets broadcast through the scalar cache; "
-                           "expanded-form lower bound, 3 FMAs per pair, tracked branch-free; the winner decided with the exact unfused "
-                           "arithmetic; the previous correspondence of each query — of the previous iteration, or of the warm-up run for "
-                           "the first timed iteration — re-evaluated exactly, seeds the bound); a search without any earlier "
-                           "correspondences (the very first of the preparation) runs the same kernel without a seed; avg_launch_ms "
-                           "averages all launches of the timed region")
-                          if default_kernels else f"nn1 variant={args.variant} qpl={args.qpl}",
-                "executed_lane_ops_per_pair": (pmc["valu_insts_per_launch"] * 64 / pairs) if have_pmc else None,
-                "issue_frac": (pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TFLOPS_NOFMA) if have_pmc else None,
-                # the warm kernel's instruction mix per (query, chunk of 16 targets) priced with the measured issue costs of
-                # each instruction form (tools/ubench/valu_rate.hip -> profiles/r01_ubench_valu_rate.txt): 80.6 ns per wave
-                "mix_bound_ms": (pairs / 16 / 64 * 80.6e-9 / 1024 * 1e3) if default_kernels else None,
-                "mix_frac": (pairs / 16 / 64 * 80.6e-9 / 1024 / kern_s) if default_kernels else None,
-                "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
-                "algorithmic": f"{OPS_PER_PAIR} f32 lane-ops per (query,target) pair (SURVEY.md 8d) x {pairs:.3e} pairs/launch; "
-                               "peak = 157.3 TF/s / 2: one op per lane per issue slot (the exact arithmetic has no FMA). "
-                               "frac can exceed 1 because the kernels need fewer than 9 issue slots per pair: the hot loop "
-                               "evaluates a cheaper filter (3 FMAs on chunk-centred targets; fused 6-op form in the cold "
-                               "kernel) and only the winning chunk exactly; issue_frac = executed lane-ops of the warm kernel "
-                               "(PMC) / time / peak counts every wave-instruction as one slot; v_pk_fma_f32 and min/max/med3 "
-                               "take about two (microbenchmark), so mix_frac = mix_bound_ms / avg_launch_ms — the loop's "
-                               "instruction mix priced per form, 1 024 SIMDs — is the share of the VALU actually used",
-                "hbm_literal": {"bound": "hbm", "achieved": compulsory_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
-                                "note": "compulsory bytes (32 B/point); brute force is VALU-bound, see DESIGN.md"}}
-            workload = ("point-to-point ICP iteration = exhaustive 1-NN correspondence 120k x 120k + Kabsch + transform; BASELINE.json "
-                        "configs[1]/[2] ('LDS-tiled brute force': the default kernels broadcast the target tiles through the scalar "
-                        "cache, faster than the LDS-tiled variant, which --variant 3 selects; same results)")
-        else:
-            # steady state of the exact grid search: the source at the final pose, a few launches timed with HIP events,
-            # one more launch with the diagnostics counters for the algorithmic bytes (SURVEY.md 8d "1-NN exact grid")
-            ca = cs.clone()
-            ctx.transform(ca, T)
-            ctx.tune("nn_method", 2)
-            ctx.nn1_async(ct, ca); ctx.sync(); ctx.prof_reset()
-            for _ in range(5):
-                ctx.nn1_async(ct, ca)
+        pairs = float(n_q) * float(n_t)
+        default_kernels = not (args.qpl or args.variant)
+        extras = not args.no_extras
+        bd = kernel_breakdown(cs, ct, main_method, min(args.steps, 10)) if extras else {}
+
+        # ---- the exact-only kernel (the 9-op convention's own kernel), the cold searches: a few launches each, HIP-event timed
+        exact_line, one_shot = None, None
+        if extras and args.nn == "brute":
+            def time_search(tgt_cloud, reps, **tunes):
+                for k, v in tunes.items():
+                    ctx.tune(k, v)
+                ctx.tune("nn_method", 1); ctx.tune("prof", 1)
+                ctx.nn1_async(tgt_cloud, cs); ctx.sync(); ctx.prof_reset()
+                for _ in range(reps):
+                    ctx.nn1_async(tgt_cloud, cs)
+                k, ms = ctx.prof_get("nn1_brute")
+                for key in tunes:
+                    ctx.tune(key, 0)
+                return ms / max(k, 1)
+            ms_exact = time_search(ct, 5, nn1_variant=2)
+            tf = OPS_PER_PAIR * pairs / (ms_exact / 1e3) / 1e12
+            exact_line = {"kernel": "pcr::nn1_track_kernel<2, 16, true> (nn1_variant 2: the exact unfused arithmetic for every pair, no filter)",
+                          "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TOPS_NOFMA, "unit": "T lane-ops/s", "frac": tf / VALU_PEAK_TOPS_NOFMA,
+                          "avg_launch_ms": ms_exact, "kernel_M_corr_per_s": n_q / ms_exact / 1e3,
+                          "algorithmic": f"{OPS_PER_PAIR} f32 lane-ops per (query, target) pair (SURVEY.md 8d: 3 sub + 3 mul + 2 add + 1 compare) x {pairs:.3e} "
+                                         "pairs; peak = 157.3 TF/s / 2 (the exact arithmetic has no FMA: one op per lane per issue slot)"}
+            fresh = ctx.cloud(tgt)                          # a target nobody has indexed: what a first, one-shot call sees
+            ms_fresh = time_search(fresh, 5)
+            fresh.free()
+            ms_indexed = time_search(ct, 5)
+            one_shot = {"note": "BASELINE configs[1]: ONE 1-NN search of the pair with no earlier correspondences (no seed)",
+                        "fresh_target": {"ms": ms_fresh, "M_corr_per_s": n_q / ms_fresh / 1e3,
+                                         "kernel": "pcr::nn1_ftrack_kernel<2, 16> (fused-form filter + exact decision; needs no index)"},
+                        "indexed_target": {"ms": ms_indexed, "M_corr_per_s": n_q / ms_indexed / 1e3,
+                                           "kernel": "pcr::nn1_etrack_kernel<4>, unseeded (the target's chunk index exists: any earlier search or ICP built it)"}}
+
+        # ---- second, separately timed pass with the exact grid index (same answers, different search): extra info only
+        grid_extra = None
+        if extras and args.nn == "brute":
+            Tg, stg, dtg = timed_icp(cs, ct, 2, src, prof=0)       # throughput without the event pairs (11 % of this much shorter step) ...
+            ctx.tune("prof", 1); ctx.prof_reset()                   # ... and the kernel time from a second, profiled run of the same loop
+            ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=args.steps, eps=0.0)
             gl, gms = ctx.prof_get("nn1_grid")
-            ctx.tune("grid_stats", 1); ctx.nn1_async(ct, ca); ctx.sync(); gs = ctx.grid_stats(); ctx.tune("grid_stats", 0)
-            ca.free()
-            steady_s = gms / 1e3 / max(gl, 1)
-            gpmc = None
-            try:
-                gpmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_grid.json")))
-                if gpmc.get("n") != n_t or n_q != n_t:
-                    gpmc = None
-            except Exception:   # noqa: BLE001
-                gpmc = None
-            alg_bytes = n_q * (12.0 + 4.0 + 8.0) + 8.0 * gs["fine_rows"] + 16.0 * gs["candidates"]
-            L2_PEAK_GBS = 34500.0    # aggregate L2 bandwidth measured on MI355X (MI355X_MICROARCH.md, L2 section)
-            roofline = {
-                "bound": "l2-gather", "achieved": alg_bytes / steady_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
-                "frac": alg_bytes / steady_s / 1e9 / L2_PEAK_GBS,
-                "traffic": (gpmc["fetch_bytes_per_launch_corrected_x2"] + gpmc["write_bytes_per_launch"]) if gpmc else None,
-                "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
-                                 f"kernel at {gpmc['n']} x {gpmc['n']}, {gpmc['source']}: the candidate records come out of L2, not HBM") if gpmc
-                                else "collected at 10M x 10M only (profiles/latest_pmc_grid.json)",
-                "vs_hbm_stream_peak": alg_bytes / steady_s / 1e9 / HBM_PEAK_GBS,
-                "kernel": "pcr::nn1_grid_kernel<16, false> (exact uniform-grid 1-NN) at the converged pose",
-                "launches": int(gl), "avg_launch_ms": steady_s * 1e3, "kernel_M_corr_per_s": n_q / steady_s / 1e6,
-                "avg_launch_ms_over_the_timed_icp": kern_s * 1e3,
-                "algorithmic": f"per query 12 B point + 4 B order + 8 B key, 8 B per opened x-row ({gs['fine_rows'] / n_q:.1f}/query) and "
-                               f"16 B per visited candidate ({gs['candidates'] / n_q:.1f}/query), counted by the kernel's diagnostics "
-                               "build.  Neighbouring queries visit the same cells, so most candidate records are served by L2 (the algorithmic "
-                               "byte rate exceeds the 8 TB/s HBM stream peak): the bound is the L2 gather rate"}
-            workload = (f"point-to-point ICP iteration on ONE {n_t} x {total_src} pair = exact grid 1-NN + Kabsch + transform"
-                        + ("; BASELINE.json configs[4] (sources sharded over the GPUs)" if args.workload == "c5" else ""))
-        out = {
-            "metric": "M correspondences/sec + ICP iter/sec, 120k-pt KITTI pair, 1/2/4/8 MI355X",
-            "value": total_corr / dt / 1e6, "unit": "M corr/s",
-            "icp_iter_per_s": args.steps / dt,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "nn": args.nn, "n_src_this_rank": n_q, "n_src_total": total_src, "n_tgt": n_t,
-                       "max_corr": 1.0, "sharding": f"sources x{world}, target replicated",
-                       "collective": collective, "pose_err_vs_gt_fro": gt_err,
-                       "kept_pairs_last_iter": int(st["last_pairs"])},
-            "roofline": roofline,
-        }
-        if grid_extra is not None:
-            out["exact_grid"] = grid_extra
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(src, tgt)
+            grid_extra = {"value": n * args.steps / dtg / 1e6, "unit": "M corr/s", "icp_iter_per_s": args.steps / dtg,
+                          "ms_per_step": dtg * 1e3 / args.steps, "avg_nn_kernel_ms": gms / max(gl, 1),
+                          "pose_bit_identical_to_brute_force": bool(np.array_equal(T.view(np.uint32), Tg.view(np.uint32))),
+                          "note": "same ICP with pcr nn_method = grid (exact uniform-grid index, csrc/grid.hip); NOT the "
+                                  "BASELINE configs[1] workload, reported for information"}
+
+        # ---- weak scaling (N > 1): every rank its own 120k-point shard of a denser source scan
+        weak = None
+        if extras and world > 1:
+            wsrc, _ = synth.kitti_like_pair(n, n_src=n, shard=rank)
+            cw = ctx.cloud(wsrc)
+            Tw, stw, dtw = timed_icp(cw, ct, main_method, wsrc, prof=0)
+            weak = {"value": world * n * args.steps / dtw / 1e6, "unit": "M corr/s", "icp_iter_per_s": args.steps / dtw, "ms_per_step": dtw * 1e3 / args.steps,
+                    "scaling": "weak", "n_src_per_rank": n, "note": "every rank owns a different 120k-point shard of the source scan, target replicated"}
+            cw.free()
+
+        if rank == 0:
+            gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
+            if args.nn == "brute":
+                achieved_tflops = ETRACK_FLOPS_PER_PAIR * pairs / kern_s / 1e12
+                compulsory_bytes = 12.0 * n_t + 12.0 * n_q + 8.0 * n_q        # targets + sources + (idx, d2) key
+                pmc = load_pmc("latest_pmc.json", sha) if (default_kernels and n_q == 120000 == n_t) else None
+                roofline = {
+                    "bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved_tflops / VALU_PEAK_TFLOPS,
+                    "traffic": (pmc["fetch_bytes_per_launch_corrected_x2"] + pmc["write_bytes_per_launch"]) if pmc else None,
+                    "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
+                                     f"kernel with this very libpcr_hip.so (sha {sha}), {pmc['source']}") if pmc else
+                                    "null: PMC counters need a rocprofv3 wrapper (tools/gpu_check.sh); none was collected with the library loaded now",
+                    "kernel": ("pcr::nn1_etrack_kernel<4> (exhaustive scan of every (query, 16-target chunk); chunk-centred targets broadcast through the "
+                               "scalar cache; expanded-form lower bound = 3 FMAs per pair (v_pk_fma_f32), min-tree + first/second minimum tracked "
+                               "branch-free; only the winning chunk is evaluated with the exact unfused arithmetic; the previous correspondence of "
+                               "each query, re-evaluated exactly, seeds the bound)") if default_kernels else f"nn1 variant={args.variant} qpl={args.qpl}",
+                    "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
+                    "algorithmic": f"{ETRACK_FLOPS_PER_PAIR} flop (3 FMAs) per (query, target) pair x {pairs:.3e} pairs per launch — the arithmetic of the "
+                                   "kernel that ran; the min-tree, the per-chunk prologue (|q - C|^2, 11 ops per 16 targets) and the exact "
+                                   "re-evaluation of the winning chunk are overhead, not numerator.  peak = 157.3 TF/s vector f32 (FMA = 2).  "
+                                   "SURVEY.md 8d's 9-op-per-pair convention describes the EXACT kernel: kernels.nn1_exact_track",
+                    "issue": ({"executed_lane_ops_per_pair": pmc["valu_insts_per_launch"] * 64 / pairs,
+                               "issue_frac": pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TOPS_NOFMA,
+                               "note": "SQ_INSTS_VALU x 64 lanes / time / 78.6 T issue slots per second (same PMC passes)"} if pmc else None),
+                    "hbm_literal": {"bound": "hbm", "achieved": compulsory_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
+                                    "note": "compulsory bytes (32 B/point); brute force is VALU-bound, see DESIGN.md"}}
+                workload = (f"point-to-point ICP iteration = exhaustive 1-NN correspondence of ONE {n} x {n_t} pair + Kabsch + transform; BASELINE.json "
+                            "configs[1]/[2] ('LDS-tiled brute force': the default kernels broadcast the target through the scalar cache, faster than "
+                            "the LDS-tiled variant, which --variant 3 selects; same results)")
+            else:
+                roofline, workload = grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha), \
+                    f"point-to-point ICP iteration on ONE {n_t} x {n} pair = exact grid 1-NN + Kabsch + transform"
+            out = {
+                "metric": METRIC, "value": n * args.steps / dt / 1e6, "unit": "M corr/s", "icp_iter_per_s": args.steps / dt,
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": workload, "nn": args.nn, "n_src_this_rank": n_q, "n_src_total": n, "n_tgt": n_t, "max_corr": 1.0,
+                           "sharding": f"sources x{world} (contiguous blocks of the ONE pair), target replicated", "collective": collective,
+                           "pose_err_vs_gt_fro": gt_err, "kept_pairs_last_iter": int(st["last_pairs"]), "lib_sha16": sha,
+                           "first_timed_iteration": "seeded by the warm-up run's correspondences (as every iteration after the first of an ICP is)"},
+                "roofline": roofline,
+                "kernels": dict(({"nn1_exact_track": exact_line} if exact_line else {}), **stream_kernels(bd, n_q, int(st["last_pairs"]) * n_q // max(n, 1))),
+            }
+            if one_shot:
+                out["one_shot"] = one_shot
+            if grid_extra is not None:
+                out["exact_grid"] = grid_extra
+            if weak is not None:
+                out["weak"] = weak
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(src, tgt)
+        cs.free(); ct.free()
+        del full_src
+
+    # ==================================================================================================== c4: configs[3]
+    if (args.workload == "c4" or (args.workload == "c2" and not args.no_c4 and not args.no_extras)) and world == 1:
+        c4 = bench_c4(ctx, pcr, synth, np, args)
+        if args.workload == "c4":
+            out = c4
+        elif out is not None:
+            out["c4"] = c4
+
+    # ==================================================================================================== c5: configs[4]
+    if args.workload == "c5" or (args.workload == "c2" and not args.no_c5 and not args.no_extras):
+        n5 = (args.points or 10_000_000) if args.workload == "c5" else args.c5_points
+        full_src, tgt = synth.kitti_like_pair(n5)
+        b, e = pcr.shard_range(n5, world, rank)
+        src = np.ascontiguousarray(full_src[:, b:e])
+        del full_src
+        cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+        steps5 = args.steps if args.workload == "c5" else min(args.steps, 10)
+        warm5 = args.warmup if args.workload == "c5" else min(args.warmup, 2)
+        T, st, dt = timed_icp(cs, ct, 2, src, prof=1, steps=steps5, warmup=warm5)
+        gl, gms = ctx.prof_get("nn1_grid")
+        kern_s = gms / 1e3 / max(gl, 1)
+        bd = kernel_breakdown(cs, ct, 2, min(steps5, 5))
+        if rank == 0:
+            n_q, n_t = src.shape[1], tgt.shape[1]
+            c5 = {"metric": METRIC, "value": n5 * steps5 / dt / 1e6, "unit": "M corr/s", "icp_iter_per_s": steps5 / dt, "n_gpus": world, "steps": steps5,
+                  "warmup": warm5, "ms_per_step": dt * 1e3 / steps5, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                  "data": "synthetic",
+                  "config": {"workload": f"point-to-point ICP iteration on ONE {n_t} x {n5} pair = exact grid 1-NN + Kabsch + transform; BASELINE.json "
+                                         "configs[4] (sources sharded over the GPUs, one all-reduce of 16 + 2N f64 per iteration)",
+                             "nn": "grid", "n_src_this_rank": n_q, "n_src_total": n5, "n_tgt": n_t, "max_corr": 1.0,
+                             "sharding": f"sources x{world}, target replicated", "collective": collective,
+                             "pose_err_vs_gt_fro": float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose())),
+                             "kept_pairs_last_iter": int(st["last_pairs"]), "lib_sha16": sha},
+                  "roofline": grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha),
+                  "kernels": stream_kernels(bd, n_q, int(st["last_pairs"]) * n_q // max(n5, 1))}
+            if args.workload == "c5":
+                out = c5
+            elif out is not None:
+                out["c5"] = c5
+        cs.free(); ct.free()
+
+    if rank == 0 and out is not None:
         print(json.dumps(out))
-    cs.free(); ct.free()
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha):
+    """steady state of the exact grid search: the source at the final pose, a few launches timed with HIP events, one more launch
+    with the diagnostics counters for the algorithmic bytes (SURVEY.md 8d "1-NN exact grid")"""
+    ca = cs.clone()
+    ctx.transform(ca, T)
+    ctx.tune("nn_method", 2); ctx.tune("prof", 1)
+    ctx.nn1_async(ct, ca); ctx.sync(); ctx.prof_reset()
+    for _ in range(5):
+        ctx.nn1_async(ct, ca)
+    gl, gms = ctx.prof_get("nn1_grid")
+    ctx.tune("grid_stats", 1); ctx.nn1_async(ct, ca); ctx.sync(); gs = ctx.grid_stats(); ctx.tune("grid_stats", 0)
+    ca.free()
+    ctx.tune("prof", 0)
+    steady_s = gms / 1e3 / max(gl, 1)
+    gpmc = load_pmc("latest_pmc_grid.json", sha)
+    if gpmc and (gpmc.get("n") != n_t or n_q != n_t):
+        gpmc = None
+    alg_bytes = n_q * (12.0 + 4.0 + 8.0) + 8.0 * gs["fine_rows"] + 16.0 * gs["candidates"]
+    L2_PEAK_GBS = 34500.0    # aggregate L2 bandwidth measured on MI355X (MI355X_MICROARCH.md, L2 section)
+    return {
+        "bound": "l2-gather", "achieved": alg_bytes / steady_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+        "frac": alg_bytes / steady_s / 1e9 / L2_PEAK_GBS,
+        "traffic": (gpmc["fetch_bytes_per_launch_corrected_x2"] + gpmc["write_bytes_per_launch"]) if gpmc else None,
+        "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
+                         f"kernel at {gpmc['n']} x {gpmc['n']} with this very library (sha {sha}), {gpmc['source']}") if gpmc
+                        else "null: no PMC pass of this kernel at this size with the library loaded now (tools/gpu_pmc_grid.sh)",
+        "compulsory_bytes": n_q * 24.0 + n_t * 16.0,
+        "vs_hbm_stream_peak": alg_bytes / steady_s / 1e9 / HBM_PEAK_GBS,
+        "kernel": "pcr::nn1_grid_kernel (exact uniform-grid 1-NN) at the converged pose",
+        "launches": int(gl), "avg_launch_ms": steady_s * 1e3, "kernel_M_corr_per_s": n_q / steady_s / 1e6,
+        "avg_launch_ms_over_the_timed_icp": kern_s * 1e3,
+        "candidates_per_query": gs["candidates"] / max(n_q, 1), "rows_per_query": gs["fine_rows"] / max(n_q, 1),
+        "algorithmic": f"per query 12 B point + 4 B order + 8 B key, 8 B per opened x-row ({gs['fine_rows'] / max(n_q, 1):.1f}/query) and "
+                       f"16 B per visited candidate ({gs['candidates'] / max(n_q, 1):.1f}/query), counted by the kernel's diagnostics "
+                       "build.  Neighbouring queries visit the same cells, so most candidate records are served by L2: the bound is the "
+                       "L2 gather rate"}
+
+
+def bench_c4(ctx, pcr, synth, np, args):
+    """BASELINE configs[3]: RANSAC ground plane (Homework4, ground_detection_ransac.py:131-153) + radius-NN on ONE 120k-point scan.
+    step = the 80-hypothesis inlier count (40 per x-segment, :54,71-72) in one pass + the radius search r = 1 of every point of
+    the scan against the scan (benchmark.hpp:14,66-70; iss_detector.cpp:48-56).  Kernel times from HIP events; the radius results
+    (12 B per neighbour) come back over PCIe at this boundary — that time is reported apart, never in `value`."""
+    n = args.points or 120000
+    scan = synth.kitti_like_scan(n)
+    ground = np.where(np.abs(scan[2] + 1.73) < 0.3)[0]
+    pick = (synth.splitmix64(9, np.arange(240, dtype=np.uint64)) % np.uint64(ground.size)).astype(np.int64).reshape(80, 3)
+    hw4 = importlib.import_module(PKG + ".hw4")
+    planes = np.stack([hw4.estimate_plane_params(scan[:, ground[p]].T.astype(np.float64)) for p in pick])
+    planes = planes[np.isfinite(planes).all(axis=1)]
+    c = ctx.cloud(scan)
+    ctx.tune("prof", 2)
+    ctx.plane_count(c, planes, 0.15); ctx.prof_reset()
+    reps = max(args.steps, 5)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        counts = ctx.plane_count(c, planes, 0.15)
+    call_ms = (time.perf_counter() - t0) * 1e3 / reps
+    k, ms = ctx.prof_get("plane_count")
+    plane_ms = ms / max(k, 1)
+    plane_bytes = 12.0 * n
+    # radius search: resident database, count-only pass and the full (count, fill, sort, distances) pass
+    db = np.ascontiguousarray(scan.T.astype(np.float64))
+    d = ctx.db64(db)
+    L = pcr.lib()
+    import ctypes as C
+    row = np.zeros(n + 1, np.int64)
+    L.pcr_db64_radius(ctx.h, d.h, db.ctypes.data, n, C.c_double(1.0), row.ctypes.data, None, None)      # builds + warms
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    L.pcr_db64_radius(ctx.h, d.h, db.ctypes.data, n, C.c_double(1.0), row.ctypes.data, None, None)
+    count_call_ms = (time.perf_counter() - t0) * 1e3
+    total = int(row[-1])
+    idx = np.zeros(max(total, 1), np.int32); dist = np.zeros(max(total, 1), np.float64)
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    rc = L.pcr_db64_radius(ctx.h, d.h, db.ctypes.data, n, C.c_double(1.0), row.ctypes.data, idx.ctypes.data, dist.ctypes.data)
+    full_call_ms = (time.perf_counter() - t0) * 1e3
+    assert rc == 0
+    kern = {}
+    for name in ("radius_grid_build", "radius_count", "radius_fill", "radius_sort", "radius_dist"):
+        k, ms = ctx.prof_get(name)
+        if k:
+            kern[name] = ms / k
+    radius_kernel_ms = sum(kern.values())
+    ctx.tune("prof", 0)
+    d.free(); c.free()
+    step_ms = plane_ms + radius_kernel_ms
+    out_bytes = 12.0 * total + 8.0 * n
+    res = {
+        "metric": "M radius queries/sec + M point-hypothesis evaluations/sec, 120k-pt KITTI scan, 1 MI355X (BASELINE configs[3])",
+        "value": n / step_ms / 1e3, "unit": "M scan points/s through (80-plane inlier count + radius-NN r = 1)", "n_gpus": 1, "steps": reps,
+        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"RANSAC plane-inlier count ({planes.shape[0]} hypotheses, thr 0.15) + radius-NN r = 1.0 of all {n} points against the scan",
+                   "n_points": n, "neighbours_reported": total, "best_plane_inliers": int(counts.max())},
+        "plane_count": {"ms": plane_ms, "call_ms_incl_h2d_d2h": call_ms, "bytes": plane_bytes, "GB/s": plane_bytes / plane_ms / 1e6,
+                        "frac_of_8TB/s": plane_bytes / plane_ms / 1e6 / HBM_PEAK_GBS,
+                        "G_point_hypothesis_per_s": n * planes.shape[0] / plane_ms / 1e6,
+                        "algorithmic": "12 B per point, ONE pass for all hypotheses (the reference reads the points once per hypothesis); 7 f64 ops per "
+                                       "point x hypothesis: 1.44 MB is launch-latency-bound at this size"},
+        "radius": {"kernel_ms": kern, "kernels_total_ms": radius_kernel_ms, "M_queries_per_s": n / radius_kernel_ms / 1e3,
+                   "G_neighbours_per_s": total / radius_kernel_ms / 1e6, "count_only_call_ms": count_call_ms, "full_call_ms_incl_d2h": full_call_ms,
+                   "result_bytes": out_bytes, "result_GB/s_of_kernels": out_bytes / radius_kernel_ms / 1e6,
+                   "note": "results are 12 B per reported neighbour (i32 index + f64 distance): the call is D2H-bound at this boundary; kernels: grid build, "
+                           "count, fill, per-row ascending-index sort, distances"},
+        "roofline": {"bound": "hbm", "achieved": out_bytes / radius_kernel_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": out_bytes / radius_kernel_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "radius pipeline (count + fill + sort + dist)",
+                     "algorithmic": "compulsory output bytes: 12 B per reported neighbour + 8 B row pointer per query"},
+    }
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orc
+        t0 = time.perf_counter()
+        oc = orc.plane_count(scan, planes, 0.15)
+        cpu_plane_ms = (time.perf_counter() - t0) * 1e3
+        assert np.array_equal(oc, counts)
+        sel = np.arange(0, n, max(1, n // 600))
+        base = {"plane_count_ms": cpu_plane_ms, "plane_kind": "port (oracle restatement of ground_detection_ransac.py:138-139, one core)", "cores": 1}
+        if orc.have_ref():
+            qs = np.ascontiguousarray(db[sel])
+            rp = np.zeros(sel.size + 1, np.int64)
+            t0 = time.perf_counter()
+            orc.ref().ref_hw2_kd_radius(db, n, 3, qs, sel.size, 1.0, 1, rp, None, None)      # one build + the searches
+            dtr = time.perf_counter() - t0
+            base.update({"radius_M_queries_per_s": sel.size / dtr / 1e6, "kind": "reference",
+                         "sample": f"the reference's hw2 kd-tree (leaf 1, build + radius 1.0 of {sel.size} of the {n} points, one core, benchmark.hpp:66-70)"})
+        else:
+            t0 = time.perf_counter()
+            orc.radius_f64(db, db[sel[:100]], 1.0)
+            dtr = time.perf_counter() - t0
+            base.update({"radius_M_queries_per_s": 100 / dtr / 1e6, "kind": "port", "sample": f"oracle exhaustive radius, 100 of {n} queries, one core"})
+        base["value"] = base["radius_M_queries_per_s"]; base["unit"] = "M radius queries/s"
+        res["cpu_baseline"] = base
+    return res
 
 
 if __name__ == "__main__":

@@ -48,7 +48,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
 # every symbol include/pcr.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [
-    "pcr_ctx_create", "pcr_ctx_destroy", "pcr_ctx_sync", "pcr_ctx_last_error", "pcr_version", "pcr_ctx_device_info",
+    "pcr_device_count", "pcr_ctx_create", "pcr_ctx_destroy", "pcr_ctx_sync", "pcr_ctx_last_error", "pcr_version", "pcr_ctx_device_info",
     "pcr_cloud_create", "pcr_cloud_clone", "pcr_cloud_assign", "pcr_cloud_read", "pcr_cloud_size", "pcr_cloud_destroy",
     "pcr_nn1_f32", "pcr_nn1_f32_async", "pcr_nn1_fetch", "pcr_transform_f32", "pcr_kabsch_sums", "pcr_kabsch_solve",
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
@@ -72,6 +72,7 @@ def lib():
     L.pcr_version.restype = C.c_char_p
     L.pcr_ctx_last_error.restype = C.c_char_p
     L.pcr_ctx_last_error.argtypes = [vp]
+    L.pcr_device_count.argtypes = [C.POINTER(C.c_int)]
     L.pcr_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.pcr_ctx_destroy.argtypes = [vp]
     L.pcr_ctx_sync.argtypes = [vp]
@@ -128,6 +129,12 @@ def lib():
     L.pcr_ransac_global_f32.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, C.c_float, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int64), vp]
     _lib = L
     return L
+
+
+def device_count() -> int:
+    """GPUs visible to this process (0 when there is none or the HIP runtime cannot start)."""
+    n = C.c_int()
+    return n.value if lib().pcr_device_count(C.byref(n)) == 0 else 0
 
 
 def shard_range(n: int, nranks: int, rank: int):

@@ -125,6 +125,16 @@ extern "C" {
 
 const char* pcr_version(void) { return "pcr-mi355x 0.1 (gfx950)"; }
 
+int pcr_device_count(int* count)
+{
+    if (!count) return PCR_ERR_ARG;
+    *count = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return PCR_ERR_HIP;
+    *count = n;
+    return PCR_OK;
+}
+
 int pcr_ctx_create(int device, pcr_ctx** out)
 {
     if (!out) return PCR_ERR_ARG;

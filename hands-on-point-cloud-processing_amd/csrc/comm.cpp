@@ -11,6 +11,8 @@
 #include <rccl/rccl.h>   // declarations only: the entry points are bound with dlopen below, their types come from here
 
 #include <mutex>
+#include <string>
+#include <vector>
 
 namespace pcr {
 
@@ -29,6 +31,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
+    std::string path;     // what dlopen was given
 };
 
 void rccl_load(Rccl& r);
@@ -43,10 +46,24 @@ Rccl& rccl()
 
 void rccl_load(Rccl& r)
 {
-    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-    for (const char* n : names) {
-        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (r.handle) break;
+    // The communicator must live in the SAME HIP runtime as this library's streams and buffers.  A process can hold two
+    // (PyTorch ships its own libamdhip64 + librccl under torch/lib; which one a bare SONAME resolves to depends on what was
+    // loaded first), so the RCCL next to the libamdhip64 that THIS library is bound to is tried first, by path.
+    std::string beside;
+    Dl_info info;
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+        beside = info.dli_fname;
+        const size_t slash = beside.rfind('/');
+        beside = slash == std::string::npos ? std::string() : beside.substr(0, slash + 1);
+    }
+    std::vector<std::string> names;
+    if (!beside.empty()) { names.push_back(beside + "librccl.so.1"); names.push_back(beside + "librccl.so"); }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const std::string& n : names) {
+        r.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) { r.path = n; break; }
     }
     if (!r.handle) { r.err = std::string("dlopen(librccl): ") + dlerror(); return; }
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");

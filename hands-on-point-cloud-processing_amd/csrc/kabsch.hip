@@ -324,7 +324,10 @@ int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* s
 
 int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev)
 {
-    hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, ctx->keys, st_dev, ctx->dev_out);
+    {
+        ProfScope p(ctx, "icp_update");
+        hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, ctx->keys, st_dev, ctx->dev_out);
+    }
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
@@ -348,6 +351,7 @@ int launch_transform_state(pcr_ctx* ctx, pcr_cloud* c, IcpState* st_dev)
 {
     if (c->n) {
         const uint32_t n4 = (uint32_t)((c->n + 3) / 4);
+        ProfScope p(ctx, "transform");
         hipLaunchKernelGGL(transform_state_kernel, dim3((n4 + 255) / 256), dim3(256), 0, ctx->stream, c->x(), c->y(), c->z(),
                            (uint32_t)c->n, n4, st_dev);
     }

@@ -45,6 +45,7 @@ enum pcr_layout {
 };
 
 /* ---- context ------------------------------------------------------------------------------------ */
+int pcr_device_count(int* count);                     /* GPUs visible to this process (hipGetDeviceCount) */
 int pcr_ctx_create(int device, pcr_ctx** out);
 int pcr_ctx_destroy(pcr_ctx* ctx);
 int pcr_ctx_sync(pcr_ctx* ctx);                       /* wait for the context's HIP stream */

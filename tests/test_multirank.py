@@ -54,12 +54,11 @@ def test_sharded_icp_four_ranks_one_gpu():
 
 
 @pytest.mark.gpu
-def test_sharded_icp_two_ranks_two_gpus_rccl_device_path():
+def test_sharded_icp_two_ranks_two_gpus_rccl_device_path(pcr):
     """The native transport with MORE than one rank: one process per GPU, ncclAllReduce enqueued on the context stream between
     icp_reduce_slots and icp_update_from_sums (csrc/icp.cpp).  Needs two GPUs in this box; the single-GPU boxes skip it
     (the driver's 8-GPU scaling run is then the first multi-rank RCCL execution)."""
-    import torch
-    if torch.cuda.device_count() < 2:        # counting devices does not initialise the GPU
+    if pcr.device_count() < 2:               # (no torch in this process: it would bring a second HIP runtime + RCCL with it)
         pytest.skip("one GPU visible: the RCCL device path needs one GPU per rank")
     out = run_workers("rccl", 2)
     assert out.count("rccl sharded icp ok") == 2

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Condense the --pmc passes of tools/gpu_pmc_grid.sh into profiles/<tag>_grid_pmc.md + profiles/latest_pmc_grid.json
 (read by bench.py --nn grid / --workload c5 for roofline.traffic).  usage: python tools/summarize_grid_pmc.py r01 10000000"""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, hashlib, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the counters describe ONE build of the library: bench.py trusts them only while the sha of the loaded libpcr_hip.so is the same
+LIB_SHA16 = hashlib.sha256(open(os.path.join(root, "hands-on-point-cloud-processing_amd", "libpcr_hip.so"), "rb").read()).hexdigest()[:16]
 go, out = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 vals, durs = {}, {}
 for d in ("pmc_grid_fetch", "pmc_grid_write", "pmc_grid_sq"):
@@ -38,7 +40,7 @@ if "FETCH_SIZE" in vals:
     lines.append(f"\nHBM-side traffic per launch: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB x 2 (gfx950 correction, MI355X_MICROARCH.md §HBM) = {fetch/1e6:.1f} MB"
                  f" + WRITE_SIZE {write/1e6:.1f} MB -> {(fetch+write)/ (ms*1e-3)/1e9:.0f} GB/s over the {ms:.2f} ms launch; compulsory: "
                  f"{n*(12+16+4+8)/1e6:.0f} MB (queries 12 B, records 16 B once, order 4 B, key 8 B)")
-    json.dump({"kernel": "pcr::nn1_grid_kernel", "n": n, "source": f"profiles/{tag}_grid_pmc.md", "fetch_bytes_per_launch_corrected_x2": fetch,
+    json.dump({"lib_sha16": LIB_SHA16, "kernel": "pcr::nn1_grid_kernel", "n": n, "source": f"profiles/{tag}_grid_pmc.md", "fetch_bytes_per_launch_corrected_x2": fetch,
                "write_bytes_per_launch": write, "launch_ms_in_pass": ms}, open(os.path.join(out, "latest_pmc_grid.json"), "w"), indent=1)
 open(os.path.join(out, f"{tag}_grid_pmc.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

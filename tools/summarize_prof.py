@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 outputs merged into gpurun_out/ into small text files under profiles/ (committed).
 usage: python tools/summarize_prof.py r01"""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, hashlib, json, os, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the counters describe ONE build of the library: bench.py trusts them only while the sha of the loaded libpcr_hip.so is the same
+LIB_SHA16 = hashlib.sha256(open(os.path.join(root, "hands-on-point-cloud-processing_amd", "libpcr_hip.so"), "rb").read()).hexdigest()[:16]
 go = os.path.join(root, "gpurun_out")
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -82,7 +84,7 @@ if pm:
                      "(compulsory: 2.88 MB read, 0.96 MB key write + memset)")
 if pm and "FETCH_SIZE" in pm:
     ms = sum(durs["pmc_sq"]) / len(durs["pmc_sq"]) if "pmc_sq" in durs else None
-    js = {"kernel": kname.replace("void ", ""), "source": f"profiles/{tag}_bench_rocprof_summary.md",
+    js = {"lib_sha16": LIB_SHA16, "kernel": kname.replace("void ", ""), "source": f"profiles/{tag}_bench_rocprof_summary.md",
           "fetch_bytes_per_launch_corrected_x2": pm["FETCH_SIZE"][0] * 2 * 1024,
           "write_bytes_per_launch": pm.get("WRITE_SIZE", (0,))[0] * 1024,
           "clock_ghz_profiled": (pm["GRBM_GUI_ACTIVE"][0] / 8 / (ms * 1e-3) / 1e9) if "GRBM_GUI_ACTIVE" in pm else None,
