@@ -50,7 +50,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 ABI_SYMBOLS = [
     "pcr_device_count", "pcr_ctx_create", "pcr_ctx_destroy", "pcr_ctx_sync", "pcr_ctx_last_error", "pcr_version", "pcr_ctx_device_info",
     "pcr_cloud_create", "pcr_cloud_clone", "pcr_cloud_assign", "pcr_cloud_read", "pcr_cloud_size", "pcr_cloud_destroy",
-    "pcr_nn1_f32", "pcr_nn1_f32_async", "pcr_nn1_fetch", "pcr_transform_f32", "pcr_kabsch_sums", "pcr_kabsch_solve",
+    "pcr_nn1_f32", "pcr_nn1_f32_async", "pcr_nn1_fetch", "pcr_transform_f32", "pcr_kabsch_sums", "pcr_kabsch_solve", "pcr_kabsch_grid_exponent", "pcr_kabsch_limbs_to_sums",
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
@@ -90,6 +90,8 @@ def lib():
     L.pcr_transform_f32.argtypes = [vp, vp, vp]
     L.pcr_kabsch_sums.argtypes = [vp, vp, vp, C.c_float, vp, C.POINTER(C.c_int64), C.POINTER(C.c_float)]
     L.pcr_kabsch_solve.argtypes = [vp, vp, vp]
+    L.pcr_kabsch_grid_exponent.argtypes = [C.c_float, C.c_float]
+    L.pcr_kabsch_limbs_to_sums.argtypes = [vp, C.c_int, vp]
     L.pcr_icp_p2p_f32.argtypes = [vp, vp, vp, vp, C.POINTER(IcpParams), vp, C.POINTER(IcpStats)]
     L.pcr_plane_count_f64.argtypes = [vp, vp, vp, sz, C.c_double, vp]
     L.pcr_plane_mask_f64.argtypes = [vp, vp, vp, C.c_double, vp, C.POINTER(C.c_int64)]
@@ -161,6 +163,21 @@ def ransac_sample_quads(src_xyz, pairs, n_hyp, seed):
     if rc != 0:
         raise PcrError(f"pcr_ransac_sample_quads failed (rc = {rc})")
     return quads
+
+
+def kabsch_grid_exponent(target_absmax: float, max_corr: float) -> int:
+    """e of the fixed-point grid of the exact Kabsch sums: 2^e bounds every coordinate of a kept pair (host logic, no GPU)."""
+    return int(lib().pcr_kabsch_grid_exponent(float(target_absmax), float(max_corr)))
+
+
+def kabsch_limbs_to_sums(row, e: int):
+    """A (summed) row of 55 limbs -> the 16 moments; carries are propagated in place on a copy (host logic, no GPU)."""
+    r = np.ascontiguousarray(row, np.float64)[:55].copy()
+    sums = np.zeros(16, np.float64)
+    rc = lib().pcr_kabsch_limbs_to_sums(r.ctypes.data, int(e), sums.ctypes.data)
+    if rc != 0:
+        raise PcrError(f"pcr_kabsch_limbs_to_sums failed (rc = {rc})")
+    return sums
 
 
 def kabsch_solve(sums):

@@ -1,5 +1,6 @@
 // api.cpp — context, cloud management and the thin extern "C" entry points of libpcr_hip.so.
 #include "pcr_internal.hpp"
+#include "numerics.hpp"
 
 #include <cmath>
 #include <limits>
@@ -95,6 +96,7 @@ void cloud_modified(pcr_cloud* c)
 {
     if (c && c->grid) { grid_free(c->grid); c->grid = nullptr; }
     if (c && c->knn_grid) { grid_free(c->knn_grid); c->knn_grid = nullptr; c->knn_grid_factor = 0.0; }
+    if (c) c->absmax = -1.f;
 }
 
 int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2)
@@ -156,10 +158,10 @@ int pcr_ctx_create(int device, pcr_ctx** out)
     CK(hipSetDevice(device));
     CK(hipGetDeviceProperties(&ctx->prop, device));
     CK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    CK(hipMalloc((void**)&ctx->partials, 8192 * 17 * sizeof(double)));   // KB_MAX_BLOCKS x (16 moments + last kept)
-    ctx->partials_cap = 8192 * 17;
-    CK(hipMalloc((void**)&ctx->dev_out, 64 * sizeof(double)));
-    CK(hipHostMalloc((void**)&ctx->host_out, 64 * sizeof(double), hipHostMallocDefault));
+    CK(hipMalloc((void**)&ctx->partials, 8192 * 58 * sizeof(double)));   // KB_MAX_BLOCKS x KB_ROW (kabsch.hip)
+    ctx->partials_cap = 8192 * 58;
+    CK(hipMalloc((void**)&ctx->dev_out, 128 * sizeof(double)));           // >= icp_nred(PCR_MAX_RANKS) = 104
+    CK(hipHostMalloc((void**)&ctx->host_out, 128 * sizeof(double), hipHostMallocDefault));
 #undef CK
     *out = ctx;
     return PCR_OK;
@@ -178,6 +180,8 @@ int pcr_ctx_destroy(pcr_ctx* ctx)
     if (ctx->icp_state_host) hipHostFree(ctx->icp_state_host);
     for (hipEvent_t ev : ctx->icp_events) if (ev) hipEventDestroy(ev);
     if (ctx->qperm) hipFree(ctx->qperm);
+    if (ctx->wpos) hipFree(ctx->wpos);
+    if (ctx->work_orig) hipFree(ctx->work_orig);
     if (ctx->grid_stats_dev) hipFree(ctx->grid_stats_dev);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->dev_out) hipFree(ctx->dev_out);
@@ -300,7 +304,8 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (ctx && ctx->qperm_src == c) ctx->qperm_src = nullptr;
     if (ctx && ctx->keys_src == c) ctx->keys_src = nullptr;
-    if (ctx && ctx->keys_tgt == c) { ctx->keys_tgt = nullptr; ctx->keys_warm = false; }
+    if (ctx && ctx->keys_tgt == c) { ctx->keys_tgt = nullptr; ctx->keys_warm = false; ctx->wpos_valid = false; }
+    if (ctx && ctx->work_orig_src == c) ctx->work_orig_src = nullptr;
     cloud_modified(c);
     if (c->base) hipFree(c->base);
     delete c;
@@ -359,13 +364,27 @@ int pcr_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, fl
         if (last_d2) *last_d2 = 0.f;
         return PCR_OK;
     }
-    int rc = launch_kabsch_sums(ctx, tgt, src, max_corr);
+    KabschPlan plan;
+    int rc = kabsch_plan(ctx, tgt, max_corr, &plan);
     if (rc) return rc;
-    PCR_HIP(ctx, hipMemcpyAsync(ctx->host_out, ctx->dev_out, 18 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    rc = launch_kabsch_sums(ctx, tgt, src, max_corr, plan);
+    if (rc) return rc;
+    PCR_HIP(ctx, hipMemcpyAsync(ctx->host_out, ctx->dev_out, 19 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->host_out[18] != 0.0) return fail(ctx, PCR_ERR_STATE, "pcr_kabsch_sums: a kept source point lies more than 2^20 target extents away from the target");
     memcpy(sums, ctx->host_out, 16 * sizeof(double));
     if (last_kept) *last_kept = (int64_t)ctx->host_out[16];
     if (last_d2) *last_d2 = (float)ctx->host_out[17];
+    return PCR_OK;
+}
+
+int pcr_kabsch_grid_exponent(float target_absmax, float max_corr) { return kabsch_grid_exponent(target_absmax, max_corr); }
+
+int pcr_kabsch_limbs_to_sums(double row[55], int e, double sums[16])
+{
+    if (!row || !sums) return PCR_ERR_ARG;
+    num::limbs_normalize_row(row);
+    num::limbs_to_sums(row, e, sums);
     return PCR_OK;
 }
 

@@ -23,6 +23,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -548,6 +549,32 @@ int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n
     hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(GR_BLOCK), 0, ctx->stream, totals, nb, grand);
     hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(GR_BLOCK), 0, ctx->stream, out, (uint32_t)n, totals);
     PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+// largest finite |coordinate| of the cloud (0 when it has no finite point), cached on the cloud until it is modified
+int cloud_absmax(pcr_ctx* ctx, const pcr_cloud* c, float* out)
+{
+    if (c->absmax >= 0.f) { *out = c->absmax; return PCR_OK; }
+    float a = 0.f;
+    if (c->n) {
+        const uint32_t bb_blocks = (uint32_t)std::min<size_t>(256, (c->n + GR_BLOCK - 1) / GR_BLOCK);
+        float* dev = nullptr;
+        PCR_HIP(ctx, hipMalloc((void**)&dev, bb_blocks * 6 * sizeof(float)));       // not the shared scratch: callers may be using it
+        hipLaunchKernelGGL(bbox_kernel, dim3(bb_blocks), dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)c->n, dev);
+        std::vector<float> hb(bb_blocks * 6);
+        hipError_t e = hipMemcpyAsync(hb.data(), dev, hb.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        hipFree(dev);
+        if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "cloud_absmax", e);
+        for (uint32_t b = 0; b < bb_blocks; b++)
+            for (int k = 0; k < 3; k++) {
+                const float lo = hb[b * 6 + k], hi = hb[b * 6 + 3 + k];
+                if (lo <= hi) a = std::max(a, std::max(std::fabs(lo), std::fabs(hi)));      // a block without a finite point reports lo > hi
+            }
+    }
+    const_cast<pcr_cloud*>(c)->absmax = a;
+    *out = a;
     return PCR_OK;
 }
 

@@ -5,6 +5,7 @@
 // The reference's quirks are kept: squared distance vs un-squared max_corr (:936), loss = d2*d2 of the last
 // kept pair (:939), `unchanged` never reset (:948-951), det<0 branch (:990-996).
 #include "pcr_internal.hpp"
+#include "numerics.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -39,60 +40,62 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
     float last_loss = 0.0f;                                                      // :915
     uint64_t unchanged = 0;                                                      // :916
     const int nranks = ctx->comm.nranks, rank = ctx->comm.rank;
-    const int nred = 16 + 2 * nranks;   // sums + one (last_kept flag, last d2) slot per rank
-    if (nred > 64) { pcr_cloud_destroy(ctx, work); return fail(ctx, PCR_ERR_ARG, "too many ranks"); }
+    const int nred = icp_nred(nranks);   // limbs of the 16 sums + overflow flag + one (kept flag, last d2) slot per rank
+    if (nranks > PCR_MAX_RANKS) { pcr_cloud_destroy(ctx, work); return fail(ctx, PCR_ERR_ARG, "too many ranks"); }
+    KabschPlan plan;                     // the fixed-point grid of the exact sums: the same on every rank (target + gate)
+    if (rc == PCR_OK) rc = kabsch_plan(ctx, tgt, prm->max_corr, &plan);
+    bool overflow = false;
 
     for (uint64_t iter = 0; rc == PCR_OK && iter < prm->max_iter; iter++) {      // :917
         if ((rc = launch_nn1(ctx, tgt, work, true, gate))) break;                      // :925-934
         double* h = ctx->host_out;
+        double sums16[16];
         double last_kept, last_d2;
         hipError_t e = hipSuccess;
-        if (ctx->comm.rccl && (nranks > 1 || tune_get(ctx, "icp_force_slots", 0) > 0)) {
-            // RCCL: the partial moments are reduced on the device, all-reduced in place on the context stream (the ONE
-            // collective of the iteration: 16 moments + one (kept flag, last d2) slot per rank so that `loss` is that of
-            // the globally last kept pair) and only then copied to the host
+        if (nranks > 1 || (ctx->comm.rccl && tune_get(ctx, "icp_force_slots", 0) > 0)) {
+            // sharded sources: the block rows are reduced on the device into the all-reduce buffer — the limbs of the exact sums
+            // + one (kept flag, last d2) slot per rank so that `loss` is that of the globally last kept pair — which is summed
+            // over the ranks by the ONE collective of the iteration (RCCL in place on the context stream, or the caller's
+            // reducer on the host copy).  Integer limbs: the result does not depend on the number of ranks.
             uint32_t blocks = 0;
-            if (work->n && (rc = launch_kabsch_partial(ctx, tgt, work, prm->max_corr, &blocks))) break;   // :936-940,:964-985
+            if (work->n && (rc = launch_kabsch_partial(ctx, tgt, work, prm->max_corr, plan, &blocks))) break;   // :936-940,:964-985
             if ((rc = launch_icp_reduce_slots(ctx, blocks, nranks, rank, work->n != 0))) break;
-            if ((rc = comm_allreduce_f64_device(ctx, ctx->dev_out, nred))) break;
+            if (ctx->comm.rccl && (rc = comm_allreduce_f64_device(ctx, ctx->dev_out, nred))) break;
             e = hipMemcpyAsync(h, ctx->dev_out, nred * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "icp d2h", e); break; }
+            if (!ctx->comm.rccl && (rc = comm_allreduce_f64(ctx, h, ctx->dev_out, nred))) break;       // host-callback transport
+            num::limbs_normalize_row(h);
+            num::limbs_to_sums(h, plan.e, sums16);
+            overflow = h[55] != 0.0;
             last_kept = -1.0; last_d2 = 0.0;
             for (int r = 0; r < nranks; r++)
-                if (h[16 + 2 * r] > 0.5) { last_kept = 1.0; last_d2 = h[17 + 2 * r]; }
+                if (h[56 + 2 * r] > 0.5) { last_kept = 1.0; last_d2 = h[57 + 2 * r]; }
         } else {
             if (work->n) {
-                if ((rc = launch_kabsch_sums(ctx, tgt, work, prm->max_corr))) break; // :936-940,:964-985
+                if ((rc = launch_kabsch_sums(ctx, tgt, work, prm->max_corr, plan))) break; // :936-940,:964-985
             } else {
-                e = hipMemsetAsync(ctx->dev_out, 0, 18 * sizeof(double), ctx->stream);
+                e = hipMemsetAsync(ctx->dev_out, 0, 19 * sizeof(double), ctx->stream);
                 if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "memset", e); break; }
             }
-            e = hipMemcpyAsync(h, ctx->dev_out, 18 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+            e = hipMemcpyAsync(h, ctx->dev_out, 19 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "icp d2h", e); break; }
+            memcpy(sums16, h, sizeof sums16);
             last_kept = work->n ? h[16] : -1.0;
             last_d2 = work->n ? h[17] : 0.0;
-            if (nranks > 1) {
-                // host-callback transport: same buffer layout, reduced by the caller's process group
-                for (int r = 0; r < nranks; r++) { h[16 + 2 * r] = 0.0; h[17 + 2 * r] = 0.0; }
-                h[16 + 2 * rank] = last_kept >= 0 ? 1.0 : 0.0;
-                h[17 + 2 * rank] = last_d2;
-                if ((rc = comm_allreduce_f64(ctx, h, ctx->dev_out, nred))) break;
-                last_kept = -1.0;
-                for (int r = 0; r < nranks; r++)
-                    if (h[16 + 2 * r] > 0.5) { last_kept = 1.0; last_d2 = h[17 + 2 * r]; }
-            }
+            overflow = work->n && h[18] != 0.0;
         }
+        if (overflow) { rc = fail(ctx, PCR_ERR_STATE, "ICP: a kept source point lies more than 2^20 target extents away from the target"); break; }
         float loss = 0.0f;
         if (last_kept >= 0) { const float d2 = (float)last_d2; loss = d2 * d2; } // :939
-        st.last_pairs = (uint64_t)h[15];
+        st.last_pairs = (uint64_t)sums16[15];
         st.last_loss = loss;
         if (std::fabs(last_loss - loss) < prm->eps) unchanged++;                 // :948-951
         if (unchanged > 15) { st.converged = 1; break; }                         // :954-958
         last_loss = loss;                                                        // :961
         float Rd[9], td[3];
-        if (kabsch_solve(h, Rd, td) != PCR_OK) { st.empty_pairs = 1; break; }    // :979-998
+        if (kabsch_solve(sums16, Rd, td) != PCR_OK) { st.empty_pairs = 1; break; }    // :979-998
         const float T_delta[16] = { Rd[0], Rd[1], Rd[2], td[0], Rd[3], Rd[4], Rd[5], td[1],
                                     Rd[6], Rd[7], Rd[8], td[2], 0, 0, 0, 1 };
         mat4_mul_f32(T_delta, T_total, T_total);                                 // :1000-1002
@@ -154,8 +157,10 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     if (e != hipSuccess) rc = fail(ctx, PCR_ERR_HIP, "icp state upload", e);
 
     const int nranks = ctx->comm.nranks, rank = ctx->comm.rank;
-    const int nred = 16 + 2 * nranks;
-    if (nred > 64) { pcr_cloud_destroy(ctx, work); return fail(ctx, PCR_ERR_ARG, "too many ranks"); }   // dev_out / host_out hold 64 f64
+    const int nred = icp_nred(nranks);
+    if (nranks > PCR_MAX_RANKS) { pcr_cloud_destroy(ctx, work); return fail(ctx, PCR_ERR_ARG, "too many ranks"); }   // dev_out / host_out hold 128 f64
+    KabschPlan plan;
+    if (rc == PCR_OK) rc = kabsch_plan(ctx, tgt, prm->max_corr, &plan);
     int64_t chunk = tune_get(ctx, "icp_chunk", 4);
     if (chunk < 1) chunk = 1;
     uint64_t enq = 0, chunks = 0;
@@ -165,13 +170,13 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
             ctx->stop_flag_dev = &dev->stop;     // correspondence kernels no-op once stop or stop_after_transform is set
             if ((rc = launch_nn1(ctx, tgt, work, true, gate))) break;                             // :925-934
             uint32_t blocks = 0;
-            if (work->n && (rc = launch_kabsch_partial(ctx, tgt, work, prm->max_corr, &blocks))) break;   // :936-940,:964-985
+            if (work->n && (rc = launch_kabsch_partial(ctx, tgt, work, prm->max_corr, plan, &blocks))) break;   // :936-940,:964-985
             if (nranks == 1 && work->n && tune_get(ctx, "icp_force_slots", 0) <= 0) {
-                if ((rc = launch_icp_update(ctx, blocks, dev))) break;                      // :948-1002
+                if ((rc = launch_icp_update(ctx, blocks, dev, plan))) break;                // :948-1002
             } else {
                 if ((rc = launch_icp_reduce_slots(ctx, blocks, nranks, rank, work->n != 0))) break;
                 if ((rc = comm_allreduce_f64_device(ctx, ctx->dev_out, nred))) break;       // the ONE collective
-                if ((rc = launch_icp_update_from_sums(ctx, nranks, dev))) break;
+                if ((rc = launch_icp_update_from_sums(ctx, nranks, dev, plan))) break;
             }
             if ((rc = launch_transform_state(ctx, work, dev))) break;                       // :1003
         }
@@ -201,6 +206,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     pcr_cloud_destroy(ctx, work);
     if (rc) return rc;
     const IcpState& f = host[RING];
+    if (f.overflow) return fail(ctx, PCR_ERR_STATE, "ICP: a kept source point lies more than 2^20 target extents away from the target");
     memcpy(out_T, f.T_total, sizeof f.T_total);                                  // :1008-1009
     st.iters_run = f.iters_run;
     st.converged = f.converged;

@@ -1,21 +1,28 @@
 // kabsch.hip — the streaming (HBM-bound) passes of one ICP iteration on gfx950:
-//   * kabsch_partial_kernel / kabsch_final_kernel: A7 accumulation — f64 sums of p, q and q p^T over the
-//     kept pairs (Homework9/hw9/src/registration.cpp:936-940,964-985), reduced per wavefront with DPP
-//     shuffles, per workgroup through LDS, and across workgroups in a fixed order (bit-reproducible for a
-//     given launch geometry; no float atomics).  Algorithmic traffic: 28 B per kept pair
-//     (12 B source + 8 B key + 12 B gathered target - the key carries idx and d2).
+//   * kabsch_partial_kernel / kabsch_final_kernel: A7 accumulation — the sums of p, q and q p^T over the kept pairs
+//     (Homework9/hw9/src/registration.cpp:936-940,964-985).  The sums are EXACT and therefore independent of the order of the
+//     additions: every term is cut into 40-bit integer limbs on one fixed-point grid (numerics.hpp), integer partial sums are
+//     reduced per wavefront with DPP shuffles, per workgroup through LDS, across workgroups by one final workgroup and across
+//     ranks by the one all-reduce of the iteration, with carry propagation between the levels.  The same bits come out for
+//     any launch geometry, any visiting order of the queries (original order, cell order) and any number of GPUs.
+//     Algorithmic traffic: 28 B per kept pair (12 B source + 8 B key + 12 B gathered target - the key carries idx and d2).
 //   * transform_kernel: A8 transformCloudInplace (registration.cpp:165-178), f32, unfused, in place,
 //     24 B per point, float4-vectorised over the SoA arrays.
-#include "pcr_internal.hpp"
+#include "grid_common.hpp"
 #include "numerics.hpp"
+
+#include <cmath>
 
 #pragma clang fp contract(off)
 
 namespace pcr {
 
 constexpr int KB_BLOCK = 256;
-constexpr int KB_NV = 16;          // 3 + 3 + 9 sums + count
+constexpr int KB_NV = 16;             // 3 + 3 + 9 sums + count
+constexpr int KB_NL = num::KB_NL;     // 55 normalised limbs (numerics.hpp)
+constexpr int KB_ROW = 58;            // a partial row: KB_NL limbs, [55] last-kept key (u64 bits), [56] overflow flag, [57] pad
 constexpr int KB_MAX_BLOCKS = 8192;   // == the capacity of ctx->partials (api.cpp)
+static_assert(KB_ROW * KB_MAX_BLOCKS == 8192 * 58, "api.cpp sizes ctx->partials as 8192 x 58 doubles");
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -24,112 +31,180 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-__device__ __forceinline__ long long wave_max(long long v)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        long long o = __shfl_down(v, off, 64);
+        const unsigned long long o = __shfl_down(v, off, 64);
         v = o > v ? o : v;
     }
     return v;
 }
 
-// partials layout: [block][KB_NV + 1] doubles; slot KB_NV holds the last kept source index as a double
-// (exact below 2^53) or -1.
+// one coordinate term into its two limbs (y = v * 2^(80 - e), |y| < 2^80)
+__device__ __forceinline__ void acc2(double v, double sc, double& a0, double& a1)
+{
+    const double y = v * sc;                                  // exact: power of two
+    const double l1 = trunc(y * num::KB_2mW);
+    const double r = fma(-l1, num::KB_2W, y);                 // exact remainder, |r| < 2^40
+    a1 += l1;
+    a0 += trunc(r);
+}
+
+// one product term into its three limbs (y = v * 2^(120 - 2e), |y| < 2^120)
+__device__ __forceinline__ void acc3(double v, double sp, double& a0, double& a1, double& a2)
+{
+    const double y = v * sp;
+    const double l2 = trunc(y * (num::KB_2mW * num::KB_2mW));
+    const double r = fma(-l2, num::KB_2W * num::KB_2W, y);    // |r| < 2^80
+    const double l1 = trunc(r * num::KB_2mW);
+    const double r2 = fma(-l1, num::KB_2W, r);                // |r2| < 2^40
+    a2 += l2;
+    a1 += l1;
+    a0 += trunc(r2);
+}
+
+// the workgroup's reduction of the per-thread limbs: tn[KB_NL] (normalised per thread) -> row[] in LDS, normalised again
+__device__ __forceinline__ void block_reduce_limbs(double (&tn)[KB_NL], unsigned long long lastkey, int overflow,
+                                                   double (&red)[KB_BLOCK / 64][KB_NL], double (&row)[KB_ROW])
+{
+    __shared__ unsigned long long red_key[KB_BLOCK / 64];
+    __shared__ int red_ovf[KB_BLOCK / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < KB_NL; k++) {
+        const double sum = wave_sum(tn[k]);                   // 64 integers below 2^40 (+ small carries): exact
+        if (lane == 0) red[wave][k] = sum;
+    }
+    const unsigned long long km = wave_max_u64(lastkey);
+    const int ov = __any(overflow) ? 1 : 0;
+    if (lane == 0) { red_key[wave] = km; red_ovf[wave] = ov; }
+    __syncthreads();
+    if (threadIdx.x < KB_NL) {
+        const int k = threadIdx.x;
+        row[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    } else if (threadIdx.x == KB_NL) {
+        unsigned long long m = red_key[0];
+        for (int w = 1; w < KB_BLOCK / 64; w++) m = red_key[w] > m ? red_key[w] : m;
+        row[55] = __longlong_as_double((long long)m);
+        row[56] = (red_ovf[0] | red_ovf[1] | red_ovf[2] | red_ovf[3]) ? 1.0 : 0.0;
+        row[57] = 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) num::limbs_normalize(row + 3 * threadIdx.x, 2);
+    else if (threadIdx.x < 15) num::limbs_normalize(row + 18 + 4 * (threadIdx.x - 6), 3);
+    __syncthreads();
+}
+
+// partials layout: [block][KB_ROW].  RECORDS: the target of pair i is grid record wpos[i] (one 16-byte gather from the cell-
+// sorted records, which neighbouring queries share) instead of the three 4-byte gathers at its original index.
+// orig: original index of query i (the working cloud of the grid ICP is cell-sorted) or nullptr = i.
+template <bool RECORDS>
 __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
     const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
-    const unsigned long long* __restrict__ keys, uint32_t ns, uint32_t nt, float max_corr,
+    const float4* __restrict__ records, const uint32_t* __restrict__ wpos, const uint32_t* __restrict__ orig,
+    const unsigned long long* __restrict__ keys, uint32_t ns, uint32_t nt, float max_corr, KabschPlan plan,
     double* __restrict__ partials)
 {
-    double acc[KB_NV];
+    double c0[6], c1[6], p0[9], p1[9], p2[9], cnt = 0.0;
 #pragma unroll
-    for (int k = 0; k < KB_NV; k++) acc[k] = 0.0;
-    long long last = -1;
-    // contiguous chunk per block, strided by lane inside it: the order of additions is a pure function of
-    // (ns, gridDim, blockDim)
+    for (int k = 0; k < 6; k++) { c0[k] = 0.0; c1[k] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 9; k++) { p0[k] = 0.0; p1[k] = 0.0; p2[k] = 0.0; }
+    unsigned long long lastkey = 0;
+    int overflow = 0;
+    // contiguous chunk per block, strided by lane inside it (coalesced); the order does not matter for the result
     const uint32_t per_block = (ns + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = min(blockIdx.x * per_block, ns);
     const uint32_t hi = min(lo + per_block, ns);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += KB_BLOCK) {
         const unsigned long long key = keys[i];
-        const float d2 = __uint_as_float((uint32_t)(key >> 32));
+        const uint32_t d2b = (uint32_t)(key >> 32);
+        const float d2 = __uint_as_float(d2b);
         const uint32_t j = (uint32_t)(key & 0xFFFFFFFFull);
         if (d2 < max_corr && j < nt) {                       // registration.cpp:936
-            const double p0 = sx[i], p1 = sy[i], p2 = sz[i];
-            const double q0 = tx[j], q1 = ty[j], q2 = tz[j];
-            acc[0] += p0; acc[1] += p1; acc[2] += p2;
-            acc[3] += q0; acc[4] += q1; acc[5] += q2;
-            acc[6] += q0 * p0; acc[7] += q0 * p1; acc[8] += q0 * p2;
-            acc[9] += q1 * p0; acc[10] += q1 * p1; acc[11] += q1 * p2;
-            acc[12] += q2 * p0; acc[13] += q2 * p1; acc[14] += q2 * p2;
-            acc[15] += 1.0;
-            last = (long long)i;
-        }
-    }
-    __shared__ double red[KB_BLOCK / 64][KB_NV + 1];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const float pf0 = sx[i], pf1 = sy[i], pf2 = sz[i];
+            float qf0, qf1, qf2;
+            if (RECORDS) {
+                const float4 r = records[wpos[i]];
+                qf0 = r.x; qf1 = r.y; qf2 = r.z;
+            } else {
+                qf0 = tx[j]; qf1 = ty[j]; qf2 = tz[j];
+            }
+            // 2^e bounds every coordinate of a kept pair (kabsch_plan); a source beyond it would overflow its limbs
+            if (!(fabsf(pf0) < plan.lim && fabsf(pf1) < plan.lim && fabsf(pf2) < plan.lim)) { overflow = 1; continue; }
+            const double P[3] = { pf0, pf1, pf2 }, Q[3] = { qf0, qf1, qf2 };
 #pragma unroll
-    for (int k = 0; k < KB_NV; k++) {
-        double s = wave_sum(acc[k]);
-        if (lane == 0) red[wave][k] = s;
-    }
-    long long lm = wave_max(last);
-    if (lane == 0) red[wave][KB_NV] = (double)lm;
-    __syncthreads();
-    if (threadIdx.x <= KB_NV) {
-        const int k = threadIdx.x;
-        double s;
-        if (k < KB_NV) {
-            s = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
-        } else {
-            s = fmax(fmax(red[0][k], red[1][k]), fmax(red[2][k], red[3][k]));
+            for (int c = 0; c < 3; c++) { acc2(P[c], plan.sc, c0[c], c1[c]); acc2(Q[c], plan.sc, c0[3 + c], c1[3 + c]); }
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc3(Q[r] * P[c], plan.sp, p0[3 * r + c], p1[3 * r + c], p2[3 * r + c]);
+            cnt += 1.0;
+            // the LAST kept pair of the reference's loop (registration.cpp:939) = the kept pair with the highest original index
+            const unsigned long long lk = ((unsigned long long)(orig ? orig[i] : i) << 32) | d2b;
+            lastkey = lk > lastkey ? lk : lastkey;
         }
-        partials[(size_t)blockIdx.x * (KB_NV + 1) + k] = s;
     }
+    double tn[KB_NL];
+#pragma unroll
+    for (int c = 0; c < 6; c++) { tn[3 * c] = c0[c]; tn[3 * c + 1] = c1[c]; tn[3 * c + 2] = 0.0; num::limbs_normalize(tn + 3 * c, 2); }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        tn[18 + 4 * k] = p0[k]; tn[19 + 4 * k] = p1[k]; tn[20 + 4 * k] = p2[k]; tn[21 + 4 * k] = 0.0;
+        num::limbs_normalize(tn + 18 + 4 * k, 3);
+    }
+    tn[54] = cnt;
+    __shared__ double red[KB_BLOCK / 64][KB_NL];
+    __shared__ double row[KB_ROW];
+    block_reduce_limbs(tn, lastkey, overflow, red, row);
+    if (threadIdx.x < KB_ROW) partials[(size_t)blockIdx.x * KB_ROW + threadIdx.x] = row[threadIdx.x];
 }
 
-// one workgroup: out[0..15] = sums, out[16] = last kept index (or -1), out[17] = d2 of that pair
-__global__ __launch_bounds__(KB_BLOCK) void kabsch_final_kernel(
-    const double* __restrict__ partials, uint32_t n_blocks, const unsigned long long* __restrict__ keys,
-    double* __restrict__ out)
+// one workgroup: the block rows -> ONE normalised row in LDS (limbs, last-kept key, overflow flag)
+__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, uint32_t n_blocks, double (&red)[KB_BLOCK / 64][KB_NL],
+                                            double (&row)[KB_ROW])
 {
-    __shared__ double red[KB_BLOCK / 64][KB_NV + 1];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double acc[KB_NV + 1];
+    double tn[KB_NL];
 #pragma unroll
-    for (int k = 0; k < KB_NV; k++) acc[k] = 0.0;
-    acc[KB_NV] = -1.0;
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += KB_BLOCK) {
+    for (int k = 0; k < KB_NL; k++) tn[k] = 0.0;
+    unsigned long long lastkey = 0;
+    int overflow = 0;
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += KB_BLOCK) {      // <= 32 rows per thread: integers below 2^45
+        const double* r = partials + (size_t)b * KB_ROW;
 #pragma unroll
-        for (int k = 0; k < KB_NV; k++) acc[k] += partials[(size_t)b * (KB_NV + 1) + k];
-        acc[KB_NV] = fmax(acc[KB_NV], partials[(size_t)b * (KB_NV + 1) + KB_NV]);
+        for (int k = 0; k < KB_NL; k++) tn[k] += r[k];
+        const unsigned long long lk = (unsigned long long)__double_as_longlong(r[55]);
+        lastkey = lk > lastkey ? lk : lastkey;
+        overflow |= r[56] != 0.0;
     }
-#pragma unroll
-    for (int k = 0; k < KB_NV; k++) {
-        double s = wave_sum(acc[k]);
-        if (lane == 0) red[wave][k] = s;
-    }
-    {
-        double m = acc[KB_NV];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-        if (lane == 0) red[wave][KB_NV] = m;
-    }
-    __syncthreads();
-    if (threadIdx.x < KB_NV) {
-        const int k = threadIdx.x;
-        out[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
-    } else if (threadIdx.x == KB_NV) {
-        const double m = fmax(fmax(red[0][KB_NV], red[1][KB_NV]), fmax(red[2][KB_NV], red[3][KB_NV]));
-        out[KB_NV] = m;
-        float d2 = 0.0f;
-        if (m >= 0.0) d2 = __uint_as_float((uint32_t)(keys[(size_t)m] >> 32));
-        out[KB_NV + 1] = (double)d2;
+    block_reduce_limbs(tn, lastkey, overflow, red, row);
+}
+
+// out (single rank): [0..15] the 16 moments, [16] original index of the last kept pair or -1, [17] its d2, [18] overflow flag
+__device__ __forceinline__ void row_to_out18(const double (&row)[KB_ROW], int e, double* out)
+{
+    if (threadIdx.x == 0) {
+        double sums[16];
+        num::limbs_to_sums(row, e, sums);
+        for (int k = 0; k < 16; k++) out[k] = sums[k];
+        const unsigned long long lk = (unsigned long long)__double_as_longlong(row[55]);
+        out[16] = sums[15] > 0.0 ? (double)(uint32_t)(lk >> 32) : -1.0;
+        out[17] = sums[15] > 0.0 ? (double)__uint_as_float((uint32_t)(lk & 0xFFFFFFFFull)) : 0.0;
+        out[18] = row[56];
     }
 }
 
-// a pure function of n: the order of the f64 additions (and so the bits of the sums) depends only on n
+__global__ __launch_bounds__(KB_BLOCK) void kabsch_final_kernel(const double* __restrict__ partials, uint32_t n_blocks, int e, double* __restrict__ out)
+{
+    __shared__ double red[KB_BLOCK / 64][KB_NL];
+    __shared__ double row[KB_ROW];
+    reduce_rows(partials, n_blocks, red, row);
+    row_to_out18(row, e, out);
+}
+
+// the order of the additions does not matter any more; the geometry only has to keep the pass busy
 static uint32_t kabsch_blocks(size_t ns)
 {
     uint32_t blocks = (uint32_t)((ns + KB_BLOCK - 1) / KB_BLOCK);          // one point per thread up to KB_MAX_BLOCKS: the pass is latency-bound
@@ -138,22 +213,66 @@ static uint32_t kabsch_blocks(size_t ns)
     return blocks;
 }
 
-int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr)
+// The fixed-point grid of one accumulation.  Every coordinate of a KEPT pair is bounded by what is known up front and is the
+// same on every rank: the target's largest finite |coordinate| (cached on the cloud) plus the gate — a pair is kept only if
+// d2 < max_corr (registration.cpp:936), so |p - q| < sqrt(max_corr).  An unbounded gate is capped at 2^20 target extents;
+// a kept source beyond 2^e then raises the overflow flag (PCR_ERR_STATE) instead of a wrong sum.
+int kabsch_grid_exponent(float amax, float max_corr)
+{
+    const double a = std::max((double)amax, 1e-30);
+    double gate = max_corr > 0.f ? 2.0 * std::sqrt((double)max_corr) : 0.0;     // NaN / <= 0: no pair is kept anyway
+    if (!(gate <= a * 1048576.0)) gate = a * 1048576.0;
+    const double M = a + gate;
+    int e = std::ilogb(M) + 2;                                                      // 2^e > 2 M
+    if (e > 140) e = 140;
+    return e;
+}
+
+int kabsch_plan(pcr_ctx* ctx, const pcr_cloud* tgt, float max_corr, KabschPlan* plan)
+{
+    float amax = 0.f;
+    int rc = cloud_absmax(ctx, tgt, &amax);
+    if (rc) return rc;
+    const int e = kabsch_grid_exponent(amax, max_corr);
+    plan->e = e;
+    plan->lim = e >= 128 ? __builtin_inff() : std::ldexp(1.0f, e);
+    plan->sc = std::ldexp(1.0, 2 * num::KB_W - e);
+    plan->sp = std::ldexp(1.0, 3 * num::KB_W - 2 * e);
+    return PCR_OK;
+}
+
+int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr, const KabschPlan& plan, uint32_t* n_blocks)
 {
     const size_t ns = src->n;
     if (ctx->keys_n != ns) return fail(ctx, PCR_ERR_STATE, "kabsch: no matching correspondence pass");
-    uint32_t blocks = kabsch_blocks(ns);
+    const uint32_t blocks = kabsch_blocks(ns);
+    // the grid search of an ICP loop leaves the record position of every winner behind (ctx->wpos): gather from the records
+    const bool rec = ctx->wpos_valid && ctx->wpos_n == ns && tgt->grid && tgt->grid->records && tune_get(ctx, "kabsch_records", 1) == 1;
+    const uint32_t* orig = (ctx->work_orig && ctx->work_orig_n == ns && ctx->work_orig_src == src) ? ctx->work_orig : nullptr;
     {
         ProfScope p(ctx, "kabsch_partial");
-        hipLaunchKernelGGL(kabsch_partial_kernel, dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream,
-                           src->x(), src->y(), src->z(), tgt->x(), tgt->y(), tgt->z(), ctx->keys,
-                           (uint32_t)ns, (uint32_t)tgt->n, max_corr, ctx->partials);
+        if (rec)
+            hipLaunchKernelGGL((kabsch_partial_kernel<true>), dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), tgt->x(), tgt->y(),
+                               tgt->z(), tgt->grid->records, ctx->wpos, orig, ctx->keys, (uint32_t)ns, (uint32_t)tgt->n, max_corr, plan, ctx->partials);
+        else
+            hipLaunchKernelGGL((kabsch_partial_kernel<false>), dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), tgt->x(), tgt->y(),
+                               tgt->z(), (const float4*)nullptr, (const uint32_t*)nullptr, orig, ctx->keys, (uint32_t)ns, (uint32_t)tgt->n, max_corr, plan,
+                               ctx->partials);
     }
     PCR_HIP(ctx, hipGetLastError());
+    *n_blocks = blocks;
+    return PCR_OK;
+}
+
+// dev_out[0..18] = moments, last kept (original index, d2), overflow flag
+int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr, const KabschPlan& plan)
+{
+    uint32_t blocks = 0;
+    int rc = launch_kabsch_partial(ctx, tgt, src, max_corr, plan, &blocks);
+    if (rc) return rc;
     {
         ProfScope p(ctx, "kabsch_final");
-        hipLaunchKernelGGL(kabsch_final_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, blocks,
-                           ctx->keys, ctx->dev_out);
+        hipLaunchKernelGGL(kabsch_final_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, blocks, plan.e, ctx->dev_out);
     }
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
@@ -163,50 +282,12 @@ int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src,
 // The pipelined ICP loop (icp.cpp) keeps the whole state machine of registration.cpp:915-1006 on the GPU so that
 // iterations are enqueued back to back without a host round trip: nn1 -> kabsch_partial -> icp_update -> transform.
 
-__device__ __forceinline__ void block_reduce_partials(const double* __restrict__ partials, uint32_t n_blocks,
-                                                      double (&red)[KB_BLOCK / 64][KB_NV + 1], double* out18,
-                                                      const unsigned long long* __restrict__ keys)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double acc[KB_NV + 1];
-#pragma unroll
-    for (int k = 0; k < KB_NV; k++) acc[k] = 0.0;
-    acc[KB_NV] = -1.0;
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += KB_BLOCK) {
-#pragma unroll
-        for (int k = 0; k < KB_NV; k++) acc[k] += partials[(size_t)b * (KB_NV + 1) + k];
-        acc[KB_NV] = fmax(acc[KB_NV], partials[(size_t)b * (KB_NV + 1) + KB_NV]);
-    }
-#pragma unroll
-    for (int k = 0; k < KB_NV; k++) {
-        double s = wave_sum(acc[k]);
-        if (lane == 0) red[wave][k] = s;
-    }
-    {
-        double m = acc[KB_NV];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-        if (lane == 0) red[wave][KB_NV] = m;
-    }
-    __syncthreads();
-    if (threadIdx.x < KB_NV) {
-        const int k = threadIdx.x;
-        out18[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
-    } else if (threadIdx.x == KB_NV) {
-        const double m = fmax(fmax(red[0][KB_NV], red[1][KB_NV]), fmax(red[2][KB_NV], red[3][KB_NV]));
-        out18[KB_NV] = m;
-        float d2 = 0.0f;
-        if (m >= 0.0) d2 = __uint_as_float((uint32_t)(keys[(size_t)m] >> 32));
-        out18[KB_NV + 1] = (double)d2;
-    }
-    __syncthreads();
-}
-
 // state machine + Kabsch solve + pose composition, one thread (registration.cpp:939-1002)
-__device__ void icp_state_step(IcpState* st, const double* sums16, bool any_kept, float last_d2)
+__device__ void icp_state_step(IcpState* st, const double* sums16, bool any_kept, float last_d2, bool overflow)
 {
     if (st->stop) return;
     if (st->stop_after_transform) { st->stop = 1; return; }   // max_iter reached: the loop is over
+    if (overflow) { st->overflow = 1; st->stop = 1; return; }  // a kept source beyond the accumulation grid (kabsch_plan)
     float loss = 0.0f;
     if (any_kept) loss = last_d2 * last_d2;                                      // :939
     st->last_pairs = (unsigned long long)sums16[15];
@@ -226,49 +307,58 @@ __device__ void icp_state_step(IcpState* st, const double* sums16, bool any_kept
     if (st->iters_run >= st->max_iter) st->stop_after_transform = 1;
 }
 
-// single rank: reduce the block partials and advance the state in one launch
-__global__ __launch_bounds__(KB_BLOCK) void icp_update_kernel(const double* __restrict__ partials, uint32_t n_blocks,
-                                                              const unsigned long long* __restrict__ keys, IcpState* st,
+// single rank: reduce the block rows and advance the state in one launch
+__global__ __launch_bounds__(KB_BLOCK) void icp_update_kernel(const double* __restrict__ partials, uint32_t n_blocks, int e, IcpState* st,
                                                               double* __restrict__ out)
 {
-    __shared__ double red[KB_BLOCK / 64][KB_NV + 1];
+    __shared__ double red[KB_BLOCK / 64][KB_NL];
+    __shared__ double row[KB_ROW];
     if (st->stop) return;
     if (st->stop_after_transform) { if (threadIdx.x == 0) st->stop = 1; return; }
-    block_reduce_partials(partials, n_blocks, red, out, keys);
-    if (threadIdx.x == 0) icp_state_step(st, out, out[KB_NV] >= 0.0, (float)out[KB_NV + 1]);
+    reduce_rows(partials, n_blocks, red, row);
+    row_to_out18(row, e, out);
+    if (threadIdx.x == 0) icp_state_step(st, out, out[16] >= 0.0, (float)out[17], out[18] != 0.0);
 }
 
-// multi rank, step 1: reduce the partials into the all-reduce buffer [16 moments][(kept flag, last d2) per rank]
+// multi rank, step 1: reduce the block rows into the all-reduce buffer
+//   [0..54] normalised limbs, [55] overflow flag, [56 + 2r] kept flag of rank r, [57 + 2r] d2 of its last kept pair
+// (every entry is summed exactly by the all-reduce: integers below 2^40 x ranks, one non-zero flag pair per rank)
 __global__ __launch_bounds__(KB_BLOCK) void icp_reduce_slots_kernel(const double* __restrict__ partials, uint32_t n_blocks,
-                                                                    const unsigned long long* __restrict__ keys,
                                                                     double* __restrict__ out, int nranks, int rank, int have_points)
 {
-    __shared__ double red[KB_BLOCK / 64][KB_NV + 1];
-    __shared__ double tmp[KB_NV + 2];
+    __shared__ double red[KB_BLOCK / 64][KB_NL];
+    __shared__ double row[KB_ROW];
     if (have_points) {
-        block_reduce_partials(partials, n_blocks, red, tmp, keys);
+        reduce_rows(partials, n_blocks, red, row);
     } else {
-        if (threadIdx.x < KB_NV + 2) tmp[threadIdx.x] = threadIdx.x == KB_NV ? -1.0 : 0.0;
+        if (threadIdx.x < KB_ROW) row[threadIdx.x] = 0.0;
         __syncthreads();
     }
-    if (threadIdx.x < KB_NV) out[threadIdx.x] = tmp[threadIdx.x];
+    if (threadIdx.x < KB_NL) out[threadIdx.x] = row[threadIdx.x];
+    if (threadIdx.x == KB_NL) out[55] = row[56];
     if ((int)threadIdx.x < 2 * nranks) {
         const int r = threadIdx.x / 2, which = threadIdx.x % 2;
         double v = 0.0;
-        if (r == rank) v = which == 0 ? (tmp[KB_NV] >= 0.0 ? 1.0 : 0.0) : tmp[KB_NV + 1];
-        out[KB_NV + threadIdx.x] = v;
+        if (r == rank && row[54] > 0.0) {
+            const unsigned long long lk = (unsigned long long)__double_as_longlong(row[55]);
+            v = which == 0 ? 1.0 : (double)__uint_as_float((uint32_t)(lk & 0xFFFFFFFFull));
+        }
+        out[56 + threadIdx.x] = v;
     }
 }
 
-// multi rank, step 2 (after the all-reduce): the loss comes from the highest rank that kept a pair
-__global__ void icp_update_from_sums_kernel(const double* __restrict__ buf, int nranks, IcpState* st)
+// multi rank, step 2 (after the all-reduce): carries, moments; the loss comes from the highest rank that kept a pair
+__global__ void icp_update_from_sums_kernel(double* __restrict__ buf, int nranks, int e, IcpState* st)
 {
     if (threadIdx.x != 0 || st->stop) return;
+    num::limbs_normalize_row(buf);
+    double sums[16];
+    num::limbs_to_sums(buf, e, sums);
     bool any = false;
     float d2 = 0.0f;
     for (int r = 0; r < nranks; r++)
-        if (buf[KB_NV + 2 * r] > 0.5) { any = true; d2 = (float)buf[KB_NV + 2 * r + 1]; }
-    icp_state_step(st, buf, any, d2);
+        if (buf[56 + 2 * r] > 0.5) { any = true; d2 = (float)buf[57 + 2 * r]; }
+    icp_state_step(st, sums, any, d2, buf[55] != 0.0);
 }
 
 __global__ __launch_bounds__(256) void transform_state_kernel(float* __restrict__ x, float* __restrict__ y,
@@ -306,27 +396,11 @@ __global__ __launch_bounds__(256) void transform_state_kernel(float* __restrict_
     reinterpret_cast<float4*>(z)[i] = oz;
 }
 
-int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr, uint32_t* n_blocks)
-{
-    const size_t ns = src->n;
-    if (ctx->keys_n != ns) return fail(ctx, PCR_ERR_STATE, "kabsch: no matching correspondence pass");
-    uint32_t blocks = kabsch_blocks(ns);
-    {
-        ProfScope p(ctx, "kabsch_partial");
-        hipLaunchKernelGGL(kabsch_partial_kernel, dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream,
-                           src->x(), src->y(), src->z(), tgt->x(), tgt->y(), tgt->z(), ctx->keys,
-                           (uint32_t)ns, (uint32_t)tgt->n, max_corr, ctx->partials);
-    }
-    PCR_HIP(ctx, hipGetLastError());
-    *n_blocks = blocks;
-    return PCR_OK;
-}
-
-int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev)
+int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev, const KabschPlan& plan)
 {
     {
         ProfScope p(ctx, "icp_update");
-        hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, ctx->keys, st_dev, ctx->dev_out);
+        hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, plan.e, st_dev, ctx->dev_out);
     }
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
@@ -334,15 +408,15 @@ int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev)
 
 int launch_icp_reduce_slots(pcr_ctx* ctx, uint32_t n_blocks, int nranks, int rank, bool have_points)
 {
-    hipLaunchKernelGGL(icp_reduce_slots_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, ctx->keys,
-                       ctx->dev_out, nranks, rank, have_points ? 1 : 0);
+    hipLaunchKernelGGL(icp_reduce_slots_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, ctx->dev_out, nranks, rank,
+                       have_points ? 1 : 0);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
 
-int launch_icp_update_from_sums(pcr_ctx* ctx, int nranks, IcpState* st_dev)
+int launch_icp_update_from_sums(pcr_ctx* ctx, int nranks, IcpState* st_dev, const KabschPlan& plan)
 {
-    hipLaunchKernelGGL(icp_update_from_sums_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->dev_out, nranks, st_dev);
+    hipLaunchKernelGGL(icp_update_from_sums_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->dev_out, nranks, plan.e, st_dev);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }

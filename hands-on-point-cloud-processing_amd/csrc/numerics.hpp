@@ -150,6 +150,76 @@ PCR_HD int kabsch_solve_as(const double sums[16], float R[9], float t[3])
 PCR_HD int kabsch_solve(const double sums[16], float R[9], float t[3]) { return kabsch_solve_as<false>(sums, R, t); }
 PCR_HD int kabsch_solve_ransac(const double sums[16], float R[9], float t[3]) { return kabsch_solve_as<true>(sums, R, t); }
 
+// ---- exact, order-independent accumulation of the Kabsch moments (kabsch.hip) -------------------------------------------
+// Every term of the 16 sums is exactly representable in f64 (an f32 coordinate, or the product of two), but an f64 running
+// sum rounds, so its bits depend on the order of the additions: on the launch geometry, on the order the queries are visited
+// in, on how many GPUs share the work.  Instead each term is cut into 40-bit integer LIMBS on one fixed-point grid per ICP
+// (unit 2^(e-80) for coordinates, 2^(2e-120) for products, where 2^e bounds every coordinate of a kept pair): limbs are
+// integers below 2^40 held in doubles, integer sums below 2^53 are exact in any order, and carries are propagated between
+// reduction levels (thread -> workgroup -> launch -> ranks).  The sums every rank / kernel / query order ends up with are
+// the same bits; bits of a term below the unit (coordinates 2^36 times smaller than the scene) are cut off per term, which
+// is deterministic too.
+//   layout of a NORMALISED row (KB_NL doubles): coordinate sum c (0..5: sum p, sum q) -> 3c + {limb 0, limb 1, carry};
+//   product k (0..8, row-major q_r p_c) -> 18 + 4k + {limb 0, limb 1, limb 2, carry}; count -> 54
+constexpr int KB_W = 40;
+constexpr int KB_NL = 55;
+constexpr double KB_2W = 1099511627776.0;              // 2^40
+constexpr double KB_2mW = 1.0 / 1099511627776.0;       // 2^-40
+
+PCR_HD double trunc_f64(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ::trunc(v);
+#else
+    return __builtin_trunc(v);
+#endif
+}
+
+// carry propagation of one sum: n real limbs + the carry limb behind them; afterwards |limb| < 2^40 (signs may differ)
+PCR_HD void limbs_normalize(double* L, int n)
+{
+    for (int j = 0; j < n; j++) {
+        const double c = trunc_f64(L[j] * KB_2mW);
+        L[j] = L[j] - c * KB_2W;          // exact: both are integers below 2^53
+        L[j + 1] = L[j + 1] + c;
+    }
+}
+
+PCR_HD void limbs_normalize_row(double* row)
+{
+    for (int c = 0; c < 6; c++) limbs_normalize(row + 3 * c, 2);
+    for (int k = 0; k < 9; k++) limbs_normalize(row + 18 + 4 * k, 3);
+}
+
+// value of n limbs (+ carry) * 2^unit_exp, evaluated top-down with an error-free two-sum: the same bits on host and device
+PCR_HD double limbs_value(const double* L, int n, int unit_exp)
+{
+    double s = 0.0, c = 0.0, w = 1.0;
+    double scale[5];
+    for (int j = 0; j <= n; j++) { scale[j] = w; w = w * KB_2W; }
+    for (int j = n; j >= 0; j--) {
+        const double t = L[j] * scale[j];     // exact: an integer below 2^53 times a power of two
+        const double u = s + t;
+        const double bb = u - s;
+        const double e1 = (s - (u - bb)) + (t - bb);
+        s = u;
+        c = c + e1;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ::ldexp(s + c, unit_exp);
+#else
+    return __builtin_ldexp(s + c, unit_exp);
+#endif
+}
+
+// normalised row -> the 16 moments of kabsch_solve (sum p, sum q, sum q p^T row-major, count)
+PCR_HD void limbs_to_sums(const double* row, int e, double sums[16])
+{
+    for (int c = 0; c < 6; c++) sums[c] = limbs_value(row + 3 * c, 2, e - 2 * KB_W);
+    for (int k = 0; k < 9; k++) sums[6 + k] = limbs_value(row + 18 + 4 * k, 3, 2 * e - 3 * KB_W);
+    sums[15] = row[54];
+}
+
 // out = A * B, 4x4 row-major f32, sequential k, unfused (registration.cpp:1002); out may alias A or B
 PCR_HD void mat4_mul_f32(const float A[16], const float B[16], float out[16])
 {

@@ -38,10 +38,20 @@ struct IcpState {
     int empty;
     int stop;                    // set by the update kernel: later kernels of the stream become no-ops
     int stop_after_transform;    // max_iter reached: stop once the last transform has been applied
+    int overflow;                // a kept source point lay beyond the fixed-point grid of the Kabsch sums (kabsch_plan): PCR_ERR_STATE
+    int pad_;
     unsigned long long unchanged;
     unsigned long long iters_run;
     unsigned long long max_iter;
     unsigned long long last_pairs;
+};
+
+// fixed-point grid of one exact Kabsch accumulation (kabsch.hip / numerics.hpp): 2^e bounds every coordinate of a kept pair
+struct KabschPlan {
+    int e = 0;
+    float lim = 0.f;      // 2^e as a float (inf when e >= 128)
+    double sc = 0.0;      // 2^(80 - e): coordinates -> two 40-bit limbs
+    double sp = 0.0;      // 2^(120 - 2e): products -> three 40-bit limbs
 };
 
 struct Comm {
@@ -60,6 +70,7 @@ struct pcr_cloud {
     pcr::Grid* grid = nullptr;   // exact-NN index over this cloud as a target; built lazily, dropped on modification
     pcr::Grid* knn_grid = nullptr;   // the same index with the wider cell of the last k-NN batch (knn_grid.hip), same lifetime
     double knn_grid_factor = 0.0;    // its cell edge / grid's cell edge
+    float absmax = -1.f;             // largest finite |coordinate| (cloud_absmax), < 0: not computed; same lifetime as the grids
     size_t n = 0;
     size_t cap = 0;     // padded length of each of x, y, z
     float* base = nullptr;   // device; x = base, y = base + cap, z = base + 2*cap
@@ -89,9 +100,19 @@ struct pcr_ctx {
     size_t qperm_cap = 0;
     size_t qperm_n = 0;
     const pcr_cloud* qperm_src = nullptr;
-    double* partials = nullptr;           // block partial sums of the Kabsch pass
+    // grid ICP: the working cloud is cell-sorted once (work_orig[t] = original index of its point t), and every search leaves
+    // the record position of each winner behind (wpos) for the next warm start and for the Kabsch gather
+    uint32_t* wpos = nullptr;
+    size_t wpos_cap = 0;
+    size_t wpos_n = 0;
+    bool wpos_valid = false;
+    uint32_t* work_orig = nullptr;
+    size_t work_orig_cap = 0;
+    size_t work_orig_n = 0;
+    const pcr_cloud* work_orig_src = nullptr;
+    double* partials = nullptr;           // block rows of the Kabsch pass (8192 x 58 doubles)
     size_t partials_cap = 0;
-    double* dev_out = nullptr;            // 32 doubles: reduced sums + bookkeeping
+    double* dev_out = nullptr;            // 128 doubles: reduced sums / limbs + bookkeeping
     double* host_out = nullptr;           // pinned mirror
     void* scratch = nullptr;              // generic device scratch
     size_t scratch_cap = 0;
@@ -155,11 +176,17 @@ int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool re
 void cloud_modified(pcr_cloud* c);
 int nn1_unpack(pcr_ctx* ctx, size_t n, uint32_t* idx_dev, float* d2_dev);
 int launch_transform(pcr_ctx* ctx, pcr_cloud* c, const float R[9], const float t[3]);
-int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr);
-int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr, uint32_t* n_blocks);
-int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev);
+int cloud_absmax(pcr_ctx* ctx, const pcr_cloud* c, float* out);       // largest finite |coordinate|, cached on the cloud (grid.hip)
+int kabsch_grid_exponent(float target_absmax, float max_corr);
+int kabsch_plan(pcr_ctx* ctx, const pcr_cloud* tgt, float max_corr, KabschPlan* plan);
+// dev_out[0..18] = the 16 moments, original index of the last kept pair (or -1), its d2, overflow flag
+int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr, const KabschPlan& plan);
+int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr, const KabschPlan& plan, uint32_t* n_blocks);
+int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev, const KabschPlan& plan);
+// dev_out[0..54] limbs, [55] overflow flag, [56 + 2r], [57 + 2r] (kept flag, last d2) of rank r: ICP_NRED(nranks) doubles to all-reduce
 int launch_icp_reduce_slots(pcr_ctx* ctx, uint32_t n_blocks, int nranks, int rank, bool have_points);
-int launch_icp_update_from_sums(pcr_ctx* ctx, int nranks, IcpState* st_dev);
+int launch_icp_update_from_sums(pcr_ctx* ctx, int nranks, IcpState* st_dev, const KabschPlan& plan);
+inline int icp_nred(int nranks) { return 56 + 2 * nranks; }
 int launch_transform_state(pcr_ctx* ctx, pcr_cloud* c, IcpState* st_dev);
 int comm_allreduce_f64_device(pcr_ctx* ctx, double* dev_buf, int n);   // RCCL on the ctx stream, no host round trip
 int launch_plane_count(pcr_ctx* ctx, const pcr_cloud* pts, const double* planes4_dev, size_t n_planes,

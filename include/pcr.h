@@ -259,6 +259,15 @@ int pcr_comm_init_callback(pcr_ctx* ctx, int nranks, int rank, pcr_allreduce_fn 
 int pcr_comm_destroy(pcr_ctx* ctx);
 /* one real ncclAllReduce on the attached RCCL communicator (any nranks, also 1), result checked */
 int pcr_comm_selftest(pcr_ctx* ctx);
+/* Wire format of the per-iteration collective (what a pcr_allreduce_fn sums): 56 + 2 * nranks doubles —
+ *   [0..54]  the 16 Kabsch moments as exact 40-bit integer limbs on a fixed-point grid shared by all ranks (unit 2^(e-80) for the
+ *            six coordinate sums: 3 doubles each = limb 0, limb 1, carry; unit 2^(2e-120) for the nine products q_r p_c: 4 doubles
+ *            each; [54] the pair count), [55] overflow flag, [56 + 2r] / [57 + 2r] (kept flag, d2 of the last kept pair) of rank r.
+ * Every entry is an integer (or one rank's value) below 2^53, so the sum is exact in any order: the pose does not depend on the
+ * number of ranks.  pcr_kabsch_limbs_to_sums (host logic, no GPU) propagates the carries of a summed row in place and returns
+ * the 16 moments pcr_kabsch_solve takes; e = pcr_kabsch_grid_exponent(largest finite |target coordinate|, max_corr). */
+int pcr_kabsch_grid_exponent(float target_absmax, float max_corr);
+int pcr_kabsch_limbs_to_sums(double row[55], int e, double sums[16]);
 /* contiguous shard [begin, end) of n items for `rank` of `nranks` (sizes differ by at most one) */
 void pcr_shard_range(size_t n, int nranks, int rank, size_t* begin, size_t* end);
 
