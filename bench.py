@@ -517,19 +517,21 @@ def grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha):
     with the diagnostics counters for the algorithmic bytes (SURVEY.md 8d "1-NN exact grid")"""
     ca = cs.clone()
     ctx.transform(ca, T)
-    ctx.tune("nn_method", 2); ctx.tune("prof", 1)
-    ctx.nn1_async(ct, ca); ctx.sync(); ctx.prof_reset()
+    # searches of a loop that has converged: each is seeded by the previous result (nn1_async_in_loop = what pcr_icp_p2p_f32 does)
+    ctx.tune("nn_method", 2); ctx.tune("prof", 1); ctx.tune("nn1_async_in_loop", 1)
+    ctx.nn1_async(ct, ca); ctx.nn1_async(ct, ca); ctx.sync(); ctx.prof_reset()
     for _ in range(5):
         ctx.nn1_async(ct, ca)
     gl, gms = ctx.prof_get("nn1_grid")
     ctx.tune("grid_stats", 1); ctx.nn1_async(ct, ca); ctx.sync(); gs = ctx.grid_stats(); ctx.tune("grid_stats", 0)
+    ctx.tune("nn1_async_in_loop", 0)
     ca.free()
     ctx.tune("prof", 0)
     steady_s = gms / 1e3 / max(gl, 1)
     gpmc = load_pmc("latest_pmc_grid.json", sha)
     if gpmc and (gpmc.get("n") != n_t or n_q != n_t):
         gpmc = None
-    alg_bytes = n_q * (12.0 + 4.0 + 8.0) + 8.0 * gs["fine_rows"] + 16.0 * gs["candidates"]
+    alg_bytes = n_q * (12.0 + 4.0 + 8.0) + 8.0 * gs["fine_rows"] + 16.0 * gs["candidates"] + 16.0 * gs["coarse_rows"]
     L2_PEAK_GBS = 34500.0    # aggregate L2 bandwidth measured on MI355X (MI355X_MICROARCH.md, L2 section)
     return {
         "bound": "l2-gather", "achieved": alg_bytes / steady_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
@@ -540,11 +542,13 @@ def grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha):
                         else "null: no PMC pass of this kernel at this size with the library loaded now (tools/gpu_pmc_grid.sh)",
         "compulsory_bytes": n_q * 24.0 + n_t * 16.0,
         "vs_hbm_stream_peak": alg_bytes / steady_s / 1e9 / HBM_PEAK_GBS,
-        "kernel": "pcr::nn1_grid_kernel (exact uniform-grid 1-NN) at the converged pose",
+        "kernel": "pcr::nn1_grid_kernel (exact uniform-grid 1-NN) at the converged pose, seeded by the previous correspondences as inside the loop",
         "launches": int(gl), "avg_launch_ms": steady_s * 1e3, "kernel_M_corr_per_s": n_q / steady_s / 1e6,
         "avg_launch_ms_over_the_timed_icp": kern_s * 1e3,
         "candidates_per_query": gs["candidates"] / max(n_q, 1), "rows_per_query": gs["fine_rows"] / max(n_q, 1),
-        "algorithmic": f"per query 12 B point + 4 B order + 8 B key, 8 B per opened x-row ({gs['fine_rows'] / max(n_q, 1):.1f}/query) and "
+        "sphere_tests_per_query": gs["coarse_rows"] / max(n_q, 1),
+        "algorithmic": f"per query 12 B point + 4 B order + 8 B key, 8 B per opened x-row ({gs['fine_rows'] / max(n_q, 1):.1f}/query), 16 B per "
+                       f"bounding sphere tested ({gs['coarse_rows'] / max(n_q, 1):.1f}/query) and "
                        f"16 B per visited candidate ({gs['candidates'] / max(n_q, 1):.1f}/query), counted by the kernel's diagnostics "
                        "build.  Neighbouring queries visit the same cells, so most candidate records are served by L2: the bound is the "
                        "L2 gather rate"}

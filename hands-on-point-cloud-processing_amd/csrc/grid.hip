@@ -91,15 +91,64 @@ __global__ __launch_bounds__(GR_BLOCK) void cell_count_kernel(const float* __res
 
 // key = (cell, order-preserving bits of x): one radix sort gives the records cell by cell and x-ascending inside a cell —
 // a deterministic layout (no atomics decide a position); x-sorted rows are what the CLIP variant of the search kernel needs (rows cut to the best-distance window).
-__global__ __launch_bounds__(GR_BLOCK) void record_keys_kernel(const float* __restrict__ x, uint32_t n, const uint32_t* __restrict__ cell_of,
-                                                               unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+__device__ __forceinline__ uint32_t spread3(uint32_t v)      // 3 bits -> bits 0, 3, 6
+{
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
+}
+
+// MORTON: the low key word is (9-bit Morton code of the point's 8 x 8 x 8 sub-cell) << 23 | (x bits >> 9): consecutive records of
+// a cell are neighbours in space, which keeps the bounding spheres of 16-record runs small.  Still a pure function of the
+// point (ties resolve by original index: the radix sort is stable).
+template <bool MORTON>
+__global__ __launch_bounds__(GR_BLOCK) void record_keys_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
+                                                               GridParams g, const uint32_t* __restrict__ cell_of, unsigned long long* __restrict__ keys,
+                                                               uint32_t* __restrict__ vals)
 {
     const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
     if (i >= n) return;
-    uint32_t u = __float_as_uint(x[i]);
+    const float px = x[i];
+    uint32_t u = __float_as_uint(px);
     u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    if (MORTON) {
+        const float py = y[i], pz = z[i];
+        uint32_t m = 0;
+        if (finite3(px, py, pz)) {
+            const float fx = (px - g.lo[0]) * g.inv_h, fy = (py - g.lo[1]) * g.inv_h, fz = (pz - g.lo[2]) * g.inv_h;
+            const int sx = min(max((int)((fx - floorf(fx)) * 8.0f), 0), 7), sy = min(max((int)((fy - floorf(fy)) * 8.0f), 0), 7),
+                      sz = min(max((int)((fz - floorf(fz)) * 8.0f), 0), 7);
+            m = spread3((uint32_t)sx) | (spread3((uint32_t)sy) << 1) | (spread3((uint32_t)sz) << 2);
+        }
+        u = (m << 23) | (u >> 9);
+    }
     keys[i] = ((unsigned long long)cell_of[i] << 32) | u;
     vals[i] = i;
+}
+
+// one thread per run of GRID_CHUNK records: bounding sphere of its finite members (centre = middle of their box, radius rounded up)
+__global__ __launch_bounds__(GR_BLOCK) void build_spheres_kernel(const float4* __restrict__ records, uint32_t n_chunks, float4* __restrict__ spheres)
+{
+    const uint32_t c = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (c >= n_chunks) return;
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int j = 0; j < GRID_CHUNK; j++) {
+        const float4 r = records[(size_t)c * GRID_CHUNK + j];
+        if (finite3(r.x, r.y, r.z)) {
+            mn[0] = fminf(mn[0], r.x); mn[1] = fminf(mn[1], r.y); mn[2] = fminf(mn[2], r.z);
+            mx[0] = fmaxf(mx[0], r.x); mx[1] = fmaxf(mx[1], r.y); mx[2] = fmaxf(mx[2], r.z);
+        }
+    }
+    if (mn[0] > mx[0]) { spheres[c] = make_float4(0.f, 0.f, 0.f, -1.0f); return; }     // no finite member: radius < 0 = never opened
+    const float cx = 0.5f * mn[0] + 0.5f * mx[0], cy = 0.5f * mn[1] + 0.5f * mx[1], cz = 0.5f * mn[2] + 0.5f * mx[2];
+    float r2 = 0.f;
+    for (int j = 0; j < GRID_CHUNK; j++) {
+        const float4 r = records[(size_t)c * GRID_CHUNK + j];
+        if (finite3(r.x, r.y, r.z)) {
+            const float dx = r.x - cx, dy = r.y - cy, dz = r.z - cz;
+            r2 = fmaxf(r2, (dx * dx + dy * dy) + dz * dz);
+        }
+    }
+    // rounded up: sqrtf and the three squares are within a few ulp; an overflowing radius (inf) simply never prunes
+    spheres[c] = make_float4(cx, cy, cz, sqrtf(r2) * 1.00001f + 1e-30f);
 }
 
 // one thread per chunk of GRID_CHUNK consecutive records: centre = mean of the finite ones, then the shifted copy (Grid::chunks)
@@ -137,11 +186,13 @@ __global__ __launch_bounds__(GR_BLOCK) void build_chunks_kernel(const float4* __
     if (bad) atomicOr(unsafe, 1);
 }
 
+// records[p] for p < n; the tail up to a whole chunk is padding (x = +inf: d2 = inf is never accepted; index = none)
 __global__ __launch_bounds__(GR_BLOCK) void gather_records_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                                                                  uint32_t n, const uint32_t* __restrict__ order, float4* __restrict__ records)
+                                                                  uint32_t n, uint32_t n_padded, const uint32_t* __restrict__ order, float4* __restrict__ records)
 {
     const uint32_t p = blockIdx.x * GR_BLOCK + threadIdx.x;
-    if (p >= n) return;
+    if (p >= n_padded) return;
+    if (p >= n) { records[p] = make_float4(__builtin_inff(), 0.f, 0.f, __uint_as_float(0xFFFFFFFFu)); return; }
     const uint32_t i = order[p];
     records[p] = make_float4(x[i], y[i], z[i], __uint_as_float(i));
 }
@@ -238,7 +289,7 @@ constexpr uint32_t FAR_DIV = 64;      // measured: profiles/r01_tune_grid.txt
 // candidates [b, e) of one x-row, strided over the G lanes of the query's sub-group: 16 B per lane, G*16 B contiguous
 template <int G>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ records, uint32_t b, uint32_t e, int l,
-                                           float qx, float qy, float qz, unsigned long long& best)
+                                           float qx, float qy, float qz, unsigned long long& best, uint32_t& bestp)
 {
     for (uint32_t p = b + l; p < e; p += G) {
         const float4 rec = records[p];
@@ -246,7 +297,7 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ records, u
         const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);   // A1, unfused
         const unsigned long long k = ((unsigned long long)d << 32) | __float_as_uint(rec.w);
         // accept only d2 < FLT_MAX (nanoflann.hpp:163,1360); min over (d2 bits, original index) = canonical rule
-        if (d < 0x7F7FFFFFu && k < best) best = k;
+        if (d < 0x7F7FFFFFu && k < best) { best = k; bestp = p; }
     }
 }
 
@@ -288,7 +339,7 @@ __device__ __forceinline__ void x_window(float qx, float bound2, float& lo, floa
 // lane; flattened, consecutive trips are independent and the unrolled loop keeps four loads in flight.
 template <int G>
 __device__ __forceinline__ void scan_flat9(const float4* __restrict__ records, const uint32_t (&rb)[9], const uint32_t (&re)[9], int l,
-                                           float qx, float qy, float qz, unsigned long long& best)
+                                           float qx, float qy, float qz, unsigned long long& best, uint32_t& bestp)
 {
     uint32_t off[10], delta[9];
     off[0] = 0;
@@ -303,46 +354,226 @@ __device__ __forceinline__ void scan_flat9(const float4* __restrict__ records, c
         const float dx = qx - rec.x, dy = qy - rec.y, dz = qz - rec.z;
         const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);   // A1, unfused
         const unsigned long long key = ((unsigned long long)d << 32) | __float_as_uint(rec.w);
-        if (d < 0x7F7FFFFFu && key < best) best = key;
+        if (d < 0x7F7FFFFFu && key < best) { best = key; bestp = p; }
     }
 }
 
+// minimum key over the sub-group, together with the record position that produced it
 template <int G>
-__device__ __forceinline__ unsigned long long group_min(unsigned long long v)
+__device__ __forceinline__ void group_min(unsigned long long& v, uint32_t& pos)
 {
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) {
         const unsigned long long w = __shfl_xor(v, o, 64);
-        v = w < v ? w : v;
+        const uint32_t wp = __shfl_xor(pos, o, 64);
+        if (w < v) { v = w; pos = wp; }
     }
-    return v;
+}
+
+// ---- bounding-sphere pruning (SPH mode) -------------------------------------------------------------------------------
+// Can a run of records with bounding sphere s hold a neighbour that beats or ties `best`?  Every member is at least
+// |q - C| - radius away (radius is rounded up at build time); the test is conservative against the few-ulp errors of the f32
+// evaluation on both sides (same margins as the cube proof) and is never trusted below TRUST or when |q - C|^2 overflows.
+__device__ __forceinline__ bool sphere_may_win(const float4 s, float qx, float qy, float qz, unsigned long long best)
+{
+    if (s.w < 0.0f) return false;                         // a run without a finite member
+    if (best == KEY_NONE) return true;
+    const float bestf = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2);
+    const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+    const float dc2 = (dx * dx + dy * dy) + dz * dz;
+    if (!(dc2 < 3.0e38f)) return true;
+    const float sep = sqrtf(dc2) * 0.99999f - s.w;
+    return !(sep > TRUST && sep * sep * 0.99999f > bestf * 1.0001f);
+}
+
+// the sub-group scans run c (GRID_CHUNK = G = 16 records: one coalesced 256-byte load)
+__device__ __forceinline__ void scan_run16(const float4* __restrict__ records, uint32_t c, int l, float qx, float qy, float qz,
+                                           unsigned long long& best, uint32_t& bestp)
+{
+    const uint32_t p = c * GRID_CHUNK + (uint32_t)l;
+    const float4 rec = records[p];
+    const float dx = qx - rec.x, dy = qy - rec.y, dz = qz - rec.z;
+    const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);   // A1, unfused
+    const unsigned long long k = ((unsigned long long)d << 32) | __float_as_uint(rec.w);
+    if (d < 0x7F7FFFFFu && k < best) { best = k; bestp = p; }
+}
+
+// the sub-group scans the runs whose bit is set in m (bit j = run held by lane j in cc): two coalesced loads in flight
+__device__ __forceinline__ void scan_hits16(const float4* __restrict__ records, uint32_t m, uint32_t cc, int l, float qx, float qy, float qz,
+                                            unsigned long long& best, uint32_t& bestp)
+{
+    while (m) {
+        const int j0 = __builtin_ctz(m);
+        m &= m - 1;
+        const uint32_t p0 = __shfl(cc, j0, 16) * GRID_CHUNK + (uint32_t)l;
+        const float4 r0 = records[p0];
+        uint32_t p1 = p0;
+        float4 r1 = r0;
+        const bool two = m != 0;
+        if (two) {
+            const int j1 = __builtin_ctz(m);
+            m &= m - 1;
+            p1 = __shfl(cc, j1, 16) * GRID_CHUNK + (uint32_t)l;
+            r1 = records[p1];
+        }
+        {
+            const float dx = qx - r0.x, dy = qy - r0.y, dz = qz - r0.z;
+            const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);   // A1, unfused
+            const unsigned long long k = ((unsigned long long)d << 32) | __float_as_uint(r0.w);
+            if (d < 0x7F7FFFFFu && k < best) { best = k; bestp = p0; }
+        }
+        if (two) {
+            const float dx = qx - r1.x, dy = qy - r1.y, dz = qz - r1.z;
+            const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+            const unsigned long long k = ((unsigned long long)d << 32) | __float_as_uint(r1.w);
+            if (d < 0x7F7FFFFFu && k < best) { best = k; bestp = p1; }
+        }
+    }
+}
+
+// records [b, e) of one x-row piece, as the runs that overlap it.  Records of a run that lie outside [b, e) are genuine
+// targets too, so scanning whole runs cannot change the result.  NB batches of 16 spheres are fetched up front (independent
+// loads), tested against the bound the pass started with, and their hits scanned; the bound is refreshed once per pass.
+template <bool STATS, int NB>
+__device__ __forceinline__ void scan_range_sph(const float4* __restrict__ records, const float4* __restrict__ spheres, uint32_t b, uint32_t e, int l,
+                                               float qx, float qy, float qz, unsigned long long& best, uint32_t& bestp,
+                                               unsigned long long& st_cand, unsigned long long& st_sph)
+{
+    if (b >= e) return;
+    const uint32_t c0 = b / GRID_CHUNK, c1 = (e - 1) / GRID_CHUNK + 1;
+    const int shift = (int)((threadIdx.x & 63) / 16 * 16);
+    for (uint32_t cb = c0; cb < c1; cb += 16 * NB) {
+        float4 sp[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const uint32_t c = cb + 16u * k + (uint32_t)l;
+            sp[k] = c < c1 ? spheres[c] : make_float4(0.f, 0.f, 0.f, -1.0f);
+        }
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const uint32_t m = (uint32_t)(__ballot(sphere_may_win(sp[k], qx, qy, qz, best)) >> shift) & 0xFFFFu;
+            if (STATS && l == 0) { st_sph += cb + 16u * k < c1 ? min(16u, c1 - cb - 16u * k) : 0u; st_cand += 16u * (uint32_t)__popc(m); }
+            if (m) { scan_hits16(records, m, cb + 16u * k + (uint32_t)l, l, qx, qy, qz, best, bestp); any = true; }
+        }
+        if (any) group_min<16>(best, bestp);       // the next pass is tested against the improved bound
+    }
+}
+
+// the nine row ranges of stage 1 as ONE flattened space of runs
+template <bool STATS, int NB>
+__device__ __forceinline__ void scan_flat9_sph(const float4* __restrict__ records, const float4* __restrict__ spheres, const uint32_t (&rb)[9],
+                                               const uint32_t (&re)[9], int l, float qx, float qy, float qz, unsigned long long& best, uint32_t& bestp,
+                                               unsigned long long& st_cand, unsigned long long& st_sph)
+{
+    uint32_t off[10], delta[9];
+    off[0] = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const uint32_t b = rb[k], e = re[k];
+        const uint32_t c0 = b < e ? b / GRID_CHUNK : 0u, c1 = b < e ? (e - 1) / GRID_CHUNK + 1 : 0u;
+        off[k + 1] = off[k] + (c1 - c0);
+        delta[k] = c0 - off[k];
+    }
+    const int shift = (int)((threadIdx.x & 63) / 16 * 16);
+    for (uint32_t f0 = 0; f0 < off[9]; f0 += 16 * NB) {
+        float4 sp[NB];
+        uint32_t cc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const uint32_t f = f0 + 16u * b + (uint32_t)l;
+            uint32_t c = f + delta[0];
+#pragma unroll
+            for (int k = 1; k < 9; k++) c = f >= off[k] ? f + delta[k] : c;
+            cc[b] = c;
+            sp[b] = f < off[9] ? spheres[c] : make_float4(0.f, 0.f, 0.f, -1.0f);
+        }
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const uint32_t m = (uint32_t)(__ballot(sphere_may_win(sp[b], qx, qy, qz, best)) >> shift) & 0xFFFFu;
+            if (STATS && l == 0) { st_sph += f0 + 16u * b < off[9] ? min(16u, off[9] - f0 - 16u * b) : 0u; st_cand += 16u * (uint32_t)__popc(m); }
+            if (m) { scan_hits16(records, m, cc[b], l, qx, qy, qz, best, bestp); any = true; }
+        }
+        if (any) group_min<16>(best, bestp);
+    }
+}
+
+// Workgroup -> chunk of queries.  The hardware deals consecutive workgroups round-robin over the 8 XCDs (b and b + 8 share
+// an L2): with the identity mapping eight spatially adjacent workgroups pull the same records into eight L2s.  Here XCD x
+// gets whole runs of GR_XCD_RUN consecutive (= spatially adjacent) query blocks, and the runs are dealt round-robin, so that
+// the load stays balanced over the XCDs (a contiguous eighth of the sorted queries per XCD does not: profiles/r01_grid_xcd_swizzle_experiment.txt).
+// Speed only: any mapping is correct.  nb8 = number of workgroups launched (a multiple of 8 * run).
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t run)
+{
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    return ((slot / run) * 8u + xcd) * run + slot % run;
+}
+
+// Distance (lower bound, >= 0) along one axis between the query coordinate q and the slab of cells with index c, u being the
+// query's own cell: 0 for its own slab, else the gap to the nearer face minus a margin that covers the binning of the targets
+// (a point may sit `slack` cells beyond the face its f32 cell index suggests) and the rounding of the face coordinate.
+__device__ __forceinline__ float axis_gap(float q, float lo, float h, int c, int u, float slack)
+{
+    if (c == u) return 0.0f;
+    const float face = c > u ? lo + (float)c * h : lo + (float)(c + 1) * h;
+    const float gap = c > u ? face - q : q - face;
+    return fmaxf(gap - slack * h - (fabsf(q) + fabsf(face)) * 1e-6f, 0.0f);
+}
+
+// x-range of cells [xa, xb] that can hold a target within sqrt(rem2) of qx (rem2 >= 0): the cell index is a monotone f32
+// function of the coordinate, so the cells of qx -+ r bracket every such target; the margin covers the rounding of qx -+ r
+__device__ __forceinline__ void ball_x_cells(const GridParams& g, float qx, float rem2, int& xa, int& xb)
+{
+    const float r = sqrtf(rem2) * 1.0001f + g.slack * g.h + fabsf(qx) * 1e-6f;
+    xa = max(xa, cell_coord(qx - r, g.lo[0], g.inv_h));
+    xb = min(xb, cell_coord(qx + r, g.lo[0], g.inv_h));
 }
 
 // G lanes cooperate on one query (G divides 64).  Stage 1 scans the 3 x 3 x-rows of the radius-1 cube with all
 // row bounds fetched up front (18 independent loads in flight); later stages double the radius.
-// CLIP: the variant for large / dense targets — long x-sorted rows are cut to the best-distance window first.
-template <int G, bool STATS, bool CLIP>
+// MODE 0: every record of an opened row is evaluated (small targets).  MODE 1 (CLIP, x-sorted rows): long rows are first cut to
+// the best-distance window in x.  MODE 2 (SPH, G = 16): rows are walked as runs of 16 records whose bounding spheres are
+// tested first — the variant for large / dense targets (a LiDAR ring packs hundreds of points into one cell at 10 M points;
+// almost all of them lie outside the ball of the current best).
+template <int G, bool STATS, int MODE>
 __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
-    const float4* __restrict__ records, const uint32_t* __restrict__ cell_start,
+    const float4* __restrict__ records, const float4* __restrict__ spheres, const uint32_t* __restrict__ cell_start,
     GridParams g, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     const uint32_t* __restrict__ perm, uint32_t ns, unsigned long long* __restrict__ keys, const int* __restrict__ stop,
     unsigned long long* __restrict__ stats, const float* __restrict__ tx, const float* __restrict__ ty,
     const float* __restrict__ tz, uint32_t nt, int warm_start, float cap2,
-    uint32_t* __restrict__ far_list, uint32_t* __restrict__ far_count, uint32_t far_cap)
+    uint32_t* __restrict__ far_list, uint32_t* __restrict__ far_count, uint32_t far_cap,
+    uint32_t* __restrict__ wpos, uint32_t xcd_run)
 {
     if (stop && (stop[0] | stop[1])) return;      // pipelined ICP: the loop has ended, the enqueued tail is a no-op
-    unsigned long long st_cand = 0, st_rows = 0, st_stages = 0;   // diagnostics (STATS builds only)
-    const uint32_t gt = blockIdx.x * GR_BLOCK + threadIdx.x;
+    constexpr bool CLIP = MODE == 1, SPH = MODE == 2;
+    static_assert(!SPH || G == 16, "the sphere walk scans one 16-record run per sub-group");
+    unsigned long long st_cand = 0, st_rows = 0, st_stages = 0, st_sph = 0;   // diagnostics (STATS builds only)
+    const uint32_t vb = xcd_run ? xcd_block(blockIdx.x, xcd_run) : blockIdx.x;
+    const uint32_t gt = vb * GR_BLOCK + threadIdx.x;
+    if ((unsigned long long)vb * GR_BLOCK >= (unsigned long long)ns * G) return;   // a surplus workgroup of the padded launch
     const uint32_t t = min(gt / G, ns - 1);          // clamp: surplus sub-groups redo the last query (same value written)
     const int l = (int)(threadIdx.x % G);
     const uint32_t i = perm ? perm[t] : t;
     const float qx = sx[i], qy = sy[i], qz = sz[i];
     unsigned long long best = KEY_NONE;
+    uint32_t bestp = 0;
     if (finite3(qx, qy, qz)) {
-        if (warm_start) {
-            // ICP: keys[] still holds this query's correspondence of the previous iteration.  That target, evaluated
-            // exactly against the moved query, is a genuine candidate: it bounds the search from the first stage on
-            // (the radius jumps straight to the proving one, rows are clipped to its ball) without changing the result.
+        if (warm_start == 2) {
+            // ICP, from the second search of a loop on: wpos[] holds the record position of this query's previous winner.
+            // That target, evaluated exactly against the moved query, is a genuine candidate: it bounds the search from the
+            // first stage on (the radius jumps straight to the proving one, rows are clipped to its ball) without changing
+            // the result.  One 16-byte load that neighbouring queries share, instead of three 4-byte gathers.
+            const uint32_t pp = wpos[i];
+            if (pp < nt) {
+                const float4 rec = records[pp];
+                const float dx = qx - rec.x, dy = qy - rec.y, dz = qz - rec.z;
+                const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                if (d < 0x7F7FFFFFu) { best = ((unsigned long long)d << 32) | __float_as_uint(rec.w); bestp = pp; }
+            }
+        } else if (warm_start == 1) {
+            // the same from keys[] (original index) when no record positions were kept
             const uint32_t pj = (uint32_t)(keys[i] & 0xFFFFFFFFull);
             if (pj < nt) {
                 const float dx = qx - tx[pj], dy = qy - ty[pj], dz = qz - tz[pj];
@@ -361,13 +592,25 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             // ---- stage 1: static 3 x 3 rows, bounds first
             const int xlo = max(ux - 1, 0), xhi = min(ux + 1, g.n[0] - 1);
             uint32_t rb[9], re[9];
+            // with a seed (the previous correspondence, re-evaluated) only the rows and cells its ball reaches can matter: at the
+            // converged pose that is the query's own cell and the odd neighbour instead of all 27 (measured: DESIGN.md 5b)
+            const bool seeded = best != KEY_NONE;
+            const float clip2s = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f;
 #pragma unroll
             for (int k = 0; k < 9; k++) {
                 const int cy = uy + (k % 3) - 1, cz = uz + (k / 3) - 1;
-                const bool ok = (cy >= 0) && (cy < g.n[1]) && (cz >= 0) && (cz < g.n[2]) && (xlo <= xhi);
+                bool ok = (cy >= 0) && (cy < g.n[1]) && (cz >= 0) && (cz < g.n[2]) && (xlo <= xhi);
+                int xa = xlo, xb = xhi;
+                if (ok && seeded) {
+                    const float gy = axis_gap(qy, g.lo[1], g.h, cy, uy, g.slack), gz = axis_gap(qz, g.lo[2], g.h, cz, uz, g.slack);
+                    const float rem2 = clip2s - (gy * gy + gz * gz) * 0.9999f;
+                    if (rem2 < 0.0f) ok = false;
+                    else { ball_x_cells(g, qx, rem2, xa, xb); ok = xa <= xb; }
+                }
                 const uint32_t row = ok ? (uint32_t)((cz * g.n[1] + cy) * g.n[0]) : 0u;
-                rb[k] = ok ? cell_start[row + xlo] : 0u;
-                re[k] = ok ? cell_start[row + xhi + 1] : 0u;
+                rb[k] = ok ? cell_start[row + xa] : 0u;
+                re[k] = ok ? cell_start[row + xb + 1] : 0u;
+                if (STATS && l == 0 && ok) st_rows++;
             }
             if (CLIP) {
                 uint32_t total = 0;
@@ -376,10 +619,10 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                 // dense neighbourhood without a warm-start candidate: the query's own row first, its best distance then
                 // cuts the other rows
                 if (best == KEY_NONE && total > 512u) {
-                    scan_range<G>(records, rb[4], re[4], l, qx, qy, qz, best);
+                    scan_range<G>(records, rb[4], re[4], l, qx, qy, qz, best, bestp);
                     if (STATS && l == 0) st_cand += re[4] - rb[4];
                     rb[4] = re[4] = 0;
-                    best = group_min<G>(best);
+                    group_min<G>(best, bestp);
                 }
                 if (best != KEY_NONE && total > 48u) {
                     float lo, hi;
@@ -399,14 +642,23 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                     }
                 }
             }
-            if (CLIP) {
-                scan_flat9<G>(records, rb, re, l, qx, qy, qz, best);      // dense rows: 8.1 -> 6.9 ms at 10 M (costs 15 % at 120 k)
+            if (SPH) {
+                if (best == KEY_NONE) {
+                    // no seed: the query's own row first, so that the other eight are tested against a real bound
+                    scan_range_sph<STATS, 1>(records, spheres, rb[4], re[4], l, qx, qy, qz, best, bestp, st_cand, st_sph);
+                    rb[4] = re[4] = 0;
+                }
+                scan_flat9_sph<STATS, 1>(records, spheres, rb, re, l, qx, qy, qz, best, bestp, st_cand, st_sph);
             } else {
+                if (CLIP) {
+                    scan_flat9<G>(records, rb, re, l, qx, qy, qz, best, bestp);      // dense rows: 8.1 -> 6.9 ms at 10 M (costs 15 % at 120 k)
+                } else {
 #pragma unroll
-                for (int k = 0; k < 9; k++) scan_range<G>(records, rb[k], re[k], l, qx, qy, qz, best);
+                    for (int k = 0; k < 9; k++) scan_range<G>(records, rb[k], re[k], l, qx, qy, qz, best, bestp);
+                }
+                if (STATS && l == 0) { for (int k = 0; k < 9; k++) st_cand += re[k] - rb[k]; }
             }
-            if (STATS && l == 0) { for (int k = 0; k < 9; k++) st_cand += re[k] - rb[k]; st_rows += 9; }
-            best = group_min<G>(best);
+            group_min<G>(best, bestp);
             const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
                                 (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
             const float reach = (1.0f - g.slack) * g.h;
@@ -465,16 +717,10 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                         int xa = xlo, xb = xhi;
                         bool open = true;
                         if (have) {
-                            const float fy = fmaxf((float)ady - 1.0f - g.slack, 0.0f) * g.h;
-                            const float fz = fmaxf((float)adz - 1.0f - g.slack, 0.0f) * g.h;
-                            const float rem2 = clip2 - (fy * fy + fz * fz);
-                            if (rem2 < 0.0f) {
-                                open = false;                                  // the whole row is outside the ball
-                            } else {
-                                const int wx = (int)fminf(sqrtf(rem2) * g.inv_h + g.slack, 16777215.0f) + 2;   // clamp BEFORE the conversion: far queries x tiny cells overflow int
-                                xa = max(xa, ux - wx);
-                                xb = min(xb, ux + wx);
-                            }
+                            const float fy = axis_gap(qy, g.lo[1], g.h, cy, uy, g.slack), fz = axis_gap(qz, g.lo[2], g.h, cz, uz, g.slack);
+                            const float rem2 = clip2 - (fy * fy + fz * fz) * 0.9999f;
+                            if (rem2 < 0.0f) open = false;                     // the whole row is outside the ball
+                            else ball_x_cells(g, qx, rem2, xa, xb);
                         }
                         if (open && xa <= xb) {
                             const uint32_t row = (uint32_t)((cz * g.n[1] + cy) * g.n[0]);
@@ -491,7 +737,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                                 clip_range_x(records, b1, e1, wlo, whi);
                                 clip_range_x(records, b2, e2, wlo, whi);
                             }
-                            if (STATS) { st_rows++; st_cand += (e1 - b1) + (e2 - b2); }
+                            if (STATS) { st_rows++; if (!SPH) st_cand += (e1 - b1) + (e2 - b2); }
                         }
                     }
                     // visit only the lanes that hold a non-empty piece (far searches are mostly empty space)
@@ -502,13 +748,18 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                         mine &= mine - 1;
                         const uint32_t jb1 = __shfl(b1, j, G), je1 = __shfl(e1, j, G);
                         const uint32_t jb2 = __shfl(b2, j, G), je2 = __shfl(e2, j, G);
-                        if (jb1 < je1) scan_range<G>(records, jb1, je1, l, qx, qy, qz, best);
-                        if (jb2 < je2) scan_range<G>(records, jb2, je2, l, qx, qy, qz, best);
+                        if (SPH) {
+                            scan_range_sph<STATS, 1>(records, spheres, jb1, je1, l, qx, qy, qz, best, bestp, st_cand, st_sph);
+                            scan_range_sph<STATS, 1>(records, spheres, jb2, je2, l, qx, qy, qz, best, bestp, st_cand, st_sph);
+                        } else {
+                            if (jb1 < je1) scan_range<G>(records, jb1, je1, l, qx, qy, qz, best, bestp);
+                            if (jb2 < je2) scan_range<G>(records, jb2, je2, l, qx, qy, qz, best, bestp);
+                        }
                     }
                 }
             }
             if (STATS && l == 0) st_stages++;
-            best = group_min<G>(best);
+            group_min<G>(best, bestp);
             const bool covers = (ux - r <= 0) && (ux + r >= g.n[0] - 1) && (uy - r <= 0) && (uy + r >= g.n[1] - 1) &&
                                 (uz - r <= 0) && (uz + r >= g.n[2] - 1);
             // every target outside the cube is farther than (r - slack) * h in some axis
@@ -523,12 +774,14 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     if (STATS && gt / G < ns) {
         if (st_cand) atomicAdd(&stats[0], st_cand);
         if (st_rows) atomicAdd(&stats[1], st_rows);
+        if (st_sph) atomicAdd(&stats[2], st_sph);
         if (st_stages) atomicAdd(&stats[3], st_stages);
     }
     if (l == 0 && gt / G < ns) {
         const uint32_t bidx = (uint32_t)(best & 0xFFFFFFFFull);
         const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : (uint32_t)(best >> 32);
         keys[i] = ((unsigned long long)bits << 32) | bidx;
+        if (wpos) wpos[i] = bidx == 0xFFFFFFFFu ? 0xFFFFFFFFu : bestp;
     }
 }
 
@@ -582,13 +835,14 @@ void grid_free(Grid* g)
 {
     if (!g) return;
     if (g->chunks) hipFree(g->chunks);
+    if (g->spheres) hipFree(g->spheres);
     if (g->records) hipFree(g->records);
     if (g->cell_start) hipFree(g->cell_start);
     delete g;
 }
 
 // scratch layout for builds / query sorting: [cell_of n][count cells+1][totals nb+1]
-int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge)
+int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, int order)
 {
     *out = nullptr;
     const size_t n = c->n;
@@ -692,7 +946,8 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge)
     uint32_t* v_in = (uint32_t*)(sc + off_vin);
     uint32_t* v_out = (uint32_t*)(sc + off_vout);
     hipError_t e = hipMalloc((void**)&g->cell_start, ncell * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&g->records, std::max<size_t>(n, 1) * sizeof(float4));
+    const size_t n_padded = (n + GRID_CHUNK - 1) / GRID_CHUNK * GRID_CHUNK;
+    if (e == hipSuccess) e = hipMalloc((void**)&g->records, std::max<size_t>(n_padded, GRID_CHUNK) * sizeof(float4));
     if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "hipMalloc(grid)", e); }
     e = hipMemsetAsync(count, 0, ncell * 4, ctx->stream);
     if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "memset(grid)", e); }
@@ -701,10 +956,15 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge)
     rc = exclusive_scan_u32(ctx, count, g->cell_start, ncell, totals, totals + nb);
     if (rc) { grid_free(g); return rc; }
     if (n) {
-        hipLaunchKernelGGL(record_keys_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), (uint32_t)n, cell_of, k_in, v_in);
+        g->x_sorted = order != GRID_ORDER_MORTON;
+        if (g->x_sorted)
+            hipLaunchKernelGGL(record_keys_kernel<false>, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of, k_in, v_in);
+        else
+            hipLaunchKernelGGL(record_keys_kernel<true>, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of, k_in, v_in);
         e = hipcub::DeviceRadixSort::SortPairs(sc + off_temp, temp_bytes, k_in, k_out, v_in, v_out, (int)n, 0, 32 + key_bits, ctx->stream);
         if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "radix sort(grid)", e); }
-        hipLaunchKernelGGL(gather_records_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)n, v_out, g->records);
+        hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)((n_padded + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(),
+                           (uint32_t)n, (uint32_t)n_padded, v_out, g->records);
     }
     // chunked, centred copy for the expanded-form brute-force filter (17 B per point)
     g->n_chunks = (n + GRID_CHUNK - 1) / GRID_CHUNK;
@@ -717,6 +977,10 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge)
         if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "memset(grid)", e); }
         hipLaunchKernelGGL(build_chunks_kernel, dim3((unsigned)((g->n_chunks + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records, (uint32_t)n,
                            (uint32_t)g->n_chunks, g->chunks, unsafe_dev);
+        e = hipMalloc((void**)&g->spheres, g->n_chunks * sizeof(float4));
+        if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "hipMalloc(grid spheres)", e); }
+        hipLaunchKernelGGL(build_spheres_kernel, dim3((unsigned)((g->n_chunks + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records,
+                           (uint32_t)g->n_chunks, g->spheres);
         e = hipMemcpyAsync(&unsafe_host, unsafe_dev, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "grid chunks", e); }
     }
@@ -775,35 +1039,91 @@ static int sort_queries(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
     return PCR_OK;
 }
 
+// the 1-NN index of a target cloud, cached on the cloud.  Large targets get the Morton-ordered records the sphere walk wants
+// (tune grid_order: 0 auto = Morton from 500 000 points, 1 = x-sorted, 2 = Morton).
+int build_target_grid(pcr_ctx* ctx, const pcr_cloud* tgt)
+{
+    if (tgt->grid) return PCR_OK;
+    const int64_t ord = tune_get(ctx, "grid_order", 0);
+    const int order = (ord == 2 || (ord == 0 && tgt->n >= 500000)) ? GRID_ORDER_MORTON : GRID_ORDER_X;
+    Grid* g = nullptr;
+    ProfScope p(ctx, "grid_build");
+    int rc = grid_build(ctx, tgt, &g, 0.0, order);
+    if (rc) return rc;
+    const_cast<pcr_cloud*>(tgt)->grid = g;
+    return PCR_OK;
+}
+
 int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
 {
-    if (!tgt->grid) {
-        Grid* g = nullptr;
-        ProfScope p(ctx, "grid_build");
-        int rc = grid_build(ctx, tgt, &g, 0.0);
-        if (rc) return rc;
-        const_cast<pcr_cloud*>(tgt)->grid = g;
-    }
+    int rcb = build_target_grid(ctx, tgt);
+    if (rcb) return rcb;
     if (src->n == 0) return PCR_OK;
     ProfScope p(ctx, "grid_sort_queries");
     return sort_queries(ctx, tgt->grid, src);
 }
 
+// dst[t] = src[perm[t]] (cell-sorted working copy of the grid ICP); the padding of dst is left alone
+__global__ __launch_bounds__(GR_BLOCK) void permute_cloud_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                                                                 const uint32_t* __restrict__ perm, uint32_t n, float* __restrict__ dx, float* __restrict__ dy,
+                                                                 float* __restrict__ dz)
+{
+    const uint32_t t = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t i = perm[t];
+    dx[t] = sx[i]; dy[t] = sy[i]; dz[t] = sz[i];
+}
+
+// Re-orders the working cloud of an ICP loop into the coarse-cell order of the target's grid, ONCE: every later search reads
+// its queries with coalesced loads (no perm indirection), writes keys / winner positions coalesced, and the Kabsch pass walks
+// pairs whose targets are neighbours in the record array.  ctx->work_orig[t] = index the point had in the caller's cloud (the
+// "last kept pair" of registration.cpp:939 is defined in that order).  The sums are exact, so the order changes no result.
+int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work)
+{
+    pcr_cloud* w = *work;
+    const size_t n = w->n;
+    ctx->work_orig_src = nullptr;
+    if (n == 0 || tune_get(ctx, "grid_sort_work", 1) != 1) return PCR_OK;
+    int rc = grid_prepare_queries(ctx, tgt, w);                  // builds the target index if needed; ctx->qperm = cell order
+    if (rc) return rc;
+    pcr_cloud* sorted = nullptr;
+    rc = pcr_cloud_clone(ctx, w, &sorted);                        // same size, padding included
+    if (rc) return rc;
+    if (ctx->work_orig_cap < n) {
+        if (ctx->work_orig) PCR_HIP(ctx, hipFree(ctx->work_orig));
+        ctx->work_orig = nullptr; ctx->work_orig_cap = 0;
+        PCR_HIP(ctx, hipMalloc((void**)&ctx->work_orig, padded(n) * sizeof(uint32_t)));
+        ctx->work_orig_cap = padded(n);
+    }
+    hipLaunchKernelGGL(permute_cloud_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), ctx->qperm,
+                       (uint32_t)n, sorted->x(), sorted->y(), sorted->z());
+    PCR_HIP(ctx, hipGetLastError());
+    PCR_HIP(ctx, hipMemcpyAsync(ctx->work_orig, ctx->qperm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    pcr_cloud_destroy(ctx, w);                                     // synchronises the stream
+    *work = sorted;
+    ctx->work_orig_src = sorted;
+    ctx->work_orig_n = n;
+    ctx->qperm_src = nullptr;                                      // the permutation belongs to the cloud that no longer exists
+    return PCR_OK;
+}
+
 int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2)
 {
     const size_t ns = src->n;
-    if (ns == 0) { ctx->keys_n = 0; return PCR_OK; }
+    if (ns == 0) { ctx->keys_n = 0; ctx->wpos_valid = false; return PCR_OK; }
     if (ns > 0xFFFFFFF0ull || tgt->n > 0xFFFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "cloud too large for u32 indices");
     int rc = ensure_keys(ctx, ns);
     if (rc) return rc;
     ctx->keys_n = ns;
-    const bool have_perm = reuse_perm && tgt->grid && ctx->qperm && ctx->qperm_n == ns && ctx->qperm_src == src;
+    // the working cloud of an ICP loop is already in cell order (grid_sort_working_cloud): no permutation to read
+    const bool sorted = reuse_perm && ctx->work_orig_src == src && ctx->work_orig_n == ns && tgt->grid;
+    const bool have_perm = sorted || (reuse_perm && tgt->grid && ctx->qperm && ctx->qperm_n == ns && ctx->qperm_src == src);
     if (!have_perm) {
         rc = grid_prepare_queries(ctx, tgt, src);
         if (rc) return rc;
     }
     const Grid* g = tgt->grid;
-    const uint32_t* perm = tune_get(ctx, "grid_sort_queries", 1) > 0 ? ctx->qperm : nullptr;
+    const uint32_t* perm = (!sorted && tune_get(ctx, "grid_sort_queries", 1) > 0) ? ctx->qperm : nullptr;
     unsigned long long* stats_dev = nullptr;
     if (tune_get(ctx, "grid_stats", 0) > 0) {     // diagnostics: candidates / fine rows / coarse rows / far stages of this launch
         if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
@@ -814,19 +1134,23 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     // Unlike the exhaustive kernels (nn1_brute.hip), the grid walk TRUSTS its seed — the radius jumps to the one that proves it —
     // so only the previous iteration of the same cloud object qualifies: correspondences left by another source cloud of the
     // same size would be valid but arbitrarily bad candidates (measured: a 5-iteration ICP 0.93 -> 12.5 ms, profiles/r01_tune_grid.txt).
-    const int warm = (reuse_perm && ctx->keys_warm && ctx->keys_src == src && ctx->keys_warm_n == ns &&
-                      tune_get(ctx, "grid_warm_start", 1) > 0) ? 1 : 0;
+    int warm = (reuse_perm && ctx->keys_warm && ctx->keys_src == src && ctx->keys_warm_n == ns &&
+                tune_get(ctx, "grid_warm_start", 1) > 0) ? 1 : 0;
+    if (warm && ctx->wpos_valid && ctx->wpos_n == ns && ctx->wpos) warm = 2;      // the winners' record positions are there: seed from the records
     ctx->keys_warm = reuse_perm;
     ctx->keys_warm_n = ns;
     ctx->keys_src = src;
     ctx->keys_tgt = tgt;
-    // x-window clipping of long rows: 14.1 -> 8.1 ms per search at 10 M x 10 M and 20.9 -> 15.9 ms per ICP iteration there
-    // (1 277 -> 462 candidates per query); on sparse clouds the extra phase costs ~25 % (38 -> 48 us at 120 k), so the
-    // plain kernel serves small targets.  Same box, same call: profiles/r01_c5_10M_single_gpu.txt.
-    // grid_clip_x: 1 = always, 2 = never (0 / unset = by target size)
-    const int64_t clip_tune = tune_get(ctx, "grid_clip_x", 0);
-    const bool clip = clip_tune == 1 || (clip_tune != 2 && tgt->n >= 500000);
-    const int G = (int)tune_get(ctx, "grid_lanes", 16);   // measured: profiles/r01_tune_grid.txt
+    // search kernel (tune grid_mode: 0 auto, 1 plain, 2 x-window clipping, 3 bounding spheres):
+    //   spheres  — Morton-ordered index (large targets, build_target_grid): runs of 16 records are tested by their bounding sphere first;
+    //   clipping — x-sorted index of a large target: 14.1 -> 8.1 ms per search at 10 M x 10 M in round 1 (1 277 -> 462 candidates per query);
+    //   plain    — small / sparse targets, where either extra phase costs more than it saves (38 -> 48 us at 120 k with clipping).
+    const int64_t mode_tune = tune_get(ctx, "grid_mode", 0);
+    int mode = 0;
+    if (mode_tune == 0) mode = (g->spheres && !g->x_sorted) ? 2 : (tgt->n >= 500000 && g->x_sorted) ? 1 : 0;
+    else if (mode_tune == 2) mode = g->x_sorted ? 1 : 0;
+    else if (mode_tune == 3) mode = g->spheres ? 2 : 0;
+    const int G = mode == 2 ? 16 : (int)tune_get(ctx, "grid_lanes", 16);   // measured: profiles/r01_tune_grid.txt
     // unbounded searches hand their far queries to the exhaustive kernel (grid_far_brute: 1 on (default), 2 off)
     uint32_t* far_list = nullptr; uint32_t* far_count = nullptr; uint32_t far_cap = 0;
     if (!(cap2 < __builtin_inff()) && tgt->n >= 4096 && tune_get(ctx, "grid_far_brute", 1) == 1) {
@@ -839,18 +1163,45 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         far_list = ctx->far_list; far_count = ctx->far_list + ctx->far_cap; far_cap = (uint32_t)std::min<size_t>(want, ctx->far_cap);
         PCR_HIP(ctx, hipMemsetAsync(far_count, 0, sizeof(uint32_t), ctx->stream));
     }
+    // winner positions: kept inside ICP loops whose searches the grid answers alone (the exhaustive hand-off merges into keys[] only)
+    uint32_t* wpos = nullptr;
+    if (reuse_perm && !far_list && warm != 1 && tune_get(ctx, "grid_wpos", 1) == 1) {
+        if (ctx->wpos_cap < ns) {
+            if (ctx->wpos) { PCR_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->wpos); ctx->wpos = nullptr; ctx->wpos_cap = 0; }
+            PCR_HIP(ctx, hipMalloc((void**)&ctx->wpos, padded(ns) * sizeof(uint32_t)));
+            ctx->wpos_cap = padded(ns);
+            if (warm == 2) warm = 1;                       // (cannot happen: a valid wpos has the capacity) — never seed from a fresh buffer
+        }
+        wpos = ctx->wpos;
+    }
+    if (warm == 2 && !wpos) warm = 1;
+    ctx->wpos_valid = wpos != nullptr;
+    ctx->wpos_n = ns;
+    // XCD-aware workgroup -> query-block mapping for large batches (tune grid_xcd_run: run length in workgroups, -1 = identity)
+    int64_t run = tune_get(ctx, "grid_xcd_run", 0);
+    const size_t nblocks = (ns * (size_t)G + GR_BLOCK - 1) / GR_BLOCK;
+    if (run == 0) run = nblocks >= 4096 ? 32 : -1;
+    size_t launch_blocks = nblocks;
+    uint32_t xcd_run = 0;
+    if (run > 0) {
+        xcd_run = (uint32_t)run;
+        const size_t unit = 8 * (size_t)xcd_run;
+        launch_blocks = (nblocks + unit - 1) / unit * unit;
+    }
     {
         ProfScope p(ctx, "nn1_grid", 1);
-#define PCR_GRID2(GG, ST, CL)                                                                                          \
-    hipLaunchKernelGGL((nn1_grid_kernel<GG, ST, CL>), dim3((unsigned)((ns * GG + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records, \
+#define PCR_GRID2(GG, ST, MD)                                                                                          \
+    hipLaunchKernelGGL((nn1_grid_kernel<GG, ST, MD>), dim3((unsigned)launch_blocks), dim3(GR_BLOCK), 0, ctx->stream, g->records, g->spheres, \
                        g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(), tgt->y(),   \
-                       tgt->z(), (uint32_t)tgt->n, warm, cap2, far_list, far_count, far_cap)
+                       tgt->z(), (uint32_t)tgt->n, warm, cap2, far_list, far_count, far_cap, wpos, xcd_run)
 #define PCR_GRID(GG)                                                                                                   \
     do {                                                                                                               \
-        if (stats_dev) { if (clip) PCR_GRID2(GG, true, true); else PCR_GRID2(GG, true, false); }                       \
-        else { if (clip) PCR_GRID2(GG, false, true); else PCR_GRID2(GG, false, false); }                               \
+        if (stats_dev) { if (mode == 1) PCR_GRID2(GG, true, 1); else PCR_GRID2(GG, true, 0); }                         \
+        else { if (mode == 1) PCR_GRID2(GG, false, 1); else PCR_GRID2(GG, false, 0); }                                 \
     } while (0)
-        switch (G) {
+        if (mode == 2) {
+            if (stats_dev) PCR_GRID2(16, true, 2); else PCR_GRID2(16, false, 2);
+        } else switch (G) {
         case 1: PCR_GRID(1); break;
         case 2: PCR_GRID(2); break;
         case 4: PCR_GRID(4); break;

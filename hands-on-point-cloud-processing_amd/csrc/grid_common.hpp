@@ -29,7 +29,17 @@ struct Grid {
     float* chunks = nullptr;
     size_t n_chunks = 0;
     bool chunk_safe = false;
+    // Order of the records inside a cell: by x (every x-row of cells is one x-sorted range: what the window-clipping consumers —
+    // k-NN, radius, ISS, the CLIP search kernel — rely on), or by the Morton code of an 8 x 8 x 8 sub-cell position (spatially
+    // compact runs: what the bounding spheres below want).
+    bool x_sorted = true;
+    // bounding sphere {Cx, Cy, Cz, radius (rounded up)} of every run of GRID_CHUNK consecutive records (n_chunks entries; the
+    // records array is padded to a whole chunk with x = +inf entries): one 16-byte load decides whether 16 records can hold a
+    // better neighbour (grid.hip, SPH search kernel)
+    float4* spheres = nullptr;
 };
+
+enum GridOrder { GRID_ORDER_X = 0, GRID_ORDER_MORTON = 1 };
 
 constexpr int GRID_CHUNK = 16;
 constexpr int GRID_CHUNK_FLOATS = 4 + 4 * GRID_CHUNK;
@@ -58,8 +68,12 @@ __device__ __forceinline__ uint32_t clamped_cell_id(const GridParams& g, float x
 }
 
 // builds the index over `c`; cell_edge > 0 forces the cell size (otherwise the heuristic of grid.hip is used)
-int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge);
+int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, int order = GRID_ORDER_X);
+// builds (and caches on tgt) the 1-NN grid if needed
+int build_target_grid(pcr_ctx* ctx, const pcr_cloud* tgt);
 // builds (and caches on tgt) the 1-NN grid if needed, then groups the queries `src` by coarse cell -> ctx->qperm
 int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
+// replaces *work by its cell-sorted copy (ctx->work_orig = original indices); no-op for empty clouds / tune grid_sort_work = 2
+int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
 
 }  // namespace pcr

@@ -12,6 +12,13 @@
 
 using namespace pcr;
 
+// the dispatcher's rule (api.cpp launch_nn1): tune nn_method 0 = auto (grid for targets >= 2048 points), 1 brute force, 2 grid
+static bool icp_uses_grid(const pcr_ctx* ctx, const pcr_cloud* tgt)
+{
+    const int64_t m = tune_get(ctx, "nn_method", 0);
+    return m == 2 || (m != 1 && tgt->n >= 2048);
+}
+
 // ---- synchronous loop: one host round trip per iteration (needed by the host-callback transport; also the
 // reference implementation of the loop the pipelined variant below must reproduce bit for bit)
 static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, const float init_T[16],
@@ -35,6 +42,7 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
     const float R0[9] = { init_T[0], init_T[1], init_T[2], init_T[4], init_T[5], init_T[6], init_T[8], init_T[9], init_T[10] };
     const float t0[3] = { init_T[3], init_T[7], init_T[11] };
     rc = launch_transform(ctx, work, R0, t0);                                    // :874
+    if (rc == PCR_OK && icp_uses_grid(ctx, tgt)) rc = grid_sort_working_cloud(ctx, tgt, &work);
     float T_total[16] = { R0[0], R0[1], R0[2], t0[0], R0[3], R0[4], R0[5], t0[1],
                           R0[6], R0[7], R0[8], t0[2], 0, 0, 0, 1 };              // :910-913
     float last_loss = 0.0f;                                                      // :915
@@ -146,6 +154,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     const float R0[9] = { init_T[0], init_T[1], init_T[2], init_T[4], init_T[5], init_T[6], init_T[8], init_T[9], init_T[10] };
     const float t0[3] = { init_T[3], init_T[7], init_T[11] };
     rc = launch_transform(ctx, work, R0, t0);                                    // :874
+    if (rc == PCR_OK && icp_uses_grid(ctx, tgt)) rc = grid_sort_working_cloud(ctx, tgt, &work);
     IcpState& h0 = host[RING];
     memset(&h0, 0, sizeof h0);
     const float T0[16] = { R0[0], R0[1], R0[2], t0[0], R0[3], R0[4], R0[5], t0[1], R0[6], R0[7], R0[8], t0[2], 0, 0, 0, 1 };
@@ -234,8 +243,7 @@ extern "C" int pcr_icp_p2p_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr_clo
     // therefore always runs synchronously.  Both loops give bit-identical results.
     const bool callback = ctx->comm.nranks > 1 && ctx->comm.cb != nullptr;
     const int64_t mode = tune_get(ctx, "icp_pipeline", 0);
-    const int64_t nn_method = tune_get(ctx, "nn_method", 0);
-    const bool grid = nn_method == 2 || (nn_method != 1 && tgt->n >= 2048);
+    const bool grid = icp_uses_grid(ctx, tgt);
     const bool pipelined = !callback && (mode > 0 || (mode == 0 && grid));
     return pipelined ? icp_pipelined(ctx, src, tgt, init_T, prm, out_T, stats) : icp_sync(ctx, src, tgt, init_T, prm, out_T, stats);
 }

@@ -204,12 +204,15 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_final_kernel(const double* __
     row_to_out18(row, e, out);
 }
 
-// the order of the additions does not matter any more; the geometry only has to keep the pass busy
-static uint32_t kabsch_blocks(size_t ns)
+// the order of the additions does not matter any more; the geometry only has to keep the pass busy: one pair per thread while
+// that needs few workgroups (the pass is latency-bound at 120 k), then a capped number of fatter workgroups — every workgroup
+// ends in a 464-byte row that ONE workgroup has to reduce afterwards (8 192 rows cost 0.22 ms at 10 M, 1 024 rows 0.05 ms, and the pass itself runs 0.27 -> 0.14 ms)
+static uint32_t kabsch_blocks(pcr_ctx* ctx, size_t ns)
 {
-    uint32_t blocks = (uint32_t)((ns + KB_BLOCK - 1) / KB_BLOCK);          // one point per thread up to KB_MAX_BLOCKS: the pass is latency-bound
+    uint32_t blocks = (uint32_t)((ns + KB_BLOCK - 1) / KB_BLOCK);
     if (blocks < 1) blocks = 1;
-    if (blocks > KB_MAX_BLOCKS) blocks = KB_MAX_BLOCKS;
+    const uint32_t cap = (uint32_t)std::min<int64_t>(KB_MAX_BLOCKS, std::max<int64_t>(1, tune_get(ctx, "kabsch_max_blocks", 1024)));
+    if (blocks > cap) blocks = cap;
     return blocks;
 }
 
@@ -245,7 +248,7 @@ int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* s
 {
     const size_t ns = src->n;
     if (ctx->keys_n != ns) return fail(ctx, PCR_ERR_STATE, "kabsch: no matching correspondence pass");
-    const uint32_t blocks = kabsch_blocks(ns);
+    const uint32_t blocks = kabsch_blocks(ctx, ns);
     // the grid search of an ICP loop leaves the record position of every winner behind (ctx->wpos): gather from the records
     const bool rec = ctx->wpos_valid && ctx->wpos_n == ns && tgt->grid && tgt->grid->records && tune_get(ctx, "kabsch_records", 1) == 1;
     const uint32_t* orig = (ctx->work_orig && ctx->work_orig_n == ns && ctx->work_orig_src == src) ? ctx->work_orig : nullptr;

@@ -205,16 +205,13 @@ __global__ __launch_bounds__(KG_BLOCK) void normals_kernel(const float* __restri
 int knn_grid_for(pcr_ctx* ctx, const pcr_cloud* db, int k, Grid** out, bool* owned)
 {
     *owned = false;
-    if (!db->grid) {
-        Grid* g = nullptr;
-        ProfScope p(ctx, "grid_build");
-        int rc = grid_build(ctx, db, &g, 0.0);
-        if (rc) return rc;
-        const_cast<pcr_cloud*>(db)->grid = g;
+    {
+        int rcb = build_target_grid(ctx, db);
+        if (rcb) return rcb;
     }
     const double scale = (double)tune_get(ctx, "knn_cell_scale_x100", 0) / 100.0;
     const double f = scale > 0 ? scale : std::min(2.0, std::sqrt(std::max(1.0, (double)k / 4.0)));   // measured: profiles/r01_knn_grid.txt
-    if (f <= 1.05) { *out = db->grid; return PCR_OK; }
+    if (f <= 1.05 && db->grid->x_sorted) { *out = db->grid; return PCR_OK; }     // (a Morton-ordered 1-NN grid cannot serve the x-window walk)
     // the widened grid is kept on the cloud as well (one slot: the factor of the last batch), so that repeated batches with
     // the same k — normals, ISS, the hw2 benchmark protocol — do not rebuild it
     pcr_cloud* mdb = const_cast<pcr_cloud*>(db);

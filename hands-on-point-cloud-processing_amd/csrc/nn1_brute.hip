@@ -495,6 +495,7 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     int rc = ensure_keys(ctx, ns);
     if (rc) return rc;
     ctx->keys_n = ns;
+    ctx->wpos_valid = false;              // keys[] is about to be rewritten without record positions
     ctx->keys_warm = in_loop;
     ctx->keys_warm_n = ns;
     ctx->keys_src = src;
@@ -509,13 +510,8 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     // cold searches take ETRACK too when its index exists or will be needed anyway (inside an ICP loop): 1.64 vs 1.82 ms at 120 k;
     // a one-shot search on a fresh target stays on FTRACK, which needs no index (0.3 ms to build)
     if (variant_tune == 4 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid))) {
-        if (!tgt->grid) {
-            Grid* g = nullptr;
-            ProfScope p(ctx, "grid_build");
-            rc = grid_build(ctx, tgt, &g, 0.0);
-            if (rc) return rc;
-            const_cast<pcr_cloud*>(tgt)->grid = g;
-        }
+        rc = build_target_grid(ctx, tgt);
+        if (rc) return rc;
         const Grid* g = tgt->grid;
         if (g->chunk_safe && g->n_chunks) {
             // queries per lane: the filter is bound by the scalar operand path (272 B per chunk per wave), more queries per lane

@@ -174,6 +174,7 @@ int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n
 // dispatcher: tune "nn_method" 0 = auto (grid for targets >= 2048 points), 1 = brute force, 2 = grid
 int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2 = __builtin_inff());
 void cloud_modified(pcr_cloud* c);
+int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
 int nn1_unpack(pcr_ctx* ctx, size_t n, uint32_t* idx_dev, float* d2_dev);
 int launch_transform(pcr_ctx* ctx, pcr_cloud* c, const float R[9], const float t[3]);
 int cloud_absmax(pcr_ctx* ctx, const pcr_cloud* c, float* out);       // largest finite |coordinate|, cached on the cloud (grid.hip)

@@ -38,7 +38,8 @@ def random_cloud32(rng, n, kind):
 
 
 def test_nn1_randomised_sweep_every_kernel(ctx, orc):
-    """120 random problems x {FTRACK, TRACK scalar, TRACK LDS, ETRACK, exact grid (both kernels)}: indices and d2 bits equal to the oracle."""
+    """120 random problems x {FTRACK, TRACK scalar, TRACK LDS, ETRACK, exact grid (plain / x-window / bounding-sphere kernels on the
+    x-sorted index, plain / bounding-sphere kernels on the Morton-ordered index)}: indices and d2 bits equal to the oracle."""
     rng = np.random.default_rng(77)
     for trial in range(120):
         kind = trial % 4
@@ -48,16 +49,24 @@ def test_nn1_randomised_sweep_every_kernel(ctx, orc):
             src[:, : min(ns, nt) // 2] = tgt[:, : min(ns, nt) // 2]
         oi, od = orc.nn1_f32(tgt, src)
         ct, cs = ctx.cloud(tgt), ctx.cloud(src)
-        for method, variant, clip in ((1, 1, 0), (1, 2, 0), (1, 3, 0), (1, 4, 0), (2, 1, 2), (2, 1, 1)):
+        for method, variant, mode in ((1, 1, 0), (1, 2, 0), (1, 3, 0), (1, 4, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)):
             ctx.tune("nn_method", method)
             ctx.tune("nn1_variant", variant)
-            ctx.tune("grid_clip_x", clip)              # 1: the x-window kernel of large targets forced; 2: the plain kernel
+            ctx.tune("grid_mode", mode)                # 1 plain, 2 x-window, 3 bounding spheres (0: by target size)
             idx, d2 = ctx.nn1(ct, cs)
-            assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (trial, kind, nt, ns, method, variant, clip)
-        cs.free(); ct.free()
+            assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (trial, kind, nt, ns, method, variant, mode)
+        ct.free()
+        ctx.tune("grid_order", 2)                      # the Morton-ordered index of large targets, forced on a fresh cloud
+        cm = ctx.cloud(tgt)
+        for method, variant, mode in ((2, 1, 3), (2, 1, 1), (1, 4, 0)):
+            ctx.tune("nn_method", method); ctx.tune("nn1_variant", variant); ctx.tune("grid_mode", mode)
+            idx, d2 = ctx.nn1(cm, cs)
+            assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (trial, kind, nt, ns, method, variant, mode, "morton")
+        ctx.tune("grid_order", 0)
+        cs.free(); cm.free()
     ctx.tune("nn_method", 0)
     ctx.tune("nn1_variant", 0)
-    ctx.tune("grid_clip_x", 0)
+    ctx.tune("grid_mode", 0)
 
 
 # ------------------------------------------------------------------ 1-NN (A1/A3/A6) vs reference goldens
@@ -172,19 +181,25 @@ def test_nn1_edge_cases(ctx, orc, variant):
 
 # ------------------------------------------------------------------ exact grid NN (same contract as brute force)
 def _grid_vs_oracle(ctx, orc, src, tgt, method=2, **tune):
-    ctx.tune("nn_method", method)
-    for k, v in tune.items():
-        ctx.tune(k, v)
-    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
-    idx, d2 = ctx.nn1(ct, cs)
-    idx2, d22 = ctx.nn1(ct, cs)                      # second call reuses the cached index
-    for k in tune:
-        ctx.tune(k, 0)
-    ctx.tune("nn_method", 0)
-    cs.free(); ct.free()
+    """the exact grid search against the oracle, twice per index flavour: what the library picks for this size, and the
+    Morton-ordered index + bounding-sphere walk of large targets forced onto it"""
     oidx, od2 = orc.nn1_f32(tgt, src)
-    assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
-    assert np.array_equal(idx2, oidx) and np.array_equal(bits32(d22), bits32(od2))
+    for extra in ({}, {"grid_order": 2, "grid_mode": 3}):
+        if "grid_lanes" in tune and extra:
+            continue                                     # the sphere walk is fixed at 16 lanes per query
+        tn = dict(tune, **extra)
+        ctx.tune("nn_method", method)
+        for k, v in tn.items():
+            ctx.tune(k, v)
+        cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+        idx, d2 = ctx.nn1(ct, cs)
+        idx2, d22 = ctx.nn1(ct, cs)                      # second call reuses the cached index
+        for k in tn:
+            ctx.tune(k, 0)
+        ctx.tune("nn_method", 0)
+        cs.free(); ct.free()
+        assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2)), extra
+        assert np.array_equal(idx2, oidx) and np.array_equal(bits32(d22), bits32(od2)), extra
 
 
 @pytest.mark.parametrize("ns,nt", [(1, 1), (63, 5), (257, 1023), (1000, 1025), (3001, 7000), (5000, 2049)])
@@ -255,17 +270,18 @@ def test_grid_equals_brute_force_at_120k(ctx, synth):
     src, tgt = synth.kitti_like_pair(120000)
     cs, ct = ctx.cloud(src), ctx.cloud(tgt)
     ctx.tune("nn_method", 1); bi, bd = ctx.nn1(ct, cs)
-    for clip in (2, 1):                                  # both grid kernels: plain, and the x-window variant of large targets
-        ctx.tune("nn_method", 2); ctx.tune("grid_clip_x", clip); gi, gd = ctx.nn1(ct, cs)
-        assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd))
+    ctx.tune("grid_order", 2); cm = ctx.cloud(tgt); ctx.tune("nn_method", 2); ctx.nn1(cm, cs); ctx.tune("grid_order", 0)   # Morton-ordered twin
+    for target, mode in ((ct, 1), (ct, 2), (ct, 3), (cm, 3), (cm, 1)):       # plain / x-window / spheres kernels on both record orders
+        ctx.tune("nn_method", 2); ctx.tune("grid_mode", mode); gi, gd = ctx.nn1(target, cs)
+        assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd)), mode
     ctx.transform(cs, synth.gt_pose().astype(np.float32))
     ctx.tune("nn_method", 1); bi, bd = ctx.nn1(ct, cs)
-    for clip in (2, 1):
-        ctx.tune("nn_method", 2); ctx.tune("grid_clip_x", clip); gi, gd = ctx.nn1(ct, cs)
-        assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd))
-    ctx.tune("nn_method", 0); ctx.tune("grid_clip_x", 0)
+    for target, mode in ((ct, 1), (ct, 2), (ct, 3), (cm, 3), (cm, 1)):
+        ctx.tune("nn_method", 2); ctx.tune("grid_mode", mode); gi, gd = ctx.nn1(target, cs)
+        assert np.array_equal(bi, gi) and np.array_equal(bits32(bd), bits32(gd)), mode
+    ctx.tune("nn_method", 0); ctx.tune("grid_mode", 0)
     assert np.median(bd) < 1e-3
-    cs.free(); ct.free()
+    cs.free(); ct.free(); cm.free()
 
 
 @pytest.mark.parametrize("method", [1, 2])

@@ -25,8 +25,8 @@ ctx.tune("nn1_qpl", qpl)
 ctx.tune("nn1_tiles_per_slice", tps)
 method = int(os.environ.get("NN_METHOD", "1"))     # 1 = brute force, 2 = exact grid
 ctx.tune("nn_method", method)
-if os.environ.get("GRID_CLIP_X"):     # 1 = x-window kernel, 2 = plain kernel (0 / unset: by target size)
-    ctx.tune("grid_clip_x", int(os.environ["GRID_CLIP_X"]))
+if os.environ.get("GRID_MODE"):     # 1 = plain kernel, 2 = x-window kernel, 3 = bounding spheres (0 / unset: by target size / index order)
+    ctx.tune("grid_mode", int(os.environ["GRID_MODE"]))
 if os.environ.get("GRID_CELL_UM"):
     ctx.tune("grid_cell_um", int(os.environ["GRID_CELL_UM"]))
 for kv in os.environ.get("PCR_TUNE", "").split(","):      # any other knob: PCR_TUNE="key=value,..."
