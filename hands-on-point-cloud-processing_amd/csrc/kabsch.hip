@@ -65,15 +65,19 @@ __device__ __forceinline__ void acc3(double v, double sp, double& a0, double& a1
 }
 
 // the workgroup's reduction of the per-thread limbs: tn[KB_NL] (normalised per thread) -> row[] in LDS, normalised again
+__device__ __forceinline__ bool is_carry_slot(int k) { return k < 18 ? (k % 3 == 2) : (k < 54 && (k - 18) % 4 == 3); }
+
+// carries: false when the carry slots of tn[] are known to be zero (no per-thread normalisation): their shuffles are skipped
 __device__ __forceinline__ void block_reduce_limbs(double (&tn)[KB_NL], unsigned long long lastkey, int overflow,
-                                                   double (&red)[KB_BLOCK / 64][KB_NL], double (&row)[KB_ROW])
+                                                   double (&red)[KB_BLOCK / 64][KB_NL], double (&row)[KB_ROW], bool carries)
 {
     __shared__ unsigned long long red_key[KB_BLOCK / 64];
     __shared__ int red_ovf[KB_BLOCK / 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < KB_NL; k++) {
-        const double sum = wave_sum(tn[k]);                   // 64 integers below 2^40 (+ small carries): exact
+        double sum = 0.0;
+        if (carries || !is_carry_slot(k)) sum = wave_sum(tn[k]);      // 64 integers below 2^46 (+ small carries): exact
         if (lane == 0) red[wave][k] = sum;
     }
     const unsigned long long km = wave_max_u64(lastkey);
@@ -119,15 +123,17 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
     const uint32_t lo = min(blockIdx.x * per_block, ns);
     const uint32_t hi = min(lo + per_block, ns);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += KB_BLOCK) {
+        // everything that does not depend on the key is requested up front: one round of coalesced loads, then the gather
         const unsigned long long key = keys[i];
+        const float pf0 = sx[i], pf1 = sy[i], pf2 = sz[i];
+        const uint32_t wp = RECORDS ? wpos[i] : 0u;
         const uint32_t d2b = (uint32_t)(key >> 32);
         const float d2 = __uint_as_float(d2b);
         const uint32_t j = (uint32_t)(key & 0xFFFFFFFFull);
         if (d2 < max_corr && j < nt) {                       // registration.cpp:936
-            const float pf0 = sx[i], pf1 = sy[i], pf2 = sz[i];
             float qf0, qf1, qf2;
             if (RECORDS) {
-                const float4 r = records[wpos[i]];
+                const float4 r = records[wp];
                 qf0 = r.x; qf1 = r.y; qf2 = r.z;
             } else {
                 qf0 = tx[j]; qf1 = ty[j]; qf2 = tz[j];
@@ -147,58 +153,82 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
             lastkey = lk > lastkey ? lk : lastkey;
         }
     }
+    // per-thread carry propagation only when a thread may hold many terms (limbs below 2^40 x terms must stay below 2^53 through
+    // the 256-thread sum): at most 16 terms per thread need none
+    const bool many = per_block > 16u * KB_BLOCK;
     double tn[KB_NL];
 #pragma unroll
-    for (int c = 0; c < 6; c++) { tn[3 * c] = c0[c]; tn[3 * c + 1] = c1[c]; tn[3 * c + 2] = 0.0; num::limbs_normalize(tn + 3 * c, 2); }
+    for (int c = 0; c < 6; c++) { tn[3 * c] = c0[c]; tn[3 * c + 1] = c1[c]; tn[3 * c + 2] = 0.0; if (many) num::limbs_normalize(tn + 3 * c, 2); }
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         tn[18 + 4 * k] = p0[k]; tn[19 + 4 * k] = p1[k]; tn[20 + 4 * k] = p2[k]; tn[21 + 4 * k] = 0.0;
-        num::limbs_normalize(tn + 18 + 4 * k, 3);
+        if (many) num::limbs_normalize(tn + 18 + 4 * k, 3);
     }
     tn[54] = cnt;
     __shared__ double red[KB_BLOCK / 64][KB_NL];
     __shared__ double row[KB_ROW];
-    block_reduce_limbs(tn, lastkey, overflow, red, row);
+    block_reduce_limbs(tn, lastkey, overflow, red, row, many);
     if (threadIdx.x < KB_ROW) partials[(size_t)blockIdx.x * KB_ROW + threadIdx.x] = row[threadIdx.x];
 }
 
-// one workgroup: the block rows -> ONE normalised row in LDS (limbs, last-kept key, overflow flag)
-__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, uint32_t n_blocks, double (&red)[KB_BLOCK / 64][KB_NL],
-                                            double (&row)[KB_ROW])
+// one workgroup of KF_BLOCK threads = 16 groups of 64 lanes: the block rows -> ONE normalised row in LDS (limbs, last-kept key,
+// overflow flag).  Lane k of a group owns column k (coalesced 464-byte row reads), group g takes rows g, g + 16, ...; column sums
+// of <= 1024 integers below 2^40 are exact.  Thread k < 16 then converts moment k: out[0..15] = the moments,
+// [16] original index of the last kept pair or -1, [17] its d2, [18] overflow flag.
+constexpr int KF_BLOCK = 1024;
+constexpr int KF_GROUPS = KF_BLOCK / 64;
+
+__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, uint32_t n_blocks, double (&red)[KF_GROUPS][64], double (&row)[KB_ROW])
 {
-    double tn[KB_NL];
-#pragma unroll
-    for (int k = 0; k < KB_NL; k++) tn[k] = 0.0;
-    unsigned long long lastkey = 0;
-    int overflow = 0;
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += KB_BLOCK) {      // <= 32 rows per thread: integers below 2^45
-        const double* r = partials + (size_t)b * KB_ROW;
-#pragma unroll
-        for (int k = 0; k < KB_NL; k++) tn[k] += r[k];
-        const unsigned long long lk = (unsigned long long)__double_as_longlong(r[55]);
-        lastkey = lk > lastkey ? lk : lastkey;
-        overflow |= r[56] != 0.0;
+    const int k = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    double acc = 0.0;
+    unsigned long long key = 0;
+    if (k < 57) {
+        for (uint32_t b = grp; b < n_blocks; b += KF_GROUPS) {
+            const double v = partials[(size_t)b * KB_ROW + k];
+            if (k == 55) { const unsigned long long lk = (unsigned long long)__double_as_longlong(v); key = lk > key ? lk : key; }
+            else if (k == 56) acc = (acc != 0.0 || v != 0.0) ? 1.0 : 0.0;
+            else acc += v;
+        }
     }
-    block_reduce_limbs(tn, lastkey, overflow, red, row);
+    red[grp][k] = k == 55 ? __longlong_as_double((long long)key) : acc;
+    __syncthreads();
+    if (threadIdx.x < 57) {
+        const int c = threadIdx.x;
+        if (c == 55) {
+            unsigned long long m = 0;
+            for (int g = 0; g < KF_GROUPS; g++) { const unsigned long long lk = (unsigned long long)__double_as_longlong(red[g][c]); m = lk > m ? lk : m; }
+            row[c] = __longlong_as_double((long long)m);
+        } else {
+            double t = 0.0;
+            for (int g = 0; g < KF_GROUPS; g++) t += red[g][c];
+            row[c] = c == 56 ? (t != 0.0 ? 1.0 : 0.0) : t;
+        }
+    }
+    if (threadIdx.x == 57) row[57] = 0.0;
+    __syncthreads();
+    if (threadIdx.x < 6) num::limbs_normalize(row + 3 * threadIdx.x, 2);
+    else if (threadIdx.x < 15) num::limbs_normalize(row + 18 + 4 * (threadIdx.x - 6), 3);
+    __syncthreads();
 }
 
-// out (single rank): [0..15] the 16 moments, [16] original index of the last kept pair or -1, [17] its d2, [18] overflow flag
 __device__ __forceinline__ void row_to_out18(const double (&row)[KB_ROW], int e, double* out)
 {
-    if (threadIdx.x == 0) {
-        double sums[16];
-        num::limbs_to_sums(row, e, sums);
-        for (int k = 0; k < 16; k++) out[k] = sums[k];
+    const int k = threadIdx.x;
+    if (k < 6) out[k] = num::limbs_value(row + 3 * k, 2, e - 2 * num::KB_W);
+    else if (k < 15) out[k] = num::limbs_value(row + 18 + 4 * (k - 6), 3, 2 * e - 3 * num::KB_W);
+    else if (k == 15) out[15] = row[54];
+    else if (k == 16) {
         const unsigned long long lk = (unsigned long long)__double_as_longlong(row[55]);
-        out[16] = sums[15] > 0.0 ? (double)(uint32_t)(lk >> 32) : -1.0;
-        out[17] = sums[15] > 0.0 ? (double)__uint_as_float((uint32_t)(lk & 0xFFFFFFFFull)) : 0.0;
+        out[16] = row[54] > 0.0 ? (double)(uint32_t)(lk >> 32) : -1.0;
+        out[17] = row[54] > 0.0 ? (double)__uint_as_float((uint32_t)(lk & 0xFFFFFFFFull)) : 0.0;
         out[18] = row[56];
     }
 }
 
-__global__ __launch_bounds__(KB_BLOCK) void kabsch_final_kernel(const double* __restrict__ partials, uint32_t n_blocks, int e, double* __restrict__ out)
+__global__ __launch_bounds__(KF_BLOCK) void kabsch_final_kernel(const double* __restrict__ partials, uint32_t n_blocks, int e, double* __restrict__ out)
 {
-    __shared__ double red[KB_BLOCK / 64][KB_NL];
+    __shared__ double red[KF_GROUPS][64];
     __shared__ double row[KB_ROW];
     reduce_rows(partials, n_blocks, red, row);
     row_to_out18(row, e, out);
@@ -275,7 +305,7 @@ int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src,
     if (rc) return rc;
     {
         ProfScope p(ctx, "kabsch_final");
-        hipLaunchKernelGGL(kabsch_final_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, blocks, plan.e, ctx->dev_out);
+        hipLaunchKernelGGL(kabsch_final_kernel, dim3(1), dim3(KF_BLOCK), 0, ctx->stream, ctx->partials, blocks, plan.e, ctx->dev_out);
     }
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
@@ -311,25 +341,28 @@ __device__ void icp_state_step(IcpState* st, const double* sums16, bool any_kept
 }
 
 // single rank: reduce the block rows and advance the state in one launch
-__global__ __launch_bounds__(KB_BLOCK) void icp_update_kernel(const double* __restrict__ partials, uint32_t n_blocks, int e, IcpState* st,
+__global__ __launch_bounds__(KF_BLOCK) void icp_update_kernel(const double* __restrict__ partials, uint32_t n_blocks, int e, IcpState* st,
                                                               double* __restrict__ out)
 {
-    __shared__ double red[KB_BLOCK / 64][KB_NL];
+    __shared__ double red[KF_GROUPS][64];
     __shared__ double row[KB_ROW];
+    __shared__ double o18[19];
     if (st->stop) return;
     if (st->stop_after_transform) { if (threadIdx.x == 0) st->stop = 1; return; }
     reduce_rows(partials, n_blocks, red, row);
-    row_to_out18(row, e, out);
-    if (threadIdx.x == 0) icp_state_step(st, out, out[16] >= 0.0, (float)out[17], out[18] != 0.0);
+    row_to_out18(row, e, o18);
+    __syncthreads();
+    if (threadIdx.x < 19) out[threadIdx.x] = o18[threadIdx.x];
+    if (threadIdx.x == 0) icp_state_step(st, o18, o18[16] >= 0.0, (float)o18[17], o18[18] != 0.0);
 }
 
 // multi rank, step 1: reduce the block rows into the all-reduce buffer
 //   [0..54] normalised limbs, [55] overflow flag, [56 + 2r] kept flag of rank r, [57 + 2r] d2 of its last kept pair
 // (every entry is summed exactly by the all-reduce: integers below 2^40 x ranks, one non-zero flag pair per rank)
-__global__ __launch_bounds__(KB_BLOCK) void icp_reduce_slots_kernel(const double* __restrict__ partials, uint32_t n_blocks,
+__global__ __launch_bounds__(KF_BLOCK) void icp_reduce_slots_kernel(const double* __restrict__ partials, uint32_t n_blocks,
                                                                     double* __restrict__ out, int nranks, int rank, int have_points)
 {
-    __shared__ double red[KB_BLOCK / 64][KB_NL];
+    __shared__ double red[KF_GROUPS][64];
     __shared__ double row[KB_ROW];
     if (have_points) {
         reduce_rows(partials, n_blocks, red, row);
@@ -403,7 +436,7 @@ int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev, const K
 {
     {
         ProfScope p(ctx, "icp_update");
-        hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, plan.e, st_dev, ctx->dev_out);
+        hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(KF_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, plan.e, st_dev, ctx->dev_out);
     }
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
@@ -411,7 +444,7 @@ int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev, const K
 
 int launch_icp_reduce_slots(pcr_ctx* ctx, uint32_t n_blocks, int nranks, int rank, bool have_points)
 {
-    hipLaunchKernelGGL(icp_reduce_slots_kernel, dim3(1), dim3(KB_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, ctx->dev_out, nranks, rank,
+    hipLaunchKernelGGL(icp_reduce_slots_kernel, dim3(1), dim3(KF_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, ctx->dev_out, nranks, rank,
                        have_points ? 1 : 0);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
