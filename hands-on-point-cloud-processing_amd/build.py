@@ -18,7 +18,7 @@ OUT = os.path.join(HERE, "libpcr_hip.so")
 OBJ = os.path.join(HERE, "build")
 
 SOURCES = ["api.cpp", "numerics.cpp", "icp.cpp", "comm.cpp", "nn1_brute.hip", "kabsch.hip", "plane.hip",
-           "search_f64.hip", "grid.hip", "voxel.hip", "iss.hip", "desc.hip", "ground.hip", "knn_grid.hip", "radius_grid.hip", "p2plane.hip"]
+           "search_f64.hip", "grid.hip", "voxel.hip", "iss.hip", "desc.hip", "ground.hip", "knn_grid.hip", "radius_grid.hip", "p2plane.hip", "sort.hip"]
 
 # -ffp-contract=off: the distance arithmetic contract is UNFUSED (nanoflann.hpp:403-406 / kdtree.hpp:341-346);
 #   one fma changes d2 in the last bit and flips near-tie winners.

@@ -44,6 +44,18 @@ int ensure_scratch(pcr_ctx* ctx, size_t bytes)
     return PCR_OK;
 }
 
+int ensure_aux(pcr_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->aux_cap) return PCR_OK;
+    if (ctx->aux) { PCR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PCR_HIP(ctx, hipFree(ctx->aux)); }
+    ctx->aux = nullptr;
+    ctx->aux_cap = 0;
+    const size_t cap = (bytes + (1 << 20)) & ~((size_t)(1 << 20) - 1);
+    PCR_HIP(ctx, hipMalloc(&ctx->aux, cap));
+    ctx->aux_cap = cap;
+    return PCR_OK;
+}
+
 int ensure_stage(pcr_ctx* ctx, size_t bytes)
 {
     if (bytes <= ctx->host_stage_cap) return PCR_OK;
@@ -96,6 +108,7 @@ void cloud_modified(pcr_cloud* c)
 {
     if (c && c->grid) { grid_free(c->grid); c->grid = nullptr; }
     if (c && c->knn_grid) { grid_free(c->knn_grid); c->knn_grid = nullptr; c->knn_grid_factor = 0.0; }
+    if (c && c->rad_grid) { grid_free(c->rad_grid); c->rad_grid = nullptr; c->rad_grid_r = 0.0; }
     if (c) c->absmax = -1.f;
 }
 
@@ -187,6 +200,7 @@ int pcr_ctx_destroy(pcr_ctx* ctx)
     if (ctx->dev_out) hipFree(ctx->dev_out);
     if (ctx->host_out) hipHostFree(ctx->host_out);
     if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->aux) hipFree(ctx->aux);
     if (ctx->host_stage) hipHostFree(ctx->host_stage);
     hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -20,7 +20,7 @@
 // Traffic (algorithmic): 12 B query + 8 B key + 16 B per visited candidate + 8 B per visited cell row.
 #include "grid_common.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include "sort.hpp"
 
 #include <cmath>
 #include <vector>
@@ -846,7 +846,7 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, i
 {
     *out = nullptr;
     const size_t n = c->n;
-    if (n > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "grid index: more than 2^31 points (hipCUB item counts are int)");
+    if (n > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "grid index: more than 2^31 points");
     Grid* g = new (std::nothrow) Grid();
     if (!g) return fail(ctx, PCR_ERR_NOMEM, "grid");
     g->n_points = n;
@@ -930,8 +930,7 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, i
     int key_bits = 1;
     while (((size_t)1 << key_bits) < cells + 1) key_bits++;
     size_t temp_bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr,
-                                       (uint32_t*)nullptr, (int)n, 0, 32 + key_bits, ctx->stream);
+    sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, 32 + key_bits, ctx->stream);
     const size_t a4 = (n * 4 + 255) & ~(size_t)255, a8 = (n * 8 + 255) & ~(size_t)255;
     const size_t off_count = a4, off_tot = off_count + ((ncell * 4 + 255) & ~(size_t)255), off_kin = off_tot + (((nb + 2) * 4 + 255) & ~(size_t)255),
                  off_kout = off_kin + a8, off_vin = off_kout + a8, off_vout = off_vin + a4, off_temp = off_vout + a4;
@@ -961,7 +960,7 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, i
             hipLaunchKernelGGL(record_keys_kernel<false>, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of, k_in, v_in);
         else
             hipLaunchKernelGGL(record_keys_kernel<true>, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of, k_in, v_in);
-        e = hipcub::DeviceRadixSort::SortPairs(sc + off_temp, temp_bytes, k_in, k_out, v_in, v_out, (int)n, 0, 32 + key_bits, ctx->stream);
+        e = sort_pairs_u64_u32(sc + off_temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, 32 + key_bits, ctx->stream);
         if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "radix sort(grid)", e); }
         hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)((n_padded + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(),
                            (uint32_t)n, (uint32_t)n_padded, v_out, g->records);

@@ -13,7 +13,7 @@
 #include "pcr_internal.hpp"
 #include "eig3.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include "sort.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -129,7 +129,7 @@ int seed_upper_bound(pcr_ctx* ctx, const pcr_cloud* c, size_t lpr_size, double t
 {
     const size_t n = c->n;
     size_t temp_bytes = 0;
-    hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 32, ctx->stream);
+    sort_keys_u32(nullptr, temp_bytes, nullptr, nullptr, n, 0, 32, ctx->stream);
     const size_t kb = (n * 4 + 255) & ~(size_t)255;
     int rc = ensure_scratch(ctx, 2 * kb + 256 + temp_bytes + 256);
     if (rc) return rc;
@@ -142,7 +142,7 @@ int seed_upper_bound(pcr_ctx* ctx, const pcr_cloud* c, size_t lpr_size, double t
     {
         ProfScope ps(ctx, "ground_seed_select", 1);
         hipLaunchKernelGGL(gd_keys_kernel, dim3((unsigned)((n + GD_BLOCK - 1) / GD_BLOCK)), dim3(GD_BLOCK), 0, ctx->stream, c->z(), (uint32_t)n, k_in, n_cand_dev);
-        PCR_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, k_in, k_out, (int)n, 0, 32, ctx->stream));
+        PCR_HIP(ctx, sort_keys_u32(temp, temp_bytes, k_in, k_out, n, 0, 32, ctx->stream));
     }
     uint32_t m = 0;
     PCR_HIP(ctx, hipMemcpyAsync(&m, n_cand_dev, 4, hipMemcpyDeviceToHost, ctx->stream));

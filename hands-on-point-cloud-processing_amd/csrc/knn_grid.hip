@@ -90,13 +90,14 @@ __device__ __forceinline__ void scan_cells(const float4* __restrict__ records, u
     }
 }
 
-// perm == nullptr: query p is grid record p (self-query), row = its original index; else query = perm[t] of (qx, qy, qz)
+// perm == nullptr, direct == 0: query p is grid record p (self-query), row = its original index; perm: query = perm[t] of
+// (qx, qy, qz); direct: query t of (qx, qy, qz)
 template <int K, bool SQ>
 __global__ __launch_bounds__(KG_BLOCK) void knn_grid_kernel(const float4* __restrict__ records, const uint32_t* __restrict__ cell_start, GridParams g,
                                                             const float* __restrict__ qxs, const float* __restrict__ qys, const float* __restrict__ qzs,
                                                             const uint32_t* __restrict__ perm, uint32_t m, int k_out, double cap_s, double empty_val,
                                                             int32_t empty_idx, int32_t* __restrict__ idx_out, double* __restrict__ val_out,
-                                                            uint32_t* __restrict__ found_out)
+                                                            uint32_t* __restrict__ found_out, int direct)
 {
     const uint32_t tq = blockIdx.x * KG_BLOCK + threadIdx.x;
     if (tq >= m) return;
@@ -105,6 +106,9 @@ __global__ __launch_bounds__(KG_BLOCK) void knn_grid_kernel(const float4* __rest
     if (perm) {
         row = perm[tq];
         fx = qxs[row]; fy = qys[row]; fz = qzs[row];
+    } else if (direct) {                 // a small batch, searched in the order given (cloud_knn_small)
+        row = tq;
+        fx = qxs[tq]; fy = qys[tq]; fz = qzs[tq];
     } else {
         const float4 rec = records[tq];
         row = __float_as_uint(rec.w);
@@ -260,10 +264,10 @@ int knn_grid_device(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k
     do {                                                                                                                                    \
         if (squared)                                                                                                                        \
             hipLaunchKernelGGL((knn_grid_kernel<KK, true>), grid, dim3(KG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, q->x(), q->y(), q->z(), \
-                               perm, (uint32_t)m, k, cap_s, empty_val, empty_idx, *idx_dev, *val_dev, *found_dev);                             \
+                               perm, (uint32_t)m, k, cap_s, empty_val, empty_idx, *idx_dev, *val_dev, *found_dev, 0);                          \
         else                                                                                                                                \
             hipLaunchKernelGGL((knn_grid_kernel<KK, false>), grid, dim3(KG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, q->x(), q->y(), q->z(), \
-                               perm, (uint32_t)m, k, cap_s, empty_val, empty_idx, *idx_dev, *val_dev, *found_dev);                             \
+                               perm, (uint32_t)m, k, cap_s, empty_val, empty_idx, *idx_dev, *val_dev, *found_dev, 0);                          \
     } while (0)
         if (k <= 1) PCR_KG(1);
         else if (k <= 4) PCR_KG(4);
@@ -280,6 +284,59 @@ int knn_grid_device(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k
 }
 
 }  // namespace
+
+// Small batches (m <= KNN_SMALL_MAX queries given on the host as f32 rows): ONE launch and one stream synchronisation — no
+// query cloud, no result allocation, no copy command.  The kernel reads the queries from pinned host memory and writes the
+// rows there (zero-copy over PCIe: a few hundred bytes per query); the widened grid of db is cached on the cloud.
+// A driver that asks one question at a time (KDTreeKNNSearch per query, nanoflann findNeighbors) pays a launch + a wake-up
+// per call instead of the 13 ms single-lane scan of the exhaustive kernel.
+int cloud_knn_small(pcr_ctx* ctx, const pcr_cloud* db, const float* q_rows, size_t m, int k, double cap_s, bool squared, double empty_val,
+                    int32_t empty_idx, int32_t* idx, double* val)
+{
+    if (m == 0) return PCR_OK;
+    Grid* g = nullptr;
+    bool owned = false;
+    int rc = knn_grid_for(ctx, db, k, &g, &owned);
+    if (rc) return rc;
+    const size_t mp = (m + 63) & ~(size_t)63;
+    const size_t off_val = (3 * mp * 4 + 255) & ~(size_t)255, off_idx = off_val + ((m * (size_t)k * 8 + 255) & ~(size_t)255),
+                 off_found = off_idx + ((m * (size_t)k * 4 + 255) & ~(size_t)255), total = off_found + m * 4 + 256;
+    rc = ensure_stage(ctx, total);
+    if (rc == PCR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, PCR_ERR_HIP, "knn small: sync");
+    if (rc) { if (owned) grid_free(g); return rc; }
+    char* st = (char*)ctx->host_stage;
+    float* qx = (float*)st; float* qy = qx + mp; float* qz = qy + mp;
+    for (size_t i = 0; i < m; i++) { qx[i] = q_rows[3 * i]; qy[i] = q_rows[3 * i + 1]; qz[i] = q_rows[3 * i + 2]; }
+    double* val_p = (double*)(st + off_val);
+    int32_t* idx_p = (int32_t*)(st + off_idx);
+    uint32_t* found_p = (uint32_t*)(st + off_found);
+    {
+        ProfScope p(ctx, "knn_grid", 1);
+        const dim3 grid((unsigned)((m + KG_BLOCK - 1) / KG_BLOCK));
+#define PCR_KG(KK)                                                                                                                          \
+    do {                                                                                                                                    \
+        if (squared)                                                                                                                        \
+            hipLaunchKernelGGL((knn_grid_kernel<KK, true>), grid, dim3(KG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, qx, qy, qz, \
+                               (const uint32_t*)nullptr, (uint32_t)m, k, cap_s, empty_val, empty_idx, idx_p, val_p, found_p, 1);             \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((knn_grid_kernel<KK, false>), grid, dim3(KG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, qx, qy, qz, \
+                               (const uint32_t*)nullptr, (uint32_t)m, k, cap_s, empty_val, empty_idx, idx_p, val_p, found_p, 1);             \
+    } while (0)
+        if (k <= 1) PCR_KG(1);
+        else if (k <= 4) PCR_KG(4);
+        else if (k <= 8) PCR_KG(8);
+        else if (k <= 16) PCR_KG(16);
+        else PCR_KG(32);
+#undef PCR_KG
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (owned) grid_free(g);
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "knn small", e);
+    memcpy(idx, idx_p, m * (size_t)k * 4);
+    memcpy(val, val_p, m * (size_t)k * 8);
+    return PCR_OK;
+}
 
 int cloud_knn_host(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k, double cap_s, bool squared, double empty_val, int32_t empty_idx,
                    int32_t* idx, double* val, uint32_t* found)

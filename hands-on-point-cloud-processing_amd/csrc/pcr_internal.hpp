@@ -70,6 +70,8 @@ struct pcr_cloud {
     pcr::Grid* grid = nullptr;   // exact-NN index over this cloud as a target; built lazily, dropped on modification
     pcr::Grid* knn_grid = nullptr;   // the same index with the wider cell of the last k-NN batch (knn_grid.hip), same lifetime
     double knn_grid_factor = 0.0;    // its cell edge / grid's cell edge
+    pcr::Grid* rad_grid = nullptr;   // the index with cell edge 1.01 r of the last radius search (radius_grid.hip), same lifetime
+    double rad_grid_r = 0.0;
     float absmax = -1.f;             // largest finite |coordinate| (cloud_absmax), < 0: not computed; same lifetime as the grids
     size_t n = 0;
     size_t cap = 0;     // padded length of each of x, y, z
@@ -118,6 +120,8 @@ struct pcr_ctx {
     size_t scratch_cap = 0;
     void* host_stage = nullptr;           // pinned staging for uploads / downloads
     size_t host_stage_cap = 0;
+    void* aux = nullptr;                  // second device scratch (partial results of sliced searches), grows on demand
+    size_t aux_cap = 0;
     pcr::IcpState* icp_state_dev = nullptr;    // pipelined ICP: device state, pinned snapshots, snapshot events
     pcr::IcpState* icp_state_host = nullptr;
     hipEvent_t icp_events[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -145,6 +149,7 @@ int fail(pcr_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
 int ensure_keys(pcr_ctx* ctx, size_t n);
 int ensure_scratch(pcr_ctx* ctx, size_t bytes);
 int ensure_stage(pcr_ctx* ctx, size_t bytes);
+int ensure_aux(pcr_ctx* ctx, size_t bytes);
 int64_t tune_get(const pcr_ctx* ctx, const char* key, int64_t dflt);
 
 // profiling: record a (start, stop) event pair around a launch on ctx->stream
@@ -168,6 +173,10 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
 // exact grid k-NN between resident clouds (knn_grid.hip); host outputs idx/val [m x k], found [m] (optional)
 int cloud_knn_host(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k, double cap_s, bool squared, double empty_val, int32_t empty_idx,
                    int32_t* idx, double* val, uint32_t* found);
+// the same for a small batch of host queries (f32 rows): one launch, zero-copy in and out
+constexpr size_t KNN_SMALL_MAX = 4096;
+int cloud_knn_small(pcr_ctx* ctx, const pcr_cloud* db, const float* q_rows, size_t m, int k, double cap_s, bool squared, double empty_val,
+                    int32_t empty_idx, int32_t* idx, double* val);
 // device-wide exclusive scan of u32 (grid.hip): totals needs ceil(n / SCAN_TILE) + 1 words
 constexpr int SCAN_TILE = 2048;
 int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* totals, uint32_t* grand);
@@ -197,9 +206,9 @@ int launch_plane_mask(pcr_ctx* ctx, const pcr_cloud* pts, const double plane4[4]
 int launch_knn_f64(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m,
                    int k, int32_t* idx_dev, double* dist_dev, bool squared);
 int launch_radius_count(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa,
-                        size_t m, double r, unsigned long long* counts_dev);
+                        size_t m, double r, unsigned long long* counts_dev, uint32_t slices);
 int launch_radius_fill(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa,
-                       size_t m, double r, const long long* row_ptr_dev, int32_t* idx_dev, double* dist_dev);
+                       size_t m, double r, const long long* row_ptr_dev, int32_t* idx_dev, double* dist_dev, uint32_t slices);
 
 // ---- host numerics ------------------------------------------------------------------------------------
 void svd3(const double A[9], double U[9], double S[3], double V[9]);

@@ -7,11 +7,11 @@
 //   pass 1  count    32 lanes per query (cell-sorted queries), membership s <= r2max (the sqrt hoisted, search_f64.hip)
 //   scan             row_ptr
 //   pass 2  fill     same walk, members compacted with a ballot prefix -> indices in grid order
-//   sort             hipCUB segmented radix sort of every row (log2(n) bits) -> ascending index, the canonical order
+//   sort             rocPRIM segmented radix sort of every row (log2(n) bits) -> ascending index, the canonical order
 //   pass 3  dist     d = sqrt(s) recomputed per reported pair
 #include "grid_common.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include "sort.hpp"
 
 #include <cmath>
 #include <vector>
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(RG_BLOCK) void radius_grid_kernel(const float4* __r
     const uint32_t tq = (blockIdx.x * RG_BLOCK + threadIdx.x) / RG_G;
     const int sub = threadIdx.x % RG_G;
     if (tq >= m) return;                                   // whole groups leave together
-    const uint32_t qi = perm[tq];
+    const uint32_t qi = perm ? perm[tq] : tq;
     const float fx = qxs[qi], fy = qys[qi], fz = qzs[qi];
     uint32_t c = 0;
     uint32_t w = FILL ? row_ptr[qi] : 0u;
@@ -146,13 +146,22 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
     *used = false;
     const size_t n = db->n, m = q->n;
     if (n == 0 || m == 0 || !(r > 0.0) || !std::isfinite(r) || r2max < 0.0) return PCR_OK;
-    Grid* g = nullptr;
-    {
+    // the index with cell edge 1.01 r is kept on the database cloud (one slot: the radius of the last search), so that a driver
+    // asking one query at a time with the same radius — KDTreeRadiusNNSearch per point — builds it once
+    pcr_cloud* mdb = const_cast<pcr_cloud*>(db);
+    if (!(mdb->rad_grid && mdb->rad_grid_r == r)) {
+        if (mdb->rad_grid) {
+            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            grid_free(mdb->rad_grid); mdb->rad_grid = nullptr; mdb->rad_grid_r = 0.0;
+        }
         ProfScope ps(ctx, "radius_grid_build");
-        int rc = grid_build(ctx, db, &g, std::max(r * 1.01, 2e-15));
+        Grid* built = nullptr;
+        int rc = grid_build(ctx, db, &built, std::max(r * 1.01, 2e-15));
         if (rc) return rc;
+        mdb->rad_grid = built;
+        mdb->rad_grid_r = r;
     }
-    struct GridGuard { Grid* g; ~GridGuard() { grid_free(g); } } guard{ g };
+    Grid* g = mdb->rad_grid;
     // the cell budget may have enlarged the cells: fine.  A cell much SMALLER than asked cannot happen; a grid of a few
     // cells only (radius ~ extent) is the exhaustive scan in disguise: leave that to the tiled kernels
     if ((double)g->p.h < r * 1.005) return fail(ctx, PCR_ERR_STATE, "radius_grid: cell smaller than the radius");
@@ -165,12 +174,12 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
         hipLaunchKernelGGL(record_index_kernel, dim3((unsigned)((m + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, ctx->stream, g->records, (uint32_t)m,
                            (uint32_t*)permbuf.p);
         perm = (const uint32_t*)permbuf.p;
-    } else {
+    } else if (m > KNN_SMALL_MAX) {
         ProfScope ps(ctx, "grid_sort_queries");
         int rc = grid_prepare_queries(ctx, db, q);           // coarse cells of db's cached 1-NN grid: any spatial grouping will do
         if (rc) return rc;
         perm = ctx->qperm;
-    }
+    }                                                         // (a small batch is searched in the order given: perm stays null)
     const float win = (float)(r * 1.00001) + 1e-30f;
     DevBuf cnt, rows;
     PCR_HIP(ctx, hipMalloc(&cnt.p, (m + 1) * 4));
@@ -188,7 +197,7 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
     uint64_t acc = 0;
     for (size_t i = 0; i < m; i++) { row_ptr_host[i] = (int64_t)acc; acc += hc[i]; }
     row_ptr_host[m] = (int64_t)acc;
-    if (acc >= 0x7FFFFFF0ull) return PCR_OK;                   // 32-bit offsets / hipCUB item counts: exhaustive path (which redoes the counts)
+    if (acc >= 0x7FFFFFF0ull) return PCR_OK;                   // 32-bit offsets / item counts: exhaustive path (which redoes the counts)
     *used = true;
     if (!idx_host || acc == 0) return PCR_OK;
     const size_t total = (size_t)acc;
@@ -207,14 +216,14 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
     int bits = 1;
     while (((size_t)1 << bits) < n) bits++;
     size_t temp_bytes = 0;
-    PCR_HIP(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, temp_bytes, (const uint32_t*)idx_a.p, (uint32_t*)idx_b.p, (int)total, (int)m,
-                                                          (const uint32_t*)rows.p, (const uint32_t*)rows.p + 1, 0, bits, ctx->stream));
+    PCR_HIP(ctx, segmented_sort_keys_u32(nullptr, temp_bytes, (const uint32_t*)idx_a.p, (uint32_t*)idx_b.p, total, m, (const uint32_t*)rows.p,
+                                         (const uint32_t*)rows.p + 1, 0, bits, ctx->stream));
     DevBuf temp;
     PCR_HIP(ctx, hipMalloc(&temp.p, std::max<size_t>(temp_bytes, 16)));
     {
         ProfScope ps(ctx, "radius_sort", 1);
-        PCR_HIP(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(temp.p, temp_bytes, (const uint32_t*)idx_a.p, (uint32_t*)idx_b.p, (int)total, (int)m,
-                                                              (const uint32_t*)rows.p, (const uint32_t*)rows.p + 1, 0, bits, ctx->stream));
+        PCR_HIP(ctx, segmented_sort_keys_u32(temp.p, temp_bytes, (const uint32_t*)idx_a.p, (uint32_t*)idx_b.p, total, m, (const uint32_t*)rows.p,
+                                             (const uint32_t*)rows.p + 1, 0, bits, ctx->stream));
     }
     {
         ProfScope ps(ctx, "radius_dist", 1);

@@ -30,10 +30,13 @@ __device__ __forceinline__ double dist2_f64(double t0, double t1, double t2, dou
 
 // SQ = false: hw2 contract (d = sqrt(s), kdtree.hpp:346); SQ = true: nanoflann contract (squared L2, no sqrt,
 // nanoflann.hpp:403-406 with T = double) - ordering then happens on s itself.
+// Small batches: the database is cut into gridDim.y slices of tiles_per_slice tiles, each (query block, slice) workgroup keeps
+// the top k of its slice (written to the slice's own [m x k] block of the output), knn_merge_kernel folds the slices in
+// ascending order — the same scan order, so the same canonical result.  gridDim.y == 1: the whole database, final output.
 template <int K, bool SQ>
 __global__ __launch_bounds__(SF_BLOCK) void knn_f64_kernel(
     const double* __restrict__ db, uint32_t n, uint32_t n_cap, const double* __restrict__ q, uint32_t m,
-    uint32_t m_cap, int k_out, int32_t* __restrict__ idx_out, double* __restrict__ dist_out)
+    uint32_t m_cap, int k_out, int32_t* __restrict__ idx_out, double* __restrict__ dist_out, uint32_t tiles_per_slice)
 {
     __shared__ double l0[SF_TILE], l1[SF_TILE], l2[SF_TILE];
     const uint32_t qi = blockIdx.x * SF_BLOCK + threadIdx.x;
@@ -44,14 +47,16 @@ __global__ __launch_bounds__(SF_BLOCK) void knn_f64_kernel(
 #pragma unroll
     // hw2: slots pre-filled with (1e10, 0), resultSet.hpp:35-42; nanoflann: worst = DBL_MAX (nanoflann.hpp:163)
     for (int s = 0; s < K; s++) { bd[s] = SQ ? 1.7976931348623157e308 : 1e10; bi[s] = SQ ? -1 : 0; }
-    for (uint32_t base = 0; base < n; base += SF_TILE) {
+    const uint32_t slice_lo = blockIdx.y * tiles_per_slice * SF_TILE;
+    const uint32_t slice_hi = (uint32_t)min((unsigned long long)n, (unsigned long long)slice_lo + (unsigned long long)tiles_per_slice * SF_TILE);
+    for (uint32_t base = slice_lo; base < slice_hi; base += SF_TILE) {
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < SF_TILE; t += SF_BLOCK) {
             const uint32_t j = base + t;    // < n_cap by construction (n_cap is a multiple of SF_TILE)
             l0[t] = db[j]; l1[t] = db[n_cap + j]; l2[t] = db[2 * (size_t)n_cap + j];
         }
         __syncthreads();
-        const uint32_t cnt = min((uint32_t)SF_TILE, n - base);
+        const uint32_t cnt = min((uint32_t)SF_TILE, slice_hi - base);
         for (uint32_t t = 0; t < cnt; t++) {
             const double s2 = dist2_f64(l0[t], l1[t], l2[t], q0, q1, q2);
             const double d = SQ ? s2 : sqrt(s2);
@@ -79,22 +84,66 @@ __global__ __launch_bounds__(SF_BLOCK) void knn_f64_kernel(
         }
     }
     if (qi < m) {
+        const size_t o = ((size_t)blockIdx.y * m + qi) * (size_t)k_out;
 #pragma unroll
         for (int s = 0; s < K; s++) {
             if (s < k_out) {
-                idx_out[(size_t)qi * k_out + s] = bi[s];
-                dist_out[(size_t)qi * k_out + s] = bd[s];
+                idx_out[o + s] = bi[s];
+                dist_out[o + s] = bd[s];
             }
         }
     }
 }
 
+// one lane per query: the per-slice top-k lists (each sorted, slices in ascending index order) -> the final list.  An entry is
+// inserted only if strictly smaller than the current worst (equal distances keep the earlier = lower index, the canonical
+// rule); a slice's list is left as soon as one of its entries fails, the rest being no smaller.
+template <int K>
+__global__ __launch_bounds__(SF_BLOCK) void knn_merge_kernel(const int32_t* __restrict__ pidx, const double* __restrict__ pdist, uint32_t m, int k_out,
+                                                             uint32_t slices, double empty_val, int32_t empty_idx, int32_t* __restrict__ idx_out,
+                                                             double* __restrict__ dist_out)
+{
+    const uint32_t qi = blockIdx.x * SF_BLOCK + threadIdx.x;
+    if (qi >= m) return;
+    double bd[K];
+    int32_t bi[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) { bd[s] = empty_val; bi[s] = empty_idx; }
+    for (uint32_t sl = 0; sl < slices; sl++) {
+        const size_t o = ((size_t)sl * m + qi) * (size_t)k_out;
+        for (int e = 0; e < k_out; e++) {
+            const double d = pdist[o + e];
+            const int32_t j = pidx[o + e];
+            if (!(d < bd[K - 1]) || (d == empty_val && j == empty_idx)) break;       // (placeholders of a short slice never enter)
+            double cd = d;
+            int32_t ci = j;
+            bool placed = false;
+#pragma unroll
+            for (int s = 0; s < K; s++) {
+                const bool sw = placed || cd < bd[s];
+                placed = sw;
+                const double td = bd[s];
+                const int32_t ti = bi[s];
+                bd[s] = sw ? cd : td;
+                bi[s] = sw ? ci : ti;
+                cd = sw ? td : cd;
+                ci = sw ? ti : ci;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < K; s++)
+        if (s < k_out) { idx_out[(size_t)qi * k_out + s] = bi[s]; dist_out[(size_t)qi * k_out + s] = bd[s]; }
+}
+
 // FILL = false: counts[q] = #{j : s_j <= r2max}; FILL = true: write idx/dist at row_ptr[q]...
+// slices as in knn_f64_kernel: counts / write offsets are per (query, slice), query-major — counts[q * gridDim.y + slice] — so
+// that the host's running sum puts the slices of a row one after the other in ascending index order
 template <bool FILL>
 __global__ __launch_bounds__(SF_BLOCK) void radius_f64_kernel(
     const double* __restrict__ db, uint32_t n, uint32_t n_cap, const double* __restrict__ q, uint32_t m,
     uint32_t m_cap, double r2max, unsigned long long* __restrict__ counts, const long long* __restrict__ row_ptr,
-    int32_t* __restrict__ idx_out, double* __restrict__ dist_out)
+    int32_t* __restrict__ idx_out, double* __restrict__ dist_out, uint32_t tiles_per_slice)
 {
     __shared__ double l0[SF_TILE], l1[SF_TILE], l2[SF_TILE];
     const uint32_t qi = blockIdx.x * SF_BLOCK + threadIdx.x;
@@ -102,15 +151,17 @@ __global__ __launch_bounds__(SF_BLOCK) void radius_f64_kernel(
     const double q0 = q[qc], q1 = q[m_cap + qc], q2 = q[2 * (size_t)m_cap + qc];
     unsigned long long c = 0;
     long long w = 0;
-    if (FILL) w = row_ptr[qc];
-    for (uint32_t base = 0; base < n; base += SF_TILE) {
+    if (FILL) w = row_ptr[(size_t)qc * gridDim.y + blockIdx.y];
+    const uint32_t slice_lo = blockIdx.y * tiles_per_slice * SF_TILE;
+    const uint32_t slice_hi = (uint32_t)min((unsigned long long)n, (unsigned long long)slice_lo + (unsigned long long)tiles_per_slice * SF_TILE);
+    for (uint32_t base = slice_lo; base < slice_hi; base += SF_TILE) {
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < SF_TILE; t += SF_BLOCK) {
             const uint32_t j = base + t;
             l0[t] = db[j]; l1[t] = db[n_cap + j]; l2[t] = db[2 * (size_t)n_cap + j];
         }
         __syncthreads();
-        const uint32_t cnt = min((uint32_t)SF_TILE, n - base);
+        const uint32_t cnt = min((uint32_t)SF_TILE, slice_hi - base);
         for (uint32_t t = 0; t < cnt; t++) {
             const double s = dist2_f64(l0[t], l1[t], l2[t], q0, q1, q2);
             if (s <= r2max) {
@@ -126,7 +177,22 @@ __global__ __launch_bounds__(SF_BLOCK) void radius_f64_kernel(
             }
         }
     }
-    if (!FILL && qi < m) counts[qi] = c;
+    if (!FILL && qi < m) counts[(size_t)qi * gridDim.y + blockIdx.y] = c;
+}
+
+// How many database slices a batch of m queries is spread over: one query per lane leaves the chip idle when m is small
+// (a single query scanned 100 000 points with ONE lane: 13 ms), so small batches cut the database into enough slices for
+// ~1024 workgroups; `bytes_per_query_slice` bounds the partial results (4 MB).
+static uint32_t search_slices(size_t n, size_t m, size_t bytes_per_query_slice)
+{
+    const size_t n_tiles = std::max<size_t>(1, (n + SF_TILE - 1) / SF_TILE);
+    const size_t qblocks = (m + SF_BLOCK - 1) / SF_BLOCK;
+    size_t slices = std::min(n_tiles, std::max<size_t>(1, 1024 / qblocks));
+    const size_t mem_cap = std::max<size_t>(1, ((size_t)4 << 20) / std::max<size_t>(1, m * bytes_per_query_slice));
+    slices = std::min(slices, mem_cap);
+    if (slices < 2) return 1;
+    const size_t tps = (n_tiles + slices - 1) / slices;
+    return (uint32_t)((n_tiles + tps - 1) / tps);
 }
 
 int launch_knn_f64(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m, int k,
@@ -134,15 +200,30 @@ int launch_knn_f64(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, c
 {
     const uint32_t blocks = (uint32_t)((m + SF_BLOCK - 1) / SF_BLOCK);
     const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
+    const size_t n_tiles = std::max<size_t>(1, (n + SF_TILE - 1) / SF_TILE);
+    const uint32_t slices = tune_get(ctx, "knn_slices", 1) == 1 ? search_slices(n, m, (size_t)k * 12) : 1u;
+    const uint32_t tps = (uint32_t)((n_tiles + slices - 1) / slices);
+    int32_t* pidx = idx_dev;
+    double* pdist = dist_dev;
+    if (slices > 1) {
+        const size_t pd = (((size_t)slices * m * (size_t)k * 8) + 255) & ~(size_t)255;
+        int rc = ensure_aux(ctx, pd + (size_t)slices * m * (size_t)k * 4 + 256);
+        if (rc) return rc;
+        pdist = (double*)ctx->aux;
+        pidx = (int32_t*)((char*)ctx->aux + pd);
+    }
     ProfScope p(ctx, "knn_f64");
 #define PCR_KNN(K)                                                                                              \
     do {                                                                                                        \
         if (squared)                                                                                            \
-            hipLaunchKernelGGL((knn_f64_kernel<K, true>), dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, db_soa,  \
-                               (uint32_t)n, (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, k, idx_dev, dist_dev); \
+            hipLaunchKernelGGL((knn_f64_kernel<K, true>), dim3(blocks, slices), dim3(SF_BLOCK), 0, ctx->stream, db_soa,  \
+                               (uint32_t)n, (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, k, pidx, pdist, tps); \
         else                                                                                                    \
-            hipLaunchKernelGGL((knn_f64_kernel<K, false>), dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, db_soa, \
-                               (uint32_t)n, (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, k, idx_dev, dist_dev); \
+            hipLaunchKernelGGL((knn_f64_kernel<K, false>), dim3(blocks, slices), dim3(SF_BLOCK), 0, ctx->stream, db_soa, \
+                               (uint32_t)n, (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, k, pidx, pdist, tps); \
+        if (slices > 1)                                                                                         \
+            hipLaunchKernelGGL((knn_merge_kernel<K>), dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, pidx, pdist, (uint32_t)m, k, slices, \
+                               squared ? 1.7976931348623157e308 : 1e10, squared ? -1 : 0, idx_dev, dist_dev);     \
     } while (0)
     if (k <= 1) PCR_KNN(1);
     else if (k <= 4) PCR_KNN(4);
@@ -154,28 +235,34 @@ int launch_knn_f64(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, c
     return PCR_OK;
 }
 
+// counts_dev: m * slices entries, query-major (see radius_f64_kernel)
 int launch_radius_count(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m,
-                        double r2max, unsigned long long* counts_dev)
+                        double r2max, unsigned long long* counts_dev, uint32_t slices)
 {
     const uint32_t blocks = (uint32_t)((m + SF_BLOCK - 1) / SF_BLOCK);
     const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
+    const size_t n_tiles = std::max<size_t>(1, (n + SF_TILE - 1) / SF_TILE);
+    const uint32_t tps = (uint32_t)((n_tiles + slices - 1) / slices);
     ProfScope p(ctx, "radius_count");
-    hipLaunchKernelGGL(radius_f64_kernel<false>, dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, db_soa, (uint32_t)n,
+    hipLaunchKernelGGL(radius_f64_kernel<false>, dim3(blocks, slices), dim3(SF_BLOCK), 0, ctx->stream, db_soa, (uint32_t)n,
                        (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, r2max, counts_dev,
-                       (const long long*)nullptr, (int32_t*)nullptr, (double*)nullptr);
+                       (const long long*)nullptr, (int32_t*)nullptr, (double*)nullptr, tps);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
 
+// row_ptr_dev: write offset of every (query, slice), query-major
 int launch_radius_fill(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m,
-                       double r2max, const long long* row_ptr_dev, int32_t* idx_dev, double* dist_dev)
+                       double r2max, const long long* row_ptr_dev, int32_t* idx_dev, double* dist_dev, uint32_t slices)
 {
     const uint32_t blocks = (uint32_t)((m + SF_BLOCK - 1) / SF_BLOCK);
     const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
+    const size_t n_tiles = std::max<size_t>(1, (n + SF_TILE - 1) / SF_TILE);
+    const uint32_t tps = (uint32_t)((n_tiles + slices - 1) / slices);
     ProfScope p(ctx, "radius_fill");
-    hipLaunchKernelGGL(radius_f64_kernel<true>, dim3(blocks), dim3(SF_BLOCK), 0, ctx->stream, db_soa, (uint32_t)n,
+    hipLaunchKernelGGL(radius_f64_kernel<true>, dim3(blocks, slices), dim3(SF_BLOCK), 0, ctx->stream, db_soa, (uint32_t)n,
                        (uint32_t)n_cap, q_soa, (uint32_t)m, (uint32_t)m_cap, r2max, (unsigned long long*)nullptr,
-                       row_ptr_dev, idx_dev, dist_dev);
+                       row_ptr_dev, idx_dev, dist_dev, tps);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
@@ -283,12 +370,15 @@ extern "C" int pcr_db64_knn(pcr_ctx* ctx, const pcr_db64* db, const double* q, s
     if (m == 0) return PCR_OK;
     if (m > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_db64_knn: too many queries");
     PCR_HIP(ctx, hipSetDevice(ctx->device));
-    // large batches on f32-representable data: the exact grid search returns the same answers (same arithmetic, same
-    // canonical order) without touching all n x m pairs; knn_method 1 forces the exhaustive scan, 2 the grid
+    // f32-representable data (KITTI / PLY floats widened to f64): the exact grid search returns the same answers (same
+    // arithmetic, same canonical order) without touching all n x m pairs — small batches through one zero-copy launch
+    // (cloud_knn_small), large ones through a query cloud; knn_method 1 forces the exhaustive scan
     const int64_t method = tune_get(ctx, "knn_method", 0);
-    if (db->twin && method != 1 && (method == 2 || (double)db->n * (double)m >= 6.7e7)) {
+    if (db->twin && method != 1) {
         std::vector<float> qf;
         if (f32_exact(q, m, qf)) {
+            if (m <= KNN_SMALL_MAX && method != 3)       // (3 = the batch route even for a small batch: A/B)
+                return cloud_knn_small(ctx, db->twin, qf.data(), m, k, INFINITY, squared != 0, squared ? 1.7976931348623157e308 : 1e10, squared ? -1 : 0, idx, dist);
             pcr_cloud* qc = nullptr;
             int rcq = pcr_cloud_create(ctx, qf.data(), m, PCR_AOS3, &qc);
             if (rcq) return rcq;
@@ -324,15 +414,30 @@ extern "C" int pcr_db64_radius(pcr_ctx* ctx, const pcr_db64* db, const double* q
     // large batches on f32-representable data: the grid walk (27 cells of edge 1.01 r, rows cut to |x - qx| <= r) returns the
     // same CSR rows without touching all n x m pairs; radius_method 1 forces the exhaustive scan, 2 the grid
     const int64_t rmethod = tune_get(ctx, "radius_method", 0);
-    if (db->twin && rmethod != 1 && (rmethod == 2 || (double)db->n * (double)m >= 6.7e7)) {
+    if (db->twin && rmethod != 1) {
         std::vector<float> qf;
         if (f32_exact(q, m, qf)) {
-            pcr_cloud* qc = nullptr;
-            int rcq = pcr_cloud_create(ctx, qf.data(), m, PCR_AOS3, &qc);
-            if (rcq) return rcq;
             bool used = false;
-            rcq = radius_grid(ctx, db->twin, qc, r, r2max, row_ptr, idx, dist, &used);
-            pcr_cloud_destroy(ctx, qc);
+            int rcq;
+            if (m <= KNN_SMALL_MAX) {
+                // small batch: the queries stay in pinned host memory (a cloud VIEW over it: no allocation, no upload)
+                const size_t mp = (m + 63) & ~(size_t)63;
+                rcq = ensure_stage(ctx, 3 * mp * 4 + 256);
+                if (rcq) return rcq;
+                PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                float* st = (float*)ctx->host_stage;
+                for (size_t i = 0; i < m; i++) { st[i] = qf[3 * i]; st[mp + i] = qf[3 * i + 1]; st[2 * mp + i] = qf[3 * i + 2]; }
+                pcr_cloud view;
+                view.n = m; view.cap = mp; view.base = st;
+                rcq = radius_grid(ctx, db->twin, &view, r, r2max, row_ptr, idx, dist, &used);
+                view.base = nullptr;
+            } else {
+                pcr_cloud* qc = nullptr;
+                rcq = pcr_cloud_create(ctx, qf.data(), m, PCR_AOS3, &qc);
+                if (rcq) return rcq;
+                rcq = radius_grid(ctx, db->twin, qc, r, r2max, row_ptr, idx, dist, &used);
+                pcr_cloud_destroy(ctx, qc);
+            }
             if (rcq) return rcq;
             prof_flush(ctx);
             if (used) return PCR_OK;
@@ -340,19 +445,27 @@ extern "C" int pcr_db64_radius(pcr_ctx* ctx, const pcr_db64* db, const double* q
     }
     const size_t n = db->n, n_cap = db->cap;
     const size_t m_cap = ((m + SF_TILE - 1) / SF_TILE) * SF_TILE;
-    const size_t bytes_q = 3 * m_cap * 8, bytes_c = (m + 1) * 8;
+    // small batches: the database in slices (search_slices); counts and write offsets are per (query, slice), query-major
+    const uint32_t slices = tune_get(ctx, "knn_slices", 1) == 1 ? search_slices(n, m, 16) : 1u;
+    const size_t ms = m * (size_t)slices;
+    const size_t bytes_q = 3 * m_cap * 8, bytes_c = (ms + 1) * 8;
     const size_t off_c = bytes_q;
     int rc = ensure_scratch(ctx, off_c + bytes_c + 64);
     if (rc) return rc;
     char* s = (char*)ctx->scratch;
     if ((rc = upload_soa_f64(ctx, q, m, m_cap, (double*)s))) return rc;
-    // pass 1: counts -> exclusive scan on the host (m+1 words)
-    if ((rc = launch_radius_count(ctx, db->dev, n, n_cap, (double*)s, m, r2max, (unsigned long long*)(s + off_c)))) return rc;
-    std::vector<unsigned long long> cnt(m);
-    PCR_HIP(ctx, hipMemcpyAsync(cnt.data(), s + off_c, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // pass 1: counts -> exclusive scan on the host
+    if ((rc = launch_radius_count(ctx, db->dev, n, n_cap, (double*)s, m, r2max, (unsigned long long*)(s + off_c), slices))) return rc;
+    std::vector<unsigned long long> cnt(ms);
+    PCR_HIP(ctx, hipMemcpyAsync(cnt.data(), s + off_c, ms * 8, hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<long long> offs(ms + 1);
     int64_t acc = 0;
-    for (size_t i = 0; i < m; i++) { row_ptr[i] = acc; acc += (int64_t)cnt[i]; }
+    for (size_t i = 0; i < m; i++) {
+        row_ptr[i] = acc;
+        for (uint32_t sl = 0; sl < slices; sl++) { offs[i * slices + sl] = acc; acc += (int64_t)cnt[i * slices + sl]; }
+    }
+    offs[ms] = acc;
     row_ptr[m] = acc;
     if (!idx || acc == 0) return PCR_OK;
     // pass 2: fill (result buffers are separate allocations: growing the scratch would drop the uploaded queries)
@@ -362,9 +475,9 @@ extern "C" int pcr_db64_radius(pcr_ctx* ctx, const pcr_db64* db, const double* q
     PCR_HIP(ctx, hipMalloc((void**)&idx_dev, total * 4));
     hipError_t e = hipMalloc((void**)&dist_dev, total * 8);
     if (e != hipSuccess) { hipFree(idx_dev); return fail(ctx, PCR_ERR_HIP, "hipMalloc(radius)", e); }
-    e = hipMemcpyAsync(s + off_c, row_ptr, (m + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    e = hipMemcpyAsync(s + off_c, offs.data(), (ms + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
-        rc = launch_radius_fill(ctx, db->dev, n, n_cap, (double*)s, m, r2max, (const long long*)(s + off_c), idx_dev, dist_dev);
+        rc = launch_radius_fill(ctx, db->dev, n, n_cap, (double*)s, m, r2max, (const long long*)(s + off_c), idx_dev, dist_dev, slices);
     if (e == hipSuccess && rc == PCR_OK) e = hipMemcpyAsync(idx, idx_dev, total * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && rc == PCR_OK) e = hipMemcpyAsync(dist, dist_dev, total * 8, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e2 = hipStreamSynchronize(ctx->stream);

@@ -4,13 +4,13 @@
 //   promotion the author ran), stable sort by h, one centroid per voxel = sequential f32 sum of its points in ascending
 //   index order / count — and the reference's quirk: a voxel is emitted when the NEXT one starts (:43-50), so the last
 //   voxel of the sorted order is dropped.
-// Pipeline: bounds (reduction) -> keys -> stable radix sort of (h, index) [hipcub] -> segment heads + scan -> one
+// Pipeline: bounds (reduction) -> keys -> stable radix sort of (h, index) [rocPRIM, sort.hip] -> segment heads + scan -> one
 // lane per voxel walks its points in order (f32 sequential sum is order dependent: no tree reduction here).
 // Algorithmic traffic: 12 B/pt read for the bounds, 12 B/pt for the keys, 12 B/pt sorted, 12 B/pt gathered + 12 B per
 // output point: an HBM-bound pass sequence.
 #include "pcr_internal.hpp"
 
-#include <hipcub/hipcub.hpp>   // stable device radix sort (a plain library sort; the rest is hand-written)
+#include "sort.hpp"   // stable device radix sort (rocPRIM, sort.hip; the rest is hand-written)
 
 #include <cfloat>
 #include <cmath>
@@ -156,8 +156,7 @@ extern "C" int pcr_voxel_filter_f32(pcr_ctx* ctx, const pcr_cloud* in, double le
     p.Dy = (long long)std::ceil((double)(float)(b5[4] - b5[1]) / leaf_size);      // :29
     // 2. keys + stable sort
     size_t temp_bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 64, ctx->stream);
+    sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, 64, ctx->stream);
     const size_t kb = ((n * 8 + 255) & ~(size_t)255), vb = ((n * 4 + 255) & ~(size_t)255);
     const size_t nb = (n + 1 + SCAN_TILE - 1) / SCAN_TILE;
     const size_t off_kout = kb, off_vin = 2 * kb, off_vout = 2 * kb + vb, off_flags = 2 * kb + 2 * vb, off_gid = off_flags + vb,
@@ -175,7 +174,7 @@ extern "C" int pcr_voxel_filter_f32(pcr_ctx* ctx, const pcr_cloud* in, double le
     uint32_t* totals = (uint32_t*)(s + off_tot);
     const dim3 gridn((unsigned)((n + VX_BLOCK - 1) / VX_BLOCK));
     hipLaunchKernelGGL(vx_keys_kernel, gridn, dim3(VX_BLOCK), 0, ctx->stream, in->x(), in->y(), in->z(), (uint32_t)n, p, k_in, v_in);
-    PCR_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(s + off_temp, temp_bytes, k_in, k_out, v_in, v_out, (int)n, 0, 64, ctx->stream));
+    PCR_HIP(ctx, sort_pairs_u64_u32(s + off_temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, 64, ctx->stream));
     // 3. segments
     hipLaunchKernelGGL(vx_heads_kernel, gridn, dim3(VX_BLOCK), 0, ctx->stream, k_out, (uint32_t)n, flags);
     rc = exclusive_scan_u32(ctx, flags, gid, n, totals, totals + nb);

@@ -73,6 +73,28 @@ int main(int argc, char** argv)
     mat_index.index->buildIndex();
 
     for (auto& query : q) dump_query(out, root, db, query, (int)k, r, mat_index);
+    // EXTENSIONS: the same questions in one batch must give the same sets as one call per query
+    {
+        std::vector<KNNResultSet> ks((size_t)m, KNNResultSet((int)k));
+        std::vector<RadiusNNResultSet> rs((size_t)m, RadiusNNResultSet(r));
+        KDTreeKNNSearchBatch(root, db, ks, q);
+        KDTreeRadiusNNSearchBatch(root, db, rs, q);
+        for (int64_t i = 0; i < m; i++) {
+            KNNResultSet one((int)k);
+            KDTreeKNNSearch(root, db, one, q[i]);
+            RadiusNNResultSet oner(r);
+            KDTreeRadiusNNSearch(root, db, oner, q[i]);
+            if (one.count != ks[i].count || oner.size() != rs[i].size()) { fprintf(stderr, "batch/count mismatch at %lld\n", (long long)i); return 6; }
+            for (int s = 0; s < (int)k; s++)
+                if (one.distIndexList[s].index != ks[i].distIndexList[s].index || one.distIndexList[s].distance != ks[i].distIndexList[s].distance) {
+                    fprintf(stderr, "batch/knn mismatch at %lld\n", (long long)i); return 6;
+                }
+            for (size_t s = 0; s < oner.distIndexList.size(); s++)
+                if (oner.distIndexList[s].index != rs[i].distIndexList[s].index || oner.distIndexList[s].distance != rs[i].distIndexList[s].distance) {
+                    fprintf(stderr, "batch/radius mismatch at %lld\n", (long long)i); return 6;
+                }
+        }
+    }
     // benchmark.hpp:59-66 protocol: database points query their own cloud (served from one batched launch)
     int64_t self = n < 64 ? n : 64;
     for (int64_t i = 0; i < self; i++) {

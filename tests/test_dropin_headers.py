@@ -53,7 +53,7 @@ def test_dropin_check_driver_compiles(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["uniform", "lattice"])
+@pytest.mark.parametrize("case", ["uniform", "lattice", "f32scan"])
 def test_dropin_headers_answer_like_the_oracle(tmp_path, orc, synth, case):
     need_lib()
     exe = tmp_path / "dropin_check"
@@ -63,6 +63,14 @@ def test_dropin_headers_answer_like_the_oracle(tmp_path, orc, synth, case):
     n, m, k, rad = 3000, 40, 8, 1.0
     if case == "uniform":
         db, q = synth.uniform_cloud(n, seed=71), synth.uniform_cloud(m, seed=72)
+    elif case == "f32scan":
+        # data that came from f32 files (test.hpp:28 widens KITTI floats): the grid routes — one zero-copy launch per query, the cached
+        # radius index, the self-query batch — instead of the sliced scan of true f64 data
+        n, rad = 6000, 0.8
+        scan = synth.kitti_like_scan(n, seed=75)
+        db = np.ascontiguousarray(scan.T.astype(np.float64))
+        rng = np.random.default_rng(76)
+        q = (db[rng.integers(0, n, m)] + rng.normal(0, 0.3, (m, 3))).astype(np.float32).astype(np.float64)
     else:
         db = np.unique(synth.lattice_cloud(n, 3, 10.0, seed=73, levels=14), axis=0)
         q = synth.lattice_cloud(m, 3, 10.0, seed=74, levels=14)
