@@ -596,7 +596,7 @@ def bench_c4(ctx, pcr, synth, np, args):
     full_call_ms = (time.perf_counter() - t0) * 1e3
     assert rc == 0
     kern = {}
-    for name in ("radius_grid_build", "radius_count", "radius_fill", "radius_sort", "radius_dist"):
+    for name in ("radius_grid_build", "radius_count", "radius_emit", "radius_fill", "radius_sort", "radius_dist"):
         k, ms = ctx.prof_get(name)
         if k:
             kern[name] = ms / k

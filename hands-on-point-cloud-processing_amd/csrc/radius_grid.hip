@@ -6,9 +6,9 @@
 //   cell edge = 1.01 r  ->  every neighbour lies in the 27-cell block = 9 x-sorted record ranges, each cut to |x - qx| <= r
 //   pass 1  count    32 lanes per query (cell-sorted queries), membership s <= r2max (the sqrt hoisted, search_f64.hip)
 //   scan             row_ptr
-//   pass 2  fill     same walk, members compacted with a ballot prefix -> indices in grid order
-//   sort             rocPRIM segmented radix sort of every row (log2(n) bits) -> ascending index, the canonical order
-//   pass 3  dist     d = sqrt(s) recomputed per reported pair
+//   pass 2  emit     one workgroup per query: a presence bitmap over the database indices in LDS puts the members in ascending
+//                    index order (the canonical order) without a sort; index + d = sqrt(s) leave with coalesced stores
+//   (databases beyond 262 144 points or rows beyond 16 384 neighbours: fill unsorted + rocPRIM segmented radix sort + distances)
 #include "grid_common.hpp"
 
 #include "sort.hpp"
@@ -125,6 +125,131 @@ __global__ __launch_bounds__(RG_BLOCK) void radius_dist_kernel(const float* __re
     }
 }
 
+// ---- fused pass 2: one workgroup per query ---------------------------------------------------------------------------------
+// The members of a row have to come out in ascending index order.  Every index occurs at most once, so the workgroup keeps a
+// PRESENCE BITMAP over the database indices in LDS (n / 8 bytes: 15 KB at 120 k points): the walk of the count pass sets one
+// bit per member (atomicOr), a popcount prefix over the bitmap words gives every member its rank, the ranked indices are staged
+// in LDS and leave with coalesced stores together with their distances.  No sort at all.  Replaces fill (4 B/neighbour
+// written, unsorted) + device-wide segmented sort (2 x 8 B/neighbour/pass) + distance pass (4 B/neighbour re-read): HBM sees
+// the 12 B/neighbour of the result and the gathers of the coordinates, nothing else.
+//   LDS: bitmap[W] | staged indices A[CAP] | 32 words of scan partials / row ranges   (W = ceil(n / 32) rounded up to 256 words)
+constexpr int RE_BLOCK = 256;
+constexpr uint32_t RE_MAX_DB = 262144;       // 32 KB of bitmap; larger databases take the segmented-sort route
+
+template <int CAP>
+__global__ __launch_bounds__(RE_BLOCK) void radius_emit_kernel(const float4* __restrict__ records, const uint32_t* __restrict__ cell_start, GridParams g,
+                                                               const float* __restrict__ qxs, const float* __restrict__ qys, const float* __restrict__ qzs,
+                                                               const uint32_t* __restrict__ list, uint32_t n_list, double r2max, float win,
+                                                               const uint32_t* __restrict__ row_ptr, const float* __restrict__ tx, const float* __restrict__ ty,
+                                                               const float* __restrict__ tz, uint32_t words, int32_t* __restrict__ idx_out,
+                                                               double* __restrict__ dist_out, int* __restrict__ err)
+{
+    extern __shared__ uint32_t re_lds[];
+    uint32_t* bm = re_lds;                       // [words]
+    uint32_t* A = re_lds + words;                // [CAP]
+    uint32_t* misc = A + CAP;                    // [0..3] scan partials, [8..25] the nine row ranges
+    if (blockIdx.x >= n_list) return;
+    const uint32_t qi = list[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (uint32_t i = tid; i < words; i += RE_BLOCK) bm[i] = 0u;
+    __syncthreads();
+    const float fx = qxs[qi], fy = qys[qi], fz = qzs[qi];
+    const uint32_t o = row_ptr[qi];
+    const uint32_t expect = row_ptr[qi + 1] - o;
+    // ---- collect: the walk and the membership test of the count pass
+    if (finite3(fx, fy, fz)) {
+        const double qx = fx, qy = fy, qz = fz;
+        const int cx = cell_coord(fx, g.lo[0], g.inv_h), cy = cell_coord(fy, g.lo[1], g.inv_h), cz = cell_coord(fz, g.lo[2], g.inv_h);
+        // the nine row ranges (bounds + x-window searches: chains of dependent loads) are resolved side by side by nine lanes
+        // (no x-window search here: its chain of ~16 dependent loads costs a one-query workgroup more than testing the extra third
+        // of a 3-cell row; membership is decided by the exact test either way)
+        if (tid < 9) {
+            const int yy = cy + (tid % 3) - 1, zz = cz + (tid / 3) - 1;
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.n[0] - 1);
+            uint32_t b = 0, e = 0;
+            if (yy >= 0 && yy < g.n[1] && zz >= 0 && zz < g.n[2] && x0 <= x1) {
+                const uint32_t row = (uint32_t)((zz * g.n[1] + yy) * g.n[0]);
+                b = cell_start[row + x0];
+                e = cell_start[row + x1 + 1];
+            }
+            misc[8 + 2 * tid] = b;
+            misc[9 + 2 * tid] = e;
+        }
+        __syncthreads();
+        for (int k = 0; k < 9; k++) {
+            const uint32_t b = misc[8 + 2 * k], e = misc[9 + 2 * k];
+            uint32_t j = b + tid;
+            for (; j + 3 * RE_BLOCK < e; j += 4 * RE_BLOCK) {            // four independent 16-byte loads in flight per thread
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) t[u] = records[j + u * RE_BLOCK];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (s_f64(t[u].x, t[u].y, t[u].z, qx, qy, qz) <= r2max) {
+                        const uint32_t id = __float_as_uint(t[u].w);
+                        atomicOr(&bm[id >> 5], 1u << (id & 31u));
+                    }
+            }
+            for (; j < e; j += RE_BLOCK) {
+                const float4 t = records[j];
+                if (s_f64(t.x, t.y, t.z, qx, qy, qz) <= r2max) {
+                    const uint32_t id = __float_as_uint(t.w);
+                    atomicOr(&bm[id >> 5], 1u << (id & 31u));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- rank: thread t owns words [t * wpt, (t + 1) * wpt)
+    const uint32_t wpt = words / RE_BLOCK;
+    uint32_t mine = 0;
+    for (uint32_t i = 0; i < wpt; i++) mine += (uint32_t)__popc(bm[tid * wpt + i]);
+    uint32_t inc = mine;
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1) {
+        const uint32_t t = __shfl_up(inc, s2, 64);
+        if (lane >= s2) inc += t;
+    }
+    if (lane == 63) misc[w] = inc;
+    __syncthreads();
+    uint32_t pos = inc - mine;
+    for (int ww = 0; ww < w; ww++) pos += misc[ww];
+    const uint32_t N = misc[0] + misc[1] + misc[2] + misc[3];
+    if (N != expect || N > CAP) { if (tid == 0) atomicExch(err, 1); return; }      // cannot happen (same walk as the count pass); never write out of bounds
+    for (uint32_t i = 0; i < wpt; i++) {
+        uint32_t bits = bm[tid * wpt + i];
+        const uint32_t base = (tid * wpt + i) << 5;
+        while (bits) {
+            const int bpos = __builtin_ctz(bits);
+            bits &= bits - 1u;
+            A[pos++] = base + (uint32_t)bpos;
+        }
+    }
+    __syncthreads();
+    // ---- emit: ascending index, distance from the original coordinates (kdtree.hpp:341-346), coalesced stores
+    const double qx = fx, qy = fy, qz = fz;
+    // four independent (LDS read -> three gathers -> sqrt -> two stores) chains in flight per thread
+    uint32_t p = tid;
+    for (; p + 3 * RE_BLOCK < N; p += 4 * RE_BLOCK) {
+        uint32_t j[4];
+        float cxs[4], cys[4], czs[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) j[u] = A[p + u * RE_BLOCK];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { cxs[u] = tx[j[u]]; cys[u] = ty[j[u]]; czs[u] = tz[j[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            idx_out[o + p + u * RE_BLOCK] = (int32_t)j[u];
+            dist_out[o + p + u * RE_BLOCK] = sqrt(s_f64(cxs[u], cys[u], czs[u], qx, qy, qz));
+        }
+    }
+    for (; p < N; p += RE_BLOCK) {
+        const uint32_t j = A[p];
+        idx_out[o + p] = (int32_t)j;
+        dist_out[o + p] = sqrt(s_f64(tx[j], ty[j], tz[j], qx, qy, qz));
+    }
+}
+
 // self-query: the records' order IS the cell order of the points -> perm[t] = original index of record t
 __global__ __launch_bounds__(RG_BLOCK) void record_index_kernel(const float4* __restrict__ rec, uint32_t n, uint32_t* __restrict__ perm)
 {
@@ -205,16 +330,73 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
     for (size_t i = 0; i <= m; i++) hr[i] = (uint32_t)row_ptr_host[i];
     PCR_HIP(ctx, hipMemcpyAsync(rows.p, hr.data(), (m + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     DevBuf idx_a, idx_b, dist;
-    PCR_HIP(ctx, hipMalloc(&idx_a.p, total * 4));
     PCR_HIP(ctx, hipMalloc(&idx_b.p, total * 4));
     PCR_HIP(ctx, hipMalloc(&dist.p, total * 8));
+    uint32_t longest = 0;
+    for (size_t i = 0; i < m; i++) longest = std::max(longest, hc[i]);
+    int bits = 1;
+    while (((size_t)1 << bits) < n) bits++;
+    const bool fused = longest <= 16384u && n <= RE_MAX_DB && tune_get(ctx, "radius_fused", 1) == 1;
+    const uint32_t words = (uint32_t)(((n + 31) / 32 + RE_BLOCK - 1) / RE_BLOCK * RE_BLOCK);
+    if (fused) {
+        // rows by length class (LDS capacity of the workgroup that sorts them), each class in the cell order of the queries
+        std::vector<uint32_t> hperm;
+        if (perm) {
+            hperm.resize(m);
+            PCR_HIP(ctx, hipMemcpyAsync(hperm.data(), perm, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        std::vector<uint32_t> lists[5];
+        for (size_t t = 0; t < m; t++) {
+            const uint32_t qi = perm ? hperm[t] : (uint32_t)t;
+            const uint32_t c = hc[qi];
+            if (c == 0) continue;
+            lists[c <= 1024u ? 0 : c <= 2048u ? 1 : c <= 4096u ? 2 : c <= 8192u ? 3 : 4].push_back(qi);
+        }
+        DevBuf lbuf, errbuf;
+        PCR_HIP(ctx, hipMalloc(&lbuf.p, (m + 1) * 4));
+        PCR_HIP(ctx, hipMalloc(&errbuf.p, 4));
+        PCR_HIP(ctx, hipMemsetAsync(errbuf.p, 0, 4, ctx->stream));
+        size_t off = 0;
+        size_t loff[5];
+        for (int c = 0; c < 5; c++) {
+            loff[c] = off;
+            if (!lists[c].empty()) PCR_HIP(ctx, hipMemcpyAsync((uint32_t*)lbuf.p + off, lists[c].data(), lists[c].size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            off += lists[c].size();
+        }
+        {
+            ProfScope ps(ctx, "radius_emit", 1);
+#define PCR_EMIT(CAPV, c)                                                                                                                     \
+    if (!lists[c].empty()) {                                                                                                                  \
+        const size_t lds = ((size_t)words + CAPV + 32) * 4;                                                                                    \
+        hipFuncSetAttribute((const void*)radius_emit_kernel<CAPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+        hipLaunchKernelGGL((radius_emit_kernel<CAPV>), dim3((unsigned)lists[c].size()), dim3(RE_BLOCK), lds, ctx->stream, g->records, g->cell_start, g->p, \
+                           q->x(), q->y(), q->z(), (const uint32_t*)lbuf.p + loff[c], (uint32_t)lists[c].size(), r2max, win, (const uint32_t*)rows.p,   \
+                           db->x(), db->y(), db->z(), words, (int32_t*)idx_b.p, (double*)dist.p, (int*)errbuf.p);                              \
+    }
+            PCR_EMIT(1024, 0)
+            PCR_EMIT(2048, 1)
+            PCR_EMIT(4096, 2)
+            PCR_EMIT(8192, 3)
+            PCR_EMIT(16384, 4)
+#undef PCR_EMIT
+        }
+        PCR_HIP(ctx, hipGetLastError());
+        int herr = 0;
+        PCR_HIP(ctx, hipMemcpyAsync(&herr, errbuf.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP(ctx, hipMemcpyAsync(idx_host, idx_b.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP(ctx, hipMemcpyAsync(dist_host, dist.p, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (herr) return fail(ctx, PCR_ERR_STATE, "radius_emit: a row changed between the count and the fill pass");
+        return PCR_OK;
+    }
+    // rows longer than the LDS of a workgroup: fill unsorted, device-wide segmented sort, distance pass
+    PCR_HIP(ctx, hipMalloc(&idx_a.p, total * 4));
     {
         ProfScope ps(ctx, "radius_fill", 1);
         hipLaunchKernelGGL(radius_grid_kernel<true>, grid, dim3(RG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, q->x(), q->y(), q->z(), perm, (uint32_t)m,
                            r2max, win, (uint32_t*)nullptr, (const uint32_t*)rows.p, (int32_t*)idx_a.p);
     }
-    int bits = 1;
-    while (((size_t)1 << bits) < n) bits++;
     size_t temp_bytes = 0;
     PCR_HIP(ctx, segmented_sort_keys_u32(nullptr, temp_bytes, (const uint32_t*)idx_a.p, (uint32_t*)idx_b.p, total, m, (const uint32_t*)rows.p,
                                          (const uint32_t*)rows.p + 1, 0, bits, ctx->stream));
