@@ -499,17 +499,6 @@ __device__ __forceinline__ void scan_flat9_sph(const float4* __restrict__ record
     }
 }
 
-// Workgroup -> chunk of queries.  The hardware deals consecutive workgroups round-robin over the 8 XCDs (b and b + 8 share
-// an L2): with the identity mapping eight spatially adjacent workgroups pull the same records into eight L2s.  Here XCD x
-// gets whole runs of GR_XCD_RUN consecutive (= spatially adjacent) query blocks, and the runs are dealt round-robin, so that
-// the load stays balanced over the XCDs (a contiguous eighth of the sorted queries per XCD does not: profiles/r01_grid_xcd_swizzle_experiment.txt).
-// Speed only: any mapping is correct.  nb8 = number of workgroups launched (a multiple of 8 * run).
-__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t run)
-{
-    const uint32_t xcd = b & 7u, slot = b >> 3;
-    return ((slot / run) * 8u + xcd) * run + slot % run;
-}
-
 // Distance (lower bound, >= 0) along one axis between the query coordinate q and the slab of cells with index c, u being the
 // query's own cell: 0 for its own slab, else the gap to the nearer face minus a margin that covers the binning of the targets
 // (a point may sit `slack` cells beyond the face its f32 cell index suggests) and the rounding of the face coordinate.
@@ -528,6 +517,125 @@ __device__ __forceinline__ void ball_x_cells(const GridParams& g, float qx, floa
     const float r = sqrtf(rem2) * 1.0001f + g.slack * g.h + fabsf(qx) * 1e-6f;
     xa = max(xa, cell_coord(qx - r, g.lo[0], g.inv_h));
     xb = min(xb, cell_coord(qx + r, g.lo[0], g.inv_h));
+}
+
+// Later stages of the sphere walk: every lane of the sub-group holds up to two record ranges (the pieces of ITS row).  Their runs
+// are laid out as one index space (exclusive scan over the lanes), so that the 16 lanes test 16 spheres per batch whatever
+// rows they come from — instead of one sparse batch per piece.  The owner of flattened run f is found by a 4-step binary
+// search over the lanes' offsets (shuffles).
+template <bool STATS>
+__device__ __forceinline__ void scan_pieces_sph(const float4* __restrict__ records, const float4* __restrict__ spheres, uint32_t b1, uint32_t e1,
+                                                uint32_t b2, uint32_t e2, int l, float qx, float qy, float qz, unsigned long long& best, uint32_t& bestp,
+                                                unsigned long long& st_cand, unsigned long long& st_sph)
+{
+    const uint32_t a0 = b1 < e1 ? b1 / GRID_CHUNK : 0u, na = b1 < e1 ? (e1 - 1) / GRID_CHUNK + 1 - a0 : 0u;
+    const uint32_t c0 = b2 < e2 ? b2 / GRID_CHUNK : 0u, nc = b2 < e2 ? (e2 - 1) / GRID_CHUNK + 1 - c0 : 0u;
+    const uint32_t cnt = na + nc;
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 16);
+        if (l >= o) inc += t;
+    }
+    const uint32_t my_off = inc - cnt;
+    const uint32_t total = __shfl(inc, 15, 16);
+    const int shift = (int)((threadIdx.x & 63) / 16 * 16);
+    for (uint32_t f0 = 0; f0 < total; f0 += 16) {
+        const uint32_t f = f0 + (uint32_t)l;
+        int owner = 0;
+#pragma unroll
+        for (int step = 8; step > 0; step >>= 1) {
+            const uint32_t o = __shfl(my_off, owner + step, 16);
+            if (o <= f) owner += step;
+        }
+        const uint32_t rel = f - __shfl(my_off, owner, 16);
+        const uint32_t oa0 = __shfl(a0, owner, 16), ona = __shfl(na, owner, 16), oc0 = __shfl(c0, owner, 16);
+        const uint32_t c = rel < ona ? oa0 + rel : oc0 + (rel - ona);
+        const bool hit = f < total && sphere_may_win(spheres[c], qx, qy, qz, best);
+        const uint32_t m = (uint32_t)(__ballot(hit) >> shift) & 0xFFFFu;
+        if (STATS && l == 0) { st_sph += min(16u, total - f0); st_cand += 16u * (uint32_t)__popc(m); }
+        if (m) {
+            scan_hits16(records, m, c, l, qx, qy, qz, best, bestp);
+            group_min<16>(best, bestp);
+        }
+    }
+}
+
+// Stage 1 of the sphere walk with ONE ROW PER LANE: lane k < 9 of the sub-group resolves row k of the 3 x 3 block (ball clipping
+// against the seed, the two cell_start bounds, the run range), an exclusive scan over the lanes lays the runs of the nine rows
+// out as one index space, and every lane then fetches the nine (offset, delta) pairs with shuffles.  The same work done
+// redundantly by all 16 lanes cost ~450 vector instructions per query; here it is ~60 + 30 shuffles.
+template <bool STATS>
+__device__ __forceinline__ void stage1_sph(const float4* __restrict__ records, const float4* __restrict__ spheres, const uint32_t* __restrict__ cell_start,
+                                           const GridParams& g, int ux, int uy, int uz, int l, float qx, float qy, float qz, unsigned long long& best,
+                                           uint32_t& bestp, unsigned long long& st_cand, unsigned long long& st_sph, unsigned long long& st_rows)
+{
+    const int xlo = max(ux - 1, 0), xhi = min(ux + 1, g.n[0] - 1);
+    const bool seeded = best != KEY_NONE;
+    const float clip2s = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f;
+    // lane k: row k (k = 4 is the query's own row); lanes 9..15 hold empty rows
+    const int k = l;
+    const int cy = uy + (k % 3) - 1, cz = uz + (k / 3) - 1;
+    bool ok = k < 9 && (cy >= 0) && (cy < g.n[1]) && (cz >= 0) && (cz < g.n[2]) && (xlo <= xhi);
+    int xa = xlo, xb = xhi;
+    if (ok && seeded) {
+        const float gy = axis_gap(qy, g.lo[1], g.h, cy, uy, g.slack), gz = axis_gap(qz, g.lo[2], g.h, cz, uz, g.slack);
+        const float rem2 = clip2s - (gy * gy + gz * gz) * 0.9999f;
+        if (rem2 < 0.0f) ok = false;
+        else { ball_x_cells(g, qx, rem2, xa, xb); ok = xa <= xb; }
+    }
+    uint32_t b = 0, e = 0;
+    if (ok) {
+        const uint32_t row = (uint32_t)((cz * g.n[1] + cy) * g.n[0]);
+        b = cell_start[row + xa];
+        e = cell_start[row + xb + 1];
+    }
+    if (STATS && ok) st_rows++;
+    if (!seeded) {
+        // no seed: the query's own row first (all 16 lanes on it), so that the other eight are tested against a real bound
+        const uint32_t b4 = __shfl(b, 4, 16), e4 = __shfl(e, 4, 16);
+        scan_range_sph<STATS, 1>(records, spheres, b4, e4, l, qx, qy, qz, best, bestp, st_cand, st_sph);
+        if (l == 4) { b = 0; e = 0; }
+    }
+    const uint32_t c0 = b < e ? b / GRID_CHUNK : 0u, c1 = b < e ? (e - 1) / GRID_CHUNK + 1 : 0u;
+    const uint32_t cnt = c1 - c0;
+    uint32_t inc = cnt;                                     // inclusive scan over the 16 lanes
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 16);
+        if (l >= o) inc += t;
+    }
+    const uint32_t my_off = inc - cnt;                      // first flattened run of my row
+    const uint32_t total = __shfl(inc, 15, 16);
+    const uint32_t my_delta = c0 - my_off;
+    uint32_t off[9], delta[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) { off[r] = __shfl(my_off, r, 16); delta[r] = __shfl(my_delta, r, 16); }
+    const int shift = (int)((threadIdx.x & 63) / 16 * 16);
+    for (uint32_t f0 = 0; f0 < total; f0 += 16) {
+        const uint32_t f = f0 + (uint32_t)l;
+        uint32_t c = f + delta[0];
+#pragma unroll
+        for (int r = 1; r < 9; r++) c = f >= off[r] ? f + delta[r] : c;
+        const bool hit = f < total && sphere_may_win(spheres[c], qx, qy, qz, best);
+        const uint32_t m = (uint32_t)(__ballot(hit) >> shift) & 0xFFFFu;
+        if (STATS && l == 0) { st_sph += min(16u, total - f0); st_cand += 16u * (uint32_t)__popc(m); }
+        if (m) {
+            scan_hits16(records, m, c, l, qx, qy, qz, best, bestp);
+            group_min<16>(best, bestp);
+        }
+    }
+}
+
+// Workgroup -> chunk of queries.  The hardware deals consecutive workgroups round-robin over the 8 XCDs (b and b + 8 share
+// an L2): with the identity mapping eight spatially adjacent workgroups pull the same records into eight L2s.  Here XCD x
+// gets whole runs of GR_XCD_RUN consecutive (= spatially adjacent) query blocks, and the runs are dealt round-robin, so that
+// the load stays balanced over the XCDs (a contiguous eighth of the sorted queries per XCD does not: profiles/r01_grid_xcd_swizzle_experiment.txt).
+// Speed only: any mapping is correct.  nb8 = number of workgroups launched (a multiple of 8 * run).
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t run)
+{
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    return ((slot / run) * 8u + xcd) * run + slot % run;
 }
 
 // G lanes cooperate on one query (G divides 64).  Stage 1 scans the 3 x 3 x-rows of the radius-1 cube with all
@@ -588,7 +696,17 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
         // a query farther from the grid box than the caller's gate (cap2) has no admissible neighbour at all
         const float out_reach = ((float)r0 - 1.0f - g.slack) * g.h;
         bool done = r0 > 1 && out_reach > TRUST && out_reach * out_reach * 0.99999f >= cap2;
-        if (r == 1) {
+        if (r == 1 && SPH) {
+            // ---- stage 1, sphere walk: one row per lane
+            stage1_sph<STATS>(records, spheres, cell_start, g, ux, uy, uz, l, qx, qy, qz, best, bestp, st_cand, st_sph, st_rows);
+            group_min<G>(best, bestp);
+            const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
+                                (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
+            const float reach = (1.0f - g.slack) * g.h;
+            done = covers || (reach > TRUST && (reach * reach * 0.99999f >= cap2 ||
+                                                (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f)));
+            r = 2;
+        } else if (r == 1) {
             // ---- stage 1: static 3 x 3 rows, bounds first
             const int xlo = max(ux - 1, 0), xhi = min(ux + 1, g.n[0] - 1);
             uint32_t rb[9], re[9];
@@ -642,14 +760,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                     }
                 }
             }
-            if (SPH) {
-                if (best == KEY_NONE) {
-                    // no seed: the query's own row first, so that the other eight are tested against a real bound
-                    scan_range_sph<STATS, 1>(records, spheres, rb[4], re[4], l, qx, qy, qz, best, bestp, st_cand, st_sph);
-                    rb[4] = re[4] = 0;
-                }
-                scan_flat9_sph<STATS, 1>(records, spheres, rb, re, l, qx, qy, qz, best, bestp, st_cand, st_sph);
-            } else {
+            {
                 if (CLIP) {
                     scan_flat9<G>(records, rb, re, l, qx, qy, qz, best, bestp);      // dense rows: 8.1 -> 6.9 ms at 10 M (costs 15 % at 120 k)
                 } else {
@@ -740,18 +851,19 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                             if (STATS) { st_rows++; if (!SPH) st_cand += (e1 - b1) + (e2 - b2); }
                         }
                     }
-                    // visit only the lanes that hold a non-empty piece (far searches are mostly empty space)
-                    const unsigned long long any = __ballot((b1 < e1) || (b2 < e2));
-                    unsigned long long mine = (any >> ((threadIdx.x & 63) / G * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
-                    while (mine) {
-                        const int j = __builtin_ctzll(mine);
-                        mine &= mine - 1;
-                        const uint32_t jb1 = __shfl(b1, j, G), je1 = __shfl(e1, j, G);
-                        const uint32_t jb2 = __shfl(b2, j, G), je2 = __shfl(e2, j, G);
-                        if (SPH) {
-                            scan_range_sph<STATS, 1>(records, spheres, jb1, je1, l, qx, qy, qz, best, bestp, st_cand, st_sph);
-                            scan_range_sph<STATS, 1>(records, spheres, jb2, je2, l, qx, qy, qz, best, bestp, st_cand, st_sph);
-                        } else {
+                    if (SPH) {
+                        // the runs of the (up to) 2 x 16 pieces as one index space: dense batches of 16 sphere tests
+                        if (__ballot((b1 < e1) || (b2 < e2)) >> ((threadIdx.x & 63) / 16 * 16) & 0xFFFFull)
+                            scan_pieces_sph<STATS>(records, spheres, b1, e1, b2, e2, l, qx, qy, qz, best, bestp, st_cand, st_sph);
+                    } else {
+                        // visit only the lanes that hold a non-empty piece (far searches are mostly empty space)
+                        const unsigned long long any = __ballot((b1 < e1) || (b2 < e2));
+                        unsigned long long mine = (any >> ((threadIdx.x & 63) / G * G)) & (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull));
+                        while (mine) {
+                            const int j = __builtin_ctzll(mine);
+                            mine &= mine - 1;
+                            const uint32_t jb1 = __shfl(b1, j, G), je1 = __shfl(e1, j, G);
+                            const uint32_t jb2 = __shfl(b2, j, G), je2 = __shfl(e2, j, G);
                             if (jb1 < je1) scan_range<G>(records, jb1, je1, l, qx, qy, qz, best, bestp);
                             if (jb2 < je2) scan_range<G>(records, jb2, je2, l, qx, qy, qz, best, bestp);
                         }

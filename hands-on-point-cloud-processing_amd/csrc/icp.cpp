@@ -236,14 +236,13 @@ extern "C" int pcr_icp_p2p_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr_clo
     if (!ctx || !src || !tgt || !init_T || !prm || !out_T) return fail(ctx, PCR_ERR_ARG, "pcr_icp_p2p_f32");
     PCR_HIP(ctx, hipSetDevice(ctx->device));
     // tune "icp_pipeline": 1 = device-resident pipelined loop, -1 = synchronous loop (one host round trip per iteration),
-    // 0 = auto: pipelined when the correspondence search is the grid (tens of microseconds per search: launch gaps and
-    // round trips dominate), synchronous for brute force — measured on MI355X: the ~45 us of idle per iteration let the
-    // chip hold a higher clock through the VALU-bound 1.6 ms kernel (1.57 ms vs 1.71 ms back to back; 32.7 vs 35.0 ms for
-    // 20 iterations, profiles/r01_icp_pipeline_vs_sync.txt).  The host-callback transport reduces on the host and
+    // 0 = auto = pipelined.  Measured on MI355X in round 2 (brute force, 120 k target, 20 iterations): 1.237 vs 1.242 ms per
+    // iteration with all 120 k sources, 0.211 vs 0.217 ms with a 1/8 shard (what one rank of an 8-GPU strong-scaling run
+    // holds), tens of microseconds per iteration with the grid search — the device-resident loop is never slower, and with
+    // RCCL it keeps the per-iteration all-reduce on the stream.  The host-callback transport reduces on the host and
     // therefore always runs synchronously.  Both loops give bit-identical results.
     const bool callback = ctx->comm.nranks > 1 && ctx->comm.cb != nullptr;
     const int64_t mode = tune_get(ctx, "icp_pipeline", 0);
-    const bool grid = icp_uses_grid(ctx, tgt);
-    const bool pipelined = !callback && (mode > 0 || (mode == 0 && grid));
+    const bool pipelined = !callback && mode >= 0;
     return pipelined ? icp_pipelined(ctx, src, tgt, init_T, prm, out_T, stats) : icp_sync(ctx, src, tgt, init_T, prm, out_T, stats);
 }

@@ -4,7 +4,7 @@ set -o pipefail
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 N=${1:-10000000}
-export TMPDIR=/tmp NN_METHOD=2 ALIGNED=1
+export TMPDIR=/tmp NN_METHOD=2 ALIGNED=1 IN_LOOP=1
 ( cd /tmp && timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_grid_fetch --output-format csv -- python3 $R/tools/run_nn1.py $N 3 > $R/gpurun_out/pmc_grid_fetch.log 2>&1; echo "pmc grid fetch rc=$?"; tail -1 $R/gpurun_out/pmc_grid_fetch.log ) &&
 ( cd /tmp && timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_grid_write --output-format csv -- python3 $R/tools/run_nn1.py $N 3 > $R/gpurun_out/pmc_grid_write.log 2>&1; echo "pmc grid write rc=$?"; tail -1 $R/gpurun_out/pmc_grid_write.log ) &&
 ( cd /tmp && timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmc_grid_sq --output-format csv -- python3 $R/tools/run_nn1.py $N 3 > $R/gpurun_out/pmc_grid_sq.log 2>&1; echo "pmc grid sq rc=$?"; tail -1 $R/gpurun_out/pmc_grid_sq.log )

@@ -38,6 +38,9 @@ if aligned:
     ctx.transform(cs, synth.gt_pose().astype(np.float32))
 ctx.tune("prof", 2)
 ctx.nn1_async(ct, cs); ctx.sync(); print("first call:", {nm: ctx.prof_get(nm) for nm in ("grid_build",) if ctx.prof_get(nm)[0]}); ctx.prof_reset()
+if os.environ.get("IN_LOOP"):       # repeated searches seeded by the previous result, as inside a converged ICP loop (grid: record-position warm start)
+    ctx.tune("nn1_async_in_loop", 1)
+    ctx.nn1_async(ct, cs); ctx.sync(); ctx.prof_reset()
 if os.environ.get("ICP_LOOP"):      # inside an ICP loop: iterations after the first run the warm-start kernel (ETRACK for brute force)
     ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=launches, eps=0.0)
 else:
