@@ -1034,6 +1034,16 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, i
             set_params(h);
         }
     }
+    if (order == GRID_ORDER_MORTON && user_um <= 0 && cell_edge <= 0.0) {
+        // The sphere walk prunes INSIDE a cell (bounding spheres over Morton-ordered records), so its cells can be larger than the
+        // occupancy rule wants: fewer x-rows for the queries that are still far from their neighbour (the first iterations of an
+        // ICP) at the price of a few more sphere tests near convergence.  Measured at 10 M (profiles/r02_c5_grid_ab.txt, same call):
+        // x1.0 12.1, x1.5 11.5, x2 11.8 (with a second sphere level), x3 12.0, x4.5 14.0 ms per ICP iteration.
+        // A second level of spheres (one per 16 runs) was built and measured too: its extra dependent round trip costs more than the
+        // sphere tests it saves at every cell size (x1.0: 12.1 -> 14.4, x1.5: 11.5 -> 12.4 ms) — dropped.
+        const double scale = (double)tune_get(ctx, "grid_cell_scale_x100", 150) / 100.0;
+        if (scale > 1.0) { h = fit(h * scale); set_params(h); }
+    }
     const size_t cells = g->n_cells;
     // 3. sort by (cell, x).  Histogram + scan give cell_start; one radix sort of (cell << 32 | x bits, index) gives the
     //    order (deterministic: no atomics decide a position).  Non-finite points go to the extra cell `cells`.
