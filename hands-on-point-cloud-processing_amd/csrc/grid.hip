@@ -279,6 +279,7 @@ __global__ __launch_bounds__(GR_BLOCK) void scatter_perm_kernel(uint32_t n, cons
 
 // ---------------------------------------------------------------------------------------- query
 constexpr unsigned long long KEY_NONE = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;   // (FLT_MAX, no index)
+__device__ __forceinline__ bool has_index(unsigned long long key) { return (uint32_t)key != 0xFFFFFFFFu; }   // a real candidate, not just a bound
 // Geometry proves "every point outside the scanned cube is farther than the best" for TRUE distances; the computed f32 d2
 // follows the true one only above the underflow range (squares below 2^-126 lose their bits, below 2^-149 they are 0:
 // a cloud of 1e-25-sized coordinates has d2 == 0 for EVERY pair, and the lowest index must win among all of them).
@@ -571,14 +572,14 @@ __device__ __forceinline__ void stage1_sph(const float4* __restrict__ records, c
                                            uint32_t& bestp, unsigned long long& st_cand, unsigned long long& st_sph, unsigned long long& st_rows)
 {
     const int xlo = max(ux - 1, 0), xhi = min(ux + 1, g.n[0] - 1);
-    const bool seeded = best != KEY_NONE;
+    const bool bounded = best != KEY_NONE, seeded = has_index(best);     // (bounded without a seed: the caller's gate, nn1_grid_kernel)
     const float clip2s = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f;
     // lane k: row k (k = 4 is the query's own row); lanes 9..15 hold empty rows
     const int k = l;
     const int cy = uy + (k % 3) - 1, cz = uz + (k / 3) - 1;
     bool ok = k < 9 && (cy >= 0) && (cy < g.n[1]) && (cz >= 0) && (cz < g.n[2]) && (xlo <= xhi);
     int xa = xlo, xb = xhi;
-    if (ok && seeded) {
+    if (ok && bounded) {
         const float gy = axis_gap(qy, g.lo[1], g.h, cy, uy, g.slack), gz = axis_gap(qz, g.lo[2], g.h, cz, uz, g.slack);
         const float rem2 = clip2s - (gy * gy + gz * gz) * 0.9999f;
         if (rem2 < 0.0f) ok = false;
@@ -665,7 +666,12 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     const int l = (int)(threadIdx.x % G);
     const uint32_t i = perm ? perm[t] : t;
     const float qx = sx[i], qy = sy[i], qz = sz[i];
-    unsigned long long best = KEY_NONE;
+    // The caller discards every neighbour with d2 >= cap2 (the ICP gate), so cap2 itself is a bound the walk may prune with from
+    // the start: the search begins with the pseudo-candidate (cap2, no index).  Rows and cells outside the cap2 ball are never
+    // opened, runs whose sphere lies outside it are never scanned, and a query with no target inside it ends with "none"
+    // (what the gate would have made of any farther neighbour).  A real candidate replaces it as soon as one is closer.
+    const unsigned long long bound0 = (cap2 > 0.0f && cap2 < 1e30f) ? (((unsigned long long)__float_as_uint(cap2) << 32) | 0xFFFFFFFFull) : KEY_NONE;
+    unsigned long long best = bound0;
     uint32_t bestp = 0;
     if (finite3(qx, qy, qz)) {
         if (warm_start == 2) {
@@ -678,7 +684,8 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                 const float4 rec = records[pp];
                 const float dx = qx - rec.x, dy = qy - rec.y, dz = qz - rec.z;
                 const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
-                if (d < 0x7F7FFFFFu) { best = ((unsigned long long)d << 32) | __float_as_uint(rec.w); bestp = pp; }
+                const unsigned long long kk = ((unsigned long long)d << 32) | __float_as_uint(rec.w);
+                if (d < 0x7F7FFFFFu && kk < best) { best = kk; bestp = pp; }
             }
         } else if (warm_start == 1) {
             // the same from keys[] (original index) when no record positions were kept
@@ -686,7 +693,8 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             if (pj < nt) {
                 const float dx = qx - tx[pj], dy = qy - ty[pj], dz = qz - tz[pj];
                 const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
-                if (d < 0x7F7FFFFFu) best = ((unsigned long long)d << 32) | pj;
+                const unsigned long long kk = ((unsigned long long)d << 32) | pj;
+                if (d < 0x7F7FFFFFu && kk < best) best = kk;
             }
         }
         const int ux = cell_coord(qx, g.lo[0], g.inv_h), uy = cell_coord(qy, g.lo[1], g.inv_h), uz = cell_coord(qz, g.lo[2], g.inv_h);
@@ -712,14 +720,14 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             uint32_t rb[9], re[9];
             // with a seed (the previous correspondence, re-evaluated) only the rows and cells its ball reaches can matter: at the
             // converged pose that is the query's own cell and the odd neighbour instead of all 27 (measured: DESIGN.md 5b)
-            const bool seeded = best != KEY_NONE;
+            const bool bounded = best != KEY_NONE;
             const float clip2s = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f;
 #pragma unroll
             for (int k = 0; k < 9; k++) {
                 const int cy = uy + (k % 3) - 1, cz = uz + (k / 3) - 1;
                 bool ok = (cy >= 0) && (cy < g.n[1]) && (cz >= 0) && (cz < g.n[2]) && (xlo <= xhi);
                 int xa = xlo, xb = xhi;
-                if (ok && seeded) {
+                if (ok && bounded) {
                     const float gy = axis_gap(qy, g.lo[1], g.h, cy, uy, g.slack), gz = axis_gap(qz, g.lo[2], g.h, cz, uz, g.slack);
                     const float rem2 = clip2s - (gy * gy + gz * gz) * 0.9999f;
                     if (rem2 < 0.0f) ok = false;
@@ -736,7 +744,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                 for (int k = 0; k < 9; k++) total += re[k] - rb[k];
                 // dense neighbourhood without a warm-start candidate: the query's own row first, its best distance then
                 // cuts the other rows
-                if (best == KEY_NONE && total > 512u) {
+                if (!has_index(best) && total > 512u) {
                     scan_range<G>(records, rb[4], re[4], l, qx, qy, qz, best, bestp);
                     if (STATS && l == 0) st_cand += re[4] - rb[4];
                     rb[4] = re[4] = 0;
@@ -790,9 +798,10 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             const bool have = best != KEY_NONE;
             const float bestf = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2);   // never reason below the trusted range
             if (have) {
-                // smallest r with ((r - slack) h)^2 * 0.99999 > best
+                // smallest r with ((r - slack) h)^2 * 0.99999 > best; with only the gate as a bound the radius keeps doubling
+                // (near shells first: a real candidate tightens the ball for the far ones) but never beyond the gate's radius
                 const int need = (int)fminf(sqrtf(bestf * 1.00002f) * g.inv_h + g.slack, 16777215.0f) + 1;
-                r = max(min(need, 1 << 24), rp + 1);
+                r = max(min(has_index(best) ? need : min(r, need), 1 << 24), rp + 1);
             }
             const int xlo = max(ux - r, 0), xhi = min(ux + r, g.n[0] - 1);
             const int ylo = max(uy - r, 0), yhi = min(uy + r, g.n[1] - 1);
@@ -827,9 +836,11 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                         const int ady = abs(cy - uy), adz = abs(cz - uz);
                         int xa = xlo, xb = xhi;
                         bool open = true;
-                        if (have) {
+                        if (best != KEY_NONE) {
+                            // (the bound of THIS batch of rows: candidates found in the earlier batches of the stage already count)
+                            const float clip2k = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f;
                             const float fy = axis_gap(qy, g.lo[1], g.h, cy, uy, g.slack), fz = axis_gap(qz, g.lo[2], g.h, cz, uz, g.slack);
-                            const float rem2 = clip2 - (fy * fy + fz * fz) * 0.9999f;
+                            const float rem2 = clip2k - (fy * fy + fz * fz) * 0.9999f;
                             if (rem2 < 0.0f) open = false;                     // the whole row is outside the ball
                             else ball_x_cells(g, qx, rem2, xa, xb);
                         }
@@ -1160,6 +1171,74 @@ static int sort_queries(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
     return PCR_OK;
 }
 
+// key of a query in the ORDER OF THE RECORDS: (cell of the target's grid, clamped << 9) | Morton code of the 8 x 8 x 8 sub-cell.
+// Non-finite queries go last.
+__global__ __launch_bounds__(GR_BLOCK) void query_keys_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
+                                                              GridParams g, uint32_t n_cells, unsigned long long* __restrict__ keys,
+                                                              uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float px = x[i], py = y[i], pz = z[i];
+    unsigned long long key = (unsigned long long)n_cells << 9;
+    if (finite3(px, py, pz)) {
+        const float p[3] = { px, py, pz };
+        int c[3], s[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            c[k] = min(max(cell_coord(p[k], g.lo[k], g.inv_h), 0), g.n[k] - 1);
+            const float f = ((p[k] - g.lo[k]) * g.inv_h - (float)c[k]) * 8.0f;     // < 0 or >= 8 for a query outside the grid box
+            s[k] = (int)fminf(fmaxf(f, 0.0f), 7.0f);
+        }
+        const uint32_t m = spread3((uint32_t)s[0]) | (spread3((uint32_t)s[1]) << 1) | (spread3((uint32_t)s[2]) << 2);
+        key = ((unsigned long long)((c[2] * g.n[1] + c[1]) * g.n[0] + c[0]) << 9) | m;
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+
+// perm[] (-> ctx->qperm) = the queries in the order of the target's records: consecutive queries are neighbours in space at the
+// resolution of an eighth of a cell, so that the 16 queries of a workgroup open the same rows, test the same spheres and scan
+// the same runs (the coarse bins of sort_queries leave the order inside a bin to the atomics).  One radix sort of the whole
+// cloud: worth it for a working cloud that is searched many times (grid_sort_working_cloud).
+static int sort_queries_fine(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
+{
+    const size_t n = src->n;
+    int key_bits = 1;
+    while (((size_t)1 << key_bits) < g->n_cells + 1) key_bits++;
+    size_t temp_bytes = 0;
+    sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, key_bits + 9, ctx->stream);
+    const size_t a4 = (n * 4 + 255) & ~(size_t)255, a8 = (n * 8 + 255) & ~(size_t)255;
+    int rc = ensure_scratch(ctx, 2 * a8 + a4 + temp_bytes + 256);
+    if (rc) return rc;
+    if (ctx->qperm_cap < n) {
+        if (ctx->qperm) PCR_HIP(ctx, hipFree(ctx->qperm));
+        ctx->qperm = nullptr; ctx->qperm_cap = 0;
+        PCR_HIP(ctx, hipMalloc((void**)&ctx->qperm, padded(n) * sizeof(uint32_t)));
+        ctx->qperm_cap = padded(n);
+    }
+    char* sc = (char*)ctx->scratch;
+    unsigned long long* k_in = (unsigned long long*)sc;
+    unsigned long long* k_out = (unsigned long long*)(sc + a8);
+    uint32_t* v_in = (uint32_t*)(sc + 2 * a8);
+    hipLaunchKernelGGL(query_keys_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), (uint32_t)n,
+                       g->p, (uint32_t)g->n_cells, k_in, v_in);
+    const hipError_t e = sort_pairs_u64_u32(sc + 2 * a8 + a4, temp_bytes, k_in, k_out, v_in, ctx->qperm, n, 0, key_bits + 9, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "radix sort(queries)", e);
+    PCR_HIP(ctx, hipGetLastError());
+    ctx->qperm_n = n;
+    ctx->qperm_src = src;
+    return PCR_OK;
+}
+
+// order of a query batch (tune grid_sort_fine: 0 auto = record order for large batches against a Morton-ordered index, where the
+// radix sort is also the faster of the two: 0.6 against 4.0 ms at 10 M queries; 1 = record order, 2 = coarse bins)
+static int sort_queries_any(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
+{
+    const int64_t fine = tune_get(ctx, "grid_sort_fine", 0);
+    return (fine == 1 || (fine == 0 && !g->x_sorted && src->n >= 65536)) ? sort_queries_fine(ctx, g, src) : sort_queries(ctx, g, src);
+}
+
 // the 1-NN index of a target cloud, cached on the cloud.  Large targets get the Morton-ordered records the sphere walk wants
 // (tune grid_order: 0 auto = Morton from 500 000 points, 1 = x-sorted, 2 = Morton).
 int build_target_grid(pcr_ctx* ctx, const pcr_cloud* tgt)
@@ -1181,7 +1260,7 @@ int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     if (rcb) return rcb;
     if (src->n == 0) return PCR_OK;
     ProfScope p(ctx, "grid_sort_queries");
-    return sort_queries(ctx, tgt->grid, src);
+    return sort_queries_any(ctx, tgt->grid, src);
 }
 
 // dst[t] = src[perm[t]] (cell-sorted working copy of the grid ICP); the padding of dst is left alone
@@ -1195,7 +1274,7 @@ __global__ __launch_bounds__(GR_BLOCK) void permute_cloud_kernel(const float* __
     dx[t] = sx[i]; dy[t] = sy[i]; dz[t] = sz[i];
 }
 
-// Re-orders the working cloud of an ICP loop into the coarse-cell order of the target's grid, ONCE: every later search reads
+// Re-orders the working cloud of an ICP loop into the order of the target's index (sort_queries_any), ONCE: every later search reads
 // its queries with coalesced loads (no perm indirection), writes keys / winner positions coalesced, and the Kabsch pass walks
 // pairs whose targets are neighbours in the record array.  ctx->work_orig[t] = index the point had in the caller's cloud (the
 // "last kept pair" of registration.cpp:939 is defined in that order).  The sums are exact, so the order changes no result.
@@ -1205,7 +1284,7 @@ int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work
     const size_t n = w->n;
     ctx->work_orig_src = nullptr;
     if (n == 0 || tune_get(ctx, "grid_sort_work", 1) != 1) return PCR_OK;
-    int rc = grid_prepare_queries(ctx, tgt, w);                  // builds the target index if needed; ctx->qperm = cell order
+    int rc = grid_prepare_queries(ctx, tgt, w);                  // builds the target index if needed; ctx->qperm = the order
     if (rc) return rc;
     pcr_cloud* sorted = nullptr;
     rc = pcr_cloud_clone(ctx, w, &sorted);                        // same size, padding included

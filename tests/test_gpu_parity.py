@@ -297,6 +297,39 @@ def test_icp_same_pose_with_either_nn_method(ctx, orc, synth, method):
     cs.free(); ct.free()
 
 
+@pytest.mark.parametrize("n", [9000, 70001])
+def test_icp_sphere_walk_gate_as_bound_and_any_working_order(ctx, synth, n):
+    """The sphere walk of large targets, forced onto a small pair.  Inside an ICP the walk starts from the caller's gate as a
+    bound (pseudo-candidate (max_corr, none)) and runs over a working cloud sorted into record order or into coarse bins.  Neither
+    may change a kept correspondence: the sums are exact, so pose, pair count and loss have to be bit-equal to the exhaustive
+    search's for every iteration count, gate and loop flavour."""
+    src, tgt = synth.kitti_like_pair(n, seed_target=147, seed_pair=148)
+    src = src.copy(); src[:, 5] = np.nan; src[2, 77] = np.inf; src[0, 100:110] += 300.0; src[2, 200:260] += 1.3   # non-finite, far and gated-out queries
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    gates = (1.0, 0.05, 4.0, 1e-9)
+    ref = {}
+    ctx.tune("nn_method", 1)
+    for gate in gates:
+        for it in (1, 2, 7):
+            ref[gate, it] = ctx.icp_point2point(cs, ct, max_corr=gate, max_iter=it, eps=0.0)
+    assert ref[1.0, 7][1]["last_pairs"] < n - 20 and ref[0.05, 1][1]["last_pairs"] < n - n // 4
+    ctx.tune("nn_method", 2); ctx.tune("grid_order", 2); ctx.tune("grid_mode", 3)
+    cm = ctx.cloud(tgt)                                  # a fresh cloud: its index is built Morton-ordered
+    for fine, pipe, bounded in ((0, 0, 0), (1, 0, 0), (1, -1, 0), (2, 0, 0), (2, 1, 0), (1, 0, 2)):
+        ctx.tune("grid_sort_fine", fine); ctx.tune("icp_pipeline", pipe); ctx.tune("icp_bounded_search", bounded)
+        for gate in gates:
+            for it in (1, 2, 7):
+                T, st = ctx.icp_point2point(cs, cm, max_corr=gate, max_iter=it, eps=0.0)
+                r = ref[gate, it]
+                assert np.array_equal(T.view(np.uint32), r[0].view(np.uint32)), (fine, pipe, bounded, gate, it)
+                for k in ("iters_run", "last_pairs", "empty_pairs"):
+                    assert st[k] == r[1][k], (k, fine, pipe, bounded, gate, it)
+                assert np.float32(st["last_loss"]).view(np.uint32) == np.float32(r[1]["last_loss"]).view(np.uint32)
+    for k in ("nn_method", "grid_order", "grid_mode", "grid_sort_fine", "icp_pipeline", "icp_bounded_search"):
+        ctx.tune(k, 0)
+    cs.free(); ct.free(); cm.free()
+
+
 def test_cloud_layouts_roundtrip(ctx, pcr, synth):
     src, _ = synth.kitti_like_pair(1234)
     c = ctx.cloud(src)
