@@ -25,8 +25,10 @@ SOURCES = ["api.cpp", "numerics.cpp", "icp.cpp", "comm.cpp", "nn1_brute.hip", "k
 # -fno-slp-vectorize: keeps the inner loop on plain v_sub/v_mul/v_add_f32; the SLP vectoriser otherwise packs
 #   pairs into v_pk_mul_f32 / v_pk_add_f32, which issue at half rate on gfx950 and need extra v_mov to form
 #   register pairs (measured: profiles/).
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified) — the brute-force filter takes the minimum
+# of its 16 accumulators with the vector ALU, and the AGPR form would cost one v_accvgpr_read per accumulator (nn1_brute.hip, MTRACK)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 
 
 def hipcc() -> str:
