@@ -16,8 +16,9 @@ value            = correspondences of the whole job per second (M corr/s) on ONE
                    120 000 sources are SHARDED N ways (contiguous blocks, target replicated): "scaling": "strong" — the reading of
                    BASELINE.json.metric ("120k-pt KITTI pair, 1/2/4/8 MI355X").  "weak" (extra key, N > 1) is the other reading:
                    every rank registers its own 120 000-point shard of a denser source scan.
-roofline         = the dominant kernel (nn1_etrack_kernel): FMA flops the kernel's algorithm needs per launch / average launch
-                   duration measured live with HIP events on the kernel's own stream (inside libpcr_hip.so) / 157.3 TFLOP/s.
+roofline         = the dominant kernel (nn1_btrack_kernel): bf16 matrix flops the kernel's algorithm needs per launch / average launch
+                   duration measured live with HIP events on the kernel's own stream (inside libpcr_hip.so) / 2 500 TFLOP/s; the
+                   same launch priced as the f32 filter (6 flop per pair against 157.3 TFLOP/s) under fp32_equivalent.
 kernels          = the same for the exact-only kernel (9-op convention of SURVEY.md 8d) and the two HBM streaming kernels.
 one_shot         = the cold configs[1] search (no previous correspondences), fresh target and indexed target.
 c4 / c5          = BASELINE configs[3] (plane count + radius-NN on the 120k scan) and configs[4] (10 M x 10 M pair, exact grid,
@@ -45,7 +46,10 @@ VALU_PEAK_TFLOPS = 157.3        # MI355X vector f32, FMA = 2 flop (MI355X_MICROA
 VALU_PEAK_TOPS_NOFMA = 78.6     # the same issue rate counted one op per lane-slot: the bound of arithmetic without FMA (A1 is unfused)
 HBM_PEAK_GBS = 8000.0
 OPS_PER_PAIR = 9                # 3 sub + 3 mul + 2 add + 1 compare per (query, target) pair — the exact kernel's work
-ETRACK_FLOPS_PER_PAIR = 6       # the filter kernel's algorithm: 3 FMAs per (query, target) pair (csrc/nn1_brute.hip, ETRACK)
+ETRACK_FLOPS_PER_PAIR = 6       # the f32 filter's algorithm: 3 FMAs per (query, target) pair (csrc/nn1_brute.hip, ETRACK)
+BTRACK_FLOPS_PER_PAIR = 54      # the bf16 filter's algorithm: 27 bf16 multiply-adds per pair that carry data (3 coordinates x 8 piece products + 3 pieces
+                                # of |t''|^2) of the 32 K-slots two v_mfma_f32_32x32x16_bf16 provide (csrc/nn1_brute.hip, BTRACK)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (MI355X_MICROARCH.md)
 METRIC = "M correspondences/sec + ICP iter/sec, 120k-pt KITTI pair, 1/2/4/8 MI355X"
 
 
@@ -202,9 +206,11 @@ def main():
 
     ctx = pcr.Context(device_index)
     sha = lib_sha16(pcr)
+    tunes_env = {}
     for kv in filter(None, os.environ.get("PCR_TUNE", "").split(",")):     # experiments: PCR_TUNE="key=value,key=value"
         k, v = kv.split("=")
         ctx.tune(k.strip(), int(v))
+        tunes_env[k.strip()] = int(v)
     if args.qpl:
         ctx.tune("nn1_qpl", args.qpl)
     if args.tiles_per_slice:
@@ -382,7 +388,10 @@ def main():
                         "fresh_target": {"ms": ms_fresh, "M_corr_per_s": n_q / ms_fresh / 1e3,
                                          "kernel": "pcr::nn1_ftrack_kernel<2, 16> (fused-form filter + exact decision; needs no index)"},
                         "indexed_target": {"ms": ms_indexed, "M_corr_per_s": n_q / ms_indexed / 1e3,
-                                           "kernel": "pcr::nn1_etrack_kernel<4>, unseeded (the target's chunk index exists: any earlier search or ICP built it)"}}
+                                           "kernel": "the default indexed kernel (pcr::nn1_btrack_kernel<4>), unseeded (the target's index exists: any earlier search or ICP built it)"}}
+            ms_f32 = time_search(ct, 5, nn1_bf16=2)
+            one_shot["indexed_target_f32_filter"] = {"ms": ms_f32, "M_corr_per_s": n_q / ms_f32 / 1e3,
+                                                     "kernel": "pcr::nn1_etrack_kernel<4> (tune nn1_bf16 = 2: the same filter as 3 vector FMAs per pair), unseeded"}
 
         # ---- second, separately timed pass with the exact grid index (same answers, different search): extra info only
         grid_extra = None
@@ -410,25 +419,43 @@ def main():
         if rank == 0:
             gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
             if args.nn == "brute":
-                achieved_tflops = ETRACK_FLOPS_PER_PAIR * pairs / kern_s / 1e12
+                bf16 = default_kernels and tunes_env.get("nn1_bf16", 0) != 2 and tunes_env.get("nn1_variant", 0) in (0, 6) and n_t >= 2048
+                flops_pp = BTRACK_FLOPS_PER_PAIR if bf16 else ETRACK_FLOPS_PER_PAIR
+                peak_tf = MFMA_BF16_PEAK_TFLOPS if bf16 else VALU_PEAK_TFLOPS
+                achieved_tflops = flops_pp * pairs / kern_s / 1e12
                 compulsory_bytes = 12.0 * n_t + 12.0 * n_q + 8.0 * n_q        # targets + sources + (idx, d2) key
                 pmc = load_pmc("latest_pmc.json", sha) if (default_kernels and n_q == 120000 == n_t) else None
                 roofline = {
-                    "bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved_tflops / VALU_PEAK_TFLOPS,
+                    "bound": "mfma" if bf16 else "valu", "achieved": achieved_tflops, "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": achieved_tflops / peak_tf,
                     "traffic": (pmc["fetch_bytes_per_launch_corrected_x2"] + pmc["write_bytes_per_launch"]) if pmc else None,
                     "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
                                      f"kernel with this very libpcr_hip.so (sha {sha}), {pmc['source']}") if pmc else
                                     "null: PMC counters need a rocprofv3 wrapper (tools/gpu_check.sh); none was collected with the library loaded now",
-                    "kernel": ("pcr::nn1_etrack_kernel<4> (exhaustive scan of every (query, 16-target chunk); chunk-centred targets broadcast through the "
-                               "scalar cache; expanded-form lower bound = 3 FMAs per pair (v_pk_fma_f32), min-tree + first/second minimum tracked "
-                               "branch-free; only the winning chunk is evaluated with the exact unfused arithmetic; the previous correspondence of "
-                               "each query, re-evaluated exactly, seeds the bound)") if default_kernels else f"nn1 variant={args.variant} qpl={args.qpl}",
+                    "kernel": (("pcr::nn1_btrack_kernel<4> (exhaustive scan of every (query, 16-target chunk): the expanded-form lower bound of ALL "
+                                "pairs on the bf16 matrix pipe — f32 operands cut into three bf16 pieces each, every piece product exact in f32, "
+                                "two v_mfma_f32_32x32x16_bf16 per 32 queries x 32 targets; the vector ALU takes the minimum of the 16 accumulators "
+                                "per lane (8 v_min3) and tracks first / second minimum branch-free; only the winning chunk is evaluated with the "
+                                "exact unfused arithmetic; the previous correspondence of each query, re-evaluated exactly, seeds the bound)") if bf16 else
+                               ("pcr::nn1_etrack_kernel<4> (exhaustive scan of every (query, 16-target chunk); chunk-centred targets broadcast through the "
+                                "scalar cache; expanded-form lower bound = 3 FMAs per pair (v_pk_fma_f32), min-tree + first/second minimum tracked "
+                                "branch-free; only the winning chunk is evaluated with the exact unfused arithmetic; the previous correspondence of "
+                                "each query, re-evaluated exactly, seeds the bound)")) if default_kernels else f"nn1 variant={args.variant} qpl={args.qpl}",
                     "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
-                    "algorithmic": f"{ETRACK_FLOPS_PER_PAIR} flop (3 FMAs) per (query, target) pair x {pairs:.3e} pairs per launch — the arithmetic of the "
-                                   "kernel that ran; the min-tree, the per-chunk prologue (|q - C|^2, 11 ops per 16 targets) and the exact "
-                                   "re-evaluation of the winning chunk are overhead, not numerator.  peak = 157.3 TF/s vector f32 (FMA = 2).  "
-                                   "SURVEY.md 8d's 9-op-per-pair convention describes the EXACT kernel: kernels.nn1_exact_track",
+                    "algorithmic": (f"{BTRACK_FLOPS_PER_PAIR} bf16 flop per (query, target) pair (27 piece products that carry data, of the 32 K-slots "
+                                    f"executed) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense bf16.  On this chip the matrix instructions and "
+                                    "the vector instructions of one SIMD's waves take turns in this loop (measured: tools/ubench/mfma_filter.hip, "
+                                    "profiles/r02_mfma_filter_experiments.txt), so the launch time is MFMA time (2 x 32 cycles per 1024 pairs) PLUS "
+                                    "vector time (about 20 instructions per 1024 pairs): fp32_equivalent prices the same launch in the f32 filter's "
+                                    "6 flop per pair against the 157.3 TF/s vector peak, kernels.nn1_exact_track is SURVEY.md 8d's 9-op convention")
+                                   if bf16 else
+                                   (f"{ETRACK_FLOPS_PER_PAIR} flop (3 FMAs) per (query, target) pair x {pairs:.3e} pairs per launch — the arithmetic of the "
+                                    "kernel that ran; the min-tree, the per-chunk prologue (|q - C|^2, 11 ops per 16 targets) and the exact "
+                                    "re-evaluation of the winning chunk are overhead, not numerator.  peak = 157.3 TF/s vector f32 (FMA = 2).  "
+                                    "SURVEY.md 8d's 9-op-per-pair convention describes the EXACT kernel: kernels.nn1_exact_track"),
+                    "fp32_equivalent": {"achieved": ETRACK_FLOPS_PER_PAIR * pairs / kern_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": ETRACK_FLOPS_PER_PAIR * pairs / kern_s / 1e12 / VALU_PEAK_TFLOPS,
+                                        "note": "the f32 filter's 3 FMAs per pair over this launch's time, against the vector f32 peak"},
                     "issue": ({"executed_lane_ops_per_pair": pmc["valu_insts_per_launch"] * 64 / pairs,
                                "issue_frac": pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TOPS_NOFMA,
                                "note": "SQ_INSTS_VALU x 64 lanes / time / 78.6 T issue slots per second (same PMC passes)"} if pmc else None),

@@ -991,6 +991,9 @@ void grid_free(Grid* g)
     if (!g) return;
     if (g->chunks) hipFree(g->chunks);
     if (g->spheres) hipFree(g->spheres);
+    if (g->bt_records) hipFree(g->bt_records);
+    if (g->bt_centres) hipFree(g->bt_centres);
+    if (g->bt_ops) hipFree(g->bt_ops);
     if (g->mt_centres) hipFree(g->mt_centres);
     if (g->mt_ops) hipFree(g->mt_ops);
     if (g->records) hipFree(g->records);
@@ -1262,6 +1265,132 @@ static int sort_queries_fine(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
     PCR_HIP(ctx, hipGetLastError());
     ctx->qperm_n = n;
     ctx->qperm_src = src;
+    return PCR_OK;
+}
+
+// ---- BTRACK index (see nn1_brute.hip for the operand layout and the error analysis)
+__global__ __launch_bounds__(GR_BLOCK) void bt_keys_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
+                                                           GridParams g, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float px = x[i], py = y[i], pz = z[i];
+    unsigned long long key = 1ull << 36;                                   // non-finite points last
+    if (finite3(px, py, pz)) {
+        const uint32_t c[3] = { (uint32_t)min(max(cell_coord(px, g.lo[0], g.inv_h), 0), g.n[0] - 1),
+                                (uint32_t)min(max(cell_coord(py, g.lo[1], g.inv_h), 0), g.n[1] - 1),
+                                (uint32_t)min(max(cell_coord(pz, g.lo[2], g.inv_h), 0), g.n[2] - 1) };
+        key = 0;
+        for (int b = 0; b < 12; b++)                                       // cells per axis <= 4002 < 2^12
+            for (int k = 0; k < 3; k++) key |= (unsigned long long)((c[k] >> b) & 1u) << (3 * b + k);
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+
+// one thread per super-tile: centre = mean of its finite records
+__global__ __launch_bounds__(GR_BLOCK) void bt_centres_kernel(const float4* __restrict__ rec, uint32_t n_super, float4* __restrict__ centres)
+{
+    const uint32_t s = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (s >= n_super) return;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    int cnt = 0;
+    for (int j = 0; j < BT_SUPER; j++) {
+        const float4 r = rec[(size_t)s * BT_SUPER + j];
+        if (finite3(r.x, r.y, r.z)) { cx += r.x; cy += r.y; cz += r.z; cnt++; }
+    }
+    if (cnt) { cx /= (float)cnt; cy /= (float)cnt; cz /= (float)cnt; }
+    centres[s] = make_float4(cx, cy, cz, 0.f);
+}
+
+// v = p1 + p2 + p3 exactly, every piece a bf16 value (top 16 bits of an f32); finite v
+__device__ __forceinline__ void bf16_split3(float v, uint32_t& p1, uint32_t& p2, uint32_t& p3)
+{
+    const float a = __uint_as_float(__float_as_uint(v) & 0xFFFF0000u);
+    const float d = v - a;                                                 // exact
+    const float b = __uint_as_float(__float_as_uint(d) & 0xFFFF0000u);
+    const float e = d - b;                                                 // exact, <= 8 significant bits
+    p1 = __float_as_uint(a) >> 16; p2 = __float_as_uint(b) >> 16; p3 = __float_as_uint(e) >> 16;
+}
+
+// one thread per MFMA row (record) of a tile: the operands of its two lanes
+__global__ __launch_bounds__(GR_BLOCK) void bt_ops_kernel(const float4* __restrict__ rec, uint32_t n_tiles, const float4* __restrict__ centres,
+                                                          uint4* __restrict__ ops, int* __restrict__ unsafe)
+{
+    const uint32_t gid = blockIdx.x * GR_BLOCK + threadIdx.x;
+    const uint32_t T = gid >> 5, m = gid & 31;
+    if (T >= n_tiles) return;
+    const uint32_t p = T * 32 + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);   // MFMA row m <-> record (nn1_brute.hip)
+    const float4 r = rec[p];
+    const float4 C = centres[T / (BT_SUPER / 32)];
+    uint32_t t[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, w[3] = { 0x7F80u, 0, 0 };      // padding / non-finite: w = +inf, never the minimum
+    bool bad = !finite3(C.x, C.y, C.z) || fabsf(C.x) > 1e18f || fabsf(C.y) > 1e18f || fabsf(C.z) > 1e18f;
+    if (finite3(r.x, r.y, r.z)) {
+        const float tx = r.x - C.x, ty = r.y - C.y, tz = r.z - C.z;
+        const float ww = ((tx * tx + ty * ty) + tz * tz) * 0.99999237060546875f;               // (1 - 2^-17)
+        if (!(fabsf(tx) < 1e18f && fabsf(ty) < 1e18f && fabsf(tz) < 1e18f) || !(ww < 3e38f)) bad = true;
+        else {
+            bf16_split3(-2.0f * tx, t[0][0], t[0][1], t[0][2]);
+            bf16_split3(-2.0f * ty, t[1][0], t[1][1], t[1][2]);
+            bf16_split3(-2.0f * tz, t[2][0], t[2][1], t[2][2]);
+            bf16_split3(ww, w[0], w[1], w[2]);
+        }
+    }
+    // K slots of one coordinate, against the query pieces [r1, r1, r2, r1, r2, r3, r2, r3]:  [t1, t2, t1, t3, t2, t1, t3, t2]
+    auto pack = [](const uint32_t (&q)[3]) {
+        return make_uint4(q[0] | (q[1] << 16), q[0] | (q[2] << 16), q[1] | (q[0] << 16), q[2] | (q[1] << 16));
+    };
+    uint4* o = ops + (size_t)T * 128;
+    o[m] = pack(t[0]);                                                     // instruction 0, lanes < 32: x
+    o[32 + m] = pack(t[1]);                                                // instruction 0, lanes >= 32: y
+    o[64 + m] = pack(t[2]);                                                // instruction 1, lanes < 32: z
+    o[96 + m] = make_uint4(w[0] | (w[1] << 16), 0u | (w[2] << 16), 0u, 0u);   // instruction 1, lanes >= 32: [w1, w2, 0, w3, 0, 0, 0, 0] against [1, 1, 0, 1, 0, 0, 0, 0]
+    if (bad) atomicOr(unsafe, 1);
+}
+
+int grid_ensure_btiles(pcr_ctx* ctx, const pcr_cloud* tgt)
+{
+    Grid* g = tgt->grid;
+    if (!g) return fail(ctx, PCR_ERR_STATE, "btiles: no index");
+    if (g->bt_ops || g->n_points == 0) return PCR_OK;
+    const size_t n = g->n_points;
+    const size_t n_super = (n + BT_SUPER - 1) / BT_SUPER, n_pad = n_super * BT_SUPER, n_tiles = n_pad / 32;
+    size_t temp_bytes = 0;
+    sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, 37, ctx->stream);
+    const size_t a4 = (n * 4 + 255) & ~(size_t)255, a8 = (n * 8 + 255) & ~(size_t)255;
+    int rc = ensure_scratch(ctx, 2 * a8 + 2 * a4 + temp_bytes + 512);
+    if (rc) return rc;
+    char* sc = (char*)ctx->scratch;
+    unsigned long long* k_in = (unsigned long long*)sc;
+    unsigned long long* k_out = (unsigned long long*)(sc + a8);
+    uint32_t* v_in = (uint32_t*)(sc + 2 * a8);
+    uint32_t* v_out = (uint32_t*)(sc + 2 * a8 + a4);
+    int* unsafe_dev = (int*)(sc + 2 * a8 + 2 * a4);
+    char* temp = sc + 2 * a8 + 2 * a4 + 256;
+    float4* rec = nullptr; float4* cen = nullptr; uint4* ops = nullptr;
+    hipError_t e = hipMalloc((void**)&rec, n_pad * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&cen, n_super * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&ops, n_tiles * 128 * sizeof(uint4));
+    if (e == hipSuccess) e = hipMemsetAsync(unsafe_dev, 0, 4, ctx->stream);
+    int unsafe_host = 1;
+    if (e == hipSuccess) {
+        const dim3 gridn((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK));
+        hipLaunchKernelGGL(bt_keys_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(), (uint32_t)n, g->p, k_in, v_in);
+        e = sort_pairs_u64_u32(temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, 37, ctx->stream);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)((n_pad + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
+                           (uint32_t)n, (uint32_t)n_pad, v_out, rec);
+        hipLaunchKernelGGL(bt_centres_kernel, dim3((unsigned)((n_super + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, rec, (uint32_t)n_super, cen);
+        hipLaunchKernelGGL(bt_ops_kernel, dim3((unsigned)((n_tiles * 32 + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, rec, (uint32_t)n_tiles, cen, ops,
+                           unsafe_dev);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&unsafe_host, unsafe_dev, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e != hipSuccess) { hipFree(rec); hipFree(cen); hipFree(ops); return fail(ctx, PCR_ERR_HIP, "btiles", e); }
+    g->bt_records = rec; g->bt_centres = cen; g->bt_ops = ops; g->n_btiles = n_tiles;
+    g->bt_safe = unsafe_host == 0;
     return PCR_OK;
 }
 

@@ -42,7 +42,17 @@ struct Grid {
     float4* mt_centres = nullptr;
     float* mt_ops = nullptr;
     size_t n_mtiles = 0;
+    // BTRACK (nn1_brute.hip): the cloud once more in Morton order of its cells — spatially compact runs — as {x, y, z, original index}
+    // records (padded to whole super-tiles of BT_SUPER records with x = +inf), one centre per super-tile, and per tile of 32
+    // records the bf16 A operands of two v_mfma_f32_32x32x16_bf16 ([tile][2][64 lanes] x 16 bytes); built on first use
+    float4* bt_records = nullptr;
+    float4* bt_centres = nullptr;
+    uint4* bt_ops = nullptr;
+    size_t n_btiles = 0;
+    bool bt_safe = false;
 };
+
+constexpr int BT_SUPER = 256;          // records per super-tile (4 tiles of 32)
 
 enum GridOrder { GRID_ORDER_X = 0, GRID_ORDER_MORTON = 1 };
 
@@ -78,6 +88,8 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, i
 int build_target_grid(pcr_ctx* ctx, const pcr_cloud* tgt);
 // builds Grid::mt_centres / mt_ops of tgt's (already built) index if they are not there yet
 int grid_ensure_mtiles(pcr_ctx* ctx, const pcr_cloud* tgt);
+// builds Grid::bt_* of tgt's (already built) index if they are not there yet
+int grid_ensure_btiles(pcr_ctx* ctx, const pcr_cloud* tgt);
 // builds (and caches on tgt) the 1-NN grid if needed, then groups the queries `src` by coarse cell -> ctx->qperm
 int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
 // replaces *work by its cell-sorted copy (ctx->work_orig = original indices); no-op for empty clouds / tune grid_sort_work = 2

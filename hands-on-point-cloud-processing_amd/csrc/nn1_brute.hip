@@ -37,6 +37,7 @@ namespace pcr {
 constexpr int NN_BLOCK = 256;
 constexpr int NN_TILE = 1024;   // targets per LDS tile: 3 * 4 KiB
 constexpr bool NN_MFMA_DEFAULT = false;
+constexpr bool NN_BF16_DEFAULT = true;     // measured: 0.90 against 1.30 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
 
 __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -551,6 +552,166 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_mtrack_kernel(
     }
 }
 
+// ---- BTRACK: the filter on the bf16 matrix pipe, which (unlike the f32 MFMA above, which shares the vector ALU's multipliers:
+// profiles/r02_mfma_filter_experiments.txt) runs BESIDE the vector ALU.  f32 values are cut into three bf16 pieces each
+// (v = v1 + v2 + v3 exactly: 3 x 8 significant bits), so that  r . t'' = sum_{i,j} r_i t''_j  with every product exact in f32;
+// v_mfma_f32_32x32x16_bf16 sums 16 such products per instruction.  Per coordinate the 8 K-slots of one lane-half hold the pairs
+// (1,1) (1,2) (2,1) (1,3) (2,2) (3,1) (2,3) (3,2); only r3 t''3 (<= 2^-28 |r_c t''_c|) is dropped.  Two instructions = 32 slots:
+//   instruction 0: lanes < 32 the x-terms, lanes >= 32 the y-terms;   instruction 1: lanes < 32 the z-terms, lanes >= 32 the three
+//   pieces of w against the "coordinate" 1.0 (pieces 1, 0, 0).
+// The vector ALU no longer multiplies: per (query, tile) it takes the minimum of 16 accumulators and tracks m1 / m2 / c1; what it does
+// per query — r = q - C, R = |r|^2, the split and the packing — is done once per SUPER-TILE of 4 tiles, which share one centre.  That
+// needs spatially compact runs of 128 targets: the target is taken in Morton order of its cells (Grid::bt_records).
+// Bound.  With Q = |r|^2, W = |t''|^2, u = 2^-24 and G the MFMA result:
+//   dropped r3 t''3 terms                                   <= 2 * 2^-28 |r||t''|            <= 0.13 u (Q + W)
+//   accumulation of the 32 slots (measured <= 4.1 u sum|a b|, tools/ubench/mfma_filter.hip; taken as 16 u):
+//       sum |a b| <= w + 2.1 |r||t''| <= 2.1 (Q + W)                                          <= 34 u (Q + W)
+//   r, t'' vs q - C, t - C; exact A1 value vs D; R vs Q; w vs W; the final fma  (as for ETRACK)  <= 4 u + 10 u + 3 u + 3 u + 2 u
+//   => d2 >= Q (1 - 56 u) + W (1 - 56 u) - 2 r.t''  >= KAPPA R + G  when  KAPPA = 1 - 2^-17 (128 u) and w = fl(W)(1 - 2^-17):
+// L = fma(R, KAPPA, min_j G_j) is a lower bound of every exact distance of the chunk; the decision is ETRACK's (exact evaluation of
+// c1, proof by m2, exact rescan otherwise), so a wrong bound could only ever cost a rescan's worth of time if it were too HIGH —
+// which the sweep tests (tests/test_gpu_parity.py) look for with adversarial magnitudes.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void bt_pack(float c, uint4& b)
+{
+    // pieces c1 + c2 + c3 = c (bf16 each, kept in the top halves), K slots [c1, c1, c2, c1, c2, c3, c2, c3]
+    const uint32_t a1 = __float_as_uint(c) & 0xFFFF0000u;
+    const float d = c - __uint_as_float(a1);
+    const uint32_t a2 = __float_as_uint(d) & 0xFFFF0000u;
+    const uint32_t a3 = __float_as_uint(d - __uint_as_float(a2));
+    const uint32_t s2 = a2 >> 16;
+    b.x = (a1 >> 16) | a1;
+    b.y = s2 | a1;
+    b.z = s2 | (a3 & 0xFFFF0000u);
+    b.w = b.z;
+}
+
+template <int QG>
+__global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
+    const float4* __restrict__ centres, const uint4* __restrict__ ops, const float4* __restrict__ records, uint32_t n_rec, uint32_t n_super,
+    uint32_t supers_per_slice, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
+    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop, unsigned long long* __restrict__ stats)
+{
+    if (stop && (stop[0] | stop[1])) return;
+    constexpr int CH = 16, TPS = BT_SUPER / 32;
+    constexpr float KAPPA = 0.99999237060546875f;             // 1 - 2^-17
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = lane & 31;
+    const bool h = lane >= 32;
+    const uint32_t qbase = (blockIdx.x * (NN_BLOCK / 64) + wave) * (32 * QG);
+    if (qbase >= ns) return;                                  // a whole wave beyond the queries (wave-uniform)
+    float qx[QG], qy[QG], qz[QG], m1[QG], m2[QG], cur0[QG];
+    uint32_t c1[QG];
+    bool okq[QG];
+#pragma unroll
+    for (int g = 0; g < QG; g++) {
+        const uint32_t i = min(qbase + g * 32 + n, ns - 1);
+        qx[g] = sx[i]; qy[g] = sy[i]; qz[g] = sz[i];
+        okq[g] = fabsf(qx[g]) < 1e18f && fabsf(qy[g]) < 1e18f && fabsf(qz[g]) < 1e18f;      // false for NaN / inf
+        m1[g] = INFINITY; m2[g] = INFINITY; c1[g] = 0xFFFFFFFFu;
+        cur0[g] = merge_atomic ? __uint_as_float((uint32_t)(__atomic_load_n(&keys[i], __ATOMIC_RELAXED) >> 32)) : INFINITY;
+    }
+    const uint32_t sb = blockIdx.y * supers_per_slice, se = min(sb + supers_per_slice, n_super);
+    float big;
+    asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(big));      // +inf the optimiser cannot see through
+    f32x16 zero;
+#pragma unroll
+    for (int j = 0; j < 16; j++) zero[j] = 0.0f;
+    uint4 a0n = make_uint4(0, 0, 0, 0), a1n = a0n;
+    if (sb < se) { a0n = ops[(size_t)sb * TPS * 128 + lane]; a1n = ops[(size_t)sb * TPS * 128 + 64 + lane]; }
+    for (uint32_t S = sb; S < se; S++) {
+        const float4 C = centres[S];                          // wave-uniform: scalar load
+        uint4 b0[QG], b1[QG];
+        float R[QG];
+#pragma unroll
+        for (int g = 0; g < QG; g++) {
+            const float rx = qx[g] - C.x, ry = qy[g] - C.y, rz = qz[g] - C.z;
+            R[g] = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
+            bt_pack(h ? ry : rx, b0[g]);
+            bt_pack(h ? 1.0f : rz, b1[g]);
+        }
+#pragma unroll 1
+        for (int tt = 0; tt < TPS; tt++) {                    // (not unrolled: the scheduler would keep all 16 accumulator tiles alive)
+            const uint32_t T = S * TPS + tt;
+            const uint4 A0 = a0n, A1 = a1n;
+            if (tt + 1 < TPS || S + 1 < se) { a0n = ops[(size_t)(T + 1) * 128 + lane]; a1n = ops[(size_t)(T + 1) * 128 + 64 + lane]; }   // next tile in flight
+            const uint32_t c = 2 * T + (h ? 1u : 0u);
+            // (Tried: reducing the PREVIOUS group's accumulators between the two MFMAs of the current one, in program order enforced with
+            // sched_group_barrier — 0.892 against 0.900 ms.  On this chip the bf16 MFMA and the vector instructions of one SIMD's waves
+            // take turns rather than overlap in this loop: tools/ubench/mfma_filter.hip part C, profiles/r02_mfma_filter_experiments.txt.)
+#pragma unroll
+            for (int g = 0; g < QG; g++) {
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), __builtin_bit_cast(bf16x8, b0[g]), zero, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1), __builtin_bit_cast(bf16x8, b1[g]), acc, 0, 0, 0);
+                // minimum of the 16 accumulators: eight v_min3 starting from an opaque +inf (a plain two-operand fminf of two MFMA
+                // results is first canonicalised: three half-rate instructions instead of one).  (No inline-asm v_min3 on the
+                // accumulators themselves: the compiler would not know to wait for the MFMA before it — measured: wrong minima.)
+                float m = big;
+#pragma unroll
+                for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc[j]), acc[j + 1]);
+                const float L = __builtin_fmaf(R[g], KAPPA, m);
+                m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], L);
+                const bool better = L < m1[g];                // (false for a NaN L: a non-finite query is rescanned exactly anyway)
+                m1[g] = better ? L : m1[g];
+                c1[g] = better ? c : c1[g];
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < QG; g++) {
+        // the two half-lanes of a query: smallest chunk value, a chunk attaining it, smallest value over all OTHER chunks
+        const float m1o = __shfl_xor(m1[g], 32, 64), m2o = __shfl_xor(m2[g], 32, 64);
+        const uint32_t c1o = (uint32_t)__shfl_xor((int)c1[g], 32, 64);
+        const bool take = m1o < m1[g] || (m1o == m1[g] && c1o < c1[g]);
+        const float M1 = take ? m1o : m1[g];
+        const float M2 = fminf(fminf(m2[g], m2o), take ? m1[g] : m1o);
+        const uint32_t C1 = take ? c1o : c1[g];
+        uint32_t best = 0x7F7FFFFFu, bidx = 0xFFFFFFFFu;      // FLT_MAX gate, nanoflann.hpp:163,1360
+        bool proven = false;
+        const float cur = cur0[g];                            // see nn1_etrack_kernel: what the other slices have published
+        const bool slice_out = okq[g] && (M1 - 1e-30f) > cur;
+        if (!slice_out && okq[g] && C1 != 0xFFFFFFFFu) {
+            // exact A1 evaluation of the 16 records of chunk C1: 8 per half-lane, merged lexicographically (d2, index)
+            const uint32_t j0 = C1 * CH + (h ? 8u : 0u);
+#pragma unroll
+            for (int j = 0; j < CH / 2; j++) {
+                const float4 rec = records[j0 + j];                                     // (padding records: x = +inf, never accepted)
+                const uint32_t e = d2_exact_bits(qx[g], qy[g], qz[g], rec.x, rec.y, rec.z);
+                const uint32_t oi = __float_as_uint(rec.w);
+                if (e < best || (e == best && e < 0x7F7FFFFFu && oi < bidx)) { best = e; bidx = oi; }
+            }
+            const uint32_t bo = (uint32_t)__shfl_xor((int)best, 32, 64), io = (uint32_t)__shfl_xor((int)bidx, 32, 64);
+            if (bo < best || (bo == best && io < bidx)) { best = bo; bidx = io; }
+            proven = (bidx != 0xFFFFFFFFu && (M2 - 1e-30f) > __uint_as_float(best)) || (M2 - 1e-30f) > cur;
+        }
+        if (!__all(proven || slice_out || sb >= se)) {
+            if (stats && lane == 0) atomicAdd(&stats[2], 1ull);          // diagnostics: (wave, query group) pairs that had to rescan
+            // exact rescan of the slice by the whole wave, each half-lane one half of it
+            const uint32_t r0 = sb * BT_SUPER, r1 = min(se * BT_SUPER, n_rec), mid = r0 + (r1 - r0) / 2;
+            unsigned long long kbest = ~0ull;
+            for (uint32_t j = h ? mid : r0; j < (h ? r1 : mid); j++) {
+                const float4 rec = records[j];
+                const uint32_t e = d2_exact_bits(qx[g], qy[g], qz[g], rec.x, rec.y, rec.z);
+                const unsigned long long key = ((unsigned long long)e << 32) | __float_as_uint(rec.w);
+                if (e < 0x7F7FFFFFu && key < kbest) kbest = key;
+            }
+            const unsigned long long ko = ((unsigned long long)(uint32_t)__shfl_xor((int)(kbest >> 32), 32, 64) << 32) |
+                                          (uint32_t)__shfl_xor((int)(uint32_t)kbest, 32, 64);
+            kbest = ko < kbest ? ko : kbest;
+            best = (uint32_t)(kbest >> 32);
+            bidx = kbest == ~0ull ? 0xFFFFFFFFu : (uint32_t)(kbest & 0xFFFFFFFFull);
+        }
+        const uint32_t i = qbase + g * 32 + n;
+        if (!h && i < ns) {
+            const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : best;
+            const unsigned long long key = ((unsigned long long)bits << 32) | bidx;
+            if (merge_atomic) merge_key(&keys[i], key);
+            else keys[i] = key;
+        }
+    }
+}
+
 // ICP iterations after the first: the previous correspondence, re-evaluated exactly against the moved query, is a genuine
 // candidate and therefore an upper bound of the new answer from the first instruction on (ETRACK settles every far slice with it).
 __global__ __launch_bounds__(NN_BLOCK) void nn1_seed_kernel(const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, uint32_t nt,
@@ -636,10 +797,59 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     const int64_t variant_tune = tune_get(ctx, "nn1_variant", 0);
     // cold searches take ETRACK too when its index exists or will be needed anyway (inside an ICP loop): 1.64 vs 1.82 ms at 120 k;
     // a one-shot search on a fresh target stays on FTRACK, which needs no index (0.3 ms to build)
-    if (variant_tune == 4 || variant_tune == 5 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid))) {
+    if (variant_tune == 4 || variant_tune == 5 || variant_tune == 6 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid))) {
         rc = build_target_grid(ctx, tgt);
         if (rc) return rc;
         const Grid* g = tgt->grid;
+        // BTRACK (variant 6, tune nn1_bf16: 1 on, 2 off): the filter on the bf16 matrix pipe
+        const int64_t bf16_tune = tune_get(ctx, "nn1_bf16", 0);
+        if (variant_tune == 6 || (variant_tune == 0 && bf16_tune != 2 && (bf16_tune == 1 || NN_BF16_DEFAULT))) {
+            rc = grid_ensure_btiles(ctx, tgt);
+            if (rc) return rc;
+        }
+        if ((variant_tune == 6 || (variant_tune == 0 && bf16_tune != 2 && (bf16_tune == 1 || NN_BF16_DEFAULT))) && g->bt_safe && g->n_btiles) {
+            int qg = (int)tune_get(ctx, "nn1_btrack_qg", 4);
+            if (qg != 1 && qg != 2) qg = 4;                                           // (8 groups per wave: hipcc 7.2 crashes on the instantiation)
+            const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                      // queries per workgroup
+            const uint32_t qblocks = (uint32_t)((ns + qpb - 1) / qpb);
+            const size_t n_super = g->n_btiles / (BT_SUPER / 32);
+            int64_t sps = tune_get(ctx, "nn1_supers_per_slice", 0);
+            if (sps <= 0) {
+                const int64_t want_blocks = tune_get(ctx, "nn1_btrack_blocks", 32768);
+                const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
+                sps = std::max<int64_t>(1, ((int64_t)n_super + slices - 1) / slices);
+            }
+            uint32_t slices = (uint32_t)((n_super + sps - 1) / sps);
+            if (slices > 65535) { slices = 65535; sps = (n_super + slices - 1) / slices; slices = (uint32_t)((n_super + sps - 1) / sps); }
+            const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
+            if (warm)
+                hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
+                                   (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
+            else if (merge_atomic)
+                PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
+            unsigned long long* stats_dev = nullptr;
+            if (tune_get(ctx, "grid_stats", 0) > 0) {
+                if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
+                PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
+                stats_dev = ctx->grid_stats_dev;
+            }
+            {
+                ProfScope p(ctx, "nn1_brute", 1);
+                const dim3 grid(qblocks, slices);
+#define PCR_BTRACK(Q)                                                                                                                   \
+    hipLaunchKernelGGL((nn1_btrack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->bt_centres, g->bt_ops, g->bt_records,                  \
+                       (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
+                       merge_atomic, ctx->stop_flag_dev, stats_dev)
+                switch (qg) {
+                case 1: PCR_BTRACK(1); break;
+                case 2: PCR_BTRACK(2); break;
+                default: PCR_BTRACK(4); break;
+                }
+#undef PCR_BTRACK
+            }
+            PCR_HIP(ctx, hipGetLastError());
+            return PCR_OK;
+        }
         // MTRACK (variant 5, tune nn1_mfma: 1 on, 2 off): the same filter on the matrix cores
         const int64_t mfma_tune = tune_get(ctx, "nn1_mfma", 0);
         const bool mfma = variant_tune == 5 || (variant_tune == 0 && mfma_tune != 2 && (mfma_tune == 1 || NN_MFMA_DEFAULT));

@@ -22,5 +22,6 @@ cd /tmp || exit 1
 stage rocprof-stats 300 $R/gpurun_out/prof_bench.log rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline || exit 1
 stage pmc-sq 300 $R/gpurun_out/pmc_sq.log rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmc_sq --output-format csv -- python3 $R/tools/run_nn1.py 120000 9 || exit 1
 stage pmc-sq2 300 $R/gpurun_out/pmc_sq2.log rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d $R/gpurun_out/pmc_sq2 --output-format csv -- python3 $R/tools/run_nn1.py 120000 9 || exit 1
+stage pmc-mfma 300 $R/gpurun_out/pmc_mfma.log rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA --kernel-trace -d $R/gpurun_out/pmc_mfma --output-format csv -- python3 $R/tools/run_nn1.py 120000 9 || exit 1
 stage pmc-fetch 300 $R/gpurun_out/pmc_fetch.log rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch --output-format csv -- python3 $R/tools/run_nn1.py 120000 9 || exit 1
 stage pmc-write 300 $R/gpurun_out/pmc_write.log rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write --output-format csv -- python3 $R/tools/run_nn1.py 120000 9 || exit 1

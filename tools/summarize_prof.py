@@ -38,14 +38,14 @@ if os.path.exists(bj):
 
 pm = collections.OrderedDict()
 durs = {}
-for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+for d in ("pmc_sq", "pmc_sq2", "pmc_mfma", "pmc_fetch", "pmc_write"):
     f = newest(f"{d}/*/*_counter_collection.csv")
     if not f:
         continue
     agg = collections.defaultdict(list)
     rows = list(csv.DictReader(open(f)))
     # the dominant kernel of the profiled ICP loop: the warm-start kernel when it ran, else the cold one
-    want = "nn1_etrack" if any("nn1_etrack" in r["Kernel_Name"] for r in rows) else "nn1_ftrack"
+    want = next((w for w in ("nn1_btrack", "nn1_etrack") if any(w in r["Kernel_Name"] for r in rows)), "nn1_ftrack")
     per_dispatch = collections.defaultdict(float)
     for r in rows:
         if want in r["Kernel_Name"]:
@@ -75,8 +75,13 @@ if pm:
                          f"**{pm['SQ_INSTS_VALU'][0]*2/cyc:.3f}**")
             lines.append(f"VALU wave-instructions per (query,target) pair x 64 lanes = {pm['SQ_INSTS_VALU'][0]*64/1.44e10:.3f} lane-ops/pair "
                          "(algorithmic convention: 9)")
-            lines.append("(the 2-cycle price undercounts this loop: v_pk_fma_f32 and the min / max / med3 class take about twice the slot of "
-                         "an add / fma — profiles/r01_ubench_valu_rate.txt; priced per form the loop needs 1.11 ms of the launch, DESIGN.md §5)")
+            lines.append("(the 2-cycle price undercounts this loop: the min / max / med3 class takes about twice the slot of an add / fma — "
+                         "profiles/r01_ubench_valu_rate.txt)")
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in pm:
+            cyc = pm["GRBM_GUI_ACTIVE"][0] / 8 * 1024
+            lines.append(f"matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles) = **{pm['SQ_VALU_MFMA_BUSY_CYCLES'][0]/cyc:.3f}** "
+                         f"({pm.get('SQ_INSTS_MFMA', (0,))[0]:.4g} MFMA instructions per launch; cycles in which matrix and vector instructions "
+                         f"execute together, SQ_VALU_MFMA_COEXEC_CYCLES: {pm.get('SQ_VALU_MFMA_COEXEC_CYCLES', (0,))[0]/cyc:.3f} of the launch)")
     if "FETCH_SIZE" in pm:
         lines.append(f"HBM traffic per launch: FETCH_SIZE {pm['FETCH_SIZE'][0]:.0f} KiB x 2 (gfx950 correction for wide coalesced "
                      f"reads, MI355X_MICROARCH.md §HBM) = {pm['FETCH_SIZE'][0]*2*1024/1e6:.2f} MB; "

@@ -33,6 +33,50 @@ __global__ void tile_kernel(const uint16_t* __restrict__ a, const uint16_t* __re
     }
 }
 
+// MODE 0: MFMA only (results summed into one register per group at the end); 1: the 8 x v_min3 + compare only, on registers that
+// no MFMA writes; 2: MFMA, then the minimum of ITS results (dependent); 3: MFMA, and the minimum of the PREVIOUS group's results;
+// 4: the waves of a SIMD split roles — even workgroups run mode 0, odd ones mode 1
+template <int MODE>
+__global__ __launch_bounds__(256) void mix_kernel(const uint4* __restrict__ ops, float* __restrict__ out, int tiles, float thr)
+{
+    constexpr int QG = 4;
+    const int lane = threadIdx.x & 63;
+    const int mode = MODE == 4 ? (blockIdx.x & 1) : MODE;
+    u16x8 bq[QG];
+    float best[QG];
+    for (int g = 0; g < QG; g++) {
+        for (int j = 0; j < 8; j++) bq[g][j] = (unsigned short)(0x3F80 + ((lane * 7 + g * 13 + j) & 63));
+        best[g] = thr;
+    }
+    f32x16 zero, pend, keep;
+    for (int j = 0; j < 16; j++) { zero[j] = 0.f; pend[j] = 1.0f + lane + j; keep[j] = 0.f; }
+    float big;
+    asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(big));
+    uint4 nxt = ops[lane];
+    for (int T = 0; T < tiles; T++) {
+        const uint4 cur = nxt;
+        nxt = ops[((T + 1) & 63) * 64 + lane];
+        const bf16x8 av = __builtin_bit_cast(bf16x8, cur);
+#pragma unroll
+        for (int g = 0; g < QG; g++) {
+            f32x16 acc = pend;
+            if (mode != 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bq[g]), zero, 0, 0, 0);
+            if (mode == 0) { keep = acc; continue; }
+            const f32x16 src = (mode == 3) ? pend : acc;
+            float m = big;
+#pragma unroll
+            for (int j = 0; j + 1 < 16; j += 2) m = fminf(fminf(m, src[j]), src[j + 1]);
+            if (m < best[g]) best[g] = m * 0.5f;
+            if (mode == 1) { pend[g] = m + 1.0f; }          // keeps the loop from being hoisted
+            if (mode == 3) pend = acc;
+        }
+    }
+    float s = 0.f;
+    for (int g = 0; g < QG; g++) s += best[g];
+    for (int j = 0; j < 16; j++) s += keep[j] + pend[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int QG>
 __global__ __launch_bounds__(256) void rate_kernel(const uint4* __restrict__ ops, float* __restrict__ out, unsigned long long* ticks, int tiles, float thr)
 {
@@ -142,6 +186,28 @@ int main()
             const double tile_groups_per_simd = (double)tiles * qg * wps;          // each SIMD holds wps waves
             printf("B waves/SIMD %d QG %d: %.3f ms -> %.1f ns per (group, tile) per SIMD = %.1f cycles at 2.4 GHz  (%.1f G pair-bounds/s chip-wide)\n", wps, qg, ms,
                    ms * 1e6 / tile_groups_per_simd, ms * 1e6 / tile_groups_per_simd * 2.4, 1024.0 * tile_groups_per_simd * cus * 4 / (ms * 1e-3) * 1e-9);
+        }
+    }
+    // ---- C: do the matrix pipe and the vector ALU overlap?
+    const char* mnames[5] = { "MFMA only", "8 x v_min3 + compare only", "MFMA -> min of its own results", "MFMA + min of the previous results", "half the waves MFMA only, half min only" };
+    for (int wps : { 2, 4 }) {
+        for (int mode = 0; mode < 5; mode++) {
+            const int blocks = cus * wps;
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int rep = 0; rep < 2; rep++) {
+                CK(hipEventRecord(e0));
+                switch (mode) {
+                case 0: hipLaunchKernelGGL(mix_kernel<0>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
+                case 1: hipLaunchKernelGGL(mix_kernel<1>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
+                case 2: hipLaunchKernelGGL(mix_kernel<2>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
+                case 3: hipLaunchKernelGGL(mix_kernel<3>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
+                default: hipLaunchKernelGGL(mix_kernel<4>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
+                }
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            }
+            float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double tg = (double)tiles * 4 * wps;
+            printf("C waves/SIMD %d  %-42s %.3f ms -> %.1f cycles at 2.4 GHz per (group, tile) per SIMD\n", wps, mnames[mode], ms, ms * 1e6 / tg * 2.4);
         }
     }
     return 0;
