@@ -29,6 +29,9 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -999,6 +1002,123 @@ int launch_nn1_brute_list(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* s
     hipLaunchKernelGGL((nn1_ftrack_kernel<Q, 16>), dim3(qblocks, slices), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
                        src->x(), src->y(), src->z(), (uint32_t)src->n, n_tiles, tps, ctx->keys, 1, ctx->stop_flag_dev, qlist, qcount, qcap);
     PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+// ---- self-test of the arithmetic BTRACK's bound rests on (pcr_selftest_mfma_bf16): one wave per tile runs the kernel's two MFMAs on
+// operands the host built, and the host compares every accumulator with the exact value in f64.
+__global__ __launch_bounds__(64) void bt_selftest_kernel(const uint4* __restrict__ ops, float* __restrict__ out)
+{
+    const uint32_t lane = threadIdx.x, T = blockIdx.x;
+    const uint4 A0 = ops[(size_t)T * 256 + lane], B0 = ops[(size_t)T * 256 + 64 + lane], A1 = ops[(size_t)T * 256 + 128 + lane], B1 = ops[(size_t)T * 256 + 192 + lane];
+    f32x16 zero;
+#pragma unroll
+    for (int j = 0; j < 16; j++) zero[j] = 0.0f;
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), __builtin_bit_cast(bf16x8, B0), zero, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1), __builtin_bit_cast(bf16x8, B1), acc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; j++) out[((size_t)T * 64 + lane) * 16 + j] = acc[j];
+}
+
+namespace {
+struct SelfRng {                                              // splitmix64: the same stream on every host
+    uint64_t s;
+    uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }                    // [0, 1)
+    float sym(float a) { return (float)((uni() * 2.0 - 1.0) * a); }
+};
+inline float bf16_to_f32(uint32_t b) { const uint32_t u = b << 16; float f; std::memcpy(&f, &u, 4); return f; }
+inline void host_split3(float v, uint32_t (&p)[3])
+{
+    uint32_t u; std::memcpy(&u, &v, 4);
+    const uint32_t a = u & 0xFFFF0000u; float fa; std::memcpy(&fa, &a, 4);
+    const float d = v - fa; uint32_t ud; std::memcpy(&ud, &d, 4);
+    const uint32_t b = ud & 0xFFFF0000u; float fb; std::memcpy(&fb, &b, 4);
+    const float e = d - fb; uint32_t ue; std::memcpy(&ue, &e, 4);
+    p[0] = a >> 16; p[1] = b >> 16; p[2] = ue >> 16;
+}
+}  // namespace
+
+// mode 0: random bf16 operands with exponents spread over 2^-20 .. 2^20 in every slot -> worst |D - exact| / (2^-24 sum |a b|);
+// mode 1: BTRACK's own operand layout for random r, t'' (|r| <= 60, |t''| <= 4) -> worst |G - (w - 2 r.t'')| / (2^-24 (|r|^2 + |t''|^2)),
+//         w = fl(|t''|^2) as the kernel stores it without the (1 - 2^-17) factor
+int bt_mfma_selftest(pcr_ctx* ctx, int trials, double worst[2])
+{
+    worst[0] = worst[1] = 0.0;
+    if (trials <= 0) return PCR_OK;
+    const size_t n_tiles = 2 * (size_t)trials;
+    std::vector<uint32_t> h(n_tiles * 256 * 4);
+    std::vector<float> rv(n_tiles * 32 * 3), tv(n_tiles * 32 * 3);
+    SelfRng rng{ 0x5EEDF00Dull };
+    auto put = [&](size_t T, int which, int lane, int j, uint32_t bf) {          // element j (0..7) of operand `which` (A0, B0, A1, B1) of a lane
+        uint32_t& w = h[((T * 4 + which) * 64 + lane) * 4 + j / 2];
+        w = (j & 1) ? ((w & 0x0000FFFFu) | (bf << 16)) : ((w & 0xFFFF0000u) | bf);
+    };
+    for (size_t T = 0; T < (size_t)trials; T++)                                  // mode 0
+        for (int which = 0; which < 4; which++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const float v = std::ldexp(rng.sym(1.0f), (int)(rng.next() % 41) - 20);
+                    uint32_t u; std::memcpy(&u, &v, 4);
+                    put(T, which, lane, j, u >> 16);
+                }
+    for (size_t T = trials; T < n_tiles; T++) {                                  // mode 1: rows = targets, columns = queries
+        const float scale_r = std::ldexp(1.0f, (int)(rng.next() % 9) - 2), scale_t = std::ldexp(1.0f, (int)(rng.next() % 6) - 3);
+        for (int m = 0; m < 32; m++) {
+            uint32_t t[3][3], w[3];
+            float tt[3];
+            for (int c = 0; c < 3; c++) { tt[c] = rng.sym(scale_t); tv[(T * 32 + m) * 3 + c] = tt[c]; host_split3(-2.0f * tt[c], t[c]); }
+            const float ww = (tt[0] * tt[0] + tt[1] * tt[1]) + tt[2] * tt[2];
+            host_split3(ww, w);
+            const int sel[8] = { 0, 1, 0, 2, 1, 0, 2, 1 };                                            // [t1, t2, t1, t3, t2, t1, t3, t2]
+            for (int j = 0; j < 8; j++) { put(T, 0, m, j, t[0][sel[j]]); put(T, 0, 32 + m, j, t[1][sel[j]]); put(T, 2, m, j, t[2][sel[j]]); }
+            const uint32_t wl[8] = { w[0], w[1], 0, w[2], 0, 0, 0, 0 };
+            for (int j = 0; j < 8; j++) put(T, 2, 32 + m, j, wl[j]);
+        }
+        for (int n = 0; n < 32; n++) {
+            uint32_t r[3][3], one[3];
+            for (int c = 0; c < 3; c++) { const float v = rng.sym(scale_r); rv[(T * 32 + n) * 3 + c] = v; host_split3(v, r[c]); }
+            host_split3(1.0f, one);
+            const int sel[8] = { 0, 0, 1, 0, 1, 2, 1, 2 };                                            // [r1, r1, r2, r1, r2, r3, r2, r3]
+            for (int j = 0; j < 8; j++) { put(T, 1, n, j, r[0][sel[j]]); put(T, 1, 32 + n, j, r[1][sel[j]]); put(T, 3, n, j, r[2][sel[j]]); put(T, 3, 32 + n, j, one[sel[j]]); }
+        }
+    }
+    uint4* dops = nullptr; float* dout = nullptr;
+    PCR_HIP(ctx, hipMalloc((void**)&dops, h.size() * 4));
+    hipError_t e = hipMalloc((void**)&dout, n_tiles * 64 * 16 * sizeof(float));
+    std::vector<float> out(n_tiles * 64 * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(dops, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bt_selftest_kernel, dim3((unsigned)n_tiles), dim3(64), 0, ctx->stream, dops, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dops); hipFree(dout);
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "mfma selftest", e);
+    auto elem = [&](size_t T, int which, int lane, int j) { const uint32_t w = h[((T * 4 + which) * 64 + lane) * 4 + j / 2]; return bf16_to_f32((j & 1) ? (w >> 16) : (w & 0xFFFFu)); };
+    for (size_t T = 0; T < n_tiles; T++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int reg = 0; reg < 16; reg++) {
+                const int n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                double ex = 0.0, mag = 0.0;
+                for (int ins = 0; ins < 2; ins++)
+                    for (int hh = 0; hh < 2; hh++)
+                        for (int j = 0; j < 8; j++) {
+                            const double p = (double)elem(T, 2 * ins, m + 32 * hh, j) * (double)elem(T, 2 * ins + 1, n + 32 * hh, j);
+                            ex += p; mag += std::fabs(p);
+                        }
+                const double got = (double)out[(T * 64 + lane) * 16 + reg];
+                if (T < (size_t)trials) {
+                    if (mag > 0.0) worst[0] = std::max(worst[0], std::fabs(got - ex) / mag * 16777216.0);
+                } else {
+                    const float* r = &rv[(T * 32 + n) * 3]; const float* t = &tv[(T * 32 + m) * 3];
+                    const double Q = (double)r[0] * r[0] + (double)r[1] * r[1] + (double)r[2] * r[2], W = (double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2];
+                    const float wf = (t[0] * t[0] + t[1] * t[1]) + t[2] * t[2];
+                    const double want = (double)wf - 2.0 * ((double)r[0] * t[0] + (double)r[1] * t[1] + (double)r[2] * t[2]);
+                    if (Q + W > 0.0) worst[1] = std::max(worst[1], std::fabs(got - want) / (Q + W) * 16777216.0);
+                }
+            }
     return PCR_OK;
 }
 

@@ -279,6 +279,11 @@ int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* t
 /* diagnostics of the last grid search launched with tune "grid_stats" = 1:
  * out = { candidates evaluated, fine x-rows opened, coarse rows tested, far stages run } summed over the queries */
 int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4]);
+/* Checks on THIS device the arithmetic the default exhaustive 1-NN filter (bf16 matrix cores, csrc/nn1_brute.hip BTRACK) relies on:
+ * `trials` random 32 x 32 tiles per mode through the kernel's own pair of v_mfma_f32_32x32x16_bf16.
+ *   worst[0] = max |D - exact| / (2^-24 sum |a_k b_k|) over operands with exponents spread over 2^-20 .. 2^20   (the bound's analysis assumes <= 16)
+ *   worst[1] = max |G - (w - 2 r.t)| / (2^-24 (|r|^2 + |t|^2)) in the kernel's three-piece operand layout        (assumes <= 34.2) */
+int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[2]);
 /* tuning / diagnostic knobs by name (value 0 = library default, except "prof"): "nn_method" 1 brute force / 2 exact grid,
  * "nn1_variant", "knn_method", "radius_method", "icp_pipeline", "prof", ... — the names are listed where they are read (csrc/) */
 int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value);

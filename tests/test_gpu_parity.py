@@ -37,6 +37,16 @@ def random_cloud32(rng, n, kind):
     return np.ascontiguousarray(a.astype(np.float32))
 
 
+def test_bf16_matrix_core_arithmetic_is_within_the_bound_the_filter_assumes(ctx):
+    """BTRACK's lower bound (csrc/nn1_brute.hip) assumes: bf16 x bf16 products exact in f32 and an accumulation error of the two
+    v_mfma_f32_32x32x16_bf16 of at most 16 x 2^-24 x sum |a b|; its three-piece operand layout then reproduces w - 2 r.t to within
+    34.2 x 2^-24 (|r|^2 + |t|^2).  Measured here on the device under test (the library's own MFMA pair, adversarial exponents), with a
+    factor two of head-room on both."""
+    acc, filt = ctx.selftest_mfma_bf16(96)
+    assert 0.0 < acc <= 8.0, acc
+    assert 0.0 < filt <= 17.0, filt
+
+
 def test_nn1_randomised_sweep_every_kernel(ctx, orc):
     """120 random problems x {FTRACK, TRACK scalar, TRACK LDS, ETRACK, MTRACK / BTRACK (matrix cores), exact grid (plain / x-window / bounding-sphere kernels on the
     x-sorted index, plain / bounding-sphere kernels on the Morton-ordered index)}: indices and d2 bits equal to the oracle."""
