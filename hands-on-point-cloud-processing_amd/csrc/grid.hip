@@ -186,38 +186,6 @@ __global__ __launch_bounds__(GR_BLOCK) void build_chunks_kernel(const float4* __
     if (bad) atomicOr(unsafe, 1);
 }
 
-// one thread per tile of 32 consecutive records: the MFMA operands of the MTRACK filter (nn1_brute.hip).  Same arithmetic as
-// build_chunks_kernel with one centre per tile; MFMA row m holds record 32 T + 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3).
-__global__ __launch_bounds__(GR_BLOCK) void build_mtiles_kernel(const float4* __restrict__ records, uint32_t n, uint32_t n_tiles, float4* __restrict__ centres,
-                                                                float* __restrict__ ops)
-{
-    const uint32_t T = blockIdx.x * GR_BLOCK + threadIdx.x;
-    if (T >= n_tiles) return;
-    float cx = 0.f, cy = 0.f, cz = 0.f;
-    int cnt = 0;
-    for (int j = 0; j < 32; j++) {
-        const uint32_t p = T * 32 + j;
-        if (p >= n) break;
-        const float4 r = records[p];
-        if (finite3(r.x, r.y, r.z)) { cx += r.x; cy += r.y; cz += r.z; cnt++; }
-    }
-    if (cnt) { cx /= (float)cnt; cy /= (float)cnt; cz /= (float)cnt; }
-    centres[T] = make_float4(cx, cy, cz, 0.f);
-    float* out = ops + (size_t)T * 128;
-    for (int m = 0; m < 32; m++) {
-        const uint32_t p = T * 32 + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
-        float tx = 0.f, ty = 0.f, tz = 0.f, w = INFINITY;                  // padding / non-finite: never the minimum
-        if (p < n) {
-            const float4 r = records[p];
-            if (finite3(r.x, r.y, r.z)) {
-                tx = r.x - cx; ty = r.y - cy; tz = r.z - cz;
-                w = ((tx * tx + ty * ty) + tz * tz) * 0.999996185302734375f;   // (1 - 2^-18): error analysis in nn1_brute.hip
-            }
-        }
-        out[m] = w; out[32 + m] = -2.0f * tz; out[64 + m] = -2.0f * ty; out[96 + m] = -2.0f * tx;
-    }
-}
-
 // records[p] for p < n; the tail up to a whole chunk is padding (x = +inf: d2 = inf is never accepted; index = none)
 __global__ __launch_bounds__(GR_BLOCK) void gather_records_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                                   uint32_t n, uint32_t n_padded, const uint32_t* __restrict__ order, float4* __restrict__ records)
@@ -994,8 +962,6 @@ void grid_free(Grid* g)
     if (g->bt_records) hipFree(g->bt_records);
     if (g->bt_centres) hipFree(g->bt_centres);
     if (g->bt_ops) hipFree(g->bt_ops);
-    if (g->mt_centres) hipFree(g->mt_centres);
-    if (g->mt_ops) hipFree(g->mt_ops);
     if (g->records) hipFree(g->records);
     if (g->cell_start) hipFree(g->cell_start);
     delete g;
@@ -1391,22 +1357,6 @@ int grid_ensure_btiles(pcr_ctx* ctx, const pcr_cloud* tgt)
     if (e != hipSuccess) { hipFree(rec); hipFree(cen); hipFree(ops); return fail(ctx, PCR_ERR_HIP, "btiles", e); }
     g->bt_records = rec; g->bt_centres = cen; g->bt_ops = ops; g->n_btiles = n_tiles;
     g->bt_safe = unsafe_host == 0;
-    return PCR_OK;
-}
-
-int grid_ensure_mtiles(pcr_ctx* ctx, const pcr_cloud* tgt)
-{
-    Grid* g = tgt->grid;
-    if (!g) return fail(ctx, PCR_ERR_STATE, "mtiles: no index");
-    if (g->mt_ops || g->n_points == 0) return PCR_OK;
-    const size_t nt = (g->n_points + 31) / 32;
-    PCR_HIP(ctx, hipMalloc((void**)&g->mt_centres, nt * sizeof(float4)));
-    hipError_t e = hipMalloc((void**)&g->mt_ops, nt * 128 * sizeof(float));
-    if (e != hipSuccess) { hipFree(g->mt_centres); g->mt_centres = nullptr; return fail(ctx, PCR_ERR_HIP, "hipMalloc(mtiles)", e); }
-    g->n_mtiles = nt;
-    hipLaunchKernelGGL(build_mtiles_kernel, dim3((unsigned)((nt + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records, (uint32_t)g->n_points,
-                       (uint32_t)nt, g->mt_centres, g->mt_ops);
-    PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }
 

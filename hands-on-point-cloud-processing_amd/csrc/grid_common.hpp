@@ -37,11 +37,6 @@ struct Grid {
     // records array is padded to a whole chunk with x = +inf entries): one 16-byte load decides whether 16 records can hold a
     // better neighbour (grid.hip, SPH search kernel)
     float4* spheres = nullptr;
-    // the same records as MFMA operands for the matrix-core brute-force filter (nn1_brute.hip, MTRACK), built on first use:
-    // per tile of 32 consecutive records its centre {Cx, Cy, Cz, 0} and 2 x 64 operand floats in lane order
-    float4* mt_centres = nullptr;
-    float* mt_ops = nullptr;
-    size_t n_mtiles = 0;
     // BTRACK (nn1_brute.hip): the cloud once more in Morton order of its cells — spatially compact runs — as {x, y, z, original index}
     // records (padded to whole super-tiles of BT_SUPER records with x = +inf), one centre per super-tile, and per tile of 32
     // records the bf16 A operands of two v_mfma_f32_32x32x16_bf16 ([tile][2][64 lanes] x 16 bytes); built on first use
@@ -86,8 +81,6 @@ __device__ __forceinline__ uint32_t clamped_cell_id(const GridParams& g, float x
 int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, int order = GRID_ORDER_X);
 // builds (and caches on tgt) the 1-NN grid if needed
 int build_target_grid(pcr_ctx* ctx, const pcr_cloud* tgt);
-// builds Grid::mt_centres / mt_ops of tgt's (already built) index if they are not there yet
-int grid_ensure_mtiles(pcr_ctx* ctx, const pcr_cloud* tgt);
 // builds Grid::bt_* of tgt's (already built) index if they are not there yet
 int grid_ensure_btiles(pcr_ctx* ctx, const pcr_cloud* tgt);
 // builds (and caches on tgt) the 1-NN grid if needed, then groups the queries `src` by coarse cell -> ctx->qperm

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
     const float4* __restrict__ records, const uint32_t* __restrict__ wpos, const uint32_t* __restrict__ orig,
     const unsigned long long* __restrict__ keys, uint32_t ns, uint32_t nt, float max_corr, KabschPlan plan,
-    double* __restrict__ partials, int probe)
+    double* __restrict__ partials)
 {
     double c0[6], c1[6], p0[9], p1[9], p2[9], cnt = 0.0;
 #pragma unroll
@@ -120,27 +120,20 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
     int overflow = 0;
     // contiguous chunk per block, strided by lane inside it (coalesced); the order does not matter for the result
     const uint32_t per_block = (ns + gridDim.x - 1) / gridDim.x;
-    const uint32_t lo = (probe & 4) ? blockIdx.x * KB_BLOCK : min(blockIdx.x * per_block, ns);
-    const uint32_t hi = (probe & 4) ? ns : min(lo + per_block, ns);
-    const uint32_t step = (probe & 4) ? gridDim.x * KB_BLOCK : KB_BLOCK;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += step) {
+    const uint32_t lo = min(blockIdx.x * per_block, ns);
+    const uint32_t hi = min(lo + per_block, ns);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += KB_BLOCK) {
         // everything that does not depend on the key is requested up front: one round of coalesced loads, then the gather
+        const unsigned long long key = keys[i];
         const float pf0 = sx[i], pf1 = sy[i], pf2 = sz[i];
         const uint32_t wp = RECORDS ? wpos[i] : 0u;
-        unsigned long long key;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (RECORDS && (probe & 1)) {
-            r = records[min(wp, nt - 1)];
-            const float dx = pf0 - r.x, dy = pf1 - r.y, dz = pf2 - r.z;
-            key = ((unsigned long long)__float_as_uint((dx * dx + dy * dy) + dz * dz) << 32) | (wp < nt ? __float_as_uint(r.w) : 0xFFFFFFFFu);
-        } else key = keys[i];
         const uint32_t d2b = (uint32_t)(key >> 32);
         const float d2 = __uint_as_float(d2b);
         const uint32_t j = (uint32_t)(key & 0xFFFFFFFFull);
         if (d2 < max_corr && j < nt) {                       // registration.cpp:936
             float qf0, qf1, qf2;
             if (RECORDS) {
-                if (!(probe & 1)) r = records[wp];
+                const float4 r = records[wp];
                 qf0 = r.x; qf1 = r.y; qf2 = r.z;
             } else {
                 qf0 = tx[j]; qf1 = ty[j]; qf2 = tz[j];
@@ -148,16 +141,6 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
             // 2^e bounds every coordinate of a kept pair (kabsch_plan); a source beyond it would overflow its limbs
             if (!(fabsf(pf0) < plan.lim && fabsf(pf1) < plan.lim && fabsf(pf2) < plan.lim)) { overflow = 1; continue; }
             const double P[3] = { pf0, pf1, pf2 }, Q[3] = { qf0, qf1, qf2 };
-            if (probe & 2) {
-#pragma unroll
-                for (int c = 0; c < 3; c++) { c0[c] += P[c]; c0[3 + c] += Q[c]; }
-#pragma unroll
-                for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) p0[3 * rr + c] = fma(Q[rr], P[c], p0[3 * rr + c]);
-                cnt += 1.0;
-                continue;
-            }
 #pragma unroll
             for (int c = 0; c < 3; c++) { acc2(P[c], plan.sc, c0[c], c1[c]); acc2(Q[c], plan.sc, c0[3 + c], c1[3 + c]); }
 #pragma unroll
@@ -303,12 +286,11 @@ int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* s
         ProfScope p(ctx, "kabsch_partial");
         if (rec)
             hipLaunchKernelGGL((kabsch_partial_kernel<true>), dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), tgt->x(), tgt->y(),
-                               tgt->z(), tgt->grid->records, ctx->wpos, orig, ctx->keys, (uint32_t)ns, (uint32_t)tgt->n, max_corr, plan, ctx->partials,
-                               (int)tune_get(ctx, "kabsch_probe", 0));
+                               tgt->z(), tgt->grid->records, ctx->wpos, orig, ctx->keys, (uint32_t)ns, (uint32_t)tgt->n, max_corr, plan, ctx->partials);
         else
             hipLaunchKernelGGL((kabsch_partial_kernel<false>), dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), tgt->x(), tgt->y(),
                                tgt->z(), (const float4*)nullptr, (const uint32_t*)nullptr, orig, ctx->keys, (uint32_t)ns, (uint32_t)tgt->n, max_corr, plan,
-                               ctx->partials, 0);
+                               ctx->partials);
     }
     PCR_HIP(ctx, hipGetLastError());
     *n_blocks = blocks;

@@ -39,7 +39,6 @@ namespace pcr {
 
 constexpr int NN_BLOCK = 256;
 constexpr int NN_TILE = 1024;   // targets per LDS tile: 3 * 4 KiB
-constexpr bool NN_MFMA_DEFAULT = false;
 constexpr bool NN_BF16_DEFAULT = true;     // measured: 0.90 against 1.30 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
 
 __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
@@ -429,134 +428,10 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_etrack_kernel(
     }
 }
 
-// ---- MTRACK: ETRACK's filter on the matrix cores.  g = w + r . (-2 t'') is a K = 4 product of [1, rz, ry, rx] and
-// [w, -2 t''z, -2 t''y, -2 t''x]: v_mfma_f32_32x32x2_f32 evaluates it for 32 queries x 32 targets per instruction pair, and its
-// result is bit for bit the k-ordered fmaf chain  fma(rx, X, fma(ry, Y, fma(rz, Z, fma(1, w, 0))))  (cdna_hip_programming.md,
-// "FP32-input MFMA") — the very chain of ETRACK, so its error analysis (above) and the constants KAPPA / (1 - 2^-18) carry over
-// unchanged.  The vector ALU keeps what it alone can do: r = q - C and R = |r|^2 per (query, tile), the minimum over the 16
-// accumulators of a lane, and the m1 / m2 / c1 tracking — about half of ETRACK's issue slots, running beside the MFMA pipe.
-// Layout.  A tile = 32 consecutive records (two 16-record chunks of the index) shifted to ONE centre (Grid::mt_centres);
-// MFMA row m <-> chunk (m >> 2) & 1 of the tile, element 4 (m >> 3) + (m & 3): the 16 accumulator rows of lane-half h
-// (row = (reg & 3) + 8 (reg >> 2) + 4 h) are exactly chunk 2 T + h.  A wave holds QG groups of 32 queries (column = lane & 31):
-// lanes n and n + 32 track the even and the odd chunks of query n and are merged after the scan.
-// Operands (Grid::mt_ops, [tile][2][64] in lane order): instruction 1 (k = 0, 1): lanes < 32  A = w_m, B = 1;  lanes >= 32
-// A = -2 t''z_m, B = rz_n;  instruction 2 (k = 2, 3): lanes < 32  A = -2 t''y_m, B = ry_n;  lanes >= 32  A = -2 t''x_m, B = rx_n.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int QG>
-__global__ __launch_bounds__(NN_BLOCK) void nn1_mtrack_kernel(
-    const float4* __restrict__ centres, const float* __restrict__ ops, const float4* __restrict__ records, uint32_t nt, uint32_t n_tiles,
-    uint32_t tiles_per_slice, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
-    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop, unsigned long long* __restrict__ stats)
-{
-    if (stop && (stop[0] | stop[1])) return;
-    constexpr int CH = 16;
-    constexpr float KAPPA = 0.99999809265136718750f;          // 1 - 2^-19
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t n = lane & 31;
-    const bool h = lane >= 32;
-    const uint32_t qbase = (blockIdx.x * (NN_BLOCK / 64) + wave) * (32 * QG);
-    if (qbase >= ns) return;                                  // a whole wave beyond the queries (wave-uniform)
-    float qx[QG], qy[QG], qz[QG], m1[QG], m2[QG], cur0[QG];
-    uint32_t c1[QG];
-    bool okq[QG];
-#pragma unroll
-    for (int g = 0; g < QG; g++) {
-        const uint32_t i = min(qbase + g * 32 + n, ns - 1);
-        qx[g] = sx[i]; qy[g] = sy[i]; qz[g] = sz[i];
-        okq[g] = fabsf(qx[g]) < 1e18f && fabsf(qy[g]) < 1e18f && fabsf(qz[g]) < 1e18f;      // false for NaN / inf
-        m1[g] = INFINITY; m2[g] = INFINITY; c1[g] = 0xFFFFFFFFu;
-        cur0[g] = merge_atomic ? __uint_as_float((uint32_t)(__atomic_load_n(&keys[i], __ATOMIC_RELAXED) >> 32)) : INFINITY;
-    }
-    const uint32_t tb = blockIdx.y * tiles_per_slice, te = min(tb + tiles_per_slice, n_tiles);
-    f32x16 zero;
-#pragma unroll
-    for (int j = 0; j < 16; j++) zero[j] = 0.0f;
-    float a1 = 0.f, a2 = 0.f;
-    float4 Cn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tb < te) { a1 = ops[(size_t)tb * 128 + lane]; a2 = ops[(size_t)tb * 128 + 64 + lane]; Cn = centres[tb]; }
-    for (uint32_t T = tb; T < te; T++) {
-        const float4 C = Cn;                                  // wave-uniform: scalar registers
-        const float A1 = a1, A2 = a2;
-        // the next tile's operands and centre are requested before this tile is consumed
-        if (T + 1 < te) { a1 = ops[(size_t)(T + 1) * 128 + lane]; a2 = ops[(size_t)(T + 1) * 128 + 64 + lane]; Cn = centres[T + 1]; }
-        const uint32_t c = 2 * T + (h ? 1u : 0u);
-#pragma unroll
-        for (int g = 0; g < QG; g++) {
-            const float rx = qx[g] - C.x, ry = qy[g] - C.y, rz = qz[g] - C.z;
-            const float R = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
-            const float b1 = h ? rz : 1.0f, b2 = h ? rx : ry;
-            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, b1, zero, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, b2, acc, 0, 0, 0);
-            float m = fminf(fminf(acc[0], acc[1]), acc[2]);
-#pragma unroll
-            for (int j = 3; j + 1 < CH; j += 2) m = fminf(fminf(m, acc[j]), acc[j + 1]);
-            m = fminf(m, acc[CH - 1]);
-            const float L = __builtin_fmaf(R, KAPPA, m);
-            m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], L);
-            const bool better = L < m1[g];                    // (false for a NaN L: a non-finite query is rescanned exactly anyway)
-            m1[g] = better ? L : m1[g];
-            c1[g] = better ? c : c1[g];
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < QG; g++) {
-        // the two half-lanes of a query: smallest chunk value, a chunk attaining it, smallest value over all OTHER chunks
-        const float m1o = __shfl_xor(m1[g], 32, 64), m2o = __shfl_xor(m2[g], 32, 64);
-        const uint32_t c1o = (uint32_t)__shfl_xor((int)c1[g], 32, 64);
-        const bool take = m1o < m1[g] || (m1o == m1[g] && c1o < c1[g]);
-        const float M1 = take ? m1o : m1[g];
-        const float M2 = fminf(fminf(m2[g], m2o), take ? m1[g] : m1o);
-        const uint32_t C1 = take ? c1o : c1[g];
-        uint32_t best = 0x7F7FFFFFu, bidx = 0xFFFFFFFFu;      // FLT_MAX gate, nanoflann.hpp:163,1360
-        bool proven = false;
-        const float cur = cur0[g];                            // see nn1_etrack_kernel: what the other slices have published
-        const bool slice_out = okq[g] && (M1 - 1e-30f) > cur;
-        if (!slice_out && okq[g] && C1 != 0xFFFFFFFFu) {
-            // exact A1 evaluation of the 16 records of chunk C1: 8 per half-lane, merged lexicographically (d2, index)
-            const uint32_t j0 = C1 * CH + (h ? 8u : 0u);
-#pragma unroll
-            for (int j = 0; j < CH / 2; j++) {
-                if (j0 + j < nt) {
-                    const float4 rec = records[j0 + j];
-                    const uint32_t e = d2_exact_bits(qx[g], qy[g], qz[g], rec.x, rec.y, rec.z);
-                    const uint32_t oi = __float_as_uint(rec.w);
-                    if (e < best || (e == best && e < 0x7F7FFFFFu && oi < bidx)) { best = e; bidx = oi; }
-                }
-            }
-            const uint32_t bo = (uint32_t)__shfl_xor((int)best, 32, 64), io = (uint32_t)__shfl_xor((int)bidx, 32, 64);
-            if (bo < best || (bo == best && io < bidx)) { best = bo; bidx = io; }
-            proven = (bidx != 0xFFFFFFFFu && (M2 - 1e-30f) > __uint_as_float(best)) || (M2 - 1e-30f) > cur;
-        }
-        if (!__all(proven || slice_out || tb >= te)) {
-            if (stats && lane == 0) atomicAdd(&stats[2], 1ull);          // diagnostics: (wave, query group) pairs that had to rescan
-            // exact rescan of the slice by the whole wave, each half-lane one half of it
-            const uint32_t r0 = tb * 2 * CH, r1 = min(te * 2 * CH, nt), mid = r0 + (r1 - r0) / 2;
-            unsigned long long kbest = ~0ull;
-            for (uint32_t j = h ? mid : r0; j < (h ? r1 : mid); j++) {
-                const float4 rec = records[j];
-                const uint32_t e = d2_exact_bits(qx[g], qy[g], qz[g], rec.x, rec.y, rec.z);
-                const unsigned long long key = ((unsigned long long)e << 32) | __float_as_uint(rec.w);
-                if (e < 0x7F7FFFFFu && key < kbest) kbest = key;
-            }
-            const unsigned long long ko = ((unsigned long long)(uint32_t)__shfl_xor((int)(kbest >> 32), 32, 64) << 32) |
-                                          (uint32_t)__shfl_xor((int)(uint32_t)kbest, 32, 64);
-            kbest = ko < kbest ? ko : kbest;
-            best = (uint32_t)(kbest >> 32);
-            bidx = kbest == ~0ull ? 0xFFFFFFFFu : (uint32_t)(kbest & 0xFFFFFFFFull);
-        }
-        const uint32_t i = qbase + g * 32 + n;
-        if (!h && i < ns) {
-            const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : best;
-            const unsigned long long key = ((unsigned long long)bits << 32) | bidx;
-            if (merge_atomic) merge_key(&keys[i], key);
-            else keys[i] = key;
-        }
-    }
-}
-
-// ---- BTRACK: the filter on the bf16 matrix pipe, which (unlike the f32 MFMA above, which shares the vector ALU's multipliers:
-// profiles/r02_mfma_filter_experiments.txt) runs BESIDE the vector ALU.  f32 values are cut into three bf16 pieces each
+// ---- BTRACK: the filter on the bf16 matrix pipe (the f32 MFMA was tried twice — it runs at the vector ALU's own FMA rate and the two
+// never overlap: DESIGN.md 5, profiles/r02_mfma_filter_experiments.txt).  f32 values are cut into three bf16 pieces each
 // (v = v1 + v2 + v3 exactly: 3 x 8 significant bits), so that  r . t'' = sum_{i,j} r_i t''_j  with every product exact in f32;
 // v_mfma_f32_32x32x16_bf16 sums 16 such products per instruction.  Per coordinate the 8 K-slots of one lane-half hold the pairs
 // (1,1) (1,2) (2,1) (1,3) (2,2) (3,1) (2,3) (3,2); only r3 t''3 (<= 2^-28 |r_c t''_c|) is dropped.  Two instructions = 32 slots:
@@ -800,7 +675,7 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     const int64_t variant_tune = tune_get(ctx, "nn1_variant", 0);
     // cold searches take ETRACK too when its index exists or will be needed anyway (inside an ICP loop): 1.64 vs 1.82 ms at 120 k;
     // a one-shot search on a fresh target stays on FTRACK, which needs no index (0.3 ms to build)
-    if (variant_tune == 4 || variant_tune == 5 || variant_tune == 6 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid))) {
+    if (variant_tune == 4 || variant_tune == 6 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid))) {
         rc = build_target_grid(ctx, tgt);
         if (rc) return rc;
         const Grid* g = tgt->grid;
@@ -849,53 +724,6 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
                 default: PCR_BTRACK(4); break;
                 }
 #undef PCR_BTRACK
-            }
-            PCR_HIP(ctx, hipGetLastError());
-            return PCR_OK;
-        }
-        // MTRACK (variant 5, tune nn1_mfma: 1 on, 2 off): the same filter on the matrix cores
-        const int64_t mfma_tune = tune_get(ctx, "nn1_mfma", 0);
-        const bool mfma = variant_tune == 5 || (variant_tune == 0 && mfma_tune != 2 && (mfma_tune == 1 || NN_MFMA_DEFAULT));
-        if (mfma && g->chunk_safe && g->n_chunks) {
-            rc = grid_ensure_mtiles(ctx, tgt);
-            if (rc) return rc;
-            int qg = (int)tune_get(ctx, "nn1_mtrack_qg", 4);
-            if (qg != 1 && qg != 2 && qg != 8) qg = 4;
-            const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                      // queries per workgroup
-            const uint32_t qblocks = (uint32_t)((ns + qpb - 1) / qpb);
-            int64_t tps = tune_get(ctx, "nn1_tiles_per_slice", 0);
-            if (tps <= 0) {
-                const int64_t want_blocks = tune_get(ctx, "nn1_mtrack_blocks", 32768);
-                const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
-                tps = std::max<int64_t>(1, ((int64_t)g->n_mtiles + slices - 1) / slices);
-            }
-            uint32_t slices = (uint32_t)((g->n_mtiles + tps - 1) / tps);
-            if (slices > 65535) { slices = 65535; tps = (g->n_mtiles + slices - 1) / slices; slices = (uint32_t)((g->n_mtiles + tps - 1) / tps); }
-            const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
-            if (warm)
-                hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
-                                   (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
-            else if (merge_atomic)
-                PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
-            unsigned long long* stats_dev = nullptr;
-            if (tune_get(ctx, "grid_stats", 0) > 0) {
-                if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
-                PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
-                stats_dev = ctx->grid_stats_dev;
-            }
-            {
-                ProfScope p(ctx, "nn1_brute", 1);
-                const dim3 grid(qblocks, slices);
-#define PCR_MTRACK(Q)                                                                                                                   \
-    hipLaunchKernelGGL((nn1_mtrack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->mt_centres, g->mt_ops, g->records, (uint32_t)tgt->n,       \
-                       (uint32_t)g->n_mtiles, (uint32_t)tps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev)
-                switch (qg) {
-                case 1: PCR_MTRACK(1); break;
-                case 2: PCR_MTRACK(2); break;
-                case 8: PCR_MTRACK(8); break;
-                default: PCR_MTRACK(4); break;
-                }
-#undef PCR_MTRACK
             }
             PCR_HIP(ctx, hipGetLastError());
             return PCR_OK;

@@ -48,7 +48,7 @@ def test_bf16_matrix_core_arithmetic_is_within_the_bound_the_filter_assumes(ctx)
 
 
 def test_nn1_randomised_sweep_every_kernel(ctx, orc):
-    """120 random problems x {FTRACK, TRACK scalar, TRACK LDS, ETRACK, MTRACK / BTRACK (matrix cores), exact grid (plain / x-window / bounding-sphere kernels on the
+    """120 random problems x {FTRACK, TRACK scalar, TRACK LDS, ETRACK, BTRACK (matrix cores), exact grid (plain / x-window / bounding-sphere kernels on the
     x-sorted index, plain / bounding-sphere kernels on the Morton-ordered index)}: indices and d2 bits equal to the oracle."""
     rng = np.random.default_rng(77)
     for trial in range(120):
@@ -59,7 +59,7 @@ def test_nn1_randomised_sweep_every_kernel(ctx, orc):
             src[:, : min(ns, nt) // 2] = tgt[:, : min(ns, nt) // 2]
         oi, od = orc.nn1_f32(tgt, src)
         ct, cs = ctx.cloud(tgt), ctx.cloud(src)
-        for method, variant, mode in ((1, 1, 0), (1, 2, 0), (1, 3, 0), (1, 4, 0), (1, 5, 0), (1, 6, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)):
+        for method, variant, mode in ((1, 1, 0), (1, 2, 0), (1, 3, 0), (1, 4, 0), (1, 6, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)):
             ctx.tune("nn_method", method)
             ctx.tune("nn1_variant", variant)
             ctx.tune("grid_mode", mode)                # 1 plain, 2 x-window, 3 bounding spheres (0: by target size)
@@ -68,7 +68,7 @@ def test_nn1_randomised_sweep_every_kernel(ctx, orc):
         ct.free()
         ctx.tune("grid_order", 2)                      # the Morton-ordered index of large targets, forced on a fresh cloud
         cm = ctx.cloud(tgt)
-        for method, variant, mode in ((2, 1, 3), (2, 1, 1), (1, 4, 0), (1, 5, 0), (1, 6, 0)):
+        for method, variant, mode in ((2, 1, 3), (2, 1, 1), (1, 4, 0), (1, 6, 0)):
             ctx.tune("nn_method", method); ctx.tune("nn1_variant", variant); ctx.tune("grid_mode", mode)
             idx, d2 = ctx.nn1(cm, cs)
             assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (trial, kind, nt, ns, method, variant, mode, "morton")
@@ -99,7 +99,7 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
 
 # variant 1: FTRACK (default: fused-filter tracking, exact decision); 2: TRACK (exact only), scalar-cache targets; 3: TRACK, LDS tiles
 # (4 exact, 5 fused filter, 6/7 the same with scalar-load targets); chunk = targets per min-tree
-VARIANTS = [(1, 8), (1, 16), (2, 8), (2, 16), (3, 8), (3, 16), (4, 16), (5, 16), (6, 16)]   # 4 = ETRACK (expanded-form filter on the grid's chunked target copy), 5 = MTRACK (the same filter as f32 MFMA), 6 = BTRACK (bf16 MFMA on three-piece operands)
+VARIANTS = [(1, 8), (1, 16), (2, 8), (2, 16), (3, 8), (3, 16), (4, 16), (6, 16)]   # 4 = ETRACK (expanded-form filter on the grid's chunked target copy), 6 = BTRACK (the filter on the bf16 matrix cores, three-piece operands)
 
 
 def set_variant(ctx, vc):
@@ -113,7 +113,7 @@ def set_variant(ctx, vc):
 @pytest.mark.parametrize("qpl", [1, 2, 4])
 @pytest.mark.parametrize("ns,nt", [(1, 1), (63, 5), (257, 1023), (1000, 1025), (3001, 7000), (5000, 2049)])
 def test_nn1_ragged_sizes_vs_oracle(ctx, orc, synth, qpl, ns, nt, variant):
-    ctx.tune("nn1_qpl", qpl); ctx.tune("nn1_mtrack_qg", qpl); ctx.tune("nn1_btrack_qg", qpl)
+    ctx.tune("nn1_qpl", qpl); ctx.tune("nn1_btrack_qg", qpl)
     set_variant(ctx, variant)
     src, _ = synth.kitti_like_pair(max(ns, 64), seed_target=7 + ns, seed_pair=11 + nt)
     tgt = synth.kitti_like_scan(max(nt, 64), seed=13 + nt)
@@ -123,7 +123,7 @@ def test_nn1_ragged_sizes_vs_oracle(ctx, orc, synth, qpl, ns, nt, variant):
     oidx, od2 = orc.nn1_f32(tgt, src)
     assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
     cs.free(); ct.free()
-    ctx.tune("nn1_qpl", 0); ctx.tune("nn1_mtrack_qg", 0); ctx.tune("nn1_btrack_qg", 0)
+    ctx.tune("nn1_qpl", 0); ctx.tune("nn1_btrack_qg", 0)
     ctx.tune("nn1_variant", 0)
     ctx.tune("nn_method", 0)
 
