@@ -673,9 +673,11 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     // nn1_variant unset: ETRACK when a warm-start bound exists or the target's index does (profiles/r01_tune_nn1_etrack.txt),
     // FTRACK otherwise; 4 forces ETRACK, 1-3 the kernels below
     const int64_t variant_tune = tune_get(ctx, "nn1_variant", 0);
-    // cold searches take ETRACK too when its index exists or will be needed anyway (inside an ICP loop): 1.64 vs 1.82 ms at 120 k;
-    // a one-shot search on a fresh target stays on FTRACK, which needs no index (0.3 ms to build)
-    if (variant_tune == 4 || variant_tune == 6 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid))) {
+    // cold searches take the indexed kernels too when the index exists or will be needed anyway (inside an ICP loop);
+    // the FIRST one-shot search on a fresh target stays on FTRACK, which needs no index (0.4 ms to build against 0.5 ms saved per
+    // search); a target that is searched a second time gets its index then
+    const bool reused = tgt->grid == nullptr && tgt->brute_searches++ >= 1;
+    if (variant_tune == 4 || variant_tune == 6 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid || reused))) {
         rc = build_target_grid(ctx, tgt);
         if (rc) return rc;
         const Grid* g = tgt->grid;

@@ -73,6 +73,7 @@ struct pcr_cloud {
     pcr::Grid* rad_grid = nullptr;   // the index with cell edge 1.01 r of the last radius search (radius_grid.hip), same lifetime
     double rad_grid_r = 0.0;
     float absmax = -1.f;             // largest finite |coordinate| (cloud_absmax), < 0: not computed; same lifetime as the grids
+    mutable uint32_t brute_searches = 0;   // exhaustive searches that found no index on this target (the second one builds it); same lifetime
     size_t n = 0;
     size_t cap = 0;     // padded length of each of x, y, z
     float* base = nullptr;   // device; x = base, y = base + cap, z = base + 2*cap
