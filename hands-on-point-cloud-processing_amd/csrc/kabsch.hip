@@ -122,19 +122,38 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
     const uint32_t per_block = (ns + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = min(blockIdx.x * per_block, ns);
     const uint32_t hi = min(lo + per_block, ns);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += KB_BLOCK) {
-        // everything that does not depend on the key is requested up front: one round of coalesced loads, then the gather
-        const unsigned long long key = keys[i];
-        const float pf0 = sx[i], pf1 = sy[i], pf2 = sz[i];
-        const uint32_t wp = RECORDS ? wpos[i] : 0u;
+    // Software pipeline: the coalesced loads of the NEXT pair are requested before the current one is consumed, and the target gather
+    // of the current pair is issued first thing, unconditionally (clamped position): one exposed round trip per iteration instead of
+    // two, twice the bytes in flight per wave (the pass is bound by latency x bytes in flight, not by bandwidth: DESIGN.md 6b).
+    uint32_t i = lo + threadIdx.x;
+    unsigned long long key_n = 0;
+    float p_n0 = 0.f, p_n1 = 0.f, p_n2 = 0.f;
+    uint32_t wp_n = 0, og_n = i;
+    if (i < hi) {
+        key_n = keys[i]; p_n0 = sx[i]; p_n1 = sy[i]; p_n2 = sz[i];
+        if (RECORDS) wp_n = wpos[i];
+        if (orig) og_n = orig[i];
+    }
+    const uint32_t last_rec = nt ? nt - 1 : 0u;
+    for (; i < hi; i += KB_BLOCK) {
+        const unsigned long long key = key_n;
+        const float pf0 = p_n0, pf1 = p_n1, pf2 = p_n2;
+        const uint32_t og = og_n;
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (RECORDS) rec = records[min(wp_n, last_rec)];
+        const uint32_t in = i + KB_BLOCK;
+        if (in < hi) {
+            key_n = keys[in]; p_n0 = sx[in]; p_n1 = sy[in]; p_n2 = sz[in];
+            if (RECORDS) wp_n = wpos[in];
+            og_n = orig ? orig[in] : in;
+        }
         const uint32_t d2b = (uint32_t)(key >> 32);
         const float d2 = __uint_as_float(d2b);
         const uint32_t j = (uint32_t)(key & 0xFFFFFFFFull);
         if (d2 < max_corr && j < nt) {                       // registration.cpp:936
             float qf0, qf1, qf2;
             if (RECORDS) {
-                const float4 r = records[wp];
-                qf0 = r.x; qf1 = r.y; qf2 = r.z;
+                qf0 = rec.x; qf1 = rec.y; qf2 = rec.z;
             } else {
                 qf0 = tx[j]; qf1 = ty[j]; qf2 = tz[j];
             }
@@ -149,7 +168,7 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
                 for (int c = 0; c < 3; c++) acc3(Q[r] * P[c], plan.sp, p0[3 * r + c], p1[3 * r + c], p2[3 * r + c]);
             cnt += 1.0;
             // the LAST kept pair of the reference's loop (registration.cpp:939) = the kept pair with the highest original index
-            const unsigned long long lk = ((unsigned long long)(orig ? orig[i] : i) << 32) | d2b;
+            const unsigned long long lk = ((unsigned long long)og << 32) | d2b;
             lastkey = lk > lastkey ? lk : lastkey;
         }
     }
