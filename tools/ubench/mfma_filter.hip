@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void mix_kernel(const uint4* __restrict__ ops,
 {
     constexpr int QG = 4;
     const int lane = threadIdx.x & 63;
-    const int mode = MODE == 4 ? (blockIdx.x & 1) : MODE;
+    const int mode = MODE == 4 ? (blockIdx.x & 1) : MODE >= 5 ? 2 : MODE;
     u16x8 bq[QG];
     float best[QG];
     for (int g = 0; g < QG; g++) {
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void mix_kernel(const uint4* __restrict__ ops,
         for (int g = 0; g < QG; g++) {
             f32x16 acc = pend;
             if (mode != 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bq[g]), zero, 0, 0, 0);
-            if (mode == 0) { keep = acc; continue; }
+            if (MODE >= 5) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, nxt), __builtin_bit_cast(bf16x8, bq[g]), acc, 0, 0, 0);   // K = 32: a dependent pair
+            if (mode == 0 || MODE == 6) { best[g] += acc[0] + acc[15]; continue; }          // MFMA only, results kept alive
             const f32x16 src = (mode == 3) ? pend : acc;
             float m = big;
 #pragma unroll
@@ -189,9 +190,10 @@ int main()
         }
     }
     // ---- C: do the matrix pipe and the vector ALU overlap?
-    const char* mnames[5] = { "MFMA only", "8 x v_min3 + compare only", "MFMA -> min of its own results", "MFMA + min of the previous results", "half the waves MFMA only, half min only" };
-    for (int wps : { 2, 4 }) {
-        for (int mode = 0; mode < 5; mode++) {
+    const char* mnames[7] = { "MFMA only", "8 x v_min3 + compare only", "MFMA -> min of its own results", "MFMA + min of the previous results", "half the waves MFMA only, half min only",
+                              "two dependent MFMAs (K = 32) -> min of the results", "two dependent MFMAs only" };
+    for (int wps : { 1, 2, 4 }) {
+        for (int mode = 0; mode < 7; mode++) {
             const int blocks = cus * wps;
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             for (int rep = 0; rep < 2; rep++) {
@@ -201,7 +203,9 @@ int main()
                 case 1: hipLaunchKernelGGL(mix_kernel<1>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
                 case 2: hipLaunchKernelGGL(mix_kernel<2>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
                 case 3: hipLaunchKernelGGL(mix_kernel<3>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
-                default: hipLaunchKernelGGL(mix_kernel<4>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
+                case 4: hipLaunchKernelGGL(mix_kernel<4>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
+                case 5: hipLaunchKernelGGL(mix_kernel<5>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
+                default: hipLaunchKernelGGL(mix_kernel<6>, dim3(blocks), dim3(256), 0, 0, ops, out, tiles, -1e30f); break;
                 }
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             }
