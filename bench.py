@@ -426,7 +426,7 @@ def main():
         if rank == 0:
             gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
             if args.nn == "brute":
-                bf16 = default_kernels and tunes_env.get("nn1_bf16", 0) != 2 and tunes_env.get("nn1_variant", 0) in (0, 6) and n_t >= 2048
+                bf16 = default_kernels and tunes_env.get("nn1_bf16", 0) != 2 and tunes_env.get("nn1_variant", 0) in (0, 6) and (n_t >= 8192 or tunes_env.get("nn1_variant", 0) == 6)
                 flops_pp = BTRACK_FLOPS_PER_PAIR if bf16 else ETRACK_FLOPS_PER_PAIR
                 peak_tf = MFMA_BF16_PEAK_TFLOPS if bf16 else VALU_PEAK_TFLOPS
                 achieved_tflops = flops_pp * pairs / kern_s / 1e12

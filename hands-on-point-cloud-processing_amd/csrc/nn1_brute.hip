@@ -682,12 +682,14 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
         if (rc) return rc;
         const Grid* g = tgt->grid;
         // BTRACK (variant 6, tune nn1_bf16: 1 on, 2 off): the filter on the bf16 matrix pipe
+        // (small targets stay on ETRACK: 44 against 53 us per ICP iteration at 4 000 points, 114 against 72 at 20 000 — profiles/r02_mfma_filter_experiments.txt)
         const int64_t bf16_tune = tune_get(ctx, "nn1_bf16", 0);
-        if (variant_tune == 6 || (variant_tune == 0 && bf16_tune != 2 && (bf16_tune == 1 || NN_BF16_DEFAULT))) {
+        const bool want_bf16 = variant_tune == 6 || (variant_tune == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)));
+        if (want_bf16) {
             rc = grid_ensure_btiles(ctx, tgt);
             if (rc) return rc;
         }
-        if ((variant_tune == 6 || (variant_tune == 0 && bf16_tune != 2 && (bf16_tune == 1 || NN_BF16_DEFAULT))) && g->bt_safe && g->n_btiles) {
+        if (want_bf16 && g->bt_safe && g->n_btiles) {
             int qg = (int)tune_get(ctx, "nn1_btrack_qg", 4);
             if (qg != 1 && qg != 2) qg = 4;                                           // (8 groups per wave: hipcc 7.2 crashes on the instantiation)
             const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                      // queries per workgroup
