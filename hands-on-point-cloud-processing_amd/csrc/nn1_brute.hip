@@ -438,8 +438,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   instruction 0: lanes < 32 the x-terms, lanes >= 32 the y-terms;   instruction 1: lanes < 32 the z-terms, lanes >= 32 the three
 //   pieces of w against the "coordinate" 1.0 (pieces 1, 0, 0).
 // The vector ALU no longer multiplies: per (query, tile) it takes the minimum of 16 accumulators and tracks m1 / m2 / c1; what it does
-// per query — r = q - C, R = |r|^2, the split and the packing — is done once per SUPER-TILE of 4 tiles, which share one centre.  That
-// needs spatially compact runs of 128 targets: the target is taken in Morton order of its cells (Grid::bt_records).
+// per query — r = q - C, R = |r|^2, the split and the packing — is done once per SUPER-TILE of 8 tiles, which share one centre.  That
+// needs spatially compact runs of 256 targets: the target is taken in Morton order of its cells (Grid::bt_records).
 // Bound.  With Q = |r|^2, W = |t''|^2, u = 2^-24 and G the MFMA result:
 //   dropped r3 t''3 terms                                   <= 2 * 2^-28 |r||t''|            <= 0.13 u (Q + W)
 //   accumulation of the 32 slots (measured <= 4.1 u sum|a b|, tools/ubench/mfma_filter.hip; taken as 16 u):
@@ -447,8 +447,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   r, t'' vs q - C, t - C; exact A1 value vs D; R vs Q; w vs W; the final fma  (as for ETRACK)  <= 4 u + 10 u + 3 u + 3 u + 2 u
 //   => d2 >= Q (1 - 56 u) + W (1 - 56 u) - 2 r.t''  >= KAPPA R + G  when  KAPPA = 1 - 2^-17 (128 u) and w = fl(W)(1 - 2^-17):
 // L = fma(R, KAPPA, min_j G_j) is a lower bound of every exact distance of the chunk; the decision is ETRACK's (exact evaluation of
-// c1, proof by m2, exact rescan otherwise), so a wrong bound could only ever cost a rescan's worth of time if it were too HIGH —
-// which the sweep tests (tests/test_gpu_parity.py) look for with adversarial magnitudes.
+// c1, proof by m2, exact rescan otherwise).  A bound that is too LOW only costs time (a rescan); one that were too HIGH could hide the
+// true neighbour, so the one assumption no document backs — how the matrix pipe accumulates — is measured on the device under test
+// (pcr_selftest_mfma_bf16: 4.1 u of the 16 u assumed, 3.7 u (Q + W) of the 34.2 u assumed for the whole filter value; asserted with
+// a factor two of head-room by tests/test_gpu_parity.py), next to the sweeps with adversarial magnitudes and tools/soak_nn1.py.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void bt_pack(float c, uint4& b)
