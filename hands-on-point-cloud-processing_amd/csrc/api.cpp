@@ -107,6 +107,7 @@ void prof_flush(pcr_ctx* ctx)
 void cloud_modified(pcr_cloud* c)
 {
     if (c && c->grid) { grid_free(c->grid); c->grid = nullptr; }
+    if (c && c->bt) { bt_free(c->bt); c->bt = nullptr; }
     if (c && c->knn_grid) { grid_free(c->knn_grid); c->knn_grid = nullptr; c->knn_grid_factor = 0.0; }
     if (c && c->rad_grid) { grid_free(c->rad_grid); c->rad_grid = nullptr; c->rad_grid_r = 0.0; }
     if (c) { c->absmax = -1.f; c->brute_searches = 0; }

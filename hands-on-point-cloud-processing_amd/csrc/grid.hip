@@ -959,9 +959,6 @@ void grid_free(Grid* g)
     if (!g) return;
     if (g->chunks) hipFree(g->chunks);
     if (g->spheres) hipFree(g->spheres);
-    if (g->bt_records) hipFree(g->bt_records);
-    if (g->bt_centres) hipFree(g->bt_centres);
-    if (g->bt_ops) hipFree(g->bt_ops);
     if (g->records) hipFree(g->records);
     if (g->cell_start) hipFree(g->cell_start);
     delete g;
@@ -1235,19 +1232,20 @@ static int sort_queries_fine(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
 }
 
 // ---- BTRACK index (see nn1_brute.hip for the operand layout and the error analysis)
+// Morton key of a point on a lattice of cubic cells over the bounding box (lo, inv = 1024 / longest extent); non-finite points last
 __global__ __launch_bounds__(GR_BLOCK) void bt_keys_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
-                                                           GridParams g, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+                                                           float lox, float loy, float loz, float ivx, float ivy, float ivz,
+                                                           unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float px = x[i], py = y[i], pz = z[i];
-    unsigned long long key = 1ull << 36;                                   // non-finite points last
+    unsigned long long key = 1ull << 30;
     if (finite3(px, py, pz)) {
-        const uint32_t c[3] = { (uint32_t)min(max(cell_coord(px, g.lo[0], g.inv_h), 0), g.n[0] - 1),
-                                (uint32_t)min(max(cell_coord(py, g.lo[1], g.inv_h), 0), g.n[1] - 1),
-                                (uint32_t)min(max(cell_coord(pz, g.lo[2], g.inv_h), 0), g.n[2] - 1) };
+        const uint32_t c[3] = { (uint32_t)fminf(fmaxf((px - lox) * ivx, 0.0f), 1023.0f), (uint32_t)fminf(fmaxf((py - loy) * ivy, 0.0f), 1023.0f),
+                                (uint32_t)fminf(fmaxf((pz - loz) * ivz, 0.0f), 1023.0f) };
         key = 0;
-        for (int b = 0; b < 12; b++)                                       // cells per axis <= 4002 < 2^12
+        for (int b = 0; b < 10; b++)
             for (int k = 0; k < 3; k++) key |= (unsigned long long)((c[k] >> b) & 1u) << (3 * b + k);
     }
     keys[i] = key;
@@ -1311,52 +1309,84 @@ __global__ __launch_bounds__(GR_BLOCK) void bt_ops_kernel(const float4* __restri
     o[32 + m] = pack(t[1]);                                                // instruction 0, lanes >= 32: y
     o[64 + m] = pack(t[2]);                                                // instruction 1, lanes < 32: z
     o[96 + m] = make_uint4(w[0] | (w[1] << 16), 0u | (w[2] << 16), 0u, 0u);   // instruction 1, lanes >= 32: [w1, w2, 0, w3, 0, 0, 0, 0] against [1, 1, 0, 1, 0, 0, 0, 0]
-    if (bad) atomicOr(unsafe, 1);
+    if (bad && unsafe) atomicOr(unsafe, 1);
 }
 
-int grid_ensure_btiles(pcr_ctx* ctx, const pcr_cloud* tgt)
+void bt_free(BtIndex* b)
 {
-    Grid* g = tgt->grid;
-    if (!g) return fail(ctx, PCR_ERR_STATE, "btiles: no index");
-    if (g->bt_ops || g->n_points == 0) return PCR_OK;
-    const size_t n = g->n_points;
+    if (!b) return;
+    if (b->block) hipFree(b->block);
+    delete b;
+}
+
+int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt)
+{
+    if (tgt->bt) return PCR_OK;
+    const size_t n = tgt->n;
+    BtIndex* bt = new (std::nothrow) BtIndex();
+    if (!bt) return fail(ctx, PCR_ERR_NOMEM, "btiles");
+    if (n == 0 || n > 0x7FFFFFF0ull) { const_cast<pcr_cloud*>(tgt)->bt = bt; return PCR_OK; }       // safe = false: the other kernels answer
     const size_t n_super = (n + BT_SUPER - 1) / BT_SUPER, n_pad = n_super * BT_SUPER, n_tiles = n_pad / 32;
+    const uint32_t bb_blocks = (uint32_t)std::min<size_t>(256, (n + GR_BLOCK - 1) / GR_BLOCK);
+    const size_t off_cen = n_pad * sizeof(float4), off_ops = off_cen + ((n_super * sizeof(float4) + 255) & ~(size_t)255),
+                 off_bb = off_ops + n_tiles * 128 * sizeof(uint4), total = off_bb + bb_blocks * 6 * sizeof(float);
     size_t temp_bytes = 0;
-    sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, 37, ctx->stream);
+    sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, 31, ctx->stream);
     const size_t a4 = (n * 4 + 255) & ~(size_t)255, a8 = (n * 8 + 255) & ~(size_t)255;
-    int rc = ensure_scratch(ctx, 2 * a8 + 2 * a4 + temp_bytes + 512);
-    if (rc) return rc;
-    char* sc = (char*)ctx->scratch;
-    unsigned long long* k_in = (unsigned long long*)sc;
-    unsigned long long* k_out = (unsigned long long*)(sc + a8);
-    uint32_t* v_in = (uint32_t*)(sc + 2 * a8);
-    uint32_t* v_out = (uint32_t*)(sc + 2 * a8 + a4);
-    int* unsafe_dev = (int*)(sc + 2 * a8 + 2 * a4);
-    char* temp = sc + 2 * a8 + 2 * a4 + 256;
-    float4* rec = nullptr; float4* cen = nullptr; uint4* ops = nullptr;
-    hipError_t e = hipMalloc((void**)&rec, n_pad * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void**)&cen, n_super * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void**)&ops, n_tiles * 128 * sizeof(uint4));
-    if (e == hipSuccess) e = hipMemsetAsync(unsafe_dev, 0, 4, ctx->stream);
-    int unsafe_host = 1;
-    if (e == hipSuccess) {
-        const dim3 gridn((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK));
-        hipLaunchKernelGGL(bt_keys_kernel, gridn, dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(), (uint32_t)n, g->p, k_in, v_in);
-        e = sort_pairs_u64_u32(temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, 37, ctx->stream);
+    int rc = ensure_scratch(ctx, 2 * a8 + 2 * a4 + temp_bytes + 256);
+    if (rc) { delete bt; return rc; }
+    char* blk = nullptr;
+    hipError_t e = hipMalloc((void**)&blk, total);
+    if (e != hipSuccess) { delete bt; return fail(ctx, PCR_ERR_HIP, "hipMalloc(btiles)", e); }
+    bt->block = blk;
+    bt->records = (float4*)blk; bt->centres = (float4*)(blk + off_cen); bt->ops = (uint4*)(blk + off_ops);
+    float* bb_dev = (float*)(blk + off_bb);
+    // the one host round trip: the bounding box of the finite points
+    hipLaunchKernelGGL(bbox_kernel, dim3(bb_blocks), dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(), (uint32_t)n, bb_dev);
+    std::vector<float> hb(bb_blocks * 6);
+    e = hipMemcpyAsync(hb.data(), bb_dev, hb.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { bt_free(bt); return fail(ctx, PCR_ERR_HIP, "btiles bbox", e); }
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (uint32_t b = 0; b < bb_blocks; b++)
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], hb[b * 6 + k]); hi[k] = std::max(hi[k], hb[b * 6 + 3 + k]); }
+    float amax = 0.f;
+    bool any = lo[0] <= hi[0];
+    for (int k = 0; k < 3 && any; k++) amax = std::max(amax, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+    if (tgt->absmax < 0.f) const_cast<pcr_cloud*>(tgt)->absmax = amax;                                // (cloud_absmax's cache, for free)
+    // |t - C| < 1e18 and |t - C|^2 < 3e38 for every finite point and any centre inside the box: what the filter's analysis wants
+    bt->safe = any && amax < 5e17f;
+    if (bt->safe) {
+        // one cell edge for all three axes (the longest extent / 1024): cubic cells keep the Morton runs compact in space — with a
+        // lattice per axis the thin z-extent of a LiDAR scan got 5 mm slabs and the runs spread over the x-y plane (measured: 1.25
+        // against 1.07 ms per search, the bound of such a run is loose)
+        const float ext = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+        float iv1 = ext > 0.f ? 1024.0f / ext : 0.0f;
+        if (!(iv1 < 3e38f)) iv1 = 0.0f;
+        const float iv[3] = { iv1, iv1, iv1 };
+        char* sc = (char*)ctx->scratch;
+        unsigned long long* k_in = (unsigned long long*)sc;
+        unsigned long long* k_out = (unsigned long long*)(sc + a8);
+        uint32_t* v_in = (uint32_t*)(sc + 2 * a8);
+        uint32_t* v_out = (uint32_t*)(sc + 2 * a8 + a4);
+        char* temp = sc + 2 * a8 + 2 * a4;
+        hipLaunchKernelGGL(bt_keys_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(), (uint32_t)n,
+                           lo[0], lo[1], lo[2], iv[0], iv[1], iv[2], k_in, v_in);
+        e = sort_pairs_u64_u32(temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, 31, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)((n_pad + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
+                               (uint32_t)n, (uint32_t)n_pad, v_out, bt->records);
+            hipLaunchKernelGGL(bt_centres_kernel, dim3((unsigned)((n_super + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_super,
+                               bt->centres);
+            hipLaunchKernelGGL(bt_ops_kernel, dim3((unsigned)((n_tiles * 32 + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_tiles,
+                               bt->centres, bt->ops, (int*)nullptr);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) { bt_free(bt); return fail(ctx, PCR_ERR_HIP, "btiles", e); }
+        bt->n_tiles = n_tiles;
+        // (stream order: the scratch may be reused by later launches on ctx->stream, which run after the sort and the gather)
     }
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)((n_pad + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
-                           (uint32_t)n, (uint32_t)n_pad, v_out, rec);
-        hipLaunchKernelGGL(bt_centres_kernel, dim3((unsigned)((n_super + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, rec, (uint32_t)n_super, cen);
-        hipLaunchKernelGGL(bt_ops_kernel, dim3((unsigned)((n_tiles * 32 + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, rec, (uint32_t)n_tiles, cen, ops,
-                           unsafe_dev);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(&unsafe_host, unsafe_dev, 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    }
-    if (e != hipSuccess) { hipFree(rec); hipFree(cen); hipFree(ops); return fail(ctx, PCR_ERR_HIP, "btiles", e); }
-    g->bt_records = rec; g->bt_centres = cen; g->bt_ops = ops; g->n_btiles = n_tiles;
-    g->bt_safe = unsafe_host == 0;
+    const_cast<pcr_cloud*>(tgt)->bt = bt;
     return PCR_OK;
 }
 

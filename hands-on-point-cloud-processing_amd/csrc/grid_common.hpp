@@ -37,14 +37,6 @@ struct Grid {
     // records array is padded to a whole chunk with x = +inf entries): one 16-byte load decides whether 16 records can hold a
     // better neighbour (grid.hip, SPH search kernel)
     float4* spheres = nullptr;
-    // BTRACK (nn1_brute.hip): the cloud once more in Morton order of its cells — spatially compact runs — as {x, y, z, original index}
-    // records (padded to whole super-tiles of BT_SUPER records with x = +inf), one centre per super-tile, and per tile of 32
-    // records the bf16 A operands of two v_mfma_f32_32x32x16_bf16 ([tile][2][64 lanes] x 16 bytes); built on first use
-    float4* bt_records = nullptr;
-    float4* bt_centres = nullptr;
-    uint4* bt_ops = nullptr;
-    size_t n_btiles = 0;
-    bool bt_safe = false;
 };
 
 constexpr int BT_SUPER = 256;          // records per super-tile (8 tiles of 32; 128 measured: 0.94 against 0.90 ms per 120k x 120k search)
@@ -81,8 +73,21 @@ __device__ __forceinline__ uint32_t clamped_cell_id(const GridParams& g, float x
 int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, int order = GRID_ORDER_X);
 // builds (and caches on tgt) the 1-NN grid if needed
 int build_target_grid(pcr_ctx* ctx, const pcr_cloud* tgt);
-// builds Grid::bt_* of tgt's (already built) index if they are not there yet
-int grid_ensure_btiles(pcr_ctx* ctx, const pcr_cloud* tgt);
+// BTRACK's index (nn1_brute.hip), independent of the cell grid: the cloud in Morton order of a lattice of cubic cells (longest extent / 1024) over its bounding
+// box — spatially compact runs — as {x, y, z, original index} records (padded to whole super-tiles of BT_SUPER records with
+// x = +inf), one centre per super-tile, and per tile of 32 records the bf16 A operands of two v_mfma_f32_32x32x16_bf16
+// ([tile][2][64 lanes] x 16 bytes).  One allocation, one host synchronisation (the bounding box) to build.
+struct BtIndex {
+    void* block = nullptr;            // the one allocation behind the three arrays
+    float4* records = nullptr;
+    float4* centres = nullptr;
+    uint4* ops = nullptr;
+    size_t n_tiles = 0;
+    bool safe = false;                // every finite coordinate below 5e17 in magnitude (and at least one finite point)
+};
+void bt_free(BtIndex* b);
+// builds (and caches on tgt) the index if it is not there yet
+int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt);
 // builds (and caches on tgt) the 1-NN grid if needed, then groups the queries `src` by coarse cell -> ctx->qperm
 int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
 // replaces *work by its cell-sorted copy (ctx->work_orig = original indices); no-op for empty clouds / tune grid_sort_work = 2

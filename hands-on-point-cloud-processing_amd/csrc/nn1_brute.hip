@@ -675,65 +675,67 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     // nn1_variant unset: ETRACK when a warm-start bound exists or the target's index does (profiles/r01_tune_nn1_etrack.txt),
     // FTRACK otherwise; 4 forces ETRACK, 1-3 the kernels below
     const int64_t variant_tune = tune_get(ctx, "nn1_variant", 0);
-    // cold searches take the indexed kernels too when the index exists or will be needed anyway (inside an ICP loop);
-    // the FIRST one-shot search on a fresh target stays on FTRACK, which needs no index (0.4 ms to build against 0.5 ms saved per
-    // search); a target that is searched a second time gets its index then
+    // BTRACK (variant 6, tune nn1_bf16: 1 on, 2 off): the filter on the bf16 matrix pipe, from a target's FIRST search on — its index
+    // (operands in Morton order, bt_ensure) costs one bounding-box round trip and ~0.2 ms at 120 k points, less than the kernel saves
+    // (small targets stay on ETRACK: 44 against 53 us per ICP iteration at 4 000 points, 114 against 72 at 20 000 — profiles/r02_mfma_filter_experiments.txt)
+    const int64_t bf16_tune = tune_get(ctx, "nn1_bf16", 0);
+    const bool want_bf16 = variant_tune == 6 || (variant_tune == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)));
+    if (want_bf16) {
+        rc = bt_ensure(ctx, tgt);
+        if (rc) return rc;
+    }
+    if (want_bf16 && tgt->bt->safe && tgt->bt->n_tiles) {
+        const BtIndex* g = tgt->bt;
+        int qg = (int)tune_get(ctx, "nn1_btrack_qg", 4);
+        if (qg != 1 && qg != 2) qg = 4;                                           // (8 groups per wave: hipcc 7.2 crashes on the instantiation)
+        const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                      // queries per workgroup
+        const uint32_t qblocks = (uint32_t)((ns + qpb - 1) / qpb);
+        const size_t n_super = g->n_tiles / (BT_SUPER / 32);
+        int64_t sps = tune_get(ctx, "nn1_supers_per_slice", 0);
+        if (sps <= 0) {
+            const int64_t want_blocks = tune_get(ctx, "nn1_btrack_blocks", 32768);
+            const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
+            sps = std::max<int64_t>(1, ((int64_t)n_super + slices - 1) / slices);
+        }
+        uint32_t slices = (uint32_t)((n_super + sps - 1) / sps);
+        if (slices > 65535) { slices = 65535; sps = (n_super + slices - 1) / slices; slices = (uint32_t)((n_super + sps - 1) / sps); }
+        const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
+        if (warm)
+            hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
+                               (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
+        else if (merge_atomic)
+            PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
+        unsigned long long* stats_dev = nullptr;
+        if (tune_get(ctx, "grid_stats", 0) > 0) {
+            if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
+            PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
+            stats_dev = ctx->grid_stats_dev;
+        }
+        {
+            ProfScope p(ctx, "nn1_brute", 1);
+            const dim3 grid(qblocks, slices);
+#define PCR_BTRACK(Q)                                                                                                                   \
+hipLaunchKernelGGL((nn1_btrack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops, g->records,                  \
+                   (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
+                   merge_atomic, ctx->stop_flag_dev, stats_dev)
+            switch (qg) {
+            case 1: PCR_BTRACK(1); break;
+            case 2: PCR_BTRACK(2); break;
+            default: PCR_BTRACK(4); break;
+            }
+#undef PCR_BTRACK
+        }
+        PCR_HIP(ctx, hipGetLastError());
+        return PCR_OK;
+    }
+    // The f32 kernels: ETRACK needs the cell index (chunked, centred copy of the target): cold searches take it when that index exists
+    // or will be needed anyway (inside an ICP loop), or on a target's second search; its FIRST one-shot search stays on FTRACK, which
+    // needs no index at all
     const bool reused = tgt->grid == nullptr && tgt->brute_searches++ >= 1;
-    if (variant_tune == 4 || variant_tune == 6 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid || reused))) {
+    if (variant_tune == 4 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid || reused))) {
         rc = build_target_grid(ctx, tgt);
         if (rc) return rc;
         const Grid* g = tgt->grid;
-        // BTRACK (variant 6, tune nn1_bf16: 1 on, 2 off): the filter on the bf16 matrix pipe
-        // (small targets stay on ETRACK: 44 against 53 us per ICP iteration at 4 000 points, 114 against 72 at 20 000 — profiles/r02_mfma_filter_experiments.txt)
-        const int64_t bf16_tune = tune_get(ctx, "nn1_bf16", 0);
-        const bool want_bf16 = variant_tune == 6 || (variant_tune == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)));
-        if (want_bf16) {
-            rc = grid_ensure_btiles(ctx, tgt);
-            if (rc) return rc;
-        }
-        if (want_bf16 && g->bt_safe && g->n_btiles) {
-            int qg = (int)tune_get(ctx, "nn1_btrack_qg", 4);
-            if (qg != 1 && qg != 2) qg = 4;                                           // (8 groups per wave: hipcc 7.2 crashes on the instantiation)
-            const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                      // queries per workgroup
-            const uint32_t qblocks = (uint32_t)((ns + qpb - 1) / qpb);
-            const size_t n_super = g->n_btiles / (BT_SUPER / 32);
-            int64_t sps = tune_get(ctx, "nn1_supers_per_slice", 0);
-            if (sps <= 0) {
-                const int64_t want_blocks = tune_get(ctx, "nn1_btrack_blocks", 32768);
-                const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
-                sps = std::max<int64_t>(1, ((int64_t)n_super + slices - 1) / slices);
-            }
-            uint32_t slices = (uint32_t)((n_super + sps - 1) / sps);
-            if (slices > 65535) { slices = 65535; sps = (n_super + slices - 1) / slices; slices = (uint32_t)((n_super + sps - 1) / sps); }
-            const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
-            if (warm)
-                hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
-                                   (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
-            else if (merge_atomic)
-                PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
-            unsigned long long* stats_dev = nullptr;
-            if (tune_get(ctx, "grid_stats", 0) > 0) {
-                if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
-                PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
-                stats_dev = ctx->grid_stats_dev;
-            }
-            {
-                ProfScope p(ctx, "nn1_brute", 1);
-                const dim3 grid(qblocks, slices);
-#define PCR_BTRACK(Q)                                                                                                                   \
-    hipLaunchKernelGGL((nn1_btrack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->bt_centres, g->bt_ops, g->bt_records,                  \
-                       (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
-                       merge_atomic, ctx->stop_flag_dev, stats_dev)
-                switch (qg) {
-                case 1: PCR_BTRACK(1); break;
-                case 2: PCR_BTRACK(2); break;
-                default: PCR_BTRACK(4); break;
-                }
-#undef PCR_BTRACK
-            }
-            PCR_HIP(ctx, hipGetLastError());
-            return PCR_OK;
-        }
         if (g->chunk_safe && g->n_chunks) {
             // queries per lane: the filter is bound by the scalar operand path (272 B per chunk per wave), more queries per lane
             // amortise it — measured: profiles/r01_tune_nn1_etrack.txt

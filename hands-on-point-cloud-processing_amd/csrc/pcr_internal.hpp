@@ -64,10 +64,11 @@ struct Comm {
 
 }  // namespace pcr
 
-namespace pcr { struct Grid; void grid_free(Grid*); }
+namespace pcr { struct Grid; void grid_free(Grid*); struct BtIndex; void bt_free(BtIndex*); }
 
 struct pcr_cloud {
     pcr::Grid* grid = nullptr;   // exact-NN index over this cloud as a target; built lazily, dropped on modification
+    pcr::BtIndex* bt = nullptr;  // the matrix-core brute-force filter's operands over this cloud as a target (nn1_brute.hip); same lifetime
     pcr::Grid* knn_grid = nullptr;   // the same index with the wider cell of the last k-NN batch (knn_grid.hip), same lifetime
     double knn_grid_factor = 0.0;    // its cell edge / grid's cell edge
     pcr::Grid* rad_grid = nullptr;   // the index with cell edge 1.01 r of the last radius search (radius_grid.hip), same lifetime
