@@ -258,7 +258,10 @@ __global__ __launch_bounds__(KF_BLOCK) void kabsch_final_kernel(const double* __
 // ends in a 464-byte row that ONE workgroup has to reduce afterwards (8 192 rows cost 0.22 ms at 10 M, 1 024 rows 0.05 ms, and the pass itself runs 0.27 -> 0.14 ms)
 static uint32_t kabsch_blocks(pcr_ctx* ctx, size_t ns)
 {
+    // one pair per thread up to 128 workgroups, then four pairs per thread, then the cap: at 120 k the 469 rows of the one-pair rule
+    // cost the reduce 24 us against 15 us for 128 rows, the pass itself the same 18 us (profiles/r02_kabsch_probes.txt)
     uint32_t blocks = (uint32_t)((ns + KB_BLOCK - 1) / KB_BLOCK);
+    if (blocks > 128) blocks = std::max<uint32_t>(128, (uint32_t)((ns + 4 * KB_BLOCK - 1) / (4 * KB_BLOCK)));
     if (blocks < 1) blocks = 1;
     const uint32_t cap = (uint32_t)std::min<int64_t>(KB_MAX_BLOCKS, std::max<int64_t>(1, tune_get(ctx, "kabsch_max_blocks", 1024)));
     if (blocks > cap) blocks = cap;
