@@ -360,15 +360,57 @@ __device__ __forceinline__ void scan_flat9(const float4* __restrict__ records, c
 }
 
 // minimum key over the sub-group, together with the record position that produced it
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+}
+
+template <int CTRL>
+__device__ __forceinline__ void min_step_dpp(unsigned long long& v, uint32_t& pos)
+{
+    const unsigned long long w = ((unsigned long long)dpp_mov<CTRL>((uint32_t)(v >> 32)) << 32) | dpp_mov<CTRL>((uint32_t)v);
+    const uint32_t wp = dpp_mov<CTRL>(pos);
+    if (w < v) { v = w; pos = wp; }
+}
+
 template <int G>
 __device__ __forceinline__ void group_min(unsigned long long& v, uint32_t& pos)
 {
+    if (G == 16) {
+        // 16 lanes = one DPP row: xor 1, xor 2 (quad permutes), then the half-row and the row mirror — each step pairs groups that are
+        // already uniform, so four vector moves per value replace four LDS-crossbar round trips (ds_bpermute: the kernel held 104)
+        min_step_dpp<0xB1>(v, pos);      // quad_perm [1, 0, 3, 2]
+        min_step_dpp<0x4E>(v, pos);      // quad_perm [2, 3, 0, 1]
+        min_step_dpp<0x141>(v, pos);     // row_half_mirror
+        min_step_dpp<0x140>(v, pos);     // row_mirror
+        return;
+    }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) {
         const unsigned long long w = __shfl_xor(v, o, 64);
         const uint32_t wp = __shfl_xor(pos, o, 64);
         if (w < v) { v = w; pos = wp; }
     }
+}
+
+// inclusive prefix sum over the 16 lanes of a DPP row (row_shr 1, 2, 4, 8 with zero fill) and the maximum over the row
+__device__ __forceinline__ uint32_t row_scan16(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t row_max16(uint32_t v)
+{
+    v = max(v, dpp_mov<0xB1>(v));
+    v = max(v, dpp_mov<0x4E>(v));
+    v = max(v, dpp_mov<0x141>(v));
+    v = max(v, dpp_mov<0x140>(v));
+    return v;
 }
 
 // ---- bounding-sphere pruning (SPH mode) -------------------------------------------------------------------------------
@@ -399,7 +441,9 @@ __device__ __forceinline__ void scan_run16(const float4* __restrict__ records, u
     if (d < 0x7F7FFFFFu && k < best) { best = k; bestp = p; }
 }
 
-// the sub-group scans the runs whose bit is set in m (bit j = run held by lane j in cc): two coalesced loads in flight
+// the sub-group scans the runs whose bit is set in m (bit j = run held by lane j in cc): two coalesced loads in flight.  (Computing
+// the run index of lane j locally instead of reading it across lanes — nine compare-selects against one ds_bpermute in front of every
+// record load — was measured: 7.29 -> 7.91 ms per 10 M ICP iteration; the vector ALU is the scarcer resource here.)
 __device__ __forceinline__ void scan_hits16(const float4* __restrict__ records, uint32_t m, uint32_t cc, int l, float qx, float qy, float qz,
                                             unsigned long long& best, uint32_t& bestp)
 {
@@ -532,14 +576,9 @@ __device__ __forceinline__ void scan_pieces_sph(const float4* __restrict__ recor
     const uint32_t a0 = b1 < e1 ? b1 / GRID_CHUNK : 0u, na = b1 < e1 ? (e1 - 1) / GRID_CHUNK + 1 - a0 : 0u;
     const uint32_t c0 = b2 < e2 ? b2 / GRID_CHUNK : 0u, nc = b2 < e2 ? (e2 - 1) / GRID_CHUNK + 1 - c0 : 0u;
     const uint32_t cnt = na + nc;
-    uint32_t inc = cnt;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, 16);
-        if (l >= o) inc += t;
-    }
+    const uint32_t inc = row_scan16(cnt);
     const uint32_t my_off = inc - cnt;
-    const uint32_t total = __shfl(inc, 15, 16);
+    const uint32_t total = row_max16(inc);                 // (the scan is non-decreasing: its maximum is lane 15's value)
     const int shift = (int)((threadIdx.x & 63) / 16 * 16);
     for (uint32_t f0 = 0; f0 < total; f0 += 16) {
         const uint32_t f = f0 + (uint32_t)l;
@@ -600,18 +639,18 @@ __device__ __forceinline__ void stage1_sph(const float4* __restrict__ records, c
     }
     const uint32_t c0 = b < e ? b / GRID_CHUNK : 0u, c1 = b < e ? (e - 1) / GRID_CHUNK + 1 : 0u;
     const uint32_t cnt = c1 - c0;
-    uint32_t inc = cnt;                                     // inclusive scan over the 16 lanes
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, 16);
-        if (l >= o) inc += t;
-    }
+    const uint32_t inc = row_scan16(cnt);                   // inclusive scan over the 16 lanes (DPP, no LDS)
     const uint32_t my_off = inc - cnt;                      // first flattened run of my row
-    const uint32_t total = __shfl(inc, 15, 16);
+    const uint32_t total = row_max16(inc);
     const uint32_t my_delta = c0 - my_off;
+    // every lane needs the nine (offset, delta) pairs: written once to the sub-group's 20 words of LDS and read back as broadcasts
+    // (18 ds_bpermute before; a wave's DS operations execute in order, and no other sub-group touches these words)
+    __shared__ uint32_t s1_pairs[GR_BLOCK / 16][20];
+    uint32_t* mine = s1_pairs[threadIdx.x / 16];
+    if (l < 9) { mine[l] = my_off; mine[10 + l] = my_delta; }
     uint32_t off[9], delta[9];
 #pragma unroll
-    for (int r = 0; r < 9; r++) { off[r] = __shfl(my_off, r, 16); delta[r] = __shfl(my_delta, r, 16); }
+    for (int r = 0; r < 9; r++) { off[r] = mine[r]; delta[r] = mine[10 + r]; }
     const int shift = (int)((threadIdx.x & 63) / 16 * 16);
     for (uint32_t f0 = 0; f0 < total; f0 += 16) {
         const uint32_t f = f0 + (uint32_t)l;
