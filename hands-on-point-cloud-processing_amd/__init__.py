@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_selftest_mfma_bf16", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
+    "pcr_grid_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_match_inter_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
@@ -115,6 +115,7 @@ def lib():
     L.pcr_tune_set.argtypes = [vp, C.c_char_p, C.c_int64]
     L.pcr_grid_stats.argtypes = [vp, vp]
     L.pcr_selftest_mfma_bf16.argtypes = [vp, C.c_int, vp]
+    L.pcr_selftest_mfma_f16.argtypes = [vp, C.c_int, vp]
     L.pcr_voxel_filter_f32.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
     L.pcr_iss_keypoints_f32.argtypes = [vp, vp, C.POINTER(IssParams), vp, vp, vp, C.POINTER(C.c_uint64)]
     L.pcr_icp_p2plane_f32.argtypes = [vp, vp, vp, vp, vp, C.POINTER(IcpParams), vp, C.POINTER(IcpStats)]
@@ -337,6 +338,12 @@ class Context:
         """(worst accumulation error in 2^-24 sum|a b|, worst filter-value error in 2^-24 (|r|^2 + |t|^2)) measured on this device"""
         out = (C.c_double * 2)()
         self._ck(lib().pcr_selftest_mfma_bf16(self.h, int(trials), out))
+        return float(out[0]), float(out[1])
+
+    def selftest_mfma_f16(self, trials: int = 64):
+        """the same for the f16 form (one MFMA per tile, two-piece scaled operands)"""
+        out = (C.c_double * 2)()
+        self._ck(lib().pcr_selftest_mfma_f16(self.h, int(trials), out))
         return float(out[0]), float(out[1])
 
     def prof_reset(self):

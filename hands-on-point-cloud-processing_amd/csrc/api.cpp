@@ -436,6 +436,12 @@ int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[2])
     return pcr::bt_mfma_selftest(ctx, trials, worst);
 }
 
+int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[2])
+{
+    if (!ctx || !worst || trials < 0 || trials > 4096) return PCR_ERR_ARG;
+    return pcr::ht_mfma_selftest(ctx, trials, worst);
+}
+
 int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4])
 {
     if (!ctx || !out) return PCR_ERR_ARG;

@@ -1292,7 +1292,7 @@ __global__ __launch_bounds__(GR_BLOCK) void bt_keys_kernel(const float* __restri
 }
 
 // one thread per super-tile: centre = mean of its finite records
-__global__ __launch_bounds__(GR_BLOCK) void bt_centres_kernel(const float4* __restrict__ rec, uint32_t n_super, float4* __restrict__ centres)
+__global__ __launch_bounds__(GR_BLOCK) void bt_centres_kernel(const float4* __restrict__ rec, uint32_t n_super, float4* __restrict__ centres, int* __restrict__ bad16)
 {
     const uint32_t s = blockIdx.x * GR_BLOCK + threadIdx.x;
     if (s >= n_super) return;
@@ -1303,7 +1303,39 @@ __global__ __launch_bounds__(GR_BLOCK) void bt_centres_kernel(const float4* __re
         if (finite3(r.x, r.y, r.z)) { cx += r.x; cy += r.y; cz += r.z; cnt++; }
     }
     if (cnt) { cx /= (float)cnt; cy /= (float)cnt; cz /= (float)cnt; }
-    centres[s] = make_float4(cx, cy, cz, 0.f);
+    // .w: the f16 form's scale, a power of two with |t - C|_inf * scale <= 2^7 (exponent clamped to [-60, 60]: bad16 when it had to be)
+    float rho = 0.f;
+    for (int j = 0; j < BT_SUPER; j++) {
+        const float4 r = rec[(size_t)s * BT_SUPER + j];
+        if (finite3(r.x, r.y, r.z)) rho = fmaxf(rho, fmaxf(fmaxf(fabsf(r.x - cx), fabsf(r.y - cy)), fabsf(r.z - cz)));
+    }
+    int k = 0;
+    if (rho > 0.f) {
+        int e2;
+        (void)frexpf(rho, &e2);                            // rho = m 2^e2, m in [0.5, 1)  ->  rho <= 2^e2
+        k = 7 - e2;
+        if (k < -60 || k > 60) { if (bad16) atomicOr(bad16, 1); k = k < 0 ? -60 : 60; }
+    }
+    centres[s] = make_float4(cx, cy, cz, ldexpf(1.0f, k));
+}
+
+// HTRACK operands: one thread per MFMA row (record) of a tile.  K slots of a lane: lanes < 32  [x: (1,1) (1,2) (2,1) (2,2) | y: the same],
+// lanes >= 32  [z: the same | w1, w2, 0, 0]  against the query side [r1, r1, r2, r2] per coordinate and [1, 1, 0, 0];  A holds the
+// two f16 pieces of -2 t'' scale (round to zero, then the remainder) and of w = |t'' scale|^2 (1 - 2^-17).
+__global__ __launch_bounds__(GR_BLOCK) void bt_ops16_kernel(const float4* __restrict__ rec, uint32_t n_tiles, const float4* __restrict__ centres,
+                                                            uint4* __restrict__ ops16)
+{
+    const uint32_t gid = blockIdx.x * GR_BLOCK + threadIdx.x;
+    const uint32_t T = gid >> 5, m = gid & 31;
+    if (T >= n_tiles) return;
+    const uint32_t p = T * 32 + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+    const float4 r = rec[p];
+    const float4 C = centres[T / (BT_SUPER / 32)];
+    const bool fin = finite3(r.x, r.y, r.z);
+    const float tx = (r.x - C.x) * C.w, ty = (r.y - C.y) * C.w, tz = (r.z - C.z) * C.w;         // exact scaling, |.| <= 2^7 (unless bad16)
+    uint4* o = ops16 + (size_t)T * 64;
+    o[m] = ht_target_operand(tx, ty, tz, fin, false);
+    o[32 + m] = ht_target_operand(tx, ty, tz, fin, true);
 }
 
 // v = p1 + p2 + p3 exactly, every piece a bf16 value (top 16 bits of an f32); finite v
@@ -1368,7 +1400,8 @@ int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt)
     const size_t n_super = (n + BT_SUPER - 1) / BT_SUPER, n_pad = n_super * BT_SUPER, n_tiles = n_pad / 32;
     const uint32_t bb_blocks = (uint32_t)std::min<size_t>(256, (n + GR_BLOCK - 1) / GR_BLOCK);
     const size_t off_cen = n_pad * sizeof(float4), off_ops = off_cen + ((n_super * sizeof(float4) + 255) & ~(size_t)255),
-                 off_bb = off_ops + n_tiles * 128 * sizeof(uint4), total = off_bb + bb_blocks * 6 * sizeof(float);
+                 off_o16 = off_ops + n_tiles * 128 * sizeof(uint4), off_bb = off_o16 + n_tiles * 64 * sizeof(uint4),
+                 off_flag = off_bb + ((bb_blocks * 6 * sizeof(float) + 255) & ~(size_t)255), total = off_flag + 256;
     size_t temp_bytes = 0;
     sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, 31, ctx->stream);
     const size_t a4 = (n * 4 + 255) & ~(size_t)255, a8 = (n * 8 + 255) & ~(size_t)255;
@@ -1379,6 +1412,9 @@ int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt)
     if (e != hipSuccess) { delete bt; return fail(ctx, PCR_ERR_HIP, "hipMalloc(btiles)", e); }
     bt->block = blk;
     bt->records = (float4*)blk; bt->centres = (float4*)(blk + off_cen); bt->ops = (uint4*)(blk + off_ops);
+    bt->ops16 = (uint4*)(blk + off_o16); bt->bad16 = (int*)(blk + off_flag);
+    e = hipMemsetAsync(bt->bad16, 0, sizeof(int), ctx->stream);
+    if (e != hipSuccess) { bt_free(bt); return fail(ctx, PCR_ERR_HIP, "btiles", e); }
     float* bb_dev = (float*)(blk + off_bb);
     // the one host round trip: the bounding box of the finite points
     hipLaunchKernelGGL(bbox_kernel, dim3(bb_blocks), dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(), (uint32_t)n, bb_dev);
@@ -1416,7 +1452,9 @@ int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt)
             hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)((n_pad + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
                                (uint32_t)n, (uint32_t)n_pad, v_out, bt->records);
             hipLaunchKernelGGL(bt_centres_kernel, dim3((unsigned)((n_super + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_super,
-                               bt->centres);
+                               bt->centres, bt->bad16);
+            hipLaunchKernelGGL(bt_ops16_kernel, dim3((unsigned)((n_tiles * 32 + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_tiles,
+                               bt->centres, bt->ops16);
             hipLaunchKernelGGL(bt_ops_kernel, dim3((unsigned)((n_tiles * 32 + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_tiles,
                                bt->centres, bt->ops, (int*)nullptr);
             e = hipGetLastError();

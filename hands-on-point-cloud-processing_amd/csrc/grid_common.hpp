@@ -82,9 +82,38 @@ struct BtIndex {
     float4* records = nullptr;
     float4* centres = nullptr;
     uint4* ops = nullptr;
+    // HTRACK (nn1_brute.hip): the same tiles as f16 operands of ONE v_mfma_f32_32x32x16_f16 ([tile][64 lanes] x 16 bytes), scaled per
+    // super-tile by the power of two in centres[].w so that |t - C| * scale <= 2^7; ok16[0] = 0 when a super-tile's scale exponent
+    // left [-60, 60] (the f16 form cannot carry such a cloud: BTRACK answers)
+    uint4* ops16 = nullptr;
+    int* bad16 = nullptr;             // device flag, read lazily (bad16_host: -1 unknown)
+    int bad16_host = -1;
     size_t n_tiles = 0;
     bool safe = false;                // every finite coordinate below 5e17 in magnitude (and at least one finite point)
 };
+// HTRACK operand helpers (device): v ~ p1 + p2 in f16 (round toward zero, then the remainder), and the 16 bytes a lane holds for
+// target row t'' (already scaled): lanes < 32  [x: t1 t2 t1 t2 | y: t1 t2 t1 t2],  lanes >= 32  [z: t1 t2 t1 t2 | w1 w2 0 0]
+__device__ __forceinline__ void ht_split(float v, uint32_t& p1, uint32_t& p2)
+{
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_amdgcn_cvt_pkrtz(v, v);
+    const float rem = v - (float)a.x;
+    const h2 b = __builtin_amdgcn_cvt_pkrtz(rem, rem);
+    p1 = __builtin_bit_cast(uint32_t, a) & 0xFFFFu; p2 = __builtin_bit_cast(uint32_t, b) & 0xFFFFu;
+}
+
+__device__ __forceinline__ uint4 ht_target_operand(float tx, float ty, float tz, bool finite, bool upper_half)
+{
+    uint32_t t[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } }, w[2] = { 0x7C00u, 0 };                  // padding / non-finite: w = +inf
+    if (finite) {
+        const float ww = ((tx * tx + ty * ty) + tz * tz) * 0.99999237060546875f;               // (1 - 2^-17), <= 3 * 2^14 < 65504
+        ht_split(-2.0f * tx, t[0][0], t[0][1]); ht_split(-2.0f * ty, t[1][0], t[1][1]); ht_split(-2.0f * tz, t[2][0], t[2][1]);
+        ht_split(fminf(ww, 65000.0f), w[0], w[1]);
+    }
+    const uint32_t qx = t[0][0] | (t[0][1] << 16), qy = t[1][0] | (t[1][1] << 16), qz = t[2][0] | (t[2][1] << 16);
+    return upper_half ? make_uint4(qz, qz, w[0] | (w[1] << 16), 0u) : make_uint4(qx, qx, qy, qy);
+}
+
 void bt_free(BtIndex* b);
 // builds (and caches on tgt) the index if it is not there yet
 int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt);

@@ -39,6 +39,7 @@ namespace pcr {
 
 constexpr int NN_BLOCK = 256;
 constexpr int NN_TILE = 1024;   // targets per LDS tile: 3 * 4 KiB
+constexpr bool NN_F16_DEFAULT = true;      // measured: 0.72 against 0.88 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
 constexpr bool NN_BF16_DEFAULT = true;     // measured: 0.90 against 1.30 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
 
 __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
@@ -467,7 +468,27 @@ __device__ __forceinline__ void bt_pack(float c, uint4& b)
     b.w = b.z;
 }
 
-template <int QG>
+// F16 (HTRACK): the same filter from ONE v_mfma_f32_32x32x16_f16 per tile.  An f16 carries 11 significant bits, so two pieces hold
+// 22 of an f32's 24 (remainder <= 2^-21 |v|), the four piece products per coordinate + two pieces of w fill 14 of the 16 K-slots,
+// and every product is exact in f32.  f16 has a narrow exponent range: the super-tile's coordinates are scaled by a power of two
+// (centres[].w: |t''| scale <= 2^7, so w <= 3 * 2^14 fits) and the query offset is CLAMPED to +-32000 per coordinate after scaling —
+// moving r towards the box that holds every t'' can only shorten |r - t''|, so the bound stays a lower bound (far tiles get a weaker
+// one, still far above anything near).  Error budget (u = 2^-24, scaled units): a two-piece f16 value misses < 2^-20 of itself, so the
+// cross term 2 r.t'' is off by <= 2 (2^-20 + 2^-20) |r||t''| <= 32 u (Q + W) and w by 16 u W; accumulation taken as 16 u sum|a b| <=
+// 34 u (Q + W); the ETRACK terms 22 u (Q + W): 104 u of the 128 u that KAPPA and w carry.  Measured on the device
+// (pcr_selftest_mfma_f16): accumulation 4.4 u, the whole filter value 10.4 u (Q + W) of the 82 u budgeted for it.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void ht_pair(float c, uint32_t& d_hi, uint32_t& d_lo)      // (c1, c1) and (c2, c2): c ~ c1 + c2 in f16
+{
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_amdgcn_cvt_pkrtz(c, c);
+    const float rem = c - (float)a.x;
+    const h2 b = __builtin_amdgcn_cvt_pkrtz(rem, rem);
+    d_hi = __builtin_bit_cast(uint32_t, a); d_lo = __builtin_bit_cast(uint32_t, b);
+}
+
+template <int QG, bool F16>
 __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
     const float4* __restrict__ centres, const uint4* __restrict__ ops, const float4* __restrict__ records, uint32_t n_rec, uint32_t n_super,
     uint32_t supers_per_slice, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
@@ -498,6 +519,45 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
     f32x16 zero;
 #pragma unroll
     for (int j = 0; j < 16; j++) zero[j] = 0.0f;
+    if (F16) {
+        uint4 an = make_uint4(0, 0, 0, 0);
+        if (sb < se) an = ops[(size_t)sb * TPS * 64 + lane];
+        for (uint32_t S = sb; S < se; S++) {
+            const float4 C = centres[S];                      // wave-uniform: scalar load; .w = the super-tile's scale (a power of two)
+            const float sc = C.w, inv2 = 1.0f / (sc * sc);    // exact: |exponent| <= 120
+            uint4 bq[QG];
+            float R[QG];
+#pragma unroll
+            for (int g = 0; g < QG; g++) {
+                const float rx = fminf(fmaxf((qx[g] - C.x) * sc, -32000.0f), 32000.0f), ry = fminf(fmaxf((qy[g] - C.y) * sc, -32000.0f), 32000.0f),
+                            rz = fminf(fmaxf((qz[g] - C.z) * sc, -32000.0f), 32000.0f);
+                R[g] = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
+                uint32_t f1, f2, s1, s2;
+                ht_pair(h ? rz : rx, f1, f2);
+                ht_pair(ry, s1, s2);
+                bq[g] = make_uint4(f1, f2, h ? 0x3C003C00u : s1, h ? 0u : s2);      // lanes >= 32: [z pieces | 1, 1, 0, 0]
+            }
+#pragma unroll 1
+            for (int tt = 0; tt < TPS; tt++) {
+                const uint32_t T = S * TPS + tt;
+                const uint4 A = an;
+                if (tt + 1 < TPS || S + 1 < se) an = ops[(size_t)(T + 1) * 64 + lane];
+                const uint32_t c = 2 * T + (h ? 1u : 0u);
+#pragma unroll
+                for (int g = 0; g < QG; g++) {
+                    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
+                    float m = big;
+#pragma unroll
+                    for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc[j]), acc[j + 1]);
+                    const float L = __builtin_fmaf(R[g], KAPPA, m) * inv2;
+                    m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], L);
+                    const bool better = L < m1[g];
+                    m1[g] = better ? L : m1[g];
+                    c1[g] = better ? c : c1[g];
+                }
+            }
+        }
+    } else {
     uint4 a0n = make_uint4(0, 0, 0, 0), a1n = a0n;
     if (sb < se) { a0n = ops[(size_t)sb * TPS * 128 + lane]; a1n = ops[(size_t)sb * TPS * 128 + 64 + lane]; }
     for (uint32_t S = sb; S < se; S++) {
@@ -537,6 +597,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
                 c1[g] = better ? c : c1[g];
             }
         }
+    }
     }
 #pragma unroll
     for (int g = 0; g < QG; g++) {
@@ -679,13 +740,24 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     // (operands in Morton order, bt_ensure) costs one bounding-box round trip and ~0.2 ms at 120 k points, less than the kernel saves
     // (small targets stay on ETRACK: 44 against 53 us per ICP iteration at 4 000 points, 114 against 72 at 20 000 — profiles/r02_mfma_filter_experiments.txt)
     const int64_t bf16_tune = tune_get(ctx, "nn1_bf16", 0);
-    const bool want_bf16 = variant_tune == 6 || (variant_tune == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)));
+    const bool want_bf16 = variant_tune == 6 || variant_tune == 7 ||
+                           (variant_tune == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)));
     if (want_bf16) {
         rc = bt_ensure(ctx, tgt);
         if (rc) return rc;
     }
     if (want_bf16 && tgt->bt->safe && tgt->bt->n_tiles) {
         const BtIndex* g = tgt->bt;
+        // HTRACK (variant 7, tune nn1_f16: 1 on, 2 off): one f16 MFMA per tile instead of two bf16 ones, when the cloud fits f16's range
+        const int64_t f16_tune = tune_get(ctx, "nn1_f16", 0);
+        bool f16 = variant_tune == 7 || (variant_tune == 0 && f16_tune != 2 && (f16_tune == 1 || NN_F16_DEFAULT));
+        if (f16 && g->bad16_host < 0) {                                            // the flag of the operand build, read once
+            int flag = 1;
+            PCR_HIP(ctx, hipMemcpyAsync(&flag, g->bad16, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            tgt->bt->bad16_host = flag;
+        }
+        if (f16 && g->bad16_host != 0) f16 = false;
         int qg = (int)tune_get(ctx, "nn1_btrack_qg", 4);
         if (qg != 1 && qg != 2) qg = 4;                                           // (8 groups per wave: hipcc 7.2 crashes on the instantiation)
         const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                      // queries per workgroup
@@ -693,7 +765,7 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
         const size_t n_super = g->n_tiles / (BT_SUPER / 32);
         int64_t sps = tune_get(ctx, "nn1_supers_per_slice", 0);
         if (sps <= 0) {
-            const int64_t want_blocks = tune_get(ctx, "nn1_btrack_blocks", 32768);
+            const int64_t want_blocks = tune_get(ctx, "nn1_btrack_blocks", f16 ? 40960 : 32768);   // (120 k: 3 / 4 super-tiles per slice, the measured optima)
             const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
             sps = std::max<int64_t>(1, ((int64_t)n_super + slices - 1) / slices);
         }
@@ -715,7 +787,10 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
             ProfScope p(ctx, "nn1_brute", 1);
             const dim3 grid(qblocks, slices);
 #define PCR_BTRACK(Q)                                                                                                                   \
-hipLaunchKernelGGL((nn1_btrack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops, g->records,                  \
+if (f16) hipLaunchKernelGGL((nn1_btrack_kernel<Q, true>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records,         \
+                   (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
+                   merge_atomic, ctx->stop_flag_dev, stats_dev);                                                                        \
+else hipLaunchKernelGGL((nn1_btrack_kernel<Q, false>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops, g->records,              \
                    (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
                    merge_atomic, ctx->stop_flag_dev, stats_dev)
             switch (qg) {
@@ -951,6 +1026,99 @@ int bt_mfma_selftest(pcr_ctx* ctx, int trials, double worst[2])
                     const float* r = &rv[(T * 32 + n) * 3]; const float* t = &tv[(T * 32 + m) * 3];
                     const double Q = (double)r[0] * r[0] + (double)r[1] * r[1] + (double)r[2] * r[2], W = (double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2];
                     const float wf = (t[0] * t[0] + t[1] * t[1]) + t[2] * t[2];
+                    const double want = (double)wf - 2.0 * ((double)r[0] * t[0] + (double)r[1] * t[1] + (double)r[2] * t[2]);
+                    if (Q + W > 0.0) worst[1] = std::max(worst[1], std::fabs(got - want) / (Q + W) * 16777216.0);
+                }
+            }
+    return PCR_OK;
+}
+
+// the same for HTRACK (pcr_selftest_mfma_f16): tiles < n_raw run the MFMA on operands the host built (f16 bit patterns); the others get
+// f32 query offsets and target offsets (already scaled) and build their operands with the kernel's own device code
+__global__ __launch_bounds__(64) void ht_selftest_kernel(const uint4* __restrict__ ab, const float* __restrict__ rt, uint32_t n_raw, float* __restrict__ out)
+{
+    const uint32_t lane = threadIdx.x, T = blockIdx.x, n = lane & 31;
+    const bool h = lane >= 32;
+    uint4 A, B;
+    if (T < n_raw) { A = ab[(size_t)T * 128 + lane]; B = ab[(size_t)T * 128 + 64 + lane]; }
+    else {
+        const float* q = rt + ((size_t)T * 64 + n) * 3;                    // query n
+        const float* t = rt + ((size_t)T * 64 + 32 + n) * 3;               // target row n (= lane & 31)
+        uint32_t f1, f2, s1, s2;
+        ht_pair(h ? q[2] : q[0], f1, f2);
+        ht_pair(q[1], s1, s2);
+        B = make_uint4(f1, f2, h ? 0x3C003C00u : s1, h ? 0u : s2);
+        A = ht_target_operand(t[0], t[1], t[2], true, h);
+    }
+    f32x16 zero;
+#pragma unroll
+    for (int j = 0; j < 16; j++) zero[j] = 0.0f;
+    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), zero, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; j++) out[((size_t)T * 64 + lane) * 16 + j] = acc[j];
+}
+
+// worst[0]: random f16 operands (exponents 2^-8 .. 2^8 in every slot) -> max |D - exact| / (2^-24 sum |a b|);
+// worst[1]: HTRACK's own operand construction for random scaled r (|r| <= 32000 in a random binade) and t'' (|t''| <= 2^7) ->
+//           max |G - (w (1 - 2^-17) - 2 r.t'')| / (2^-24 (|r|^2 + |t''|^2)), w = fl(|t''|^2)
+int ht_mfma_selftest(pcr_ctx* ctx, int trials, double worst[2])
+{
+    worst[0] = worst[1] = 0.0;
+    if (trials <= 0) return PCR_OK;
+    const size_t n_raw = (size_t)trials, n_tiles = 2 * n_raw;
+    std::vector<uint32_t> hab(n_raw * 128 * 4);
+    std::vector<float> rt(n_tiles * 64 * 3, 0.f);
+    SelfRng rng{ 0xF16F16F1ull };
+    auto f16_to_f64 = [](uint32_t b) {                                      // normal f16 only (the generator below makes no others)
+        const int e = (int)((b >> 10) & 31) - 15; const double m = 1.0 + (double)(b & 1023) / 1024.0;
+        return ((b & 0x8000u) ? -1.0 : 1.0) * std::ldexp(m, e);
+    };
+    for (auto& w : hab) {
+        uint32_t two = 0;
+        for (int k = 0; k < 2; k++) {
+            const uint32_t e = 15 - 8 + (uint32_t)(rng.next() % 17), man = (uint32_t)(rng.next() & 1023), sg = (uint32_t)(rng.next() & 1);
+            two |= ((sg << 15) | (e << 10) | man) << (16 * k);
+        }
+        w = two;
+    }
+    for (size_t T = n_raw; T < n_tiles; T++) {
+        const float scale_r = std::ldexp(1.0f, (int)(rng.next() % 15)), scale_t = std::ldexp(1.0f, (int)(rng.next() % 8));      // up to 2^14 * 1.95, 2^7
+        for (int n = 0; n < 32; n++)
+            for (int c = 0; c < 3; c++) {
+                rt[(T * 64 + n) * 3 + c] = std::min(std::max(rng.sym(1.95f) * scale_r, -32000.0f), 32000.0f);
+                rt[(T * 64 + 32 + n) * 3 + c] = rng.sym(1.0f) * scale_t * 0.57f;          // |t''| <= 2^7 in norm terms too: w <= 3 * (0.57 * 128)^2 < 65000
+            }
+    }
+    uint4* dab = nullptr; float* drt = nullptr; float* dout = nullptr;
+    PCR_HIP(ctx, hipMalloc((void**)&dab, hab.size() * 4));
+    hipError_t e = hipMalloc((void**)&drt, rt.size() * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, n_tiles * 64 * 16 * sizeof(float));
+    std::vector<float> out(n_tiles * 64 * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(dab, hab.data(), hab.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(drt, rt.data(), rt.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ht_selftest_kernel, dim3((unsigned)n_tiles), dim3(64), 0, ctx->stream, dab, drt, (uint32_t)n_raw, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dab); hipFree(drt); hipFree(dout);
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "mfma f16 selftest", e);
+    auto el = [&](size_t T, int which, int lane, int j) { const uint32_t w = hab[((T * 2 + which) * 64 + lane) * 4 + j / 2]; return f16_to_f64((j & 1) ? (w >> 16) : (w & 0xFFFFu)); };
+    for (size_t T = 0; T < n_tiles; T++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int reg = 0; reg < 16; reg++) {
+                const int n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const double got = (double)out[(T * 64 + lane) * 16 + reg];
+                if (T < n_raw) {
+                    double ex = 0.0, mag = 0.0;
+                    for (int hh = 0; hh < 2; hh++)
+                        for (int j = 0; j < 8; j++) { const double p = el(T, 0, m + 32 * hh, j) * el(T, 1, n + 32 * hh, j); ex += p; mag += std::fabs(p); }
+                    if (mag > 0.0) worst[0] = std::max(worst[0], std::fabs(got - ex) / mag * 16777216.0);
+                } else {
+                    const float* r = &rt[(T * 64 + n) * 3]; const float* t = &rt[(T * 64 + 32 + m) * 3];
+                    const double Q = (double)r[0] * r[0] + (double)r[1] * r[1] + (double)r[2] * r[2], W = (double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2];
+                    const float wf = ((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]) * 0.99999237060546875f;
                     const double want = (double)wf - 2.0 * ((double)r[0] * t[0] + (double)r[1] * t[1] + (double)r[2] * t[2]);
                     if (Q + W > 0.0) worst[1] = std::max(worst[1], std::fabs(got - want) / (Q + W) * 16777216.0);
                 }

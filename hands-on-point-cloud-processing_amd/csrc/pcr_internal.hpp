@@ -166,6 +166,7 @@ void prof_flush(pcr_ctx* ctx);
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int bt_mfma_selftest(pcr_ctx* ctx, int trials, double worst[2]);
+int ht_mfma_selftest(pcr_ctx* ctx, int trials, double worst[2]);
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool in_loop);
 int launch_nn1_brute_list(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, const uint32_t* qlist, const uint32_t* qcount, uint32_t qcap);
 // cap2: the caller only uses neighbours with d2 < cap2 (ICP's max_corres_dist gate) — the walk may stop once no such target can exist

@@ -284,6 +284,10 @@ int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4]);
  *   worst[0] = max |D - exact| / (2^-24 sum |a_k b_k|) over operands with exponents spread over 2^-20 .. 2^20   (the bound's analysis assumes <= 16)
  *   worst[1] = max |G - (w - 2 r.t)| / (2^-24 (|r|^2 + |t|^2)) in the kernel's three-piece operand layout        (assumes <= 34.2) */
 int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[2]);
+/* The same for the f16 form the default filter uses when the target's coordinates fit f16's range after per-tile scaling (HTRACK):
+ *   worst[0] = max |D - exact| / (2^-24 sum |a_k b_k|) of one v_mfma_f32_32x32x16_f16 on random f16 operands          (assumed <= 16)
+ *   worst[1] = max |G - (w - 2 r.t)| / (2^-24 (|r|^2 + |t|^2)) with the operands built by the kernel's own two-piece code (assumed <= 82) */
+int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[2]);
 /* tuning / diagnostic knobs by name (value 0 = library default, except "prof"): "nn_method" 1 brute force / 2 exact grid,
  * "nn1_variant", "knn_method", "radius_method", "icp_pipeline", "prof", ... — the names are listed where they are read (csrc/) */
 int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value);

@@ -45,6 +45,10 @@ def test_bf16_matrix_core_arithmetic_is_within_the_bound_the_filter_assumes(ctx)
     acc, filt = ctx.selftest_mfma_bf16(96)
     assert 0.0 < acc <= 8.0, acc
     assert 0.0 < filt <= 17.0, filt
+    # the f16 form (HTRACK, the default where the cloud fits f16's range): accumulation <= 16 assumed, filter value <= 82 assumed
+    acc16, filt16 = ctx.selftest_mfma_f16(96)
+    assert 0.0 < acc16 <= 8.0, acc16
+    assert 0.0 < filt16 <= 41.0, filt16
 
 
 def test_nn1_randomised_sweep_every_kernel(ctx, orc):
@@ -59,7 +63,7 @@ def test_nn1_randomised_sweep_every_kernel(ctx, orc):
             src[:, : min(ns, nt) // 2] = tgt[:, : min(ns, nt) // 2]
         oi, od = orc.nn1_f32(tgt, src)
         ct, cs = ctx.cloud(tgt), ctx.cloud(src)
-        for method, variant, mode in ((1, 1, 0), (1, 2, 0), (1, 3, 0), (1, 4, 0), (1, 6, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)):
+        for method, variant, mode in ((1, 1, 0), (1, 2, 0), (1, 3, 0), (1, 4, 0), (1, 6, 0), (1, 7, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)):
             ctx.tune("nn_method", method)
             ctx.tune("nn1_variant", variant)
             ctx.tune("grid_mode", mode)                # 1 plain, 2 x-window, 3 bounding spheres (0: by target size)
@@ -68,7 +72,7 @@ def test_nn1_randomised_sweep_every_kernel(ctx, orc):
         ct.free()
         ctx.tune("grid_order", 2)                      # the Morton-ordered index of large targets, forced on a fresh cloud
         cm = ctx.cloud(tgt)
-        for method, variant, mode in ((2, 1, 3), (2, 1, 1), (1, 4, 0), (1, 6, 0)):
+        for method, variant, mode in ((2, 1, 3), (2, 1, 1), (1, 4, 0), (1, 6, 0), (1, 7, 0)):
             ctx.tune("nn_method", method); ctx.tune("nn1_variant", variant); ctx.tune("grid_mode", mode)
             idx, d2 = ctx.nn1(cm, cs)
             assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (trial, kind, nt, ns, method, variant, mode, "morton")
@@ -99,7 +103,7 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
 
 # variant 1: FTRACK (default: fused-filter tracking, exact decision); 2: TRACK (exact only), scalar-cache targets; 3: TRACK, LDS tiles
 # (4 exact, 5 fused filter, 6/7 the same with scalar-load targets); chunk = targets per min-tree
-VARIANTS = [(1, 8), (1, 16), (2, 8), (2, 16), (3, 8), (3, 16), (4, 16), (6, 16)]   # 4 = ETRACK (expanded-form filter on the grid's chunked target copy), 6 = BTRACK (the filter on the bf16 matrix cores, three-piece operands)
+VARIANTS = [(1, 8), (1, 16), (2, 8), (2, 16), (3, 8), (3, 16), (4, 16), (6, 16), (7, 16)]   # 4 = ETRACK (expanded-form filter on the grid's chunked target copy), 6 = BTRACK (the filter on the bf16 matrix cores, three-piece operands), 7 = HTRACK (one f16 MFMA per tile, two-piece scaled operands)
 
 
 def set_variant(ctx, vc):
