@@ -16,7 +16,7 @@ value            = correspondences of the whole job per second (M corr/s) on ONE
                    120 000 sources are SHARDED N ways (contiguous blocks, target replicated): "scaling": "strong" — the reading of
                    BASELINE.json.metric ("120k-pt KITTI pair, 1/2/4/8 MI355X").  "weak" (extra key, N > 1) is the other reading:
                    every rank registers its own 120 000-point shard of a denser source scan.
-roofline         = the dominant kernel (nn1_btrack_kernel): bf16 matrix flops the kernel's algorithm needs per launch / average launch
+roofline         = the dominant kernel (nn1_btrack_kernel, f16 form): matrix flops the kernel's algorithm needs per launch / average launch
                    duration measured live with HIP events on the kernel's own stream (inside libpcr_hip.so) / 2 500 TFLOP/s; the
                    same launch priced as the f32 filter (6 flop per pair against 157.3 TFLOP/s) under fp32_equivalent.
 kernels          = the same for the exact-only kernel (9-op convention of SURVEY.md 8d) and the two HBM streaming kernels.
@@ -47,6 +47,8 @@ VALU_PEAK_TOPS_NOFMA = 78.6     # the same issue rate counted one op per lane-sl
 HBM_PEAK_GBS = 8000.0
 OPS_PER_PAIR = 9                # 3 sub + 3 mul + 2 add + 1 compare per (query, target) pair — the exact kernel's work
 ETRACK_FLOPS_PER_PAIR = 6       # the f32 filter's algorithm: 3 FMAs per (query, target) pair (csrc/nn1_brute.hip, ETRACK)
+HTRACK_FLOPS_PER_PAIR = 28      # the f16 filter's algorithm: 14 f16 multiply-adds per pair that carry data (3 coordinates x 4 piece products + 2 pieces of
+                                # |t''|^2) of the 16 K-slots ONE v_mfma_f32_32x32x16_f16 provides (csrc/nn1_brute.hip, HTRACK)
 BTRACK_FLOPS_PER_PAIR = 54      # the bf16 filter's algorithm: 27 bf16 multiply-adds per pair that carry data (3 coordinates x 8 piece products + 3 pieces
                                 # of |t''|^2) of the 32 K-slots two v_mfma_f32_32x32x16_bf16 provide (csrc/nn1_brute.hip, BTRACK)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (MI355X_MICROARCH.md)
@@ -405,12 +407,15 @@ def main():
                         "fresh_target": {"ms": ms_fresh, "M_corr_per_s": n_q / ms_fresh / 1e3, "kernel_ms": ms_fresh_kernel,
                                          "kernel": "the FIRST search of a target cloud, wall time of the call (median of 7, host launch + completion wait "
                                                    "included): the Morton-ordered bf16 operands are built (one bounding-box round trip, radix sort) and "
-                                                   "pcr::nn1_btrack_kernel<4> runs",
+                                                   "the default kernel (HTRACK) runs",
                                          "f32_kernels_ms": ms_fresh_f32,
                                          "f32_kernels": "the same call with nn1_bf16 = 2: pcr::nn1_ftrack_kernel<2, 16>, which needs no index"},
                         "indexed_target": {"ms": ms_indexed, "M_corr_per_s": n_q / ms_indexed / 1e3,
-                                           "kernel": "the default indexed kernel (pcr::nn1_btrack_kernel<4>), unseeded, kernel time (the target's operands exist: any earlier search built them)"}}
+                                           "kernel": "the default kernel (HTRACK), unseeded, kernel time (the target's operands exist: any earlier search built them)"}}
             ms_f32 = time_search(ct, 5, nn1_bf16=2)
+            ms_bf16 = time_search(ct, 5, nn1_f16=2)
+            one_shot["indexed_target_bf16_filter"] = {"ms": ms_bf16, "M_corr_per_s": n_q / ms_bf16 / 1e3,
+                                                      "kernel": "BTRACK (tune nn1_f16 = 2: the filter as two bf16 MFMAs per tile; what a cloud outside f16's range gets), unseeded"}
             one_shot["indexed_target_f32_filter"] = {"ms": ms_f32, "M_corr_per_s": n_q / ms_f32 / 1e3,
                                                      "kernel": "pcr::nn1_etrack_kernel<4> (tune nn1_bf16 = 2: the same filter as 3 vector FMAs per pair), unseeded"}
 
@@ -440,8 +445,9 @@ def main():
         if rank == 0:
             gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
             if args.nn == "brute":
-                bf16 = default_kernels and tunes_env.get("nn1_bf16", 0) != 2 and tunes_env.get("nn1_variant", 0) in (0, 6) and (n_t >= 8192 or tunes_env.get("nn1_variant", 0) == 6)
-                flops_pp = BTRACK_FLOPS_PER_PAIR if bf16 else ETRACK_FLOPS_PER_PAIR
+                bf16 = default_kernels and tunes_env.get("nn1_bf16", 0) != 2 and tunes_env.get("nn1_variant", 0) in (0, 6, 7) and (n_t >= 8192 or tunes_env.get("nn1_variant", 0) in (6, 7))
+                f16 = bf16 and tunes_env.get("nn1_f16", 0) != 2 and tunes_env.get("nn1_variant", 0) in (0, 7)
+                flops_pp = HTRACK_FLOPS_PER_PAIR if f16 else BTRACK_FLOPS_PER_PAIR if bf16 else ETRACK_FLOPS_PER_PAIR
                 peak_tf = MFMA_BF16_PEAK_TFLOPS if bf16 else VALU_PEAK_TFLOPS
                 achieved_tflops = flops_pp * pairs / kern_s / 1e12
                 compulsory_bytes = 12.0 * n_t + 12.0 * n_q + 8.0 * n_q        # targets + sources + (idx, d2) key
@@ -453,7 +459,13 @@ def main():
                     "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
                                      f"kernel with this very libpcr_hip.so (sha {sha}), {pmc['source']}") if pmc else
                                     "null: PMC counters need a rocprofv3 wrapper (tools/gpu_check.sh); none was collected with the library loaded now",
-                    "kernel": (("pcr::nn1_btrack_kernel<4> (exhaustive scan of every (query, 16-target chunk): the expanded-form lower bound of ALL "
+                    "kernel": (("pcr::nn1_btrack_kernel<4, true> = HTRACK (exhaustive scan of every (query, 16-target chunk): the expanded-form lower "
+                                "bound of ALL pairs on the f16 matrix pipe — operands scaled per 256-target super-tile and cut into two f16 pieces each, "
+                                "every piece product exact in f32, ONE v_mfma_f32_32x32x16_f16 per 32 queries x 32 targets; the vector ALU takes the "
+                                "minimum of the 16 accumulators per lane (8 v_min3) and tracks first / second minimum branch-free; only the winning "
+                                "chunk is evaluated with the exact unfused arithmetic; the previous correspondence of each query, re-evaluated "
+                                "exactly, seeds the bound)") if f16 else
+                               ("pcr::nn1_btrack_kernel<4, false> = BTRACK (exhaustive scan of every (query, 16-target chunk): the expanded-form lower bound of ALL "
                                 "pairs on the bf16 matrix pipe — f32 operands cut into three bf16 pieces each, every piece product exact in f32, "
                                 "two v_mfma_f32_32x32x16_bf16 per 32 queries x 32 targets; the vector ALU takes the minimum of the 16 accumulators "
                                 "per lane (8 v_min3) and tracks first / second minimum branch-free; only the winning chunk is evaluated with the "
@@ -463,12 +475,13 @@ def main():
                                 "branch-free; only the winning chunk is evaluated with the exact unfused arithmetic; the previous correspondence of "
                                 "each query, re-evaluated exactly, seeds the bound)")) if default_kernels else f"nn1 variant={args.variant} qpl={args.qpl}",
                     "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
-                    "algorithmic": (f"{BTRACK_FLOPS_PER_PAIR} bf16 flop per (query, target) pair (27 piece products that carry data, of the 32 K-slots "
-                                    f"executed) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense bf16.  On this chip the matrix instructions and "
-                                    "the vector instructions of one SIMD's waves take turns in this loop (measured: tools/ubench/mfma_filter.hip, "
-                                    "profiles/r02_mfma_filter_experiments.txt), so the launch time is MFMA time (2 x 32 cycles per 1024 pairs) PLUS "
-                                    "vector time (about 20 instructions per 1024 pairs): fp32_equivalent prices the same launch in the f32 filter's "
-                                    "6 flop per pair against the 157.3 TF/s vector peak, kernels.nn1_exact_track is SURVEY.md 8d's 9-op convention")
+                    "algorithmic": (f"{flops_pp} {'f16' if f16 else 'bf16'} flop per (query, target) pair ({flops_pp // 2} piece products that carry data, of "
+                                    f"the {16 if f16 else 32} K-slots executed) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16 / bf16.  On this chip "
+                                    "the matrix instructions and the vector instructions of one SIMD's waves take turns in this loop (measured: "
+                                    "tools/ubench/mfma_filter.hip, profiles/r02_mfma_filter_experiments.txt), so the launch time is MFMA time "
+                                    f"({1 if f16 else 2} x 32 cycles per 1024 pairs) PLUS vector time (about 20 instructions per 1024 pairs, the larger "
+                                    "share): fp32_equivalent prices the same launch in the f32 filter's 6 flop per pair against the 157.3 TF/s vector "
+                                    "peak, kernels.nn1_exact_track is SURVEY.md 8d's 9-op convention")
                                    if bf16 else
                                    (f"{ETRACK_FLOPS_PER_PAIR} flop (3 FMAs) per (query, target) pair x {pairs:.3e} pairs per launch — the arithmetic of the "
                                     "kernel that ran; the min-tree, the per-chunk prologue (|q - C|^2, 11 ops per 16 targets) and the exact "
