@@ -529,9 +529,10 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
             float R[QG];
 #pragma unroll
             for (int g = 0; g < QG; g++) {
-                const float rx = fminf(fmaxf((qx[g] - C.x) * sc, -32000.0f), 32000.0f), ry = fminf(fmaxf((qy[g] - C.y) * sc, -32000.0f), 32000.0f),
-                            rz = fminf(fmaxf((qz[g] - C.z) * sc, -32000.0f), 32000.0f);
-                R[g] = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
+                const float rx = __builtin_amdgcn_fmed3f((qx[g] - C.x) * sc, -32000.0f, 32000.0f), ry = __builtin_amdgcn_fmed3f((qy[g] - C.y) * sc, -32000.0f, 32000.0f),
+                            rz = __builtin_amdgcn_fmed3f((qz[g] - C.z) * sc, -32000.0f, 32000.0f);
+                // (R KAPPA / scale^2 once per super-tile: the bound of a tile is then ONE fma, m / scale^2 + that — the division is exact)
+                R[g] = (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) * KAPPA) * inv2;
                 uint32_t f1, f2, s1, s2;
                 ht_pair(h ? rz : rx, f1, f2);
                 ht_pair(ry, s1, s2);
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
                     float m = big;
 #pragma unroll
                     for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc[j]), acc[j + 1]);
-                    const float L = __builtin_fmaf(R[g], KAPPA, m) * inv2;
+                    const float L = __builtin_fmaf(m, inv2, R[g]);
                     m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], L);
                     const bool better = L < m1[g];
                     m1[g] = better ? L : m1[g];

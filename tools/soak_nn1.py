@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak of the correspondence kernels on random inputs: the default path (FTRACK on a target's first search, the bf16
-matrix-core filter BTRACK afterwards and inside ICP loops), the cold ETRACK and BTRACK searches and the exact grid search must give
+matrix-core filters HTRACK / BTRACK from 8 192 target points on), the cold ETRACK, BTRACK and HTRACK searches and the exact grid search must give
 the bits of the exact-only brute-force kernel (nn1_variant = 2) on every input.
 usage: soak_nn1.py [cases=60] [seed0=1]"""
 import importlib, os, sys, time
@@ -50,7 +50,7 @@ for case in range(cases):
     rng = np.random.default_rng(seed0 + case)
     kind, t, s, scale = make(rng)
     res = {}
-    for name, tunes in (("exact", {"nn1_variant": 2}), ("default", {}), ("etrack_cold", {"nn1_variant": 4}), ("btrack_cold", {"nn1_variant": 6}), ("grid", {"nn_method": 2})):
+    for name, tunes in (("exact", {"nn1_variant": 2}), ("default", {}), ("etrack_cold", {"nn1_variant": 4}), ("btrack_cold", {"nn1_variant": 6}), ("htrack_cold", {"nn1_variant": 7}), ("grid", {"nn_method": 2})):
         ctx = pcr.Context(0)
         ctx.tune("nn_method", 1)
         for k, v in tunes.items():
@@ -63,7 +63,7 @@ for case in range(cases):
             out.append(T.view(np.uint32).copy()); out.append(np.array([st["iters_run"], st["last_pairs"]]))
         res[name] = out
         ctx.close()
-    for name in ("default", "etrack_cold", "btrack_cold", "grid"):
+    for name in ("default", "etrack_cold", "btrack_cold", "htrack_cold", "grid"):
         ok = all(np.array_equal(a, b) for a, b in zip(res["exact"], res[name]))
         if not ok:
             bad += 1
