@@ -998,6 +998,7 @@ void grid_free(Grid* g)
     if (!g) return;
     if (g->chunks) hipFree(g->chunks);
     if (g->spheres) hipFree(g->spheres);
+    if (g->by_index) hipFree(g->by_index);
     if (g->records) hipFree(g->records);
     if (g->cell_start) hipFree(g->cell_start);
     delete g;

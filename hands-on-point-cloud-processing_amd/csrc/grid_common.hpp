@@ -37,6 +37,9 @@ struct Grid {
     // records array is padded to a whole chunk with x = +inf entries): one 16-byte load decides whether 16 records can hold a
     // better neighbour (grid.hip, SPH search kernel)
     float4* spheres = nullptr;
+    // the points once more as {x, y, z, 0} in ORIGINAL order (radius_grid.hip: one 16-byte gather per reported neighbour instead of
+    // three 4-byte ones); built on first use
+    float4* by_index = nullptr;
 };
 
 constexpr int BT_SUPER = 256;          // records per super-tile (8 tiles of 32; measured per 120k x 120k search: 128 -> 0.94, 256 -> 0.90, 512 -> 0.97 ms)

@@ -31,6 +31,26 @@ __device__ __forceinline__ double s_f64(float tx, float ty, float tz, double qx,
     return (e0 * e0 + e1 * e1) + e2 * e2;
 }
 
+// Membership d^2 <= r2max (f64, kdtree.hpp:343-346) decided in f32 wherever f32 can: the f32 value of (dx^2 + dy^2) + dz^2 is within
+// 5 * 2^-24 of the true one (the inputs are exact f32, every term is non-negative), so outside a band of 2^-20 around r2max the f32
+// comparison IS the f64 one; inside the band the f64 arithmetic decides.  flo / fhi = r2max (1 -+ 2^-20) as floats (0 / inf when
+// r2max is outside the float range: everything goes to f64).
+__device__ __forceinline__ bool member(float tx, float ty, float tz, float qfx, float qfy, float qfz, double qx, double qy, double qz, double r2max,
+                                       float flo, float fhi)
+{
+    const float dx = tx - qfx, dy = ty - qfy, dz = tz - qfz;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    if (d2 < flo) return true;
+    if (d2 > fhi) return false;
+    return s_f64(tx, ty, tz, qx, qy, qz) <= r2max;          // the band, NaN, overflow
+}
+
+__device__ __forceinline__ void member_band(double r2max, float& flo, float& fhi)
+{
+    flo = 0.0f; fhi = __builtin_inff();
+    if (r2max > 1e-30 && r2max < 1e30) { flo = (float)(r2max * (1.0 - 9.5367431640625e-07)); fhi = (float)(r2max * (1.0 + 9.5367431640625e-07)); }
+}
+
 __device__ __forceinline__ void clip_x(const float4* __restrict__ records, uint32_t& b, uint32_t& e, float lo, float hi)
 {
     if (e - b <= 256u) return;
@@ -81,6 +101,8 @@ __global__ __launch_bounds__(RG_BLOCK) void radius_grid_kernel(const float4* __r
         const int cx = cell_coord(fx, g.lo[0], g.inv_h), cy = cell_coord(fy, g.lo[1], g.inv_h), cz = cell_coord(fz, g.lo[2], g.inv_h);
         const float pad = (fabsf(fx) + win) * 2.4e-7f;
         const float lo = fx - win - pad, hi = fx + win + pad;
+        float flo, fhi;
+        member_band(r2max, flo, fhi);
         for (int k = 0; k < 9; k++) {
             uint32_t b, e;
             row_k(g, cell_start, records, cx, cy, cz, k, lo, hi, b, e);
@@ -90,7 +112,7 @@ __global__ __launch_bounds__(RG_BLOCK) void radius_grid_kernel(const float4* __r
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (j < e) {
                     t = records[j];
-                    in = s_f64(t.x, t.y, t.z, qx, qy, qz) <= r2max;
+                    in = member(t.x, t.y, t.z, fx, fy, fz, qx, qy, qz, r2max, flo, fhi);
                 }
                 if (FILL) {
                     const unsigned long long all = __ballot(in);
@@ -134,14 +156,15 @@ __global__ __launch_bounds__(RG_BLOCK) void radius_dist_kernel(const float* __re
 // the 12 B/neighbour of the result and the gathers of the coordinates, nothing else.
 //   LDS: bitmap[W] | staged indices A[CAP] | 32 words of scan partials / row ranges   (W = ceil(n / 32) rounded up to 256 words)
 constexpr int RE_BLOCK = 256;
+constexpr int RE_UNROLL = 4;       // candidate loads in flight per thread (8 measured: no change)
 constexpr uint32_t RE_MAX_DB = 262144;       // 32 KB of bitmap; larger databases take the segmented-sort route
 
 template <int CAP>
 __global__ __launch_bounds__(RE_BLOCK) void radius_emit_kernel(const float4* __restrict__ records, const uint32_t* __restrict__ cell_start, GridParams g,
                                                                const float* __restrict__ qxs, const float* __restrict__ qys, const float* __restrict__ qzs,
                                                                const uint32_t* __restrict__ list, uint32_t n_list, double r2max, float win,
-                                                               const uint32_t* __restrict__ row_ptr, const float* __restrict__ tx, const float* __restrict__ ty,
-                                                               const float* __restrict__ tz, uint32_t words, int32_t* __restrict__ idx_out,
+                                                               const uint32_t* __restrict__ row_ptr, const float4* __restrict__ by_index,
+                                                               uint32_t words, int32_t* __restrict__ idx_out,
                                                                double* __restrict__ dist_out, int* __restrict__ err)
 {
     extern __shared__ uint32_t re_lds[];
@@ -159,6 +182,8 @@ __global__ __launch_bounds__(RE_BLOCK) void radius_emit_kernel(const float4* __r
     // ---- collect: the walk and the membership test of the count pass
     if (finite3(fx, fy, fz)) {
         const double qx = fx, qy = fy, qz = fz;
+        float flo, fhi;
+        member_band(r2max, flo, fhi);
         const int cx = cell_coord(fx, g.lo[0], g.inv_h), cy = cell_coord(fy, g.lo[1], g.inv_h), cz = cell_coord(fz, g.lo[2], g.inv_h);
         // the nine row ranges (bounds + x-window searches: chains of dependent loads) are resolved side by side by nine lanes
         // (no x-window search here: its chain of ~16 dependent loads costs a one-query workgroup more than testing the extra third
@@ -179,20 +204,20 @@ __global__ __launch_bounds__(RE_BLOCK) void radius_emit_kernel(const float4* __r
         for (int k = 0; k < 9; k++) {
             const uint32_t b = misc[8 + 2 * k], e = misc[9 + 2 * k];
             uint32_t j = b + tid;
-            for (; j + 3 * RE_BLOCK < e; j += 4 * RE_BLOCK) {            // four independent 16-byte loads in flight per thread
-                float4 t[4];
+            for (; j + (RE_UNROLL - 1) * RE_BLOCK < e; j += RE_UNROLL * RE_BLOCK) {            // independent 16-byte loads in flight per thread
+                float4 t[RE_UNROLL];
 #pragma unroll
-                for (int u = 0; u < 4; u++) t[u] = records[j + u * RE_BLOCK];
+                for (int u = 0; u < RE_UNROLL; u++) t[u] = records[j + u * RE_BLOCK];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (s_f64(t[u].x, t[u].y, t[u].z, qx, qy, qz) <= r2max) {
+                for (int u = 0; u < RE_UNROLL; u++)
+                    if (member(t[u].x, t[u].y, t[u].z, fx, fy, fz, qx, qy, qz, r2max, flo, fhi)) {
                         const uint32_t id = __float_as_uint(t[u].w);
                         atomicOr(&bm[id >> 5], 1u << (id & 31u));
                     }
             }
             for (; j < e; j += RE_BLOCK) {
                 const float4 t = records[j];
-                if (s_f64(t.x, t.y, t.z, qx, qy, qz) <= r2max) {
+                if (member(t.x, t.y, t.z, fx, fy, fz, qx, qy, qz, r2max, flo, fhi)) {
                     const uint32_t id = __float_as_uint(t.w);
                     atomicOr(&bm[id >> 5], 1u << (id & 31u));
                 }
@@ -232,22 +257,30 @@ __global__ __launch_bounds__(RE_BLOCK) void radius_emit_kernel(const float4* __r
     uint32_t p = tid;
     for (; p + 3 * RE_BLOCK < N; p += 4 * RE_BLOCK) {
         uint32_t j[4];
-        float cxs[4], cys[4], czs[4];
+        float4 c[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) j[u] = A[p + u * RE_BLOCK];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { cxs[u] = tx[j[u]]; cys[u] = ty[j[u]]; czs[u] = tz[j[u]]; }
+        for (int u = 0; u < 4; u++) c[u] = by_index[j[u]];         // one 16-byte gather per neighbour (three 4-byte ones cost the texture path 3 x 64 lane-cycles)
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             idx_out[o + p + u * RE_BLOCK] = (int32_t)j[u];
-            dist_out[o + p + u * RE_BLOCK] = sqrt(s_f64(cxs[u], cys[u], czs[u], qx, qy, qz));
+            dist_out[o + p + u * RE_BLOCK] = sqrt(s_f64(c[u].x, c[u].y, c[u].z, qx, qy, qz));
         }
     }
     for (; p < N; p += RE_BLOCK) {
         const uint32_t j = A[p];
+        const float4 c = by_index[j];
         idx_out[o + p] = (int32_t)j;
-        dist_out[o + p] = sqrt(s_f64(tx[j], ty[j], tz[j], qx, qy, qz));
+        dist_out[o + p] = sqrt(s_f64(c.x, c.y, c.z, qx, qy, qz));
     }
+}
+
+__global__ __launch_bounds__(RG_BLOCK) void aos4_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
+                                                        float4* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (i < n) out[i] = make_float4(x[i], y[i], z[i], 0.f);
 }
 
 // self-query: the records' order IS the cell order of the points -> perm[t] = original index of record t
@@ -353,6 +386,11 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
             if (c == 0) continue;
             lists[c <= 1024u ? 0 : c <= 2048u ? 1 : c <= 4096u ? 2 : c <= 8192u ? 3 : 4].push_back(qi);
         }
+        if (!g->by_index) {
+            PCR_HIP(ctx, hipMalloc((void**)&g->by_index, std::max<size_t>(n, 1) * sizeof(float4)));
+            hipLaunchKernelGGL(aos4_kernel, dim3((unsigned)((n + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, ctx->stream, db->x(), db->y(), db->z(), (uint32_t)n,
+                               g->by_index);
+        }
         DevBuf lbuf, errbuf;
         PCR_HIP(ctx, hipMalloc(&lbuf.p, (m + 1) * 4));
         PCR_HIP(ctx, hipMalloc(&errbuf.p, 4));
@@ -372,7 +410,7 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
         hipFuncSetAttribute((const void*)radius_emit_kernel<CAPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         hipLaunchKernelGGL((radius_emit_kernel<CAPV>), dim3((unsigned)lists[c].size()), dim3(RE_BLOCK), lds, ctx->stream, g->records, g->cell_start, g->p, \
                            q->x(), q->y(), q->z(), (const uint32_t*)lbuf.p + loff[c], (uint32_t)lists[c].size(), r2max, win, (const uint32_t*)rows.p,   \
-                           db->x(), db->y(), db->z(), words, (int32_t*)idx_b.p, (double*)dist.p, (int*)errbuf.p);                              \
+                           g->by_index, words, (int32_t*)idx_b.p, (double*)dist.p, (int*)errbuf.p);                                            \
     }
             PCR_EMIT(1024, 0)
             PCR_EMIT(2048, 1)
