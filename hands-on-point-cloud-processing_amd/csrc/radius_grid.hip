@@ -87,7 +87,8 @@ template <bool FILL>
 __global__ __launch_bounds__(RG_BLOCK) void radius_grid_kernel(const float4* __restrict__ records, const uint32_t* __restrict__ cell_start, GridParams g,
                                                                const float* __restrict__ qxs, const float* __restrict__ qys, const float* __restrict__ qzs,
                                                                const uint32_t* __restrict__ perm, uint32_t m, double r2max, float win,
-                                                               uint32_t* __restrict__ counts, const uint32_t* __restrict__ row_ptr, int32_t* __restrict__ idx_out)
+                                                               uint32_t* __restrict__ counts, const uint32_t* __restrict__ row_ptr, int32_t* __restrict__ idx_out,
+                                                               uint32_t* __restrict__ bounds)
 {
     const uint32_t tq = (blockIdx.x * RG_BLOCK + threadIdx.x) / RG_G;
     const int sub = threadIdx.x % RG_G;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(RG_BLOCK) void radius_grid_kernel(const float4* __r
         for (int k = 0; k < 9; k++) {
             uint32_t b, e;
             row_k(g, cell_start, records, cx, cy, cz, k, lo, hi, b, e);
+            if (!FILL && bounds && sub == k) { bounds[(size_t)qi * 18 + 2 * k] = b; bounds[(size_t)qi * 18 + 2 * k + 1] = e; }   // for the emit pass
             for (uint32_t j0 = b; j0 < e; j0 += RG_G) {    // uniform trip count over the group (ballot below)
                 const uint32_t j = j0 + sub;
                 bool in = false;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(RE_BLOCK) void radius_emit_kernel(const float4* __r
                                                                const uint32_t* __restrict__ list, uint32_t n_list, double r2max, float win,
                                                                const uint32_t* __restrict__ row_ptr, const float4* __restrict__ by_index,
                                                                uint32_t words, int32_t* __restrict__ idx_out,
-                                                               double* __restrict__ dist_out, int* __restrict__ err)
+                                                               double* __restrict__ dist_out, int* __restrict__ err, const uint32_t* __restrict__ bounds)
 {
     extern __shared__ uint32_t re_lds[];
     uint32_t* bm = re_lds;                       // [words]
@@ -185,21 +187,9 @@ __global__ __launch_bounds__(RE_BLOCK) void radius_emit_kernel(const float4* __r
         float flo, fhi;
         member_band(r2max, flo, fhi);
         const int cx = cell_coord(fx, g.lo[0], g.inv_h), cy = cell_coord(fy, g.lo[1], g.inv_h), cz = cell_coord(fz, g.lo[2], g.inv_h);
-        // the nine row ranges (bounds + x-window searches: chains of dependent loads) are resolved side by side by nine lanes
-        // (no x-window search here: its chain of ~16 dependent loads costs a one-query workgroup more than testing the extra third
-        // of a 3-cell row; membership is decided by the exact test either way)
-        if (tid < 9) {
-            const int yy = cy + (tid % 3) - 1, zz = cz + (tid / 3) - 1;
-            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.n[0] - 1);
-            uint32_t b = 0, e = 0;
-            if (yy >= 0 && yy < g.n[1] && zz >= 0 && zz < g.n[2] && x0 <= x1) {
-                const uint32_t row = (uint32_t)((zz * g.n[1] + yy) * g.n[0]);
-                b = cell_start[row + x0];
-                e = cell_start[row + x1 + 1];
-            }
-            misc[8 + 2 * tid] = b;
-            misc[9 + 2 * tid] = e;
-        }
+        // the nine row ranges, already cut to the x window, as the count pass resolved them (18 words per query: recomputing them here
+        // meant cell_start look-ups plus a chain of ~16 dependent loads per clipped row, in front of the whole workgroup)
+        if (tid < 18) misc[8 + tid] = bounds[(size_t)qi * 18 + tid];
         __syncthreads();
         for (int k = 0; k < 9; k++) {
             const uint32_t b = misc[8 + 2 * k], e = misc[9 + 2 * k];
@@ -241,13 +231,26 @@ __global__ __launch_bounds__(RE_BLOCK) void radius_emit_kernel(const float4* __r
     for (int ww = 0; ww < w; ww++) pos += misc[ww];
     const uint32_t N = misc[0] + misc[1] + misc[2] + misc[3];
     if (N != expect || N > CAP) { if (tid == 0) atomicExch(err, 1); return; }      // cannot happen (same walk as the count pass); never write out of bounds
+    // Stage the members in index order.  Neighbours of a scan point have CLUSTERED indices (runs along a beam ring), so the bitmap
+    // words are empty or nearly full: a thread walking the bits of its own words made the wave wait for the fullest word of every
+    // step (1.28 of the pass's 2.4 ms).  Instead the wave takes its non-empty words two at a time, 32 lanes on the 32 bits of one:
+    // lane b of a half writes member (word, b) to the word's start position + popcount of the bits below b.
     for (uint32_t i = 0; i < wpt; i++) {
-        uint32_t bits = bm[tid * wpt + i];
-        const uint32_t base = (tid * wpt + i) << 5;
-        while (bits) {
-            const int bpos = __builtin_ctz(bits);
-            bits &= bits - 1u;
-            A[pos++] = base + (uint32_t)bpos;
+        const uint32_t wv = bm[tid * wpt + i];
+        const uint32_t wp = pos;
+        pos += (uint32_t)__popc(wv);
+        unsigned long long nz = __ballot(wv != 0u);
+        while (nz) {                                         // wave-uniform
+            const int l0 = __builtin_ctzll(nz);
+            nz &= nz - 1ull;
+            int l1 = l0;
+            const bool two = nz != 0ull;
+            if (two) { l1 = __builtin_ctzll(nz); nz &= nz - 1ull; }
+            const int srcl = lane < 32 ? l0 : l1;
+            const uint32_t word = (uint32_t)__shfl((int)wv, srcl, 64), p0 = (uint32_t)__shfl((int)wp, srcl, 64);
+            const uint32_t bit = (uint32_t)lane & 31u;
+            if ((lane < 32 || two) && ((word >> bit) & 1u))
+                A[p0 + (uint32_t)__popc(word & ((1u << bit) - 1u))] = ((uint32_t)(w * 64 + srcl) * wpt + i) * 32u + bit;
         }
     }
     __syncthreads();
@@ -339,14 +342,15 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
         perm = ctx->qperm;
     }                                                         // (a small batch is searched in the order given: perm stays null)
     const float win = (float)(r * 1.00001) + 1e-30f;
-    DevBuf cnt, rows;
+    DevBuf cnt, rows, bnd;
+    PCR_HIP(ctx, hipMalloc(&bnd.p, std::max<size_t>(m, 1) * 18 * 4));
     PCR_HIP(ctx, hipMalloc(&cnt.p, (m + 1) * 4));
     PCR_HIP(ctx, hipMalloc(&rows.p, (m + 2) * 4));
     const dim3 grid((unsigned)((m * RG_G + RG_BLOCK - 1) / RG_BLOCK));
     {
         ProfScope ps(ctx, "radius_count", 1);
         hipLaunchKernelGGL(radius_grid_kernel<false>, grid, dim3(RG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, q->x(), q->y(), q->z(), perm, (uint32_t)m,
-                           r2max, win, (uint32_t*)cnt.p, (const uint32_t*)nullptr, (int32_t*)nullptr);
+                           r2max, win, (uint32_t*)cnt.p, (const uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)bnd.p);
     }
     PCR_HIP(ctx, hipGetLastError());
     std::vector<uint32_t> hc(m);
@@ -410,7 +414,7 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
         hipFuncSetAttribute((const void*)radius_emit_kernel<CAPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         hipLaunchKernelGGL((radius_emit_kernel<CAPV>), dim3((unsigned)lists[c].size()), dim3(RE_BLOCK), lds, ctx->stream, g->records, g->cell_start, g->p, \
                            q->x(), q->y(), q->z(), (const uint32_t*)lbuf.p + loff[c], (uint32_t)lists[c].size(), r2max, win, (const uint32_t*)rows.p,   \
-                           g->by_index, words, (int32_t*)idx_b.p, (double*)dist.p, (int*)errbuf.p);                                            \
+                           g->by_index, words, (int32_t*)idx_b.p, (double*)dist.p, (int*)errbuf.p, (const uint32_t*)bnd.p);                                            \
     }
             PCR_EMIT(1024, 0)
             PCR_EMIT(2048, 1)
@@ -433,7 +437,7 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
     {
         ProfScope ps(ctx, "radius_fill", 1);
         hipLaunchKernelGGL(radius_grid_kernel<true>, grid, dim3(RG_BLOCK), 0, ctx->stream, g->records, g->cell_start, g->p, q->x(), q->y(), q->z(), perm, (uint32_t)m,
-                           r2max, win, (uint32_t*)nullptr, (const uint32_t*)rows.p, (int32_t*)idx_a.p);
+                           r2max, win, (uint32_t*)nullptr, (const uint32_t*)rows.p, (int32_t*)idx_a.p, (uint32_t*)nullptr);
     }
     size_t temp_bytes = 0;
     PCR_HIP(ctx, segmented_sort_keys_u32(nullptr, temp_bytes, (const uint32_t*)idx_a.p, (uint32_t*)idx_b.p, total, m, (const uint32_t*)rows.p,
