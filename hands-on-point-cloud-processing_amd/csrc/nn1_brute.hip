@@ -671,6 +671,35 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_seed_kernel(const float* __restr
     keys[i] = key;
 }
 
+// Seeds for a COLD search over BTRACK's index: the super-tile whose centre is nearest to the query (a scan of the few hundred
+// centres, wave-uniform loads), then 32 of its 256 records evaluated exactly — a genuine candidate a few centimetres to decimetres
+// from the true neighbour.  With it published in keys[] the main pass settles nearly every slice in its prologue, as in a warm ICP
+// iteration (0.95 -> ? ms per unseeded 120 k x 120 k search); without it every slice evaluates a chunk exactly and proves it.
+__global__ __launch_bounds__(NN_BLOCK) void bt_seed_kernel(const float4* __restrict__ centres, const float4* __restrict__ records, uint32_t n_super, uint32_t centre_step,
+                                                           const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
+                                                           unsigned long long* __restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * NN_BLOCK + threadIdx.x;
+    if (i >= ns) return;
+    const float qx = sx[i], qy = sy[i], qz = sz[i];
+    float bc = INFINITY;
+    uint32_t sc = 0;
+    for (uint32_t S = 0; S < n_super; S += centre_step) {
+        const float4 C = centres[S];
+        const float dx = qx - C.x, dy = qy - C.y, dz = qz - C.z;
+        const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        if (d < bc) { bc = d; sc = S; }
+    }
+    unsigned long long key = ~0ull;
+    for (int j = 0; j < 32; j++) {
+        const float4 rec = records[(size_t)sc * BT_SUPER + (uint32_t)j * (BT_SUPER / 32) + (i & (BT_SUPER / 32 - 1))];
+        const uint32_t e = d2_exact_bits(qx, qy, qz, rec.x, rec.y, rec.z);
+        const unsigned long long k = ((unsigned long long)e << 32) | __float_as_uint(rec.w);
+        if (e < 0x7F7FFFFFu && k < key) key = k;                                   // FLT_MAX gate; padding records have x = +inf
+    }
+    keys[i] = key;
+}
+
 // keys -> (idx, d2) split for the host-facing API
 __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, uint32_t n,
                                   uint32_t* __restrict__ idx, float* __restrict__ d2)
@@ -772,11 +801,13 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
         }
         uint32_t slices = (uint32_t)((n_super + sps - 1) / sps);
         if (slices > 65535) { slices = 65535; sps = (n_super + slices - 1) / slices; slices = (uint32_t)((n_super + sps - 1) / sps); }
+        // a cold, sliced search seeds itself from the nearest super-tile (tune nn1_cold_seed: 1 on (default), 2 off)
+        const bool cold_seed = !warm && slices > 1 && tune_get(ctx, "nn1_cold_seed", 1) == 1;
         const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
         if (warm)
             hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
                                (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
-        else if (merge_atomic)
+        else if (merge_atomic && !cold_seed)
             PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
         unsigned long long* stats_dev = nullptr;
         if (tune_get(ctx, "grid_stats", 0) > 0) {
@@ -786,6 +817,9 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
         }
         {
             ProfScope p(ctx, "nn1_brute", 1);
+            if (cold_seed)                                                          // (inside the timed scope: it is part of the cold search)
+                hipLaunchKernelGGL(bt_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->records,
+                                   (uint32_t)n_super, (uint32_t)std::max<size_t>(1, n_super / 1024), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
             const dim3 grid(qblocks, slices);
 #define PCR_BTRACK(Q)                                                                                                                   \
 if (f16) hipLaunchKernelGGL((nn1_btrack_kernel<Q, true>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records,         \
