@@ -411,13 +411,13 @@ def main():
                                          "f32_kernels_ms": ms_fresh_f32,
                                          "f32_kernels": "the same call with nn1_bf16 = 2: pcr::nn1_ftrack_kernel<2, 16>, which needs no index"},
                         "indexed_target": {"ms": ms_indexed, "M_corr_per_s": n_q / ms_indexed / 1e3,
-                                           "kernel": "the default kernel (HTRACK), unseeded, kernel time (the target's operands exist: any earlier search built them)"}}
+                                           "kernel": "the default kernel (HTRACK), cold — no earlier correspondences; the search seeds itself from the nearest super-tile (bt_seed_kernel, inside the timed scope) — kernel time (the target's operands exist: any earlier search built them)"}}
             ms_f32 = time_search(ct, 5, nn1_bf16=2)
             ms_bf16 = time_search(ct, 5, nn1_f16=2)
             one_shot["indexed_target_bf16_filter"] = {"ms": ms_bf16, "M_corr_per_s": n_q / ms_bf16 / 1e3,
-                                                      "kernel": "BTRACK (tune nn1_f16 = 2: the filter as two bf16 MFMAs per tile; what a cloud outside f16's range gets), unseeded"}
+                                                      "kernel": "BTRACK (tune nn1_f16 = 2: the filter as two bf16 MFMAs per tile; what a cloud outside f16's range gets), cold"}
             one_shot["indexed_target_f32_filter"] = {"ms": ms_f32, "M_corr_per_s": n_q / ms_f32 / 1e3,
-                                                     "kernel": "pcr::nn1_etrack_kernel<4> (tune nn1_bf16 = 2: the same filter as 3 vector FMAs per pair), unseeded"}
+                                                     "kernel": "pcr::nn1_etrack_kernel<4> (tune nn1_bf16 = 2: the same filter as 3 vector FMAs per pair), cold and unseeded"}
 
         # ---- second, separately timed pass with the exact grid index (same answers, different search): extra info only
         grid_extra = None
