@@ -186,7 +186,6 @@ __global__ __launch_bounds__(RE_BLOCK) void radius_emit_kernel(const float4* __r
         const double qx = fx, qy = fy, qz = fz;
         float flo, fhi;
         member_band(r2max, flo, fhi);
-        const int cx = cell_coord(fx, g.lo[0], g.inv_h), cy = cell_coord(fy, g.lo[1], g.inv_h), cz = cell_coord(fz, g.lo[2], g.inv_h);
         // the nine row ranges, already cut to the x window, as the count pass resolved them (18 words per query: recomputing them here
         // meant cell_start look-ups plus a chain of ~16 dependent loads per clipped row, in front of the whole workgroup)
         if (tid < 18) misc[8 + tid] = bounds[(size_t)qi * 18 + tid];
