@@ -65,20 +65,79 @@ __device__ __forceinline__ void acc3(double v, double sp, double& a0, double& a1
 }
 
 // the workgroup's reduction of the per-thread limbs: tn[KB_NL] (normalised per thread) -> row[] in LDS, normalised again
-__device__ __forceinline__ bool is_carry_slot(int k) { return k < 18 ? (k % 3 == 2) : (k < 54 && (k - 18) % 4 == 3); }
+__host__ __device__ constexpr bool is_carry_slot(int k) { return k < 18 ? (k % 3 == 2) : (k < 54 && (k - 18) % 4 == 3); }
 
-// carries: false when the carry slots of tn[] are known to be zero (no per-thread normalisation): their shuffles are skipped
+// Wave totals of N values per lane by a butterfly that HALVES what a lane holds at every step: with partner distance D the lanes
+// whose bit D is clear keep the lower half of their values and send the upper half, the others the reverse; both add what they
+// receive.  After the six steps lane l holds the wave's total of ONE value, number slot(l) (or nothing: slot < 0) — N - 1 + (a few
+// for odd halves) exchanged values per lane in all, where one shuffle tree per value costs 6 N: 41 against 240 for the 40 limbs of
+// the usual case.  The totals are integers below 2^53, so the order of the additions does not matter (numerics.hpp).
+template <int N, int D>
+__device__ __forceinline__ void bfly_halve(double (&v)[KB_NL], bool up)
+{
+    constexpr int H = (N + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+        const double a = v[i], b = (H + i < N) ? v[H + i] : 0.0;
+        const double send = up ? a : b, keep = up ? b : a;
+        v[i] = keep + __shfl_xor(send, D, 64);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ int wave_totals(double (&v)[KB_NL], int lane)
+{
+    static_assert(N >= 1 && N <= 64, "six halvings must leave one value");
+    constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
+    bfly_halve<N, 32>(v, (lane & 32) != 0);
+    bfly_halve<N1, 16>(v, (lane & 16) != 0);
+    bfly_halve<N2, 8>(v, (lane & 8) != 0);
+    bfly_halve<N3, 4>(v, (lane & 4) != 0);
+    bfly_halve<N4, 2>(v, (lane & 2) != 0);
+    bfly_halve<N5, 1>(v, (lane & 1) != 0);
+    // which value this lane ended up with: its position in the arrays of the six steps, innermost first
+    int p = 0;
+    bool ok = true;
+    p += (lane & 1) ? (N5 + 1) / 2 : 0;  ok = ok && p < N5;
+    p += (lane & 2) ? (N4 + 1) / 2 : 0;  ok = ok && p < N4;
+    p += (lane & 4) ? (N3 + 1) / 2 : 0;  ok = ok && p < N3;
+    p += (lane & 8) ? (N2 + 1) / 2 : 0;  ok = ok && p < N2;
+    p += (lane & 16) ? (N1 + 1) / 2 : 0; ok = ok && p < N1;
+    p += (lane & 32) ? (N + 1) / 2 : 0;  ok = ok && p < N;
+    return ok ? p : -1;
+}
+
+constexpr int KB_NLC = 40;            // the limbs that are not carry slots (12 + 27) + the count
+
+// carries: false when the carry slots of tn[] are known to be zero (no per-thread normalisation): they are not exchanged at all
+// BFLY: the halving butterfly over the 40 live limbs (needs carries == false); it keeps all of them in registers at once (~160
+// VGPRs), so only the instance for few terms per thread — where the reduction IS the pass — is built with it
+template <bool BFLY>
 __device__ __forceinline__ void block_reduce_limbs(double (&tn)[KB_NL], unsigned long long lastkey, int overflow,
                                                    double (&red)[KB_BLOCK / 64][KB_NL], double (&row)[KB_ROW], bool carries)
 {
     __shared__ unsigned long long red_key[KB_BLOCK / 64];
     __shared__ int red_ovf[KB_BLOCK / 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (!BFLY) {
 #pragma unroll
-    for (int k = 0; k < KB_NL; k++) {
-        double sum = 0.0;
-        if (carries || !is_carry_slot(k)) sum = wave_sum(tn[k]);      // 64 integers below 2^46 (+ small carries): exact
-        if (lane == 0) red[wave][k] = sum;
+        for (int k = 0; k < KB_NL; k++) {
+            double sum = 0.0;
+            if (carries || !is_carry_slot(k)) sum = wave_sum(tn[k]);      // 64 integers below 2^46 (+ small carries): exact
+            if (lane == 0) red[wave][k] = sum;
+        }
+    } else {
+        int j = 0;
+#pragma unroll
+        for (int k = 0; k < KB_NL; k++)
+            if (!is_carry_slot(k)) tn[j++] = tn[k];                       // compact: the 40 live limbs (static indices)
+        const int p = wave_totals<KB_NLC>(tn, lane);
+        if (p >= 0) {
+            // live limb p -> its slot of the row: coordinates 2 of every 3 slots, products 3 of every 4, the count last
+            const int slot = p < 12 ? 3 * (p / 2) + p % 2 : (p < 39 ? 18 + 4 * ((p - 12) / 3) + (p - 12) % 3 : 54);
+            red[wave][slot] = tn[0];
+        }
+        if (lane < 15) red[wave][lane < 6 ? 3 * lane + 2 : 18 + 4 * (lane - 6) + 3] = 0.0;      // the 15 carry slots
     }
     const unsigned long long km = wave_max_u64(lastkey);
     const int ov = __any(overflow) ? 1 : 0;
@@ -103,7 +162,8 @@ __device__ __forceinline__ void block_reduce_limbs(double (&tn)[KB_NL], unsigned
 // partials layout: [block][KB_ROW].  RECORDS: the target of pair i is grid record wpos[i] (one 16-byte gather from the cell-
 // sorted records, which neighbouring queries share) instead of the three 4-byte gathers at its original index.
 // orig: original index of query i (the working cloud of the grid ICP is cell-sorted) or nullptr = i.
-template <bool RECORDS>
+// SMALL: at most 4 pairs per thread (clouds up to ~1 M points): no per-thread carries, butterfly reduction.
+template <bool RECORDS, bool SMALL>
 __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
     const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
@@ -174,7 +234,7 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
     }
     // per-thread carry propagation only when a thread may hold many terms (limbs below 2^40 x terms must stay below 2^53 through
     // the 256-thread sum): at most 16 terms per thread need none
-    const bool many = per_block > 16u * KB_BLOCK;
+    const bool many = !SMALL && per_block > 16u * KB_BLOCK;
     double tn[KB_NL];
 #pragma unroll
     for (int c = 0; c < 6; c++) { tn[3 * c] = c0[c]; tn[3 * c + 1] = c1[c]; tn[3 * c + 2] = 0.0; if (many) num::limbs_normalize(tn + 3 * c, 2); }
@@ -186,7 +246,7 @@ __global__ __launch_bounds__(KB_BLOCK) void kabsch_partial_kernel(
     tn[54] = cnt;
     __shared__ double red[KB_BLOCK / 64][KB_NL];
     __shared__ double row[KB_ROW];
-    block_reduce_limbs(tn, lastkey, overflow, red, row, many);
+    block_reduce_limbs<SMALL>(tn, lastkey, overflow, red, row, many);
     if (threadIdx.x < KB_ROW) partials[(size_t)blockIdx.x * KB_ROW + threadIdx.x] = row[threadIdx.x];
 }
 
@@ -306,13 +366,14 @@ int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* s
     const uint32_t* orig = (ctx->work_orig && ctx->work_orig_n == ns && ctx->work_orig_src == src) ? ctx->work_orig : nullptr;
     {
         ProfScope p(ctx, "kabsch_partial");
-        if (rec)
-            hipLaunchKernelGGL((kabsch_partial_kernel<true>), dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), tgt->x(), tgt->y(),
-                               tgt->z(), tgt->grid->records, ctx->wpos, orig, ctx->keys, (uint32_t)ns, (uint32_t)tgt->n, max_corr, plan, ctx->partials);
-        else
-            hipLaunchKernelGGL((kabsch_partial_kernel<false>), dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), tgt->x(), tgt->y(),
-                               tgt->z(), (const float4*)nullptr, (const uint32_t*)nullptr, orig, ctx->keys, (uint32_t)ns, (uint32_t)tgt->n, max_corr, plan,
-                               ctx->partials);
+        const uint32_t per_block = (uint32_t)((ns + blocks - 1) / blocks);      // as the kernel computes it
+        const bool small = per_block <= 4u * KB_BLOCK && tune_get(ctx, "kabsch_bfly", 1) == 1;
+#define PCR_KABSCH(R, S, RECS, WPOS)                                                                                                      \
+        hipLaunchKernelGGL((kabsch_partial_kernel<R, S>), dim3(blocks), dim3(KB_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), tgt->x(),  \
+                           tgt->y(), tgt->z(), RECS, WPOS, orig, ctx->keys, (uint32_t)ns, (uint32_t)tgt->n, max_corr, plan, ctx->partials)
+        if (rec) { if (small) PCR_KABSCH(true, true, tgt->grid->records, ctx->wpos); else PCR_KABSCH(true, false, tgt->grid->records, ctx->wpos); }
+        else { if (small) PCR_KABSCH(false, true, (const float4*)nullptr, (const uint32_t*)nullptr); else PCR_KABSCH(false, false, (const float4*)nullptr, (const uint32_t*)nullptr); }
+#undef PCR_KABSCH
     }
     PCR_HIP(ctx, hipGetLastError());
     *n_blocks = blocks;
@@ -337,8 +398,10 @@ int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src,
 // The pipelined ICP loop (icp.cpp) keeps the whole state machine of registration.cpp:915-1006 on the GPU so that
 // iterations are enqueued back to back without a host round trip: nn1 -> kabsch_partial -> icp_update -> transform.
 
-// state machine + Kabsch solve + pose composition, one thread (registration.cpp:939-1002)
-__device__ void icp_state_step(IcpState* st, const double* sums16, bool any_kept, float last_d2, bool overflow)
+// state machine + Kabsch solve + pose composition, one thread (registration.cpp:939-1002).  `st` is the workgroup's LDS copy of
+// the state (icp_state_stage): the step is one thread's serial chain, and every field it touched in HBM was a dependent memory
+// round trip of that chain (stop -> stop_after_transform -> last_loss, eps -> unchanged -> T_total ...).
+__device__ __forceinline__ void icp_state_step(IcpState* st, const double* sums16, bool any_kept, float last_d2, bool overflow)
 {
     if (st->stop) return;
     if (st->stop_after_transform) { st->stop = 1; return; }   // max_iter reached: the loop is over
@@ -362,6 +425,17 @@ __device__ void icp_state_step(IcpState* st, const double* sums16, bool any_kept
     if (st->iters_run >= st->max_iter) st->stop_after_transform = 1;
 }
 
+// the whole state in ONE coalesced read: thread w copies 32-bit word w into the workgroup's LDS copy (ends in a barrier)
+constexpr int ST_WORDS = (int)(sizeof(IcpState) / 4);
+static_assert(sizeof(IcpState) % 4 == 0 && ST_WORDS <= 64, "IcpState is staged by one wave, one word per lane");
+
+__device__ __forceinline__ void icp_state_stage(const IcpState* st, IcpState* lds)
+{
+    if (threadIdx.x < ST_WORDS)
+        __builtin_memcpy(reinterpret_cast<char*>(lds) + 4 * threadIdx.x, reinterpret_cast<const char*>(st) + 4 * threadIdx.x, 4);
+    __syncthreads();
+}
+
 // single rank: reduce the block rows and advance the state in one launch
 __global__ __launch_bounds__(KF_BLOCK) void icp_update_kernel(const double* __restrict__ partials, uint32_t n_blocks, int e, IcpState* st,
                                                               double* __restrict__ out)
@@ -369,13 +443,18 @@ __global__ __launch_bounds__(KF_BLOCK) void icp_update_kernel(const double* __re
     __shared__ double red[KF_GROUPS][64];
     __shared__ double row[KB_ROW];
     __shared__ double o18[19];
-    if (st->stop) return;
-    if (st->stop_after_transform) { if (threadIdx.x == 0) st->stop = 1; return; }
+    __shared__ IcpState s_st;
+    icp_state_stage(st, &s_st);
+    if (s_st.stop) return;
+    if (s_st.stop_after_transform) { if (threadIdx.x == 0) st->stop = 1; return; }
     reduce_rows(partials, n_blocks, red, row);
     row_to_out18(row, e, o18);
     __syncthreads();
     if (threadIdx.x < 19) out[threadIdx.x] = o18[threadIdx.x];
-    if (threadIdx.x == 0) icp_state_step(st, o18, o18[16] >= 0.0, (float)o18[17], o18[18] != 0.0);
+    if (threadIdx.x == 0) {
+        icp_state_step(&s_st, o18, o18[16] >= 0.0, (float)o18[17], o18[18] != 0.0);
+        *st = s_st;
+    }
 }
 
 // multi rank, step 1: reduce the block rows into the all-reduce buffer
@@ -405,31 +484,43 @@ __global__ __launch_bounds__(KF_BLOCK) void icp_reduce_slots_kernel(const double
     }
 }
 
-// multi rank, step 2 (after the all-reduce): carries, moments; the loss comes from the highest rank that kept a pair
-__global__ void icp_update_from_sums_kernel(double* __restrict__ buf, int nranks, int e, IcpState* st)
+// multi rank, step 2 (after the all-reduce): carries and moments (thread k converts moment k, as row_to_out18 does for one rank);
+// the loss comes from the highest rank that kept a pair.  One wave.
+__global__ __launch_bounds__(64) void icp_update_from_sums_kernel(double* __restrict__ buf, int nranks, int e, IcpState* st)
 {
-    if (threadIdx.x != 0 || st->stop) return;
-    num::limbs_normalize_row(buf);
-    double sums[16];
-    num::limbs_to_sums(buf, e, sums);
+    __shared__ double row[KB_NL + 1];
+    __shared__ double sums[16];
+    __shared__ IcpState s_st;
+    const int k = threadIdx.x;
+    if (k < KB_NL) row[k] = buf[k];
+    icp_state_stage(st, &s_st);
+    if (s_st.stop) return;
+    if (k < 6) { num::limbs_normalize(row + 3 * k, 2); sums[k] = num::limbs_value(row + 3 * k, 2, e - 2 * num::KB_W); }
+    else if (k < 15) { num::limbs_normalize(row + 18 + 4 * (k - 6), 3); sums[k] = num::limbs_value(row + 18 + 4 * (k - 6), 3, 2 * e - 3 * num::KB_W); }
+    else if (k == 15) sums[15] = row[54];
+    __syncthreads();
+    if (k != 0) return;
     bool any = false;
     float d2 = 0.0f;
     for (int r = 0; r < nranks; r++)
         if (buf[56 + 2 * r] > 0.5) { any = true; d2 = (float)buf[57 + 2 * r]; }
-    icp_state_step(st, sums, any, d2, buf[55] != 0.0);
+    icp_state_step(&s_st, sums, any, d2, buf[55] != 0.0);
+    *st = s_st;
 }
 
 __global__ __launch_bounds__(256) void transform_state_kernel(float* __restrict__ x, float* __restrict__ y,
                                                               float* __restrict__ z, uint32_t n, uint32_t n4, IcpState* st)
 {
-    if (st->stop) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    const float r0 = st->Rd[0], r1 = st->Rd[1], r2 = st->Rd[2], r3 = st->Rd[3], r4 = st->Rd[4], r5 = st->Rd[5],
-                r6 = st->Rd[6], r7 = st->Rd[7], r8 = st->Rd[8], t0 = st->td[0], t1 = st->td[1], t2 = st->td[2];
+    // the points, the delta pose and the stop flag are requested together (one memory round trip, not three in a row)
     float4 px = reinterpret_cast<float4*>(x)[i];
     float4 py = reinterpret_cast<float4*>(y)[i];
     float4 pz = reinterpret_cast<float4*>(z)[i];
+    const float r0 = st->Rd[0], r1 = st->Rd[1], r2 = st->Rd[2], r3 = st->Rd[3], r4 = st->Rd[4], r5 = st->Rd[5],
+                r6 = st->Rd[6], r7 = st->Rd[7], r8 = st->Rd[8], t0 = st->td[0], t1 = st->td[1], t2 = st->td[2];
+    const int stop = st->stop;
+    if (stop) return;
     float4 ox, oy, oz;
 #define PCR_ROW(o, a, b, c, tt)                      \
     o.x = ((a * px.x + b * py.x) + c * pz.x) + tt;   \

@@ -40,6 +40,7 @@ namespace pcr {
 constexpr int NN_BLOCK = 256;
 constexpr int NN_TILE = 1024;   // targets per LDS tile: 3 * 4 KiB
 constexpr bool NN_F16_DEFAULT = true;      // measured: 0.72 against 0.88 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
+constexpr int NN_XCD_DEFAULT = 4;          // XCD-aware launch of the matrix-core kernels (tune nn1_xcd), see nn1_btrack_kernel
 constexpr bool NN_BF16_DEFAULT = true;     // measured: 0.90 against 1.30 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
 
 __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
@@ -492,7 +493,8 @@ template <int QG, bool F16>
 __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
     const float4* __restrict__ centres, const uint4* __restrict__ ops, const float4* __restrict__ records, uint32_t n_rec, uint32_t n_super,
     uint32_t supers_per_slice, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
-    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop, unsigned long long* __restrict__ stats)
+    unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop, unsigned long long* __restrict__ stats,
+    uint32_t xq, uint32_t qblocks, uint32_t slices)
 {
     if (stop && (stop[0] | stop[1])) return;
     constexpr int CH = 16, TPS = BT_SUPER / 32;
@@ -500,7 +502,17 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = lane & 31;
     const bool h = lane >= 32;
-    const uint32_t qbase = (blockIdx.x * (NN_BLOCK / 64) + wave) * (32 * QG);
+    // (query block, slice) of this workgroup.  xq = 0: the plain 2-D launch — workgroups go to the 8 XCDs round-robin, so every XCD's
+    // L2 pulls in ALL operands and ALL queries.  xq = 1 / 2 / 4: a 1-D launch in which XCD k = id % 8 owns the query blocks = k % xq
+    // (mod xq) and the slices = k / xq (mod 8 / xq): its L2 holds 1 / xq of the queries and xq / 8 of the operands.
+    uint32_t qb = blockIdx.x, sl = blockIdx.y;
+    if (xq) {
+        const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, xs = 8u / xq, qb_per = (qblocks + xq - 1) / xq;
+        qb = (j % qb_per) * xq + k % xq;
+        sl = (j / qb_per) * xs + k / xq;
+        if (qb >= qblocks || sl >= slices) return;             // (the padding of an uneven split: block-uniform)
+    }
+    const uint32_t qbase = (qb * (NN_BLOCK / 64) + wave) * (32 * QG);
     if (qbase >= ns) return;                                  // a whole wave beyond the queries (wave-uniform)
     float qx[QG], qy[QG], qz[QG], m1[QG], m2[QG], cur0[QG];
     uint32_t c1[QG];
@@ -513,7 +525,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
         m1[g] = INFINITY; m2[g] = INFINITY; c1[g] = 0xFFFFFFFFu;
         cur0[g] = merge_atomic ? __uint_as_float((uint32_t)(__atomic_load_n(&keys[i], __ATOMIC_RELAXED) >> 32)) : INFINITY;
     }
-    const uint32_t sb = blockIdx.y * supers_per_slice, se = min(sb + supers_per_slice, n_super);
+    const uint32_t sb = sl * supers_per_slice, se = min(sb + supers_per_slice, n_super);
     float big;
     asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(big));      // +inf the optimiser cannot see through
     f32x16 zero;
@@ -820,14 +832,19 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
             if (cold_seed)                                                          // (inside the timed scope: it is part of the cold search)
                 hipLaunchKernelGGL(bt_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->records,
                                    (uint32_t)n_super, (uint32_t)std::max<size_t>(1, n_super / 1024), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
-            const dim3 grid(qblocks, slices);
+            // XCD-aware launch (tune nn1_xcd: 1 / 2 / 4 = query-block groups per 8 XCDs, -1 = the plain 2-D launch): see the kernel
+            int64_t xq = tune_get(ctx, "nn1_xcd", NN_XCD_DEFAULT);
+            if (xq != 1 && xq != 2 && xq != 4) xq = 0;
+            if (slices < 8 || (uint64_t)qblocks * slices >= (1ull << 27)) xq = 0;
+            dim3 grid(qblocks, slices);
+            if (xq) grid = dim3(8u * ((qblocks + (uint32_t)xq - 1) / (uint32_t)xq) * ((slices + 8u / (uint32_t)xq - 1) / (8u / (uint32_t)xq)), 1);
 #define PCR_BTRACK(Q)                                                                                                                   \
 if (f16) hipLaunchKernelGGL((nn1_btrack_kernel<Q, true>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records,         \
                    (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
-                   merge_atomic, ctx->stop_flag_dev, stats_dev);                                                                        \
+                   merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices);                                         \
 else hipLaunchKernelGGL((nn1_btrack_kernel<Q, false>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops, g->records,              \
                    (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
-                   merge_atomic, ctx->stop_flag_dev, stats_dev)
+                   merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices)
             switch (qg) {
             case 1: PCR_BTRACK(1); break;
             case 2: PCR_BTRACK(2); break;

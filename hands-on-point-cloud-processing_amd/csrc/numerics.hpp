@@ -20,21 +20,56 @@ struct M3 {
     double a[3][3];
 };
 
-PCR_HD double col_dot(const M3& m, int p, int q)
+// (Every index below is a compile-time constant — the pair loop is a template, the descending order is a network of conditional
+// column swaps, the rank-1 pivot is picked with selects — so that on the device the two 3x3 work matrices live in registers: with
+// run-time column indices they sat in scratch memory, a dependent memory round trip per access inside one thread's serial chain.
+// The arithmetic — operations, operands and order — is that of the loops it replaces; host and device share it.)
+template <int P, int Q>
+PCR_HD double col_dot(const M3& m)
 {
-    return m.a[0][p] * m.a[0][q] + m.a[1][p] * m.a[1][q] + m.a[2][p] * m.a[2][q];
+    return m.a[0][P] * m.a[0][Q] + m.a[1][P] * m.a[1][Q] + m.a[2][P] * m.a[2][Q];
 }
 
-PCR_HD void rotate_cols(M3& m, int p, int q, double c, double s)
+template <int P, int Q>
+PCR_HD void rotate_cols(M3& m, double c, double s)
 {
     for (int r = 0; r < 3; r++) {
-        const double mp = m.a[r][p], mq = m.a[r][q];
-        m.a[r][p] = c * mp - s * mq;
-        m.a[r][q] = s * mp + c * mq;
+        const double mp = m.a[r][P], mq = m.a[r][Q];
+        m.a[r][P] = c * mp - s * mq;
+        m.a[r][Q] = s * mp + c * mq;
     }
 }
 
 PCR_HD double dabs(double v) { return v < 0 ? -v : v; }
+
+// one Jacobi rotation of the column pair (P, Q); false when the pair is already orthogonal to working precision
+template <int P, int Q>
+PCR_HD bool jacobi_pair(M3& W, M3& R)
+{
+    const double eps = 2.220446049250313e-16;   // DBL_EPSILON
+    const double alpha = col_dot<P, P>(W), beta = col_dot<Q, Q>(W), gamma = col_dot<P, Q>(W);
+    if (gamma == 0.0 || dabs(gamma) <= eps * sqrt(alpha * beta)) return false;
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double tn = (zeta >= 0 ? 1.0 : -1.0) / (dabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + tn * tn), s = c * tn;
+    rotate_cols<P, Q>(W, c, s);
+    rotate_cols<P, Q>(R, c, s);
+    return true;
+}
+
+// columns A and B of (sv, W, R) change places when the later one carries the larger singular value
+template <int A, int B>
+PCR_HD void order_cols(double sv[3], M3& W, M3& R)
+{
+    const bool sw = sv[B] > sv[A];
+    const double sa = sv[A], sb = sv[B];
+    sv[A] = sw ? sb : sa; sv[B] = sw ? sa : sb;
+    for (int r = 0; r < 3; r++) {
+        const double wa = W.a[r][A], wb = W.a[r][B], ra = R.a[r][A], rb = R.a[r][B];
+        W.a[r][A] = sw ? wb : wa; W.a[r][B] = sw ? wa : wb;
+        R.a[r][A] = sw ? rb : ra; R.a[r][B] = sw ? ra : rb;
+    }
+}
 
 // A row-major; A = U diag(S) V^T, S descending
 PCR_HD void svd3(const double A[9], double U[9], double S[3], double V[9])
@@ -44,34 +79,23 @@ PCR_HD void svd3(const double A[9], double U[9], double S[3], double V[9])
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) { W.a[r][c] = A[3 * r + c]; R.a[r][c] = r == c ? 1.0 : 0.0; }
     for (int sweep = 0; sweep < 60; sweep++) {
-        bool rotated = false;
-        for (int pair = 0; pair < 3; pair++) {
-            const int p = pair == 2 ? 1 : 0, q = pair == 0 ? 1 : 2;      // (0,1), (0,2), (1,2)
-            const double alpha = col_dot(W, p, p), beta = col_dot(W, q, q), gamma = col_dot(W, p, q);
-            if (gamma == 0.0 || dabs(gamma) <= eps * sqrt(alpha * beta)) continue;
-            const double zeta = (beta - alpha) / (2.0 * gamma);
-            const double tn = (zeta >= 0 ? 1.0 : -1.0) / (dabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double c = 1.0 / sqrt(1.0 + tn * tn), s = c * tn;
-            rotate_cols(W, p, q, c, s);
-            rotate_cols(R, p, q, c, s);
-            rotated = true;
-        }
-        if (!rotated) break;
+        const bool r01 = jacobi_pair<0, 1>(W, R);
+        const bool r02 = jacobi_pair<0, 2>(W, R);
+        const bool r12 = jacobi_pair<1, 2>(W, R);
+        if (!(r01 || r02 || r12)) break;
     }
     double sv[3];
-    int ord[3] = { 0, 1, 2 };
-    for (int c = 0; c < 3; c++) sv[c] = sqrt(col_dot(W, c, c));
-    for (int a = 0; a < 2; a++)
-        for (int b = a + 1; b < 3; b++)
-            if (sv[ord[b]] > sv[ord[a]]) { int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
-    const double smax = sv[ord[0]];
+    sv[0] = sqrt(col_dot<0, 0>(W)); sv[1] = sqrt(col_dot<1, 1>(W)); sv[2] = sqrt(col_dot<2, 2>(W));
+    order_cols<0, 1>(sv, W, R);          // the exchange network (0,1) (0,2) (1,2) on '>' — ties keep their column order
+    order_cols<0, 2>(sv, W, R);
+    order_cols<1, 2>(sv, W, R);
+    const double smax = sv[0];
     bool have[3] = { false, false, false };
     for (int c = 0; c < 3; c++) {
-        const int o = ord[c];
-        S[c] = sv[o];
-        for (int r = 0; r < 3; r++) V[3 * r + c] = R.a[r][o];
-        if (sv[o] > 0.0 && sv[o] > smax * eps * 8.0) {
-            for (int r = 0; r < 3; r++) U[3 * r + c] = W.a[r][o] / sv[o];
+        S[c] = sv[c];
+        for (int r = 0; r < 3; r++) V[3 * r + c] = R.a[r][c];
+        if (sv[c] > 0.0 && sv[c] > smax * eps * 8.0) {
+            for (int r = 0; r < 3; r++) U[3 * r + c] = W.a[r][c] / sv[c];
             have[c] = true;
         } else {
             for (int r = 0; r < 3; r++) U[3 * r + c] = 0.0;
@@ -85,10 +109,11 @@ PCR_HD void svd3(const double A[9], double U[9], double S[3], double V[9])
     if (!have[1]) {   // rank 1: any unit vector orthogonal to u0
         const double u0[3] = { U[0], U[3], U[6] };
         int k = 0;
-        if (dabs(u0[1]) < dabs(u0[k])) k = 1;
-        if (dabs(u0[2]) < dabs(u0[k])) k = 2;
-        double v[3] = { -u0[k] * u0[0], -u0[k] * u0[1], -u0[k] * u0[2] };
-        v[k] += 1.0;
+        double uk = u0[0];
+        if (dabs(u0[1]) < dabs(uk)) { k = 1; uk = u0[1]; }
+        if (dabs(u0[2]) < dabs(uk)) { k = 2; uk = u0[2]; }
+        double v[3] = { -uk * u0[0], -uk * u0[1], -uk * u0[2] };
+        for (int i = 0; i < 3; i++) v[i] = i == k ? v[i] + 1.0 : v[i];
         const double nv = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         U[1] = v[0] / nv; U[4] = v[1] / nv; U[7] = v[2] / nv;
     }
