@@ -694,7 +694,9 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     uint32_t* __restrict__ far_list, uint32_t* __restrict__ far_count, uint32_t far_cap,
     uint32_t* __restrict__ wpos, uint32_t xcd_run)
 {
-    if (stop && (stop[0] | stop[1])) return;      // pipelined ICP: the loop has ended, the enqueued tail is a no-op
+    // pipelined ICP: once the loop has ended the enqueued tail is a no-op.  The flags are REQUESTED here and tested below, after the
+    // query's own loads have been issued: one memory round trip of every launch's serial chain less.
+    const int stopv = stop ? (stop[0] | stop[1]) : 0;
     constexpr bool CLIP = MODE == 1, SPH = MODE == 2;
     static_assert(!SPH || G == 16, "the sphere walk scans one 16-record run per sub-group");
     unsigned long long st_cand = 0, st_rows = 0, st_stages = 0, st_sph = 0;   // diagnostics (STATS builds only)
@@ -705,6 +707,8 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     const int l = (int)(threadIdx.x % G);
     const uint32_t i = perm ? perm[t] : t;
     const float qx = sx[i], qy = sy[i], qz = sz[i];
+    const uint32_t pp0 = (warm_start == 2) ? wpos[i] : 0xFFFFFFFFu;
+    if (stopv) return;
     // The caller discards every neighbour with d2 >= cap2 (the ICP gate), so cap2 itself is a bound the walk may prune with from
     // the start: the search begins with the pseudo-candidate (cap2, no index).  Rows and cells outside the cap2 ball are never
     // opened, runs whose sphere lies outside it are never scanned, and a query with no target inside it ends with "none"
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
             // That target, evaluated exactly against the moved query, is a genuine candidate: it bounds the search from the
             // first stage on (the radius jumps straight to the proving one, rows are clipped to its ball) without changing
             // the result.  One 16-byte load that neighbouring queries share, instead of three 4-byte gathers.
-            const uint32_t pp = wpos[i];
+            const uint32_t pp = pp0;
             if (pp < nt) {
                 const float4 rec = records[pp];
                 const float dx = qx - rec.x, dy = qy - rec.y, dz = qz - rec.z;

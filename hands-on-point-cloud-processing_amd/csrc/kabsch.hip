@@ -263,11 +263,22 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials,
     double acc = 0.0;
     unsigned long long key = 0;
     if (k < 57) {
-        for (uint32_t b = grp; b < n_blocks; b += KF_GROUPS) {
-            const double v = partials[(size_t)b * KB_ROW + k];
-            if (k == 55) { const unsigned long long lk = (unsigned long long)__double_as_longlong(v); key = lk > key ? lk : key; }
-            else if (k == 56) acc = (acc != 0.0 || v != 0.0) ? 1.0 : 0.0;
-            else acc += v;
+        // eight rows of the group in flight at once (a row that does not exist reads as 0.0, neutral for the sum, the key maximum
+        // and the flag alike): one memory round trip per eight rows instead of one per row — the additions are exact, any order
+        constexpr int INF = 8;
+        for (uint32_t b = grp; b < n_blocks; b += KF_GROUPS * INF) {
+            double v[INF];
+#pragma unroll
+            for (int j = 0; j < INF; j++) {
+                const uint32_t bb = b + (uint32_t)j * KF_GROUPS;
+                v[j] = bb < n_blocks ? partials[(size_t)bb * KB_ROW + k] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < INF; j++) {
+                if (k == 55) { const unsigned long long lk = (unsigned long long)__double_as_longlong(v[j]); key = lk > key ? lk : key; }
+                else if (k == 56) acc = (acc != 0.0 || v[j] != 0.0) ? 1.0 : 0.0;
+                else acc += v[j];
+            }
         }
     }
     red[grp][k] = k == 55 ? __longlong_as_double((long long)key) : acc;
@@ -321,7 +332,8 @@ static uint32_t kabsch_blocks(pcr_ctx* ctx, size_t ns)
     // one pair per thread up to 128 workgroups, then four pairs per thread, then the cap: at 120 k the 469 rows of the one-pair rule
     // cost the reduce 24 us against 15 us for 128 rows, the pass itself the same 18 us (profiles/r02_kabsch_probes.txt)
     uint32_t blocks = (uint32_t)((ns + KB_BLOCK - 1) / KB_BLOCK);
-    if (blocks > 128) blocks = std::max<uint32_t>(128, (uint32_t)((ns + 4 * KB_BLOCK - 1) / (4 * KB_BLOCK)));
+    const uint32_t one_pair = (uint32_t)std::min<int64_t>(KB_MAX_BLOCKS, std::max<int64_t>(1, tune_get(ctx, "kabsch_one_pair_blocks", 128)));
+    if (blocks > one_pair) blocks = std::max<uint32_t>(one_pair, (uint32_t)((ns + 4 * KB_BLOCK - 1) / (4 * KB_BLOCK)));
     if (blocks < 1) blocks = 1;
     const uint32_t cap = (uint32_t)std::min<int64_t>(KB_MAX_BLOCKS, std::max<int64_t>(1, tune_get(ctx, "kabsch_max_blocks", 1024)));
     if (blocks > cap) blocks = cap;

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
     unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop, unsigned long long* __restrict__ stats,
     uint32_t xq, uint32_t qblocks, uint32_t slices)
 {
-    if (stop && (stop[0] | stop[1])) return;
+    const int stopv = stop ? (stop[0] | stop[1]) : 0;         // requested here, tested after the query loads are on their way
     constexpr int CH = 16, TPS = BT_SUPER / 32;
     constexpr float KAPPA = 0.99999237060546875f;             // 1 - 2^-17
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -525,6 +525,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
         m1[g] = INFINITY; m2[g] = INFINITY; c1[g] = 0xFFFFFFFFu;
         cur0[g] = merge_atomic ? __uint_as_float((uint32_t)(__atomic_load_n(&keys[i], __ATOMIC_RELAXED) >> 32)) : INFINITY;
     }
+    if (stopv) return;
     const uint32_t sb = sl * supers_per_slice, se = min(sb + supers_per_slice, n_super);
     float big;
     asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(big));      // +inf the optimiser cannot see through
