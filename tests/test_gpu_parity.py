@@ -393,6 +393,29 @@ def test_kabsch_sums_vs_oracle(ctx, orc, synth):
     cs.free(); ct.free()
 
 
+def test_kabsch_reduction_paths_agree_bit_for_bit(ctx, synth):
+    """The workgroup reduction of the Kabsch pass has two forms — the halving butterfly over the 40 live limbs (at most four pairs per
+    thread) and one shuffle tree per limb (tune kabsch_bfly = 2; always beyond ~1 M points) — and the pass several launch geometries
+    (tune kabsch_max_blocks).  The sums are exact integers, so every combination must give the same bits; sizes sit on the edges of a
+    wave, a workgroup, the one-pair-per-thread rule (128 workgroups) and the four-pairs rule (1 024 workgroups)."""
+    rng = np.random.default_rng(23)
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 1000, 32768, 32769, 40001, 140000, 1048576, 1100003):
+        tgt = rng.normal(0, 5, (3, min(n, 50000))).astype(np.float32)
+        src = (tgt[:, rng.integers(0, tgt.shape[1], n)] + rng.normal(0, 0.05, (3, n))).astype(np.float32)
+        ct, cs = ctx.cloud(tgt), ctx.cloud(src)
+        ctx.nn1_async(ct, cs)
+        got = []
+        for bfly, cap in ((1, 0), (2, 0), (1, 64), (2, 7)):
+            ctx.tune("kabsch_bfly", bfly); ctx.tune("kabsch_max_blocks", cap)
+            sums, last, last_d2 = ctx.kabsch_sums(ct, cs, 0.004)
+            got.append((bits64(sums).tobytes(), last, np.float32(last_d2).tobytes()))
+        ctx.tune("kabsch_bfly", 0); ctx.tune("kabsch_max_blocks", 0)
+        assert all(g == got[0] for g in got[1:]), n
+        kept = np.frombuffer(got[0][0], np.float64)[15]
+        assert 0 <= kept <= n and (n < 1000 or 0 < kept < n), (n, kept)
+        cs.free(); ct.free()
+
+
 def test_kabsch_sums_are_exact_and_order_independent(ctx, pcr, orc, synth):
     """The 16 moments are accumulated as integer limbs (csrc/numerics.hpp): exactly the rounded value of the true sum, whatever the
     order of the pairs, the launch geometry or the magnitude of the coordinates."""
