@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(job):
         src, obj = job
-        cmd = [cc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [cc, *FLAGS, *os.environ.get("PCR_EXTRA_FLAGS", "").split(), "-c", src, "-o", obj]      # A/B builds: PCR_EXTRA_FLAGS="-DPCR_..."
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

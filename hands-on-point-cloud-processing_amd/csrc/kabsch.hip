@@ -263,21 +263,31 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials,
     double acc = 0.0;
     unsigned long long key = 0;
     if (k < 57) {
-        // eight rows of the group in flight at once (a row that does not exist reads as 0.0, neutral for the sum, the key maximum
-        // and the flag alike): one memory round trip per eight rows instead of one per row — the additions are exact, any order
-        constexpr int INF = 8;
-        for (uint32_t b = grp; b < n_blocks; b += KF_GROUPS * INF) {
-            double v[INF];
-#pragma unroll
-            for (int j = 0; j < INF; j++) {
-                const uint32_t bb = b + (uint32_t)j * KF_GROUPS;
-                v[j] = bb < n_blocks ? partials[(size_t)bb * KB_ROW + k] : 0.0;
+        // more rows than groups: eight rows of a group in flight at once (a row that does not exist reads as 0.0, neutral for the sum,
+        // the key maximum and the flag alike) — one memory round trip per eight rows instead of one per row; the additions are exact,
+        // any order.  Few rows (small clouds, where this kernel is pure latency): the one-row loop, a fraction of the code to fetch.
+        if (n_blocks <= (uint32_t)KF_GROUPS) {
+            if ((uint32_t)grp < n_blocks) {
+                const double v = partials[(size_t)grp * KB_ROW + k];
+                if (k == 55) key = (unsigned long long)__double_as_longlong(v);
+                else if (k == 56) acc = v != 0.0 ? 1.0 : 0.0;
+                else acc = v;
             }
+        } else {
+            constexpr int INF = 8;
+            for (uint32_t b = grp; b < n_blocks; b += KF_GROUPS * INF) {
+                double v[INF];
 #pragma unroll
-            for (int j = 0; j < INF; j++) {
-                if (k == 55) { const unsigned long long lk = (unsigned long long)__double_as_longlong(v[j]); key = lk > key ? lk : key; }
-                else if (k == 56) acc = (acc != 0.0 || v[j] != 0.0) ? 1.0 : 0.0;
-                else acc += v[j];
+                for (int j = 0; j < INF; j++) {
+                    const uint32_t bb = b + (uint32_t)j * KF_GROUPS;
+                    v[j] = bb < n_blocks ? partials[(size_t)bb * KB_ROW + k] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < INF; j++) {
+                    if (k == 55) { const unsigned long long lk = (unsigned long long)__double_as_longlong(v[j]); key = lk > key ? lk : key; }
+                    else if (k == 56) acc = (acc != 0.0 || v[j] != 0.0) ? 1.0 : 0.0;
+                    else acc += v[j];
+                }
             }
         }
     }

@@ -44,7 +44,8 @@ PCR_HD double dabs(double v) { return v < 0 ? -v : v; }
 
 // one Jacobi rotation of the column pair (P, Q); false when the pair is already orthogonal to working precision.
 // (Measured and dropped: selecting the rotated columns instead of branching, so that the convergence test's square root runs beside
-// the rotation's own chain — the converged pairs of the last sweep then pay the whole chain: update kernel 8.5 -> 10.9 us.)
+// the rotation's own chain — the converged pairs of the last sweep then pay the whole chain: update kernel 8.5 -> 10.9 us; only the
+// first division hoisted above the branch: no difference.)
 template <int P, int Q>
 PCR_HD bool jacobi_pair(M3& W, M3& R)
 {
