@@ -40,7 +40,7 @@ namespace pcr {
 constexpr int NN_BLOCK = 256;
 constexpr int NN_TILE = 1024;   // targets per LDS tile: 3 * 4 KiB
 constexpr bool NN_F16_DEFAULT = true;      // measured: 0.72 against 0.88 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
-constexpr int NN_XCD_DEFAULT = 4;          // XCD-aware launch of the matrix-core kernels (tune nn1_xcd), see nn1_btrack_kernel
+constexpr int NN_XCD_DEFAULT = 4;          // XCD-aware launch of the matrix-core kernels (tune nn1_xcd; nn1_btrack_kernel): 24.6 against 68.5 MiB fetched per 120k x 120k launch, same time
 constexpr bool NN_BF16_DEFAULT = true;     // measured: 0.90 against 1.30 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
 
 __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
