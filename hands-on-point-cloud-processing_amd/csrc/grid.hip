@@ -571,7 +571,7 @@ __device__ __forceinline__ void ball_x_cells(const GridParams& g, float qx, floa
 template <bool STATS>
 __device__ __forceinline__ void scan_pieces_sph(const float4* __restrict__ records, const float4* __restrict__ spheres, uint32_t b1, uint32_t e1,
                                                 uint32_t b2, uint32_t e2, int l, float qx, float qy, float qz, unsigned long long& best, uint32_t& bestp,
-                                                unsigned long long& st_cand, unsigned long long& st_sph)
+                                                unsigned long long& st_cand, unsigned long long& st_sph, uint32_t seed_run)
 {
     const uint32_t a0 = b1 < e1 ? b1 / GRID_CHUNK : 0u, na = b1 < e1 ? (e1 - 1) / GRID_CHUNK + 1 - a0 : 0u;
     const uint32_t c0 = b2 < e2 ? b2 / GRID_CHUNK : 0u, nc = b2 < e2 ? (e2 - 1) / GRID_CHUNK + 1 - c0 : 0u;
@@ -591,7 +591,7 @@ __device__ __forceinline__ void scan_pieces_sph(const float4* __restrict__ recor
         const uint32_t rel = f - __shfl(my_off, owner, 16);
         const uint32_t oa0 = __shfl(a0, owner, 16), ona = __shfl(na, owner, 16), oc0 = __shfl(c0, owner, 16);
         const uint32_t c = rel < ona ? oa0 + rel : oc0 + (rel - ona);
-        const bool hit = f < total && sphere_may_win(spheres[c], qx, qy, qz, best);
+        const bool hit = f < total && c != seed_run && sphere_may_win(spheres[c], qx, qy, qz, best);
         const uint32_t m = (uint32_t)(__ballot(hit) >> shift) & 0xFFFFu;
         if (STATS && l == 0) { st_sph += min(16u, total - f0); st_cand += 16u * (uint32_t)__popc(m); }
         if (m) {
@@ -608,7 +608,8 @@ __device__ __forceinline__ void scan_pieces_sph(const float4* __restrict__ recor
 template <bool STATS>
 __device__ __forceinline__ void stage1_sph(const float4* __restrict__ records, const float4* __restrict__ spheres, const uint32_t* __restrict__ cell_start,
                                            const GridParams& g, int ux, int uy, int uz, int l, float qx, float qy, float qz, unsigned long long& best,
-                                           uint32_t& bestp, unsigned long long& st_cand, unsigned long long& st_sph, unsigned long long& st_rows)
+                                           uint32_t& bestp, unsigned long long& st_cand, unsigned long long& st_sph, unsigned long long& st_rows,
+                                           uint32_t seed_run)
 {
     const int xlo = max(ux - 1, 0), xhi = min(ux + 1, g.n[0] - 1);
     const bool bounded = best != KEY_NONE, seeded = has_index(best);     // (bounded without a seed: the caller's gate, nn1_grid_kernel)
@@ -657,7 +658,7 @@ __device__ __forceinline__ void stage1_sph(const float4* __restrict__ records, c
         uint32_t c = f + delta[0];
 #pragma unroll
         for (int r = 1; r < 9; r++) c = f >= off[r] ? f + delta[r] : c;
-        const bool hit = f < total && sphere_may_win(spheres[c], qx, qy, qz, best);
+        const bool hit = f < total && c != seed_run && sphere_may_win(spheres[c], qx, qy, qz, best);
         const uint32_t m = (uint32_t)(__ballot(hit) >> shift) & 0xFFFFu;
         if (STATS && l == 0) { st_sph += min(16u, total - f0); st_cand += 16u * (uint32_t)__popc(m); }
         if (m) {
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     const int l = (int)(threadIdx.x % G);
     const uint32_t i = perm ? perm[t] : t;
     const float qx = sx[i], qy = sy[i], qz = sz[i];
-    const uint32_t pp0 = (warm_start == 2) ? wpos[i] : 0xFFFFFFFFu;
+    const uint32_t pp0 = (warm_start >= 2) ? wpos[i] : 0xFFFFFFFFu;
     if (stopv) return;
     // The caller discards every neighbour with d2 >= cap2 (the ICP gate), so cap2 itself is a bound the walk may prune with from
     // the start: the search begins with the pseudo-candidate (cap2, no index).  Rows and cells outside the cap2 ball are never
@@ -716,8 +717,16 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
     const unsigned long long bound0 = (cap2 > 0.0f && cap2 < 1e30f) ? (((unsigned long long)__float_as_uint(cap2) << 32) | 0xFFFFFFFFull) : KEY_NONE;
     unsigned long long best = bound0;
     uint32_t bestp = 0;
+    uint32_t seed_run = 0xFFFFFFFFu;             // the run scanned ahead of the walk (warm_start 3), which then skips it
     if (finite3(qx, qy, qz)) {
-        if (warm_start == 2) {
+        if (SPH && warm_start == 3 && pp0 < nt) {
+            // The previous winner's whole RUN (its 16 Morton neighbours, one coalesced 256-byte load, a record per lane) instead of the
+            // winner alone: while the pose still moves by centimetres per iteration, one of the neighbours is often the new nearest
+            // point or close to it, and the ball every later sphere test and row clip works with is that much smaller.
+            seed_run = pp0 / GRID_CHUNK;
+            scan_run16(records, seed_run, l, qx, qy, qz, best, bestp);
+            group_min<16>(best, bestp);
+        } else if (warm_start >= 2) {
             // ICP, from the second search of a loop on: wpos[] holds the record position of this query's previous winner.
             // That target, evaluated exactly against the moved query, is a genuine candidate: it bounds the search from the
             // first stage on (the radius jumps straight to the proving one, rows are clipped to its ball) without changing
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
         bool done = r0 > 1 && out_reach > TRUST && out_reach * out_reach * 0.99999f >= cap2;
         if (r == 1 && SPH) {
             // ---- stage 1, sphere walk: one row per lane
-            stage1_sph<STATS>(records, spheres, cell_start, g, ux, uy, uz, l, qx, qy, qz, best, bestp, st_cand, st_sph, st_rows);
+            stage1_sph<STATS>(records, spheres, cell_start, g, ux, uy, uz, l, qx, qy, qz, best, bestp, st_cand, st_sph, st_rows, seed_run);
             group_min<G>(best, bestp);
             const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
                                 (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
@@ -908,7 +917,7 @@ __global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
                     if (SPH) {
                         // the runs of the (up to) 2 x 16 pieces as one index space: dense batches of 16 sphere tests
                         if (__ballot((b1 < e1) || (b2 < e2)) >> ((threadIdx.x & 63) / 16 * 16) & 0xFFFFull)
-                            scan_pieces_sph<STATS>(records, spheres, b1, e1, b2, e2, l, qx, qy, qz, best, bestp, st_cand, st_sph);
+                            scan_pieces_sph<STATS>(records, spheres, b1, e1, b2, e2, l, qx, qy, qz, best, bestp, st_cand, st_sph, seed_run);
                     } else {
                         // visit only the lanes that hold a non-empty piece (far searches are mostly empty space)
                         const unsigned long long any = __ballot((b1 < e1) || (b2 < e2));
@@ -1616,6 +1625,9 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         wpos = ctx->wpos;
     }
     if (warm == 2 && !wpos) warm = 1;
+    // sphere walk with record-position seeds: the previous winner's whole run is scanned ahead of the walk (tune grid_seed_run: 2 = off)
+    // (the plain walk of small targets gains nothing from it: measured, 52.5 against 53.2 us per 120 k iteration)
+    if (warm == 2 && mode == 2 && tune_get(ctx, "grid_seed_run", 1) == 1) warm = 3;
     ctx->wpos_valid = wpos != nullptr;
     ctx->wpos_n = ns;
     // XCD-aware workgroup -> query-block mapping for large batches (tune grid_xcd_run: run length in workgroups, -1 = identity)
