@@ -801,7 +801,10 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
             tgt->bt->bad16_host = flag;
         }
         if (f16 && g->bad16_host != 0) f16 = false;
-        int qg = (int)tune_get(ctx, "nn1_btrack_qg", 4);
+        // query groups (of 32) per wave: four amortise the per-tile operand loads best on a full batch; a source shard of a
+        // strong-scaling run (15-30 k queries against the whole target) fills the chip better with two — measured, per ICP iteration:
+        // 15 k queries 0.158 -> 0.137 ms, 30 k 0.241 -> 0.218, 60 k 0.378 / 0.375, 120 k 0.664 -> 0.723
+        int qg = (int)tune_get(ctx, "nn1_btrack_qg", ns <= 49152 ? 2 : 4);
         if (qg != 1 && qg != 2) qg = 4;                                           // (8 groups per wave: hipcc 7.2 crashes on the instantiation)
         const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                      // queries per workgroup
         const uint32_t qblocks = (uint32_t)((ns + qpb - 1) / qpb);
