@@ -12,12 +12,8 @@
 
 using namespace pcr;
 
-// the dispatcher's rule (api.cpp launch_nn1): tune nn_method 0 = auto (grid for targets >= 2048 points), 1 brute force, 2 grid
-static bool icp_uses_grid(const pcr_ctx* ctx, const pcr_cloud* tgt)
-{
-    const int64_t m = tune_get(ctx, "nn_method", 0);
-    return m == 2 || (m != 1 && tgt->n >= 2048);
-}
+// the dispatcher's rule (api.cpp nn1_auto_grid) for the searches of a loop
+static bool icp_uses_grid(const pcr_ctx* ctx, const pcr_cloud* tgt) { return nn1_auto_grid(ctx, tgt, true); }
 
 // ---- synchronous loop: one host round trip per iteration (needed by the host-callback transport; also the
 // reference implementation of the loop the pipelined variant below must reproduce bit for bit)
@@ -27,6 +23,7 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
     const auto t_begin = std::chrono::steady_clock::now();
     pcr_icp_stats st;
     memset(&st, 0, sizeof st);
+    const LoopHint hint(ctx, prm->max_iter);
 
     // prof bookkeeping: report only this call's nn1 time
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -132,6 +129,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     const auto t_begin = std::chrono::steady_clock::now();
     pcr_icp_stats st;
     memset(&st, 0, sizeof st);
+    const LoopHint hint(ctx, prm->max_iter);
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_flush(ctx);
     const uint64_t nn_l0 = ctx->prof["nn1_brute"].launches + ctx->prof["nn1_grid"].launches;
@@ -139,7 +137,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
 
     constexpr int RING = 4;
     if (!ctx->icp_state_dev) {
-        PCR_HIP(ctx, hipMalloc((void**)&ctx->icp_state_dev, sizeof(IcpState)));
+        PCR_HIP(ctx, hipMalloc((void**)&ctx->icp_state_dev, 2 * sizeof(IcpState)));      // [1]: the other buffer of the fused solve + move
         PCR_HIP(ctx, hipHostMalloc((void**)&ctx->icp_state_host, (RING + 1) * sizeof(IcpState), hipHostMallocDefault));
         for (int k = 0; k < RING; k++) PCR_HIP(ctx, hipEventCreateWithFlags(&ctx->icp_events[k], hipEventDisableTiming));
     }
@@ -172,15 +170,24 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     if (rc == PCR_OK) rc = kabsch_plan(ctx, tgt, prm->max_corr, &plan);
     int64_t chunk = tune_get(ctx, "icp_chunk", 4);
     if (chunk < 1) chunk = 1;
+    const bool force_slots = tune_get(ctx, "icp_force_slots", 0) > 0;
+    // small clouds on one rank: the solve and the move share a launch (kabsch.hip icp_update_move_kernel; tune icp_fused_move: 2 = off);
+    // the state then alternates between dev[0] and dev[1]: iteration k reads dev[k & 1] and writes dev[(k + 1) & 1]
+    const bool fused = nranks == 1 && !force_slots && work->n > 0 && work->n <= 32768 && tune_get(ctx, "icp_fused_move", 1) == 1;
     uint64_t enq = 0, chunks = 0;
     bool stopped = false;
     while (rc == PCR_OK && !stopped && enq < prm->max_iter) {
         for (int64_t c = 0; rc == PCR_OK && c < chunk && enq < prm->max_iter; c++, enq++) {   // :917
-            ctx->stop_flag_dev = &dev->stop;     // correspondence kernels no-op once stop or stop_after_transform is set
+            IcpState* cur = fused ? dev + (enq & 1) : dev;                                        // the state this iteration starts from
+            ctx->stop_flag_dev = &cur->stop;     // correspondence kernels no-op once stop or stop_after_transform is set
             if ((rc = launch_nn1(ctx, tgt, work, true, gate))) break;                             // :925-934
             uint32_t blocks = 0;
             if (work->n && (rc = launch_kabsch_partial(ctx, tgt, work, prm->max_corr, plan, &blocks))) break;   // :936-940,:964-985
-            if (nranks == 1 && work->n && tune_get(ctx, "icp_force_slots", 0) <= 0) {
+            if (fused) {
+                if ((rc = launch_icp_update_move(ctx, blocks, cur, dev + ((enq + 1) & 1), plan, work))) break;   // :948-1003
+                continue;
+            }
+            if (nranks == 1 && work->n && !force_slots) {
                 if ((rc = launch_icp_update(ctx, blocks, dev, plan))) break;                // :948-1002
             } else {
                 if ((rc = launch_icp_reduce_slots(ctx, blocks, nranks, rank, work->n != 0))) break;
@@ -192,7 +199,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
         ctx->stop_flag_dev = nullptr;
         if (rc) break;
         const int slot = (int)(chunks % RING);
-        e = hipMemcpyAsync(&host[slot], dev, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream);
+        e = hipMemcpyAsync(&host[slot], fused ? dev + (enq & 1) : dev, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(ctx->icp_events[slot], ctx->stream);
         if (e != hipSuccess) { rc = fail(ctx, PCR_ERR_HIP, "icp snapshot", e); break; }
         chunks++;
@@ -206,7 +213,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     }
     ctx->stop_flag_dev = nullptr;
     if (rc == PCR_OK) {
-        e = hipMemcpyAsync(&host[RING], dev, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream);
+        e = hipMemcpyAsync(&host[RING], fused ? dev + (enq & 1) : dev, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = fail(ctx, PCR_ERR_HIP, "icp state download", e);
     } else {

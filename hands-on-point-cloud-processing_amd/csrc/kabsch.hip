@@ -479,6 +479,64 @@ __global__ __launch_bounds__(KF_BLOCK) void icp_update_kernel(const double* __re
     }
 }
 
+// Small clouds, single rank: the solve AND the move in one launch — one link less in the latency chain of an iteration
+// (search -> sums -> solve -> move), which is all an iteration is at hw9's own size.  Every workgroup repeats the reduce and the 3 x 3
+// solve on its own LDS copy of the state it read from st_in (deterministic arithmetic on the same rows: all of them arrive at the
+// same new state), workgroup 0 publishes it to st_out — the OTHER buffer of a pair, so nobody reads what is being written; the
+// next search tests the stop flags there — and each workgroup moves its own 4 096 points, whose loads were issued before the solve.
+// The exits are those of icp_update_kernel + transform_state_kernel: a stopped loop stays as it is, stop_after_transform turns
+// into stop without a move, a step that stops (converged, no pair, overflow) does not move, any other step moves.
+__global__ __launch_bounds__(KF_BLOCK) void icp_update_move_kernel(const double* __restrict__ partials, uint32_t n_blocks, int e, const IcpState* __restrict__ st_in,
+                                                                   IcpState* __restrict__ st_out, double* __restrict__ out, float* __restrict__ x,
+                                                                   float* __restrict__ y, float* __restrict__ z, uint32_t n, uint32_t n4)
+{
+    __shared__ double red[KF_GROUPS][64];
+    __shared__ double row[KB_ROW];
+    __shared__ double o18[19];
+    __shared__ IcpState s_st;
+    const uint32_t i = blockIdx.x * KF_BLOCK + threadIdx.x;
+    const bool mine = i < n4;
+    float4 px = make_float4(0.f, 0.f, 0.f, 0.f), py = px, pz = px;
+    if (mine) { px = reinterpret_cast<float4*>(x)[i]; py = reinterpret_cast<float4*>(y)[i]; pz = reinterpret_cast<float4*>(z)[i]; }
+    icp_state_stage(st_in, &s_st);
+    const int phase = s_st.stop ? 0 : (s_st.stop_after_transform ? 1 : 2);       // (uniform over the workgroup)
+    if (phase == 2) {
+        reduce_rows(partials, n_blocks, red, row);
+        row_to_out18(row, e, o18);
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < 19) out[threadIdx.x] = o18[threadIdx.x];
+        if (threadIdx.x == 0) icp_state_step(&s_st, o18, o18[16] >= 0.0, (float)o18[17], o18[18] != 0.0);
+    } else if (phase == 1) {
+        if (threadIdx.x == 0) s_st.stop = 1;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *st_out = s_st;
+    if (s_st.stop || !mine) return;
+    const float r0 = s_st.Rd[0], r1 = s_st.Rd[1], r2 = s_st.Rd[2], r3 = s_st.Rd[3], r4 = s_st.Rd[4], r5 = s_st.Rd[5],
+                r6 = s_st.Rd[6], r7 = s_st.Rd[7], r8 = s_st.Rd[8], t0 = s_st.td[0], t1 = s_st.td[1], t2 = s_st.td[2];
+    float4 ox, oy, oz;
+#define PCR_ROW(o, a, b, c, tt)                      \
+    o.x = ((a * px.x + b * py.x) + c * pz.x) + tt;   \
+    o.y = ((a * px.y + b * py.y) + c * pz.y) + tt;   \
+    o.z = ((a * px.z + b * py.z) + c * pz.z) + tt;   \
+    o.w = ((a * px.w + b * py.w) + c * pz.w) + tt;
+    PCR_ROW(ox, r0, r1, r2, t0)
+    PCR_ROW(oy, r3, r4, r5, t1)
+    PCR_ROW(oz, r6, r7, r8, t2)
+#undef PCR_ROW
+    const uint32_t base = 4 * i;                     // (the padding invariant of the tail group: transform_state_kernel)
+    if (base + 3 >= n) {
+        const float inf = __builtin_inff();
+        if (base + 0 >= n) { ox.x = inf; oy.x = 0.f; oz.x = 0.f; }
+        if (base + 1 >= n) { ox.y = inf; oy.y = 0.f; oz.y = 0.f; }
+        if (base + 2 >= n) { ox.z = inf; oy.z = 0.f; oz.z = 0.f; }
+        if (base + 3 >= n) { ox.w = inf; oy.w = 0.f; oz.w = 0.f; }
+    }
+    reinterpret_cast<float4*>(x)[i] = ox;
+    reinterpret_cast<float4*>(y)[i] = oy;
+    reinterpret_cast<float4*>(z)[i] = oz;
+}
+
 // multi rank, step 1: reduce the block rows into the all-reduce buffer
 //   [0..54] normalised limbs, [55] overflow flag, [56 + 2r] kept flag of rank r, [57 + 2r] d2 of its last kept pair
 // (every entry is summed exactly by the all-reduce: integers below 2^40 x ranks, one non-zero flag pair per rank)
@@ -572,6 +630,18 @@ int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev, const K
     {
         ProfScope p(ctx, "icp_update");
         hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(KF_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, plan.e, st_dev, ctx->dev_out);
+    }
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+int launch_icp_update_move(pcr_ctx* ctx, uint32_t n_blocks, const IcpState* st_in, IcpState* st_out, const KabschPlan& plan, pcr_cloud* c)
+{
+    const uint32_t n4 = (uint32_t)((c->n + 3) / 4);
+    {
+        ProfScope p(ctx, "icp_update");
+        hipLaunchKernelGGL(icp_update_move_kernel, dim3((n4 + KF_BLOCK - 1) / KF_BLOCK), dim3(KF_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, plan.e, st_in,
+                           st_out, ctx->dev_out, c->x(), c->y(), c->z(), (uint32_t)c->n, n4);
     }
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;

@@ -136,6 +136,7 @@ extern "C" int pcr_icp_p2plane_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr
         if (e != hipSuccess) rc = fail(ctx, PCR_ERR_HIP, "hipMalloc(p2plane)", e);
     }
     std::vector<double> hp((size_t)blocks * PP_NV);
+    const LoopHint hint(ctx, prm->max_iter);       // (api.cpp nn1_auto_grid: small targets take the grid inside a loop)
     for (uint64_t iter = 0; rc == PCR_OK && iter < prm->max_iter; iter++) {
         if ((rc = launch_nn1(ctx, tgt, work, true, tune_get(ctx, "icp_bounded_search", 1) == 1 ? prm->max_corr : __builtin_inff()))) break;                              // :768-781
         double s[64];

@@ -129,6 +129,7 @@ struct pcr_ctx {
     hipEvent_t icp_events[4] = { nullptr, nullptr, nullptr, nullptr };
     unsigned long long* grid_stats_dev = nullptr;   // diagnostics of the grid search (tune grid_stats)
     const int* stop_flag_dev = nullptr;        // when set, the correspondence kernels exit early once *flag != 0
+    uint64_t loop_iters_hint = 0;              // set by an iterated loop (ICP) for its duration: how many searches of one target may follow (nn1_auto_grid)
     uint32_t* far_list = nullptr;              // far queries handed from the grid walk to the exhaustive kernel: [cap] indices + [1] count
     size_t far_cap = 0;
     pcr::Comm comm;
@@ -185,6 +186,16 @@ int cloud_knn_small(pcr_ctx* ctx, const pcr_cloud* db, const float* q_rows, size
 constexpr int SCAN_TILE = 2048;
 int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* totals, uint32_t* grand);
 // dispatcher: tune "nn_method" 0 = auto (grid for targets >= 2048 points), 1 = brute force, 2 = grid
+// (auto inside an iterated loop: the grid from 128 points on, nn1_auto_grid)
+bool nn1_auto_grid(const pcr_ctx* ctx, const pcr_cloud* tgt, bool in_loop);
+// tells the dispatcher for the duration of a loop how many searches of one target may follow
+struct LoopHint {
+    pcr_ctx* ctx;
+    LoopHint(pcr_ctx* c, uint64_t iters) : ctx(c) { ctx->loop_iters_hint = iters; }
+    ~LoopHint() { ctx->loop_iters_hint = 0; }
+    LoopHint(const LoopHint&) = delete;
+    LoopHint& operator=(const LoopHint&) = delete;
+};
 int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2 = __builtin_inff());
 void cloud_modified(pcr_cloud* c);
 int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
@@ -202,6 +213,8 @@ int launch_icp_reduce_slots(pcr_ctx* ctx, uint32_t n_blocks, int nranks, int ran
 int launch_icp_update_from_sums(pcr_ctx* ctx, int nranks, IcpState* st_dev, const KabschPlan& plan);
 inline int icp_nred(int nranks) { return 56 + 2 * nranks; }
 int launch_transform_state(pcr_ctx* ctx, pcr_cloud* c, IcpState* st_dev);
+// small clouds, one rank: icp_update + transform_state in one launch; the state alternates between the two buffers st_in / st_out
+int launch_icp_update_move(pcr_ctx* ctx, uint32_t n_blocks, const IcpState* st_in, IcpState* st_out, const KabschPlan& plan, pcr_cloud* c);
 int comm_allreduce_f64_device(pcr_ctx* ctx, double* dev_buf, int n);   // RCCL on the ctx stream, no host round trip
 int launch_plane_count(pcr_ctx* ctx, const pcr_cloud* pts, const double* planes4_dev, size_t n_planes,
                        double thr, unsigned long long* counts_dev);
