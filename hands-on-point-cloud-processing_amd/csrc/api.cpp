@@ -113,23 +113,29 @@ void cloud_modified(pcr_cloud* c)
     if (c) { c->absmax = -1.f; c->brute_searches = 0; }
 }
 
-// nn_method: 0 auto, 1 brute force, 2 uniform grid.  Auto = the exact grid for targets >= 2048 points; inside an iterated loop (ICP:
-// the index is built once, every later search starts from the previous correspondence) already from 128 points on when at least
-// five searches may follow or the index exists — measured, whole ICP calls on FRESH targets of 256 / 1 000 / 2 000 points: the grid
-// is ahead from the 4th-5th iteration (5 iterations 284 / 306 / 350 us against 328 / 342 / 355; 20 iterations 577 / 637 / 666 against
-// 1 091 / 1 167 / 1 220), per iteration 20-24 us against 51-58 us; at 64 points the two meet only at ~20 iterations.
-bool nn1_auto_grid(const pcr_ctx* ctx, const pcr_cloud* tgt, bool in_loop)
+// nn_method: 0 auto, 1 brute force, 2 uniform grid.  Auto:
+// * inside an iterated loop (ICP: the index is built once, every later search starts from the previous correspondence) the exact
+//   grid for targets >= 2048 points, and already from 128 points on when at least five searches may follow or the index exists —
+//   measured, whole ICP calls on FRESH targets of 256 / 1 000 / 2 000 points: the grid is ahead from the 4th-5th iteration (5
+//   iterations 284 / 306 / 350 us against 328 / 342 / 355; 20 iterations 577 / 637 / 666 against 1 091 / 1 167 / 1 220), per iteration
+//   20-24 us against 51-58 us; at 64 points the two meet only at ~20 iterations;
+// * a one-shot search takes the grid when the target's index exists already; on a target without one the exhaustive kernels are
+//   ahead while queries x targets stays below ~2e9 — first search of a fresh n x n pair, wall: n = 2 048 76 against 222 us, 4 096 76 /
+//   236, 8 192 209 / 264, 16 384 248 / 281, 32 768 326 / 383, then 65 536 576 / 462, 120 000 1 030 / 706 (profiles/r02_kabsch_probes.txt).
+bool nn1_auto_grid(const pcr_ctx* ctx, const pcr_cloud* tgt, bool in_loop, size_t ns)
 {
     const int64_t method = tune_get(ctx, "nn_method", 0);
     if (method == 2) return true;
     if (method == 1) return false;
-    if (tgt->n >= 2048) return true;
-    return in_loop && tgt->n >= 128 && (tgt->grid != nullptr || ctx->loop_iters_hint >= 5);
+    if (in_loop) return tgt->n >= 2048 || (tgt->n >= 128 && (tgt->grid != nullptr || ctx->loop_iters_hint >= 5));
+    if (tgt->n < 2048) return false;
+    if (tgt->grid != nullptr) return true;
+    return tgt->n >= 65536 || (double)ns * (double)tgt->n > 2.0e9;
 }
 
 int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2)
 {
-    return nn1_auto_grid(ctx, tgt, reuse_perm) ? launch_nn1_grid(ctx, tgt, src, reuse_perm, cap2) : launch_nn1_brute(ctx, tgt, src, reuse_perm);
+    return nn1_auto_grid(ctx, tgt, reuse_perm, src->n) ? launch_nn1_grid(ctx, tgt, src, reuse_perm, cap2) : launch_nn1_brute(ctx, tgt, src, reuse_perm);
 }
 
 static int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out)

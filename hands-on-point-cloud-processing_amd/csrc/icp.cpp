@@ -13,7 +13,7 @@
 using namespace pcr;
 
 // the dispatcher's rule (api.cpp nn1_auto_grid) for the searches of a loop
-static bool icp_uses_grid(const pcr_ctx* ctx, const pcr_cloud* tgt) { return nn1_auto_grid(ctx, tgt, true); }
+static bool icp_uses_grid(const pcr_ctx* ctx, const pcr_cloud* tgt) { return nn1_auto_grid(ctx, tgt, true, 0); }
 
 // ---- synchronous loop: one host round trip per iteration (needed by the host-callback transport; also the
 // reference implementation of the loop the pipelined variant below must reproduce bit for bit)

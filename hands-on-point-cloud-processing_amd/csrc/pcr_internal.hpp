@@ -186,8 +186,9 @@ int cloud_knn_small(pcr_ctx* ctx, const pcr_cloud* db, const float* q_rows, size
 constexpr int SCAN_TILE = 2048;
 int exclusive_scan_u32(pcr_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* totals, uint32_t* grand);
 // dispatcher: tune "nn_method" 0 = auto (grid for targets >= 2048 points), 1 = brute force, 2 = grid
-// (auto inside an iterated loop: the grid from 128 points on, nn1_auto_grid)
-bool nn1_auto_grid(const pcr_ctx* ctx, const pcr_cloud* tgt, bool in_loop);
+// (auto: api.cpp nn1_auto_grid — inside an iterated loop the grid from 128 points on; one-shot searches of a target without an index
+// stay exhaustive while queries x targets is small)
+bool nn1_auto_grid(const pcr_ctx* ctx, const pcr_cloud* tgt, bool in_loop, size_t ns);
 // tells the dispatcher for the duration of a loop how many searches of one target may follow
 struct LoopHint {
     pcr_ctx* ctx;
