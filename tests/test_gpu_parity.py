@@ -487,6 +487,28 @@ def test_icp_state_machine_matches_oracle(ctx, orc, synth):
     cs.free(); ct.free(); far.free()
 
 
+@pytest.mark.parametrize("n", [100, 128, 300, 1500, 2047, 2048])
+def test_icp_auto_dispatch_of_small_targets_changes_no_bit(ctx, synth, n):
+    """Inside a loop the dispatcher sends targets from 128 points on to the exact grid (api.cpp nn1_auto_grid: max_iter >= 5 or an
+    existing index), below that and for short loops to the exhaustive kernels: pose, statistics and loss are those of either search
+    forced, bit for bit — for long and short loops, fresh targets and targets whose index exists."""
+    src, tgt = synth.kitti_like_pair(n, seed_target=501 + n, seed_pair=502 + n)
+    for kw in (dict(max_iter=14, eps=1e-8), dict(max_iter=3, eps=0.0), dict(max_iter=30, eps=1e30)):
+        got = []
+        for method in (1, 2, 0, 0):
+            ctx.tune("nn_method", method)
+            cs = ctx.cloud(src)
+            ct = ctx.cloud(tgt) if len(got) < 3 else ct        # the fourth run searches the target the third one indexed (or did not)
+            T, st = ctx.icp_point2point(cs, ct, **kw)
+            got.append((T.view(np.uint32).tobytes(), st["iters_run"], st["converged"], st["empty_pairs"], st["last_pairs"],
+                        np.float32(st["last_loss"]).tobytes()))
+            cs.free()
+            if len(got) < 3: ct.free()
+        ct.free()
+        ctx.tune("nn_method", 0)
+        assert all(g == got[0] for g in got[1:]), (n, kw)
+
+
 @pytest.mark.parametrize("method", [1, 2])
 def test_icp_pipelined_equals_synchronous_loop(ctx, synth, method):
     """The device-resident pipelined loop (default) and the synchronous host loop share one numerics header:
@@ -502,14 +524,16 @@ def test_icp_pipelined_equals_synchronous_loop(ctx, synth, method):
     for cloud, kw in cases:
         ctx.tune("icp_pipeline", -1)
         Ts, ss = ctx.icp_point2point(cloud, ct, **kw)
-        for chunk, slots in ((1, 0), (4, 0), (7, 0), (4, 1)):
-            ctx.tune("icp_pipeline", 1); ctx.tune("icp_chunk", chunk); ctx.tune("icp_force_slots", slots)
+        # (fused: 0 = default — solve + move in ONE launch at this size, state double-buffered; 2 = the separate update and move kernels;
+        #  slots 1 = the multi-rank kernels reduce_slots + update_from_sums)
+        for chunk, slots, fused in ((1, 0, 0), (4, 0, 0), (7, 0, 0), (4, 1, 0), (4, 0, 2), (3, 0, 2)):
+            ctx.tune("icp_pipeline", 1); ctx.tune("icp_chunk", chunk); ctx.tune("icp_force_slots", slots); ctx.tune("icp_fused_move", fused)
             Tp, sp = ctx.icp_point2point(cloud, ct, **kw)
-            assert np.array_equal(Ts.view(np.uint32), Tp.view(np.uint32)), (kw, chunk, slots)
+            assert np.array_equal(Ts.view(np.uint32), Tp.view(np.uint32)), (kw, chunk, slots, fused)
             for k in ("iters_run", "converged", "empty_pairs", "last_pairs"):
-                assert ss[k] == sp[k], (k, kw, chunk, slots, ss, sp)
+                assert ss[k] == sp[k], (k, kw, chunk, slots, fused, ss, sp)
             assert np.float32(ss["last_loss"]).view(np.uint32) == np.float32(sp["last_loss"]).view(np.uint32)
-    for k in ("icp_pipeline", "icp_chunk", "icp_force_slots", "nn_method"):
+    for k in ("icp_pipeline", "icp_chunk", "icp_force_slots", "icp_fused_move", "nn_method"):
         ctx.tune(k, 0)
     cs.free(); ct.free(); far.free()
 
