@@ -34,8 +34,11 @@ try:
     print(f"  CPU oracle (1 thread, f64): {tc*1e3:.1f} ms -> x{tc/dt:.0f}; counts equal: {np.array_equal(oc, counts)}")
 except Exception as e:  # noqa: BLE001
     print("  oracle unavailable:", e)
-t0 = time.perf_counter(); idx, params = hw4.my_ransac(pts, np.arange(n), 40, 0.15, ctx=ctx, rng=np.random.default_rng(1)); t1 = time.perf_counter() - t0
-print(f"my_ransac (40 iterations, one segment): {t1*1e3:.2f} ms, {idx.size} ground points, plane {np.round(params, 4)}")
+t0 = time.perf_counter(); idx, params = hw4.my_ransac(pts, np.arange(n), 40, 0.15, ctx=ctx, rng=np.random.default_rng(1)); t_first = time.perf_counter() - t0
+t1 = 1e9
+for rep in range(5):       # (the first call loads the code objects of the seed-selection kernels: 30 ms; steady state below)
+    t0 = time.perf_counter(); idx, params = hw4.my_ransac(pts, np.arange(n), 40, 0.15, ctx=ctx, rng=np.random.default_rng(1)); t1 = min(t1, time.perf_counter() - t0)
+print(f"my_ransac (40 iterations, one segment): {t1*1e3:.2f} ms (first call {t_first*1e3:.1f} ms), {idx.size} ground points, plane {np.round(params, 4)}")
 # --- radius-NN r = 1.0 (the value benchmark.hpp:14 intended), every point queries its own scan
 db = pts.astype(np.float64)
 h = ctx.db64(db)
