@@ -40,6 +40,7 @@ namespace pcr {
 constexpr int NN_BLOCK = 256;
 constexpr int NN_TILE = 1024;   // targets per LDS tile: 3 * 4 KiB
 constexpr bool NN_F16_DEFAULT = true;      // measured: 0.72 against 0.88 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
+constexpr int NN_LDS_OPS_DEFAULT = 1;      // matrix-core operands staged through LDS per workgroup (tune nn1_lds_ops: 1 on, 2 off): 0.706 against 0.737 ms per 120k x 120k search
 constexpr int NN_XCD_DEFAULT = 4;          // XCD-aware launch of the matrix-core kernels (tune nn1_xcd; nn1_btrack_kernel): 24.6 against 68.5 MiB fetched per 120k x 120k launch, same time
 constexpr bool NN_BF16_DEFAULT = true;     // measured: 0.90 against 1.30 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
 
@@ -489,7 +490,7 @@ __device__ __forceinline__ void ht_pair(float c, uint32_t& d_hi, uint32_t& d_lo)
     d_hi = __builtin_bit_cast(uint32_t, a); d_lo = __builtin_bit_cast(uint32_t, b);
 }
 
-template <int QG, bool F16>
+template <int QG, bool F16, bool LDSA = false>
 __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
     const float4* __restrict__ centres, const uint4* __restrict__ ops, const float4* __restrict__ records, uint32_t n_rec, uint32_t n_super,
     uint32_t supers_per_slice, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
@@ -505,6 +506,11 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
     // (query block, slice) of this workgroup.  xq = 0: the plain 2-D launch — workgroups go to the 8 XCDs round-robin, so every XCD's
     // L2 pulls in ALL operands and ALL queries.  xq = 1 / 2 / 4: a 1-D launch in which XCD k = id % 8 owns the query blocks = k % xq
     // (mod xq) and the slices = k / xq (mod 8 / xq): its L2 holds 1 / xq of the queries and xq / 8 of the operands.
+    // lds (F16 only, tune nn1_lds_ops, bit 8 of xq): the four waves of a workgroup scan the SAME tiles for different queries; instead of
+    // four per-wave streams of 16-byte loads from L1 / L2, the workgroup stages the operands of one super-tile (8 KB; bf16: 16 KB) in LDS, the next
+    // one prefetched into registers a whole super-tile ahead, one barrier per super-tile.  (A wave beyond the queries then stays for
+    // the barriers: it repeats the last query and stores nothing.)
+    constexpr bool lds = LDSA;
     uint32_t qb = blockIdx.x, sl = blockIdx.y;
     if (xq) {
         const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, xs = 8u / xq, qb_per = (qblocks + xq - 1) / xq;
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
         if (qb >= qblocks || sl >= slices) return;             // (the padding of an uneven split: block-uniform)
     }
     const uint32_t qbase = (qb * (NN_BLOCK / 64) + wave) * (32 * QG);
-    if (qbase >= ns) return;                                  // a whole wave beyond the queries (wave-uniform)
+    if (qbase >= ns && !lds) return;                          // a whole wave beyond the queries (wave-uniform)
     float qx[QG], qy[QG], qz[QG], m1[QG], m2[QG], cur0[QG];
     uint32_t c1[QG];
     bool okq[QG];
@@ -533,9 +539,21 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
 #pragma unroll
     for (int j = 0; j < 16; j++) zero[j] = 0.0f;
     if (F16) {
-        uint4 an = make_uint4(0, 0, 0, 0);
-        if (sb < se) an = ops[(size_t)sb * TPS * 64 + lane];
+        __shared__ uint4 sA[lds ? 2 : 1][lds ? TPS * 64 : 1];      // (lds) the operands of two super-tiles: 16 KB
+        uint4 an = make_uint4(0, 0, 0, 0), pre0 = an, pre1 = an;
+        if (lds) {
+            if (sb < se) {
+                sA[0][lds ? threadIdx.x : 0] = ops[(size_t)sb * TPS * 64 + threadIdx.x];
+                sA[0][lds ? NN_BLOCK + threadIdx.x : 0] = ops[(size_t)sb * TPS * 64 + NN_BLOCK + threadIdx.x];
+            }
+            __syncthreads();
+        } else if (sb < se) an = ops[(size_t)sb * TPS * 64 + lane];
         for (uint32_t S = sb; S < se; S++) {
+            const uint32_t buf = (S - sb) & 1u;
+            if (lds && S + 1 < se) {                          // the next super-tile: in flight during this one's eight tiles
+                pre0 = ops[(size_t)(S + 1) * TPS * 64 + threadIdx.x];
+                pre1 = ops[(size_t)(S + 1) * TPS * 64 + NN_BLOCK + threadIdx.x];
+            }
             const float4 C = centres[S];                      // wave-uniform: scalar load; .w = the super-tile's scale (a power of two)
             const float sc = C.w, inv2 = 1.0f / (sc * sc);    // exact: |exponent| <= 120
             uint4 bq[QG];
@@ -554,8 +572,12 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
 #pragma unroll 1
             for (int tt = 0; tt < TPS; tt++) {
                 const uint32_t T = S * TPS + tt;
-                const uint4 A = an;
-                if (tt + 1 < TPS || S + 1 < se) an = ops[(size_t)(T + 1) * 64 + lane];
+                uint4 A;
+                if (lds) A = sA[lds ? buf : 0][lds ? tt * 64 + lane : 0];
+                else {
+                    A = an;
+                    if (tt + 1 < TPS || S + 1 < se) an = ops[(size_t)(T + 1) * 64 + lane];
+                }
                 const uint32_t c = 2 * T + (h ? 1u : 0u);
 #pragma unroll
                 for (int g = 0; g < QG; g++) {
@@ -570,11 +592,27 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
                     c1[g] = better ? c : c1[g];
                 }
             }
+            if (lds) {
+                if (S + 1 < se) { sA[lds ? buf ^ 1u : 0][lds ? threadIdx.x : 0] = pre0; sA[lds ? buf ^ 1u : 0][lds ? NN_BLOCK + threadIdx.x : 0] = pre1; }
+                __syncthreads();
+            }
         }
     } else {
-    uint4 a0n = make_uint4(0, 0, 0, 0), a1n = a0n;
-    if (sb < se) { a0n = ops[(size_t)sb * TPS * 128 + lane]; a1n = ops[(size_t)sb * TPS * 128 + 64 + lane]; }
+    __shared__ uint4 sB[lds ? 2 : 1][lds ? TPS * 128 : 1];     // (lds) the operands of two super-tiles: 32 KB
+    uint4 a0n = make_uint4(0, 0, 0, 0), a1n = a0n, pre[4] = { a0n, a0n, a0n, a0n };
+    if (lds) {
+        if (sb < se) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) sB[0][lds ? j * NN_BLOCK + threadIdx.x : 0] = ops[(size_t)sb * TPS * 128 + j * NN_BLOCK + threadIdx.x];
+        }
+        __syncthreads();
+    } else if (sb < se) { a0n = ops[(size_t)sb * TPS * 128 + lane]; a1n = ops[(size_t)sb * TPS * 128 + 64 + lane]; }
     for (uint32_t S = sb; S < se; S++) {
+        const uint32_t buf = (S - sb) & 1u;
+        if (lds && S + 1 < se) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) pre[j] = ops[(size_t)(S + 1) * TPS * 128 + j * NN_BLOCK + threadIdx.x];
+        }
         const float4 C = centres[S];                          // wave-uniform: scalar load
         uint4 b0[QG], b1[QG];
         float R[QG];
@@ -588,8 +626,12 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
 #pragma unroll 1
         for (int tt = 0; tt < TPS; tt++) {                    // (not unrolled: the scheduler would keep all 16 accumulator tiles alive)
             const uint32_t T = S * TPS + tt;
-            const uint4 A0 = a0n, A1 = a1n;
-            if (tt + 1 < TPS || S + 1 < se) { a0n = ops[(size_t)(T + 1) * 128 + lane]; a1n = ops[(size_t)(T + 1) * 128 + 64 + lane]; }   // next tile in flight
+            uint4 A0, A1;
+            if (lds) { A0 = sB[lds ? buf : 0][lds ? tt * 128 + lane : 0]; A1 = sB[lds ? buf : 0][lds ? tt * 128 + 64 + lane : 0]; }
+            else {
+                A0 = a0n; A1 = a1n;
+                if (tt + 1 < TPS || S + 1 < se) { a0n = ops[(size_t)(T + 1) * 128 + lane]; a1n = ops[(size_t)(T + 1) * 128 + 64 + lane]; }   // next tile in flight
+            }
             const uint32_t c = 2 * T + (h ? 1u : 0u);
             // (Tried: reducing the PREVIOUS group's accumulators between the two MFMAs of the current one, in program order enforced with
             // sched_group_barrier — 0.892 against 0.900 ms.  On this chip the bf16 MFMA and the vector instructions of one SIMD's waves
@@ -610,6 +652,13 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
                 m1[g] = better ? L : m1[g];
                 c1[g] = better ? c : c1[g];
             }
+        }
+        if (lds) {
+            if (S + 1 < se) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) sB[lds ? buf ^ 1u : 0][lds ? j * NN_BLOCK + threadIdx.x : 0] = pre[j];
+            }
+            __syncthreads();
         }
     }
     }
@@ -841,9 +890,18 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
             if (xq != 1 && xq != 2 && xq != 4) xq = 0;
             if (slices < 8 || (uint64_t)qblocks * slices >= (1ull << 27)) xq = 0;
             dim3 grid(qblocks, slices);
+            // (the f16 form by default; the bf16 form — two MFMAs per tile, more matrix time per byte — measured 0.933 ms either way: tune 3 stages it too)
+            const int64_t lds_tune = tune_get(ctx, "nn1_lds_ops", NN_LDS_OPS_DEFAULT);
+            const uint32_t lds_flag = (lds_tune == 3 || (lds_tune == 1 && f16)) ? 1u : 0u;
             if (xq) grid = dim3(8u * ((qblocks + (uint32_t)xq - 1) / (uint32_t)xq) * ((slices + 8u / (uint32_t)xq - 1) / (8u / (uint32_t)xq)), 1);
 #define PCR_BTRACK(Q)                                                                                                                   \
-if (f16) hipLaunchKernelGGL((nn1_btrack_kernel<Q, true>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records,         \
+if (f16 && lds_flag) hipLaunchKernelGGL((nn1_btrack_kernel<Q, true, true>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records, \
+                   (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
+                   merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices);                                         \
+else if (f16) hipLaunchKernelGGL((nn1_btrack_kernel<Q, true>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records,    \
+                   (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
+                   merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices);                                         \
+else if (lds_flag) hipLaunchKernelGGL((nn1_btrack_kernel<Q, false, true>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops, g->records, \
                    (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
                    merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices);                                         \
 else hipLaunchKernelGGL((nn1_btrack_kernel<Q, false>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops, g->records,              \
