@@ -470,7 +470,7 @@ def main():
                     "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
                                      f"kernel with this very libpcr_hip.so (sha {sha}), {pmc['source']}") if pmc else
                                     "null: PMC counters need a rocprofv3 wrapper (tools/gpu_check.sh); none was collected with the library loaded now",
-                    "kernel": (("pcr::nn1_btrack_kernel<4, true> = HTRACK (exhaustive scan of every (query, 16-target chunk): the expanded-form lower "
+                    "kernel": (("pcr::nn1_btrack_kernel<4, true, true> = HTRACK, operands staged through LDS per workgroup (exhaustive scan of every (query, 16-target chunk): the expanded-form lower "
                                 "bound of ALL pairs on the f16 matrix pipe — operands scaled per 256-target super-tile and cut into two f16 pieces each, "
                                 "every piece product exact in f32, ONE v_mfma_f32_32x32x16_f16 per 32 queries x 32 targets; the vector ALU takes the "
                                 "minimum of the 16 accumulators per lane (8 v_min3) and tracks first / second minimum branch-free; only the winning "
