@@ -490,6 +490,23 @@ __device__ __forceinline__ void ht_pair(float c, uint32_t& d_hi, uint32_t& d_lo)
     d_hi = __builtin_bit_cast(uint32_t, a); d_lo = __builtin_bit_cast(uint32_t, b);
 }
 
+// the f16 form's query operands for one super-tile (centre C.xyz, scale C.w): clamped scaled offset, two f16 pieces per coordinate in the
+// lane-half's K-slots (lanes >= 32: [z pieces | 1, 1, 0, 0]), and R = KAPPA |r|^2 / scale^2 (the bound of a tile is then ONE fma:
+// m / scale^2 + R — the division is exact)
+__device__ __forceinline__ void ht_setup(float qx, float qy, float qz, const float4 C, bool h, uint4& bq, float& R, float& inv2)
+{
+    constexpr float KAPPA = 0.99999237060546875f;             // 1 - 2^-17
+    const float sc = C.w;
+    inv2 = 1.0f / (sc * sc);                                  // exact: |exponent| <= 120
+    const float rx = __builtin_amdgcn_fmed3f((qx - C.x) * sc, -32000.0f, 32000.0f), ry = __builtin_amdgcn_fmed3f((qy - C.y) * sc, -32000.0f, 32000.0f),
+                rz = __builtin_amdgcn_fmed3f((qz - C.z) * sc, -32000.0f, 32000.0f);
+    R = (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) * KAPPA) * inv2;
+    uint32_t f1, f2, s1, s2;
+    ht_pair(h ? rz : rx, f1, f2);
+    ht_pair(ry, s1, s2);
+    bq = make_uint4(f1, f2, h ? 0x3C003C00u : s1, h ? 0u : s2);
+}
+
 template <int QG, bool F16, bool LDSA = false>
 __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
     const float4* __restrict__ centres, const uint4* __restrict__ ops, const float4* __restrict__ records, uint32_t n_rec, uint32_t n_super,
@@ -555,20 +572,11 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
                 pre1 = ops[(size_t)(S + 1) * TPS * 64 + NN_BLOCK + threadIdx.x];
             }
             const float4 C = centres[S];                      // wave-uniform: scalar load; .w = the super-tile's scale (a power of two)
-            const float sc = C.w, inv2 = 1.0f / (sc * sc);    // exact: |exponent| <= 120
+            float inv2 = 0.0f;
             uint4 bq[QG];
             float R[QG];
 #pragma unroll
-            for (int g = 0; g < QG; g++) {
-                const float rx = __builtin_amdgcn_fmed3f((qx[g] - C.x) * sc, -32000.0f, 32000.0f), ry = __builtin_amdgcn_fmed3f((qy[g] - C.y) * sc, -32000.0f, 32000.0f),
-                            rz = __builtin_amdgcn_fmed3f((qz[g] - C.z) * sc, -32000.0f, 32000.0f);
-                // (R KAPPA / scale^2 once per super-tile: the bound of a tile is then ONE fma, m / scale^2 + that — the division is exact)
-                R[g] = (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) * KAPPA) * inv2;
-                uint32_t f1, f2, s1, s2;
-                ht_pair(h ? rz : rx, f1, f2);
-                ht_pair(ry, s1, s2);
-                bq[g] = make_uint4(f1, f2, h ? 0x3C003C00u : s1, h ? 0u : s2);      // lanes >= 32: [z pieces | 1, 1, 0, 0]
-            }
+            for (int g = 0; g < QG; g++) ht_setup(qx[g], qy[g], qz[g], C, h, bq[g], R[g], inv2);
 #pragma unroll 1
             for (int tt = 0; tt < TPS; tt++) {
                 const uint32_t T = S * TPS + tt;
@@ -689,9 +697,48 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
             if (bo < best || (bo == best && io < bidx)) { best = bo; bidx = io; }
             proven = (bidx != 0xFFFFFFFFu && (M2 - 1e-30f) > __uint_as_float(best)) || (M2 - 1e-30f) > cur;
         }
-        if (!__all(proven || slice_out || sb >= se)) {
+        const bool unsettled = !__all(proven || slice_out || sb >= se);
+        if (F16 && unsettled && __all(okq[g])) {
+            // Some query of this group could not be settled by its best chunk alone: another chunk's bound lies at or below the exact
+            // distance found (or nothing was found).  The slice is FILTERED again for this group — one MFMA per tile as in the main
+            // pass, operands straight from memory — and every chunk whose bound does not exceed the query's threshold (the exact best so
+            // far, or what the other slices have published) is evaluated exactly by its half-lane; a record at or below the threshold
+            // can only sit in such a chunk, and the threshold only falls.  A tenth of the whole-slice exact rescan this replaces (which
+            // cost 9 % of a warm 120 k x 120 k launch and tied the slice length to three super-tiles).
+            if (stats && lane == 0) atomicAdd(&stats[2], 1ull);
+            const bool active = !(proven || slice_out);
+            float thr = active ? fminf(bidx != 0xFFFFFFFFu ? __uint_as_float(best) : INFINITY, cur) : -INFINITY;
+            for (uint32_t S = sb; S < se; S++) {
+                uint4 bqg;
+                float Rg, inv2;
+                ht_setup(qx[g], qy[g], qz[g], centres[S], h, bqg, Rg, inv2);
+#pragma unroll 1
+                for (int tt = 0; tt < TPS; tt++) {
+                    const uint32_t T = S * TPS + tt;
+                    const uint4 A = ops[(size_t)T * 64 + lane];
+                    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, bqg), zero, 0, 0, 0);
+                    float m = big;
+#pragma unroll
+                    for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc[j]), acc[j + 1]);
+                    const float L = __builtin_fmaf(m, inv2, Rg);
+                    if (!((L - 1e-30f) > thr)) {                     // (also taken for a NaN bound: evaluating a chunk is always safe)
+                        const uint32_t j0 = (2 * T + (h ? 1u : 0u)) * CH;
+#pragma unroll 4
+                        for (int j = 0; j < CH; j++) {
+                            const float4 rec = records[j0 + j];
+                            const uint32_t e = d2_exact_bits(qx[g], qy[g], qz[g], rec.x, rec.y, rec.z);
+                            const uint32_t oi = __float_as_uint(rec.w);
+                            if (e < best || (e == best && e < 0x7F7FFFFFu && oi < bidx)) { best = e; bidx = oi; }
+                        }
+                        if (bidx != 0xFFFFFFFFu) thr = fminf(thr, __uint_as_float(best));
+                    }
+                }
+            }
+            const uint32_t bo = (uint32_t)__shfl_xor((int)best, 32, 64), io = (uint32_t)__shfl_xor((int)bidx, 32, 64);
+            if (bo < best || (bo == best && io < bidx)) { best = bo; bidx = io; }
+        } else if (unsettled) {
             if (stats && lane == 0) atomicAdd(&stats[2], 1ull);          // diagnostics: (wave, query group) pairs that had to rescan
-            // exact rescan of the slice by the whole wave, each half-lane one half of it
+            // exact rescan of the slice by the whole wave, each half-lane one half of it (bf16 form; non-finite queries)
             const uint32_t r0 = sb * BT_SUPER, r1 = min(se * BT_SUPER, n_rec), mid = r0 + (r1 - r0) / 2;
             unsigned long long kbest = ~0ull;
             for (uint32_t j = h ? mid : r0; j < (h ? r1 : mid); j++) {
@@ -860,7 +907,9 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
         const size_t n_super = g->n_tiles / (BT_SUPER / 32);
         int64_t sps = tune_get(ctx, "nn1_supers_per_slice", 0);
         if (sps <= 0) {
-            const int64_t want_blocks = tune_get(ctx, "nn1_btrack_blocks", f16 ? 40960 : 32768);   // (120 k: 3 / 4 super-tiles per slice, the measured optima)
+            // (120 k: 8 / 4 super-tiles per slice, the measured optima — the f16 form since its unsettled queries are filtered again instead
+            // of rescanned exactly: 3 super-tiles per slice before that)
+            const int64_t want_blocks = tune_get(ctx, "nn1_btrack_blocks", f16 ? 14336 : 32768);
             const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
             sps = std::max<int64_t>(1, ((int64_t)n_super + slices - 1) / slices);
         }
