@@ -474,7 +474,8 @@ def main():
                                 "bound of ALL pairs on the f16 matrix pipe — operands scaled per 256-target super-tile and cut into two f16 pieces each, "
                                 "every piece product exact in f32, ONE v_mfma_f32_32x32x16_f16 per 32 queries x 32 targets; the vector ALU takes the "
                                 "minimum of the 16 accumulators per lane (8 v_min3) and tracks first / second minimum branch-free; only the winning "
-                                "chunk is evaluated with the exact unfused arithmetic; the previous correspondence of each query, re-evaluated "
+                                "chunk is evaluated with the exact unfused arithmetic — a query it does not settle gets its slice filtered again and "
+                                "every chunk at or below its threshold evaluated; the previous correspondence of each query, re-evaluated "
                                 "exactly, seeds the bound)") if f16 else
                                ("pcr::nn1_btrack_kernel<4, false> = BTRACK (exhaustive scan of every (query, 16-target chunk): the expanded-form lower bound of ALL "
                                 "pairs on the bf16 matrix pipe — f32 operands cut into three bf16 pieces each, every piece product exact in f32, "
