@@ -736,9 +736,46 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
             }
             const uint32_t bo = (uint32_t)__shfl_xor((int)best, 32, 64), io = (uint32_t)__shfl_xor((int)bidx, 32, 64);
             if (bo < best || (bo == best && io < bidx)) { best = bo; bidx = io; }
+        } else if (!F16 && unsettled && __all(okq[g])) {
+            // the same for the bf16 form: two MFMAs per tile, operands of three pieces, bound = fma(|r|^2, KAPPA, min)
+            if (stats && lane == 0) atomicAdd(&stats[2], 1ull);
+            const bool active = !(proven || slice_out);
+            float thr = active ? fminf(bidx != 0xFFFFFFFFu ? __uint_as_float(best) : INFINITY, cur) : -INFINITY;
+            for (uint32_t S = sb; S < se; S++) {
+                const float4 C = centres[S];
+                const float rx = qx[g] - C.x, ry = qy[g] - C.y, rz = qz[g] - C.z;
+                const float Rg = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
+                uint4 b0g, b1g;
+                bt_pack(h ? ry : rx, b0g);
+                bt_pack(h ? 1.0f : rz, b1g);
+#pragma unroll 1
+                for (int tt = 0; tt < TPS; tt++) {
+                    const uint32_t T = S * TPS + tt;
+                    const uint4 A0 = ops[(size_t)T * 128 + lane], A1 = ops[(size_t)T * 128 + 64 + lane];
+                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), __builtin_bit_cast(bf16x8, b0g), zero, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1), __builtin_bit_cast(bf16x8, b1g), acc, 0, 0, 0);
+                    float m = big;
+#pragma unroll
+                    for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc[j]), acc[j + 1]);
+                    const float L = __builtin_fmaf(Rg, KAPPA, m);
+                    if (!((L - 1e-30f) > thr)) {
+                        const uint32_t j0 = (2 * T + (h ? 1u : 0u)) * CH;
+#pragma unroll 4
+                        for (int j = 0; j < CH; j++) {
+                            const float4 rec = records[j0 + j];
+                            const uint32_t e = d2_exact_bits(qx[g], qy[g], qz[g], rec.x, rec.y, rec.z);
+                            const uint32_t oi = __float_as_uint(rec.w);
+                            if (e < best || (e == best && e < 0x7F7FFFFFu && oi < bidx)) { best = e; bidx = oi; }
+                        }
+                        if (bidx != 0xFFFFFFFFu) thr = fminf(thr, __uint_as_float(best));
+                    }
+                }
+            }
+            const uint32_t bo = (uint32_t)__shfl_xor((int)best, 32, 64), io = (uint32_t)__shfl_xor((int)bidx, 32, 64);
+            if (bo < best || (bo == best && io < bidx)) { best = bo; bidx = io; }
         } else if (unsettled) {
             if (stats && lane == 0) atomicAdd(&stats[2], 1ull);          // diagnostics: (wave, query group) pairs that had to rescan
-            // exact rescan of the slice by the whole wave, each half-lane one half of it (bf16 form; non-finite queries)
+            // exact rescan of the slice by the whole wave, each half-lane one half of it (non-finite queries)
             const uint32_t r0 = sb * BT_SUPER, r1 = min(se * BT_SUPER, n_rec), mid = r0 + (r1 - r0) / 2;
             unsigned long long kbest = ~0ull;
             for (uint32_t j = h ? mid : r0; j < (h ? r1 : mid); j++) {
@@ -907,9 +944,9 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
         const size_t n_super = g->n_tiles / (BT_SUPER / 32);
         int64_t sps = tune_get(ctx, "nn1_supers_per_slice", 0);
         if (sps <= 0) {
-            // (120 k: 8 / 4 super-tiles per slice, the measured optima — the f16 form since its unsettled queries are filtered again instead
-            // of rescanned exactly: 3 super-tiles per slice before that)
-            const int64_t want_blocks = tune_get(ctx, "nn1_btrack_blocks", f16 ? 14336 : 32768);
+            // (120 k: 8 super-tiles per slice, the measured optimum of both forms since their unsettled queries are filtered again instead
+            // of rescanned exactly: 3 (f16) / 4 (bf16) super-tiles per slice before that)
+            const int64_t want_blocks = tune_get(ctx, "nn1_btrack_blocks", 14336);
             const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
             sps = std::max<int64_t>(1, ((int64_t)n_super + slices - 1) / slices);
         }
