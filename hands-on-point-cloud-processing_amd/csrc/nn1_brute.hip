@@ -523,7 +523,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
     // (query block, slice) of this workgroup.  xq = 0: the plain 2-D launch — workgroups go to the 8 XCDs round-robin, so every XCD's
     // L2 pulls in ALL operands and ALL queries.  xq = 1 / 2 / 4: a 1-D launch in which XCD k = id % 8 owns the query blocks = k % xq
     // (mod xq) and the slices = k / xq (mod 8 / xq): its L2 holds 1 / xq of the queries and xq / 8 of the operands.
-    // lds (F16 only, tune nn1_lds_ops, bit 8 of xq): the four waves of a workgroup scan the SAME tiles for different queries; instead of
+    // lds (template LDSA; tune nn1_lds_ops: 1 = the f16 form (default), 3 = both forms, 2 = off): the four waves of a workgroup scan the SAME tiles for different queries; instead of
     // four per-wave streams of 16-byte loads from L1 / L2, the workgroup stages the operands of one super-tile (8 KB; bf16: 16 KB) in LDS, the next
     // one prefetched into registers a whole super-tile ahead, one barrier per super-tile.  (A wave beyond the queries then stays for
     // the barriers: it repeats the last query and stores nothing.)
