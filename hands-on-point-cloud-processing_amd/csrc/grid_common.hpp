@@ -92,6 +92,7 @@ struct BtIndex {
     int* bad16 = nullptr;             // device flag, read lazily (bad16_host: -1 unknown)
     int bad16_host = -1;
     size_t n_tiles = 0;
+    float key_lo[3] = { 0.f, 0.f, 0.f }, key_inv = 0.f;   // the lattice of the Morton keys the records are ordered by (bt_sort_working_cloud)
     bool safe = false;                // every finite coordinate below 5e17 in magnitude (and at least one finite point)
 };
 // HTRACK operand helpers (device): v ~ p1 + p2 in f16 (round toward zero, then the remainder), and the 16 bytes a lane holds for
@@ -124,5 +125,7 @@ int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt);
 int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
 // replaces *work by its cell-sorted copy (ctx->work_orig = original indices); no-op for empty clouds / tune grid_sort_work = 2
 int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
+// the same for a brute-force loop over the matrix-core index: *work in the Morton order of the target's super-tiles (no-op without that index)
+int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
 
 }  // namespace pcr

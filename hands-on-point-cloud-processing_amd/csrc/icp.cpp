@@ -15,6 +15,17 @@ using namespace pcr;
 // the dispatcher's rule (api.cpp nn1_auto_grid) for the searches of a loop
 static bool icp_uses_grid(const pcr_ctx* ctx, const pcr_cloud* tgt) { return nn1_auto_grid(ctx, tgt, true, 0); }
 
+// a brute-force loop over a target that takes the matrix-core kernels (>= 8 192 points): the working cloud in the order of the
+// target's super-tiles when the loop is long enough to pay for the sort (csrc/grid.hip bt_sort_working_cloud)
+static int icp_sort_for_brute(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, uint64_t max_iter)
+{
+    ctx->work_orig_src = nullptr;
+    if (max_iter < 8 || tgt->n < 8192 || tune_get(ctx, "nn1_bf16", 0) == 2) return PCR_OK;      // (the sort costs ~0.1 ms at 120 k, an iteration gains ~0.02 ms)
+    const int64_t v = tune_get(ctx, "nn1_variant", 0);
+    if (v != 0 && v != 6 && v != 7) return PCR_OK;
+    return bt_sort_working_cloud(ctx, tgt, work);
+}
+
 // ---- synchronous loop: one host round trip per iteration (needed by the host-callback transport; also the
 // reference implementation of the loop the pipelined variant below must reproduce bit for bit)
 static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, const float init_T[16],
@@ -39,7 +50,7 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
     const float R0[9] = { init_T[0], init_T[1], init_T[2], init_T[4], init_T[5], init_T[6], init_T[8], init_T[9], init_T[10] };
     const float t0[3] = { init_T[3], init_T[7], init_T[11] };
     rc = launch_transform(ctx, work, R0, t0);                                    // :874
-    if (rc == PCR_OK && icp_uses_grid(ctx, tgt)) rc = grid_sort_working_cloud(ctx, tgt, &work);
+    if (rc == PCR_OK) rc = icp_uses_grid(ctx, tgt) ? grid_sort_working_cloud(ctx, tgt, &work) : icp_sort_for_brute(ctx, tgt, &work, prm->max_iter);
     float T_total[16] = { R0[0], R0[1], R0[2], t0[0], R0[3], R0[4], R0[5], t0[1],
                           R0[6], R0[7], R0[8], t0[2], 0, 0, 0, 1 };              // :910-913
     float last_loss = 0.0f;                                                      // :915
@@ -152,7 +163,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     const float R0[9] = { init_T[0], init_T[1], init_T[2], init_T[4], init_T[5], init_T[6], init_T[8], init_T[9], init_T[10] };
     const float t0[3] = { init_T[3], init_T[7], init_T[11] };
     rc = launch_transform(ctx, work, R0, t0);                                    // :874
-    if (rc == PCR_OK && icp_uses_grid(ctx, tgt)) rc = grid_sort_working_cloud(ctx, tgt, &work);
+    if (rc == PCR_OK) rc = icp_uses_grid(ctx, tgt) ? grid_sort_working_cloud(ctx, tgt, &work) : icp_sort_for_brute(ctx, tgt, &work, prm->max_iter);
     IcpState& h0 = host[RING];
     memset(&h0, 0, sizeof h0);
     const float T0[16] = { R0[0], R0[1], R0[2], t0[0], R0[3], R0[4], R0[5], t0[1], R0[6], R0[7], R0[8], t0[2], 0, 0, 0, 1 };
