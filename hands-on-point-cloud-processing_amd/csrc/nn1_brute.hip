@@ -40,6 +40,7 @@ namespace pcr {
 constexpr int NN_BLOCK = 256;
 constexpr int NN_TILE = 1024;   // targets per LDS tile: 3 * 4 KiB
 constexpr bool NN_F16_DEFAULT = true;      // measured: 0.72 against 0.88 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
+constexpr bool NN_PAIR_CHUNKS = true;      // LDS-staged f16 form: first / second minimum tracked per pair of tiles (chunks of 32 records)
 constexpr int NN_LDS_OPS_DEFAULT = 1;      // matrix-core operands staged through LDS per workgroup (tune nn1_lds_ops: 1 on, 2 off): 0.706 against 0.737 ms per 120k x 120k search
 constexpr int NN_XCD_DEFAULT = 4;          // XCD-aware launch of the matrix-core kernels (tune nn1_xcd; nn1_btrack_kernel): 24.6 against 68.5 MiB fetched per 120k x 120k launch, same time
 constexpr bool NN_BF16_DEFAULT = true;     // measured: 0.90 against 1.30 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
@@ -507,8 +508,13 @@ __device__ __forceinline__ void ht_setup(float qx, float qy, float qz, const flo
     bq = make_uint4(f1, f2, h ? 0x3C003C00u : s1, h ? 0u : s2);
 }
 
+// waves per SIMD the headline instance (four query groups, f16, LDS-staged) is built for: 5 = at most 96 VGPRs (two spilled outside the
+// tile loop) — measured 0.574 (130 VGPRs, unbounded) / 0.559 (4 waves, 128) / 0.551 ms (5 waves) per 120 k x 120 k search
+#ifndef PCR_BT_WAVES
+#define PCR_BT_WAVES 5
+#endif
 template <int QG, bool F16, bool LDSA = false>
-__global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
+__global__ __launch_bounds__(NN_BLOCK, (F16 && LDSA && QG == 4) ? PCR_BT_WAVES : 1) void nn1_btrack_kernel(
     const float4* __restrict__ centres, const uint4* __restrict__ ops, const float4* __restrict__ records, uint32_t n_rec, uint32_t n_super,
     uint32_t supers_per_slice, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
     unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop, unsigned long long* __restrict__ stats,
@@ -528,6 +534,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
     // one prefetched into registers a whole super-tile ahead, one barrier per super-tile.  (A wave beyond the queries then stays for
     // the barriers: it repeats the last query and stores nothing.)
     constexpr bool lds = LDSA;
+    constexpr bool PAIR = F16 && LDSA && NN_PAIR_CHUNKS;      // chunks of 32 records (two tiles), see the f16 loop
     uint32_t qb = blockIdx.x, sl = blockIdx.y;
     if (xq) {
         const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, xs = 8u / xq, qb_per = (qblocks + xq - 1) / xq;
@@ -577,6 +584,33 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
             float R[QG];
 #pragma unroll
             for (int g = 0; g < QG; g++) ht_setup(qx[g], qy[g], qz[g], C, h, bq[g], R[g], inv2);
+            if (PAIR) {
+                // chunks of 32: the minimum chain of a lane runs on through the two tiles of a pair (the second tile's chain starts from the
+                // first tile's minimum), and first / second minimum and the winning chunk are tracked once per PAIR — 3 of the 22 vector
+                // issue slots of a tile less.  Chunk 2 P + h = the records of half-lane h in tiles 2 P and 2 P + 1 (two runs of 16).
+                static_assert(TPS % 2 == 0, "pairs of tiles must not straddle super-tiles");
+#pragma unroll 1
+                for (int tp = 0; tp < TPS / 2; tp++) {
+                    const uint32_t Pr = (S * TPS) / 2 + tp;
+                    const uint4 A0 = sA[lds ? buf : 0][lds ? (2 * tp) * 64 + lane : 0], A1 = sA[lds ? buf : 0][lds ? (2 * tp + 1) * 64 + lane : 0];
+                    const uint32_t c = 2 * Pr + (h ? 1u : 0u);
+#pragma unroll
+                    for (int g = 0; g < QG; g++) {
+                        const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A0), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
+                        float m = big;
+#pragma unroll
+                        for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc0[j]), acc0[j + 1]);
+                        const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A1), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc1[j]), acc1[j + 1]);
+                        const float L = __builtin_fmaf(m, inv2, R[g]);
+                        m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], L);
+                        const bool better = L < m1[g];
+                        m1[g] = better ? L : m1[g];
+                        c1[g] = better ? c : c1[g];
+                    }
+                }
+            } else {
 #pragma unroll 1
             for (int tt = 0; tt < TPS; tt++) {
                 const uint32_t T = S * TPS + tt;
@@ -599,6 +633,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
                     m1[g] = better ? L : m1[g];
                     c1[g] = better ? c : c1[g];
                 }
+            }
             }
             if (lds) {
                 if (S + 1 < se) { sA[lds ? buf ^ 1u : 0][lds ? threadIdx.x : 0] = pre0; sA[lds ? buf ^ 1u : 0][lds ? NN_BLOCK + threadIdx.x : 0] = pre1; }
@@ -684,10 +719,11 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_btrack_kernel(
         const float cur = cur0[g];                            // see nn1_etrack_kernel: what the other slices have published
         const bool slice_out = okq[g] && (M1 - 1e-30f) > cur;
         if (!slice_out && okq[g] && C1 != 0xFFFFFFFFu) {
-            // exact A1 evaluation of the 16 records of chunk C1: 8 per half-lane, merged lexicographically (d2, index)
-            const uint32_t j0 = C1 * CH + (h ? 8u : 0u);
+            // exact A1 evaluation of the records of chunk C1, split over the two half-lanes, merged lexicographically (d2, index):
+            // 16 records = 8 each; a pair chunk (PAIR) = the winner's half-lane run of 16 in each of its two tiles, one run each
+            const uint32_t j0 = PAIR ? (4u * (C1 >> 1) + (C1 & 1u) + (h ? 2u : 0u)) * CH : C1 * CH + (h ? 8u : 0u);
 #pragma unroll
-            for (int j = 0; j < CH / 2; j++) {
+            for (int j = 0; j < (PAIR ? CH : CH / 2); j++) {
                 const float4 rec = records[j0 + j];                                     // (padding records: x = +inf, never accepted)
                 const uint32_t e = d2_exact_bits(qx[g], qy[g], qz[g], rec.x, rec.y, rec.z);
                 const uint32_t oi = __float_as_uint(rec.w);
