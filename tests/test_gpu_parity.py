@@ -487,6 +487,40 @@ def test_icp_state_machine_matches_oracle(ctx, orc, synth):
     cs.free(); ct.free(); far.free()
 
 
+def test_matrix_core_search_switches_change_no_bit(ctx, synth):
+    """The launch / staging / ordering switches of the matrix-core brute-force search are speed only: LDS-staged operands on / off / for
+    both forms (nn1_lds_ops), XCD-aware launch off / 1 / 2 / 4 (nn1_xcd), the loop's sorted working cloud off (bt_sort_work), slice length
+    (nn1_supers_per_slice), query groups per wave (nn1_btrack_qg), each for the f16 and the bf16 form — same keys as the exact-only kernel
+    for a one-shot search, same pose / statistics / loss for a 10-iteration loop."""
+    n = 21000                                                       # > 8 192: the matrix-core kernels answer; 83 super-tiles
+    src, tgt = synth.kitti_like_pair(n, seed_target=601, seed_pair=602)
+    ctx.tune("nn_method", 1)
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    ctx.tune("nn1_variant", 2)
+    ref_idx, ref_d2 = ctx.nn1(ct, cs)
+    ctx.tune("nn1_variant", 0)
+    T0, st0 = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=10, eps=0.0)
+    switches = [dict(nn1_lds_ops=2), dict(nn1_lds_ops=3), dict(nn1_xcd=-1), dict(nn1_xcd=1), dict(nn1_xcd=2), dict(bt_sort_work=2),
+                dict(nn1_supers_per_slice=1), dict(nn1_supers_per_slice=5), dict(nn1_supers_per_slice=40), dict(nn1_btrack_qg=2), dict(nn1_btrack_qg=1),
+                dict(nn1_f16=2), dict(nn1_f16=2, nn1_lds_ops=3), dict(nn1_f16=2, nn1_lds_ops=2, nn1_supers_per_slice=2)]
+    for sw in switches:
+        for k, v in sw.items():
+            ctx.tune(k, v)
+        fresh = ctx.cloud(tgt)                                      # cold, unseeded search of a target without an index
+        idx, d2 = ctx.nn1(fresh, cs)
+        assert np.array_equal(idx, ref_idx) and np.array_equal(bits32(d2), bits32(ref_d2)), sw
+        T, st = ctx.icp_point2point(cs, fresh, max_corr=1.0, max_iter=10, eps=0.0)
+        assert np.array_equal(T.view(np.uint32), T0.view(np.uint32)), sw
+        for k in ("iters_run", "converged", "empty_pairs", "last_pairs"):
+            assert st[k] == st0[k], (k, sw)
+        assert np.float32(st["last_loss"]).view(np.uint32) == np.float32(st0["last_loss"]).view(np.uint32), sw
+        fresh.free()
+        for k in sw:
+            ctx.tune(k, 0)
+    ctx.tune("nn_method", 0)
+    cs.free(); ct.free()
+
+
 @pytest.mark.parametrize("n", [100, 128, 300, 1500, 2047, 2048])
 def test_icp_auto_dispatch_of_small_targets_changes_no_bit(ctx, synth, n):
     """Inside a loop the dispatcher sends targets from 128 points on to the exact grid (api.cpp nn1_auto_grid: max_iter >= 5 or an
