@@ -40,10 +40,6 @@ namespace pcr {
 constexpr int NN_BLOCK = 256;
 constexpr int NN_TILE = 1024;   // targets per LDS tile: 3 * 4 KiB
 constexpr bool NN_F16_DEFAULT = true;      // measured: 0.72 against 0.88 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
-#ifndef PCR_CHUNK_TILES
-#define PCR_CHUNK_TILES 2
-#endif
-constexpr int NN_CHUNK_TILES = PCR_CHUNK_TILES;   // tiles per chunk of the LDS-staged f16 form (2: chunks of 32 records)
 constexpr bool NN_PAIR_CHUNKS = true;      // LDS-staged f16 form: first / second minimum tracked per pair of tiles (chunks of 32 records)
 constexpr int NN_LDS_OPS_DEFAULT = 1;      // matrix-core operands staged through LDS per workgroup (tune nn1_lds_ops: 1 on, 2 off): 0.706 against 0.737 ms per 120k x 120k search
 constexpr int NN_XCD_DEFAULT = 4;          // XCD-aware launch of the matrix-core kernels (tune nn1_xcd; nn1_btrack_kernel): 24.6 against 68.5 MiB fetched per 120k x 120k launch, same time
@@ -538,8 +534,7 @@ __global__ __launch_bounds__(NN_BLOCK, (F16 && LDSA && QG == 4) ? PCR_BT_WAVES :
     // one prefetched into registers a whole super-tile ahead, one barrier per super-tile.  (A wave beyond the queries then stays for
     // the barriers: it repeats the last query and stores nothing.)
     constexpr bool lds = LDSA;
-    constexpr bool PAIR = F16 && LDSA && NN_PAIR_CHUNKS;      // chunks of 16 NT records (NT tiles), see the f16 loop
-    constexpr int NT = NN_CHUNK_TILES;
+    constexpr bool PAIR = F16 && LDSA && NN_PAIR_CHUNKS;      // chunks of 32 records (two tiles), see the f16 loop
     uint32_t qb = blockIdx.x, sl = blockIdx.y;
     if (xq) {
         const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, xs = 8u / xq, qb_per = (qblocks + xq - 1) / xq;
@@ -590,27 +585,24 @@ __global__ __launch_bounds__(NN_BLOCK, (F16 && LDSA && QG == 4) ? PCR_BT_WAVES :
 #pragma unroll
             for (int g = 0; g < QG; g++) ht_setup(qx[g], qy[g], qz[g], C, h, bq[g], R[g], inv2);
             if (PAIR) {
-                // chunks of 16 NT records (NT = 2): the minimum chain of a lane runs on through the NT tiles of a group (each tile's chain
-                // starts from the previous tile's minimum), and first / second minimum and the winning chunk are tracked once per group of
-                // tiles — 3 of the 22 vector issue slots of a tile less at NT = 2.  Chunk NT-group P, half-lane h: id 2 P + h = the
-                // records of half-lane h in tiles NT P .. NT P + NT - 1 (NT runs of 16).
-                static_assert(TPS % NT == 0, "groups of tiles must not straddle super-tiles");
+                // chunks of 32: the minimum chain of a lane runs on through the two tiles of a pair (the second tile's chain starts from the
+                // first tile's minimum), and first / second minimum and the winning chunk are tracked once per PAIR — 3 of the 22 vector
+                // issue slots of a tile less.  Chunk 2 P + h = the records of half-lane h in tiles 2 P and 2 P + 1 (two runs of 16).
+                static_assert(TPS % 2 == 0, "pairs of tiles must not straddle super-tiles");
 #pragma unroll 1
-                for (int tp = 0; tp < TPS / NT; tp++) {
-                    const uint32_t Pr = (S * TPS) / NT + tp;
-                    uint4 A[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; t++) A[t] = sA[lds ? buf : 0][lds ? (NT * tp + t) * 64 + lane : 0];
+                for (int tp = 0; tp < TPS / 2; tp++) {
+                    const uint32_t Pr = (S * TPS) / 2 + tp;
+                    const uint4 A0 = sA[lds ? buf : 0][lds ? (2 * tp) * 64 + lane : 0], A1 = sA[lds ? buf : 0][lds ? (2 * tp + 1) * 64 + lane : 0];
                     const uint32_t c = 2 * Pr + (h ? 1u : 0u);
 #pragma unroll
                     for (int g = 0; g < QG; g++) {
+                        const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A0), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
                         float m = big;
 #pragma unroll
-                        for (int t = 0; t < NT; t++) {
-                            const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[t]), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
+                        for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc0[j]), acc0[j + 1]);
+                        const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A1), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
 #pragma unroll
-                            for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc[j]), acc[j + 1]);
-                        }
+                        for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc1[j]), acc1[j + 1]);
                         const float L = __builtin_fmaf(m, inv2, R[g]);
                         m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], L);
                         const bool better = L < m1[g];
@@ -729,17 +721,13 @@ __global__ __launch_bounds__(NN_BLOCK, (F16 && LDSA && QG == 4) ? PCR_BT_WAVES :
         if (!slice_out && okq[g] && C1 != 0xFFFFFFFFu) {
             // exact A1 evaluation of the records of chunk C1, split over the two half-lanes, merged lexicographically (d2, index):
             // 16 records = 8 each; a pair chunk (PAIR) = the winner's half-lane run of 16 in each of its two tiles, one run each
-            // (chunk 2 P + hw of the NT-tile form: tile NT P + t holds its run t at old chunk id 2 (NT P + t) + hw; half-lane h takes t = h, h + 2, ..)
+            const uint32_t j0 = PAIR ? (4u * (C1 >> 1) + (C1 & 1u) + (h ? 2u : 0u)) * CH : C1 * CH + (h ? 8u : 0u);
 #pragma unroll
-            for (int t = 0; t < (PAIR ? NT / 2 : 1); t++) {
-                const uint32_t j0 = PAIR ? (2u * ((uint32_t)NT * (C1 >> 1) + 2u * (uint32_t)t + (h ? 1u : 0u)) + (C1 & 1u)) * CH : C1 * CH + (h ? 8u : 0u);
-#pragma unroll
-                for (int j = 0; j < (PAIR ? CH : CH / 2); j++) {
-                    const float4 rec = records[j0 + j];                                 // (padding records: x = +inf, never accepted)
-                    const uint32_t e = d2_exact_bits(qx[g], qy[g], qz[g], rec.x, rec.y, rec.z);
-                    const uint32_t oi = __float_as_uint(rec.w);
-                    if (e < best || (e == best && e < 0x7F7FFFFFu && oi < bidx)) { best = e; bidx = oi; }
-                }
+            for (int j = 0; j < (PAIR ? CH : CH / 2); j++) {
+                const float4 rec = records[j0 + j];                                     // (padding records: x = +inf, never accepted)
+                const uint32_t e = d2_exact_bits(qx[g], qy[g], qz[g], rec.x, rec.y, rec.z);
+                const uint32_t oi = __float_as_uint(rec.w);
+                if (e < best || (e == best && e < 0x7F7FFFFFu && oi < bidx)) { best = e; bidx = oi; }
             }
             const uint32_t bo = (uint32_t)__shfl_xor((int)best, 32, 64), io = (uint32_t)__shfl_xor((int)bidx, 32, 64);
             if (bo < best || (bo == best && io < bidx)) { best = bo; bidx = io; }
