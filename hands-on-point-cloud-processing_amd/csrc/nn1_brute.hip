@@ -745,9 +745,19 @@ __global__ __launch_bounds__(NN_BLOCK, (F16 && LDSA && QG == 4) ? PCR_BT_WAVES :
             const bool active = !(proven || slice_out);
             float thr = active ? fminf(bidx != 0xFFFFFFFFu ? __uint_as_float(best) : INFINITY, cur) : -INFINITY;
             for (uint32_t S = sb; S < se; S++) {
+                const float4 C = centres[S];
+                // A super-tile none of whose records can lie within the threshold of any unsettled query of the group is not filtered again
+                // (its pairs WERE evaluated by the main pass): every record lies within 128 / scale of the centre in each coordinate
+                // (bt_centres_kernel), so |q - t| >= |q - C| - sqrt(3) 128 / scale.
+                {
+                    const float dx = qx[g] - C.x, dy = qy[g] - C.y, dz = qz[g] - C.z;
+                    const float gap = sqrtf((dx * dx + dy * dy) + dz * dz) * 0.99999f - (221.7026f / C.w) * 1.00001f;
+                    const bool cannot = !active || (gap > 0.0f && gap * gap * 0.99999f > thr);        // (false for NaN: scanned)
+                    if (__all(cannot)) continue;
+                }
                 uint4 bqg;
                 float Rg, inv2;
-                ht_setup(qx[g], qy[g], qz[g], centres[S], h, bqg, Rg, inv2);
+                ht_setup(qx[g], qy[g], qz[g], C, h, bqg, Rg, inv2);
 #pragma unroll 1
                 for (int tt = 0; tt < TPS; tt++) {
                     const uint32_t T = S * TPS + tt;
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(NN_BLOCK, (F16 && LDSA && QG == 4) ? PCR_BT_WAVES :
                     const float L = __builtin_fmaf(m, inv2, Rg);
                     if (!((L - 1e-30f) > thr)) {                     // (also taken for a NaN bound: evaluating a chunk is always safe)
                         const uint32_t j0 = (2 * T + (h ? 1u : 0u)) * CH;
-#pragma unroll 4
+#pragma unroll
                         for (int j = 0; j < CH; j++) {
                             const float4 rec = records[j0 + j];
                             const uint32_t e = d2_exact_bits(qx[g], qy[g], qz[g], rec.x, rec.y, rec.z);
