@@ -500,8 +500,10 @@ def main():
                                     "re-evaluation of the winning chunk are overhead, not numerator.  peak = 157.3 TF/s vector f32 (FMA = 2).  "
                                     "SURVEY.md 8d's 9-op-per-pair convention describes the EXACT kernel: kernels.nn1_exact_track"),
                     "fp32_equivalent": {"achieved": ETRACK_FLOPS_PER_PAIR * pairs / kern_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": ETRACK_FLOPS_PER_PAIR * pairs / kern_s / 1e12 / VALU_PEAK_TFLOPS,
-                                        "note": "the f32 filter's 3 FMAs per pair over this launch's time, against the vector f32 peak"},
+                                        "ratio": ETRACK_FLOPS_PER_PAIR * pairs / kern_s / 1e12 / VALU_PEAK_TFLOPS,
+                                        "note": "the f32 filter's 3 FMAs per pair over this launch's time, against the vector f32 peak — an "
+                                                "EQUIVALENT, not a bound (for the f16 / bf16 kernels the matrix cores do these multiplications: "
+                                                "the ratio may pass 1); the roofline fraction of the kernel that ran is roofline.frac"},
                     "issue": ({"executed_lane_ops_per_pair": pmc["valu_insts_per_launch"] * 64 / pairs,
                                "issue_frac": pmc["valu_insts_per_launch"] * 64 / kern_s / 1e12 / VALU_PEAK_TOPS_NOFMA,
                                "note": "SQ_INSTS_VALU x 64 lanes / time / 78.6 T issue slots per second (same PMC passes)"} if pmc else None),
