@@ -9,7 +9,7 @@
 
 A *step* is one point-to-point ICP iteration on the BASELINE.json configs[1]/[2] workload: 1-NN correspondence of the source
 points against the 120 000-point target (exhaustive / brute force) + Kabsch accumulation + (N > 1: one RCCL all-reduce of
-16 + 2N f64) + 3x3 SVD + in-place transform.  W untimed iterations, then exactly K iterations timed between
+56 + 2N f64) + 3x3 SVD + in-place transform.  W untimed iterations, then exactly K iterations timed between
 barrier + torch.cuda.synchronize() on both sides; max over ranks.
 
 value            = correspondences of the whole job per second (M corr/s) on ONE 120 000 x 120 000 pair; with N > 1 ranks the
@@ -224,7 +224,7 @@ def main():
     if world > 1:
         collective = args.collective
         if collective == "rccl":
-            # native transport: the library's own RCCL communicator (one ncclAllReduce of 16 + 2N f64 per iteration, enqueued
+            # native transport: the library's own RCCL communicator (one ncclAllReduce of 56 + 2N f64 per iteration, enqueued
             # on the context stream).  Every step below is collective-safe: rank 0 ALWAYS broadcasts (the id or None),
             # and the ranks agree on the outcome before anybody uses the communicator.
             uid = [None]
@@ -354,12 +354,31 @@ def main():
         T, st, dt = timed_icp(cs, ct, main_method, src)
         nn_name = "nn1_brute" if args.nn == "brute" else "nn1_grid"
         nn_launches, nn_ms = ctx.prof_get(nn_name)
+        family = ctx.mfma_check()["last_nn1_kernel"]        # which kernel family the library's dispatcher took for the timed searches
         kern_s = nn_ms / 1e3 / max(nn_launches, 1)
         n_q, n_t = src.shape[1], tgt.shape[1]
         pairs = float(n_q) * float(n_t)
         default_kernels = not (args.qpl or args.variant)
         extras = not args.no_extras
         bd = kernel_breakdown(cs, ct, main_method, min(args.steps, 10)) if extras else {}
+
+        # ---- the shader clock the chip holds under the headline kernel's own load: s_memtime / s_memrealtime stamps of a diagnostics
+        # launch (tune grid_stats) that follows 40 back-to-back launches of the same seeded search; median of 3
+        clock_mhz = None
+        if extras and args.nn == "brute" and family in ("htrack", "btrack"):
+            ca = cs.clone(); ctx.transform(ca, T)
+            ctx.tune("nn_method", 1); ctx.tune("prof", 0); ctx.tune("nn1_async_in_loop", 1)
+            clocks = []
+            for _ in range(3):
+                for _ in range(40):
+                    ctx.nn1_async(ct, ca)
+                ctx.tune("grid_stats", 1); ctx.nn1_async(ct, ca); ctx.tune("grid_stats", 0)
+                w = ctx.nn1_stats()
+                if w[5]:
+                    clocks.append(w[4] / w[5] * 100.0)
+            ctx.tune("nn1_async_in_loop", 0)
+            ca.free()
+            clock_mhz = sorted(clocks)[len(clocks) // 2] if clocks else None
 
         # ---- the exact-only kernel (the 9-op convention's own kernel), the cold searches: a few launches each, HIP-event timed
         exact_line, one_shot = None, None
@@ -456,8 +475,9 @@ def main():
         if rank == 0:
             gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
             if args.nn == "brute":
-                bf16 = default_kernels and tunes_env.get("nn1_bf16", 0) != 2 and tunes_env.get("nn1_variant", 0) in (0, 6, 7) and (n_t >= 8192 or tunes_env.get("nn1_variant", 0) in (6, 7))
-                f16 = bf16 and tunes_env.get("nn1_f16", 0) != 2 and tunes_env.get("nn1_variant", 0) in (0, 7)
+                f16 = family == "htrack"
+                bf16 = family in ("htrack", "btrack")
+                slots_pp = 32 if f16 else 64                 # flop per pair of ALL K-slots the matrix instruction(s) execute (16 / 2 x 16 multiply-adds)
                 flops_pp = HTRACK_FLOPS_PER_PAIR if f16 else BTRACK_FLOPS_PER_PAIR if bf16 else ETRACK_FLOPS_PER_PAIR
                 peak_tf = MFMA_BF16_PEAK_TFLOPS if bf16 else VALU_PEAK_TFLOPS
                 achieved_tflops = flops_pp * pairs / kern_s / 1e12
@@ -499,6 +519,26 @@ def main():
                                     "kernel that ran; the min-tree, the per-chunk prologue (|q - C|^2, 11 ops per 16 targets) and the exact "
                                     "re-evaluation of the winning chunk are overhead, not numerator.  peak = 157.3 TF/s vector f32 (FMA = 2).  "
                                     "SURVEY.md 8d's 9-op-per-pair convention describes the EXACT kernel: kernels.nn1_exact_track"),
+                    "kernel_family": family,
+                    "survey_8d_convention": {"achieved": OPS_PER_PAIR * pairs / kern_s / 1e12, "peak": VALU_PEAK_TOPS_NOFMA, "unit": "T lane-ops/s",
+                                             "ratio": OPS_PER_PAIR * pairs / kern_s / 1e12 / VALU_PEAK_TOPS_NOFMA,
+                                             "note": "SURVEY.md 8d's own figure: 9 f32 lane-ops per (query, target) pair / 78.6 T lane-ops/s.  It "
+                                                     "exceeds 1 for the matrix-core kernels because the products run on the matrix pipe (every pair "
+                                                     "is still evaluated: SQ_INSTS_MFMA = pairs / 1024 per MFMA of the form) — a ratio, not a bound; "
+                                                     "the kernel this convention describes is kernels.nn1_exact_track"},
+                    "executed_slots": ({"flop_per_pair": slots_pp, "achieved": slots_pp * pairs / kern_s / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": slots_pp * pairs / kern_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                        "note": "every K-slot the matrix instructions execute (16 multiply-adds per pair and MFMA), data-carrying or not"}
+                                       if bf16 else None),
+                    "shader_clock": ({"mhz": clock_mhz, "nominal_mhz": 2400.0,
+                                      "peak_at_measured_clock": peak_tf * clock_mhz / 2400.0,
+                                      "frac_at_measured_clock": achieved_tflops / (peak_tf * clock_mhz / 2400.0),
+                                      "note": "sum of s_memtime cycles / sum of s_memrealtime ticks (100 MHz) over the workgroups of a diagnostics "
+                                              "launch that follows 40 back-to-back launches of the same seeded search (median of 3): the peak the "
+                                              "chip could reach at the clock it actually holds under this kernel"} if clock_mhz else None),
+                    "reproduce": (f"achieved = {flops_pp} x {n_q} x {n_t} / (avg_launch_ms / 1e3) / 1e12; frac = achieved / {peak_tf:g}; avg_launch_ms = HIP "
+                                  "events around every search of the timed region (same kernel's average in profiles/*_bench_rocprof_summary.md); "
+                                  "traffic = 2 x FETCH_SIZE + WRITE_SIZE per launch of the --pmc passes stamped with lib_sha16"),
                     "fp32_equivalent": {"achieved": ETRACK_FLOPS_PER_PAIR * pairs / kern_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "ratio": ETRACK_FLOPS_PER_PAIR * pairs / kern_s / 1e12 / VALU_PEAK_TFLOPS,
                                         "note": "the f32 filter's 3 FMAs per pair over this launch's time, against the vector f32 peak — an "
@@ -523,7 +563,12 @@ def main():
                 "config": {"workload": workload, "nn": args.nn, "n_src_this_rank": n_q, "n_src_total": n, "n_tgt": n_t, "max_corr": 1.0,
                            "sharding": f"sources x{world} (contiguous blocks of the ONE pair), target replicated", "collective": collective,
                            "pose_err_vs_gt_fro": gt_err, "kept_pairs_last_iter": int(st["last_pairs"]), "lib_sha16": sha,
-                           "first_timed_iteration": "seeded by the warm-up run's correspondences (as every iteration after the first of an ICP is)"},
+                           "first_timed_iteration": "seeded by the warm-up run's correspondences (as every iteration after the first of an ICP is)",
+                           "M_corr_per_s_three_readings": ({"warm_icp_iteration (= value)": n * args.steps / dt / 1e6,
+                                                            "one_shot_indexed_target (kernel, cold)": one_shot["indexed_target"]["M_corr_per_s"],
+                                                            "one_shot_fresh_target (wall, index build included)": one_shot["fresh_target"]["M_corr_per_s"]}
+                                                           if (one_shot and world == 1) else None),
+                           "pose_bits": "".join(f"{int(v):08x}" for v in np.ascontiguousarray(T, np.float32).view(np.uint32).ravel())},
                 "roofline": roofline,
                 "kernels": dict(({"nn1_exact_track": exact_line} if exact_line else {}), **stream_kernels(bd, n_q, int(st["last_pairs"]) * n_q // max(n, 1))),
             }
@@ -566,11 +611,12 @@ def main():
                   "warmup": warm5, "ms_per_step": dt * 1e3 / steps5, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                   "data": "synthetic",
                   "config": {"workload": f"point-to-point ICP iteration on ONE {n_t} x {n5} pair = exact grid 1-NN + Kabsch + transform; BASELINE.json "
-                                         "configs[4] (sources sharded over the GPUs, one all-reduce of 16 + 2N f64 per iteration)",
+                                         "configs[4] (sources sharded over the GPUs, one all-reduce of 56 + 2N f64 per iteration)",
                              "nn": "grid", "n_src_this_rank": n_q, "n_src_total": n5, "n_tgt": n_t, "max_corr": 1.0,
                              "sharding": f"sources x{world}, target replicated", "collective": collective,
                              "pose_err_vs_gt_fro": float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose())),
-                             "kept_pairs_last_iter": int(st["last_pairs"]), "lib_sha16": sha},
+                             "kept_pairs_last_iter": int(st["last_pairs"]), "lib_sha16": sha,
+                             "pose_bits": "".join(f"{int(v):08x}" for v in np.ascontiguousarray(T, np.float32).view(np.uint32).ravel())},
                   "roofline": grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha),
                   "kernels": stream_kernels(bd, n_q, int(st["last_pairs"]) * n_q // max(n5, 1))}
             if args.workload == "c5":

@@ -44,6 +44,11 @@ class IcpStats(C.Structure):
                 ("ms_total", C.c_double), ("ms_nn", C.c_double), ("nn_launches", C.c_uint64)]
 
 
+class MfmaCheck(C.Structure):
+    _fields_ = [("f16_ok", C.c_int32), ("bf16_ok", C.c_int32), ("f16_worst", C.c_double * 4), ("bf16_worst", C.c_double * 4),
+                ("check_ms", C.c_double), ("last_nn1_kernel", C.c_char * 16)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
 # every symbol include/pcr.h declares (checked by tests/test_abi.py against the header text)
@@ -54,7 +59,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
+    "pcr_grid_stats", "pcr_nn1_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_ctx_mfma_check", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_match_inter_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
 
@@ -114,8 +119,10 @@ def lib():
     L.pcr_prof_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.pcr_tune_set.argtypes = [vp, C.c_char_p, C.c_int64]
     L.pcr_grid_stats.argtypes = [vp, vp]
+    L.pcr_nn1_stats.argtypes = [vp, vp]
     L.pcr_selftest_mfma_bf16.argtypes = [vp, C.c_int, vp]
     L.pcr_selftest_mfma_f16.argtypes = [vp, C.c_int, vp]
+    L.pcr_ctx_mfma_check.argtypes = [vp, C.c_int, C.POINTER(MfmaCheck)]
     L.pcr_voxel_filter_f32.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
     L.pcr_iss_keypoints_f32.argtypes = [vp, vp, C.POINTER(IssParams), vp, vp, vp, C.POINTER(C.c_uint64)]
     L.pcr_icp_p2plane_f32.argtypes = [vp, vp, vp, vp, vp, C.POINTER(IcpParams), vp, C.POINTER(IcpStats)]
@@ -324,7 +331,7 @@ class Context:
         ncu = C.c_int()
         hbm = C.c_uint64()
         self._ck(lib().pcr_ctx_device_info(self.h, arch, 64, C.byref(ncu), C.byref(hbm)))
-        return {"arch": arch.value.decode(), "cus": ncu.value, "hbm_bytes": hbm.value}
+        return {"arch": arch.value.decode(), "cus": ncu.value, "hbm_bytes": hbm.value, "mfma_check": self.mfma_check()}
 
     def tune(self, key: str, value: int):
         self._ck(lib().pcr_tune_set(self.h, key.encode(), int(value)))
@@ -334,17 +341,32 @@ class Context:
         self._ck(lib().pcr_grid_stats(self.h, out))
         return {"candidates": out[0], "fine_rows": out[1], "coarse_rows": out[2], "far_stages": out[3]}
 
+    def nn1_stats(self):
+        """the eight diagnostics words of the last 1-NN launch made with tune grid_stats = 1 (include/pcr.h)"""
+        out = (C.c_uint64 * 8)()
+        self._ck(lib().pcr_nn1_stats(self.h, out))
+        return [int(v) for v in out]
+
     def selftest_mfma_bf16(self, trials: int = 64):
-        """(worst accumulation error in 2^-24 sum|a b|, worst filter-value error in 2^-24 (|r|^2 + |t|^2)) measured on this device"""
-        out = (C.c_double * 2)()
+        """(accumulation error on random operands in 2^-24 sum|a b|, filter-value error in 2^-24 (|r|^2 + |t|^2), absolute error in 2^-24
+        in the small-magnitude regime, accumulation error on the structured tiles) measured on this device — include/pcr.h"""
+        out = (C.c_double * 4)()
         self._ck(lib().pcr_selftest_mfma_bf16(self.h, int(trials), out))
-        return float(out[0]), float(out[1])
+        return tuple(float(v) for v in out)
 
     def selftest_mfma_f16(self, trials: int = 64):
         """the same for the f16 form (one MFMA per tile, two-piece scaled operands)"""
-        out = (C.c_double * 2)()
+        out = (C.c_double * 4)()
         self._ck(lib().pcr_selftest_mfma_f16(self.h, int(trials), out))
-        return float(out[0]), float(out[1])
+        return tuple(float(v) for v in out)
+
+    def mfma_check(self, run_now: bool = False):
+        """The verdicts of the library's own once-per-context check of the matrix-core arithmetic (-1 = not run yet), the figures
+        behind them, the host time they took and the kernel family of the last 1-NN search."""
+        m = MfmaCheck()
+        self._ck(lib().pcr_ctx_mfma_check(self.h, 1 if run_now else 0, C.byref(m)))
+        return {"f16_ok": m.f16_ok, "bf16_ok": m.bf16_ok, "f16_worst": [float(v) for v in m.f16_worst], "bf16_worst": [float(v) for v in m.bf16_worst],
+                "check_ms": m.check_ms, "last_nn1_kernel": m.last_nn1_kernel.decode()}
 
     def prof_reset(self):
         self._ck(lib().pcr_prof_reset(self.h))

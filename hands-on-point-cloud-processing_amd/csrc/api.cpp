@@ -447,16 +447,30 @@ int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* t
     return PCR_OK;
 }
 
-int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[2])
+int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[4])
 {
     if (!ctx || !worst || trials < 0 || trials > 4096) return PCR_ERR_ARG;
     return pcr::bt_mfma_selftest(ctx, trials, worst);
 }
 
-int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[2])
+int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[4])
 {
     if (!ctx || !worst || trials < 0 || trials > 4096) return PCR_ERR_ARG;
     return pcr::ht_mfma_selftest(ctx, trials, worst);
+}
+
+int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out)
+{
+    if (!ctx || !out) return PCR_ERR_ARG;
+    if (run_now) { (void)pcr::mfma_verdict(ctx, true); (void)pcr::mfma_verdict(ctx, false); }
+    const int64_t force = tune_get(ctx, "mfma_force_fail", 0);
+    out->f16_ok = (force > 0 && (force & 1)) ? 0 : ctx->mfma_ok16;
+    out->bf16_ok = (force > 0 && (force & 2)) ? 0 : ctx->mfma_okbf;
+    for (int k = 0; k < 4; k++) { out->f16_worst[k] = ctx->mfma_worst16[k]; out->bf16_worst[k] = ctx->mfma_worstbf[k]; }
+    out->check_ms = ctx->mfma_check_ms;
+    strncpy(out->last_nn1_kernel, ctx->last_nn1_kernel, sizeof(out->last_nn1_kernel) - 1);
+    out->last_nn1_kernel[sizeof(out->last_nn1_kernel) - 1] = 0;
+    return PCR_OK;
 }
 
 int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4])
@@ -468,6 +482,18 @@ int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4])
     PCR_HIP(ctx, hipMemcpyAsync(h, ctx->grid_stats_dev, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 4; k++) out[k] = h[k];
+    return PCR_OK;
+}
+
+int pcr_nn1_stats(pcr_ctx* ctx, uint64_t out[8])
+{
+    if (!ctx || !out) return PCR_ERR_ARG;
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    if (!ctx->grid_stats_dev) return PCR_OK;
+    unsigned long long h[8];
+    PCR_HIP(ctx, hipMemcpyAsync(h, ctx->grid_stats_dev, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 8; k++) out[k] = h[k];
     return PCR_OK;
 }
 

@@ -1,4 +1,4 @@
-// comm.cpp — the one collective of the path: all-reduce(sum) of <= 64 f64 per ICP iteration.
+// comm.cpp — the one collective of the path: all-reduce(sum) of 56 + 2 * nranks <= 128 f64 per ICP iteration.
 // Transport 1: RCCL over xGMI (one process per GPU).  librccl is bound with dlopen at first use so that a
 // single-GPU process never loads it and so that, inside a PyTorch process, the already loaded
 // librccl.so.1 (same SONAME) is shared instead of a second copy.
@@ -141,10 +141,12 @@ int pcr_comm_unique_id(char id[PCR_COMM_ID_BYTES])
     return PCR_OK;
 }
 
+static_assert(56 + 2 * PCR_MAX_RANKS <= 128, "dev_out / host_out hold 128 doubles (api.cpp); icp_nred(nranks) = 56 + 2 * nranks");
+
 int pcr_comm_init_rccl(pcr_ctx* ctx, int nranks, int rank, const char id[PCR_COMM_ID_BYTES])
 {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_rccl");
-    if (nranks > PCR_MAX_RANKS) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_rccl: more than PCR_MAX_RANKS ranks (the reduce buffer holds 16 + 2 * nranks <= 64 f64)");
+    if (nranks > PCR_MAX_RANKS) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_rccl: more than PCR_MAX_RANKS ranks (the reduce buffer holds 56 + 2 * nranks <= 128 f64)");
     pcr_comm_destroy(ctx);
     Rccl& r = rccl();
     if (!r.handle) return fail(ctx, PCR_ERR_COMM, r.err.c_str());
@@ -166,7 +168,7 @@ int pcr_comm_init_rccl(pcr_ctx* ctx, int nranks, int rank, const char id[PCR_COM
 int pcr_comm_init_callback(pcr_ctx* ctx, int nranks, int rank, pcr_allreduce_fn fn, void* user)
 {
     if (!ctx || !fn || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_callback");
-    if (nranks > PCR_MAX_RANKS) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_callback: more than PCR_MAX_RANKS ranks (the reduce buffer holds 16 + 2 * nranks <= 64 f64)");
+    if (nranks > PCR_MAX_RANKS) return fail(ctx, PCR_ERR_ARG, "pcr_comm_init_callback: more than PCR_MAX_RANKS ranks (the reduce buffer holds 56 + 2 * nranks <= 128 f64)");
     pcr_comm_destroy(ctx);
     ctx->comm.nranks = nranks;
     ctx->comm.rank = rank;

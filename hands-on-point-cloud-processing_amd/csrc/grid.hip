@@ -1537,19 +1537,20 @@ int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work
     if (n == 0 || tune_get(ctx, "grid_sort_work", 1) != 1) return PCR_OK;
     int rc = grid_prepare_queries(ctx, tgt, w);                  // builds the target index if needed; ctx->qperm = the order
     if (rc) return rc;
-    pcr_cloud* sorted = nullptr;
-    rc = pcr_cloud_clone(ctx, w, &sorted);                        // same size, padding included
-    if (rc) return rc;
-    if (ctx->work_orig_cap < n) {
+    if (ctx->work_orig_cap < n) {                                 // (before the clone: nothing to give back on these error paths)
         if (ctx->work_orig) PCR_HIP(ctx, hipFree(ctx->work_orig));
         ctx->work_orig = nullptr; ctx->work_orig_cap = 0;
         PCR_HIP(ctx, hipMalloc((void**)&ctx->work_orig, padded(n) * sizeof(uint32_t)));
         ctx->work_orig_cap = padded(n);
     }
+    pcr_cloud* sorted = nullptr;
+    rc = pcr_cloud_clone(ctx, w, &sorted);                        // same size, padding included
+    if (rc) return rc;
     hipLaunchKernelGGL(permute_cloud_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), ctx->qperm,
                        (uint32_t)n, sorted->x(), sorted->y(), sorted->z());
-    PCR_HIP(ctx, hipGetLastError());
-    PCR_HIP(ctx, hipMemcpyAsync(ctx->work_orig, ctx->qperm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->work_orig, ctx->qperm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) { pcr_cloud_destroy(ctx, sorted); return fail(ctx, PCR_ERR_HIP, "grid_sort_working_cloud", e); }
     pcr_cloud_destroy(ctx, w);                                     // synchronises the stream
     *work = sorted;
     ctx->work_orig_src = sorted;
@@ -1585,15 +1586,15 @@ int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work)
     uint32_t* v_in = (uint32_t*)(sc + 2 * a8);
     uint32_t* v_out = (uint32_t*)(sc + 2 * a8 + a4);
     char* temp = sc + 2 * a8 + 2 * a4;
-    pcr_cloud* sorted = nullptr;
-    rc = pcr_cloud_clone(ctx, w, &sorted);                        // same size, padding included
-    if (rc) return rc;
-    if (ctx->work_orig_cap < n) {
+    if (ctx->work_orig_cap < n) {                                 // (before the clone: nothing to give back on these error paths)
         if (ctx->work_orig) PCR_HIP(ctx, hipFree(ctx->work_orig));
         ctx->work_orig = nullptr; ctx->work_orig_cap = 0;
         PCR_HIP(ctx, hipMalloc((void**)&ctx->work_orig, padded(n) * sizeof(uint32_t)));
         ctx->work_orig_cap = padded(n);
     }
+    pcr_cloud* sorted = nullptr;
+    rc = pcr_cloud_clone(ctx, w, &sorted);                        // same size, padding included
+    if (rc) return rc;
     const unsigned blocks = (unsigned)((n + GR_BLOCK - 1) / GR_BLOCK);
     hipLaunchKernelGGL(bt_keys_kernel, dim3(blocks), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), (uint32_t)n, bt->key_lo[0], bt->key_lo[1],
                        bt->key_lo[2], bt->key_inv, bt->key_inv, bt->key_inv, k_in, v_in);
@@ -1696,6 +1697,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         const size_t unit = 8 * (size_t)xcd_run;
         launch_blocks = (nblocks + unit - 1) / unit * unit;
     }
+    ctx->last_nn1_kernel = "grid";
     {
         ProfScope p(ctx, "nn1_grid", 1);
 #define PCR_GRID2(GG, ST, MD)                                                                                          \

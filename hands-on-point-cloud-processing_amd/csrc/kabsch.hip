@@ -347,6 +347,10 @@ static uint32_t kabsch_blocks(pcr_ctx* ctx, size_t ns)
     if (blocks < 1) blocks = 1;
     const uint32_t cap = (uint32_t)std::min<int64_t>(KB_MAX_BLOCKS, std::max<int64_t>(1, tune_get(ctx, "kabsch_max_blocks", 1024)));
     if (blocks > cap) blocks = cap;
+    // exactness before tuning: a thread's limb accumulators are normalised only after its whole chunk, every term adds < 2^40 to
+    // each, so a thread may hold < 2^13 terms: never fewer workgroups than 4 096 pairs per thread need (10 M points: 10)
+    const uint32_t need = (uint32_t)((ns + (size_t)4096 * KB_BLOCK - 1) / ((size_t)4096 * KB_BLOCK));
+    if (blocks < need) blocks = need;
     return blocks;
 }
 

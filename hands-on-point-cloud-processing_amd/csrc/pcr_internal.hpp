@@ -137,6 +137,12 @@ struct pcr_ctx {
     int prof_level = 0;                   // 0 off (default: an event pair costs ~6 us of stream time on each side of the kernel),
                                           // 1 correspondence kernels only, 2 every kernel
     std::map<std::string, int64_t> tune;
+    // what mfma_verdict (nn1_brute.hip) measured on this device before a matrix-core 1-NN kernel was first chosen: -1 not run yet,
+    // 1 = within half of every bound the kernel's analysis assumes, 0 = not (the form is never used on this context)
+    int mfma_ok16 = -1, mfma_okbf = -1;
+    double mfma_worst16[4] = { 0, 0, 0, 0 }, mfma_worstbf[4] = { 0, 0, 0, 0 };
+    double mfma_check_ms = 0.0;           // host wall time the checks took (once per context and form)
+    const char* last_nn1_kernel = "";     // family of the last 1-NN launch: htrack / btrack / etrack / ftrack / track / grid
 };
 
 namespace pcr {
@@ -166,8 +172,9 @@ struct ProfScope {
 void prof_flush(pcr_ctx* ctx);
 
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
-int bt_mfma_selftest(pcr_ctx* ctx, int trials, double worst[2]);
-int ht_mfma_selftest(pcr_ctx* ctx, int trials, double worst[2]);
+int bt_mfma_selftest(pcr_ctx* ctx, int trials, double worst[4]);
+int ht_mfma_selftest(pcr_ctx* ctx, int trials, double worst[4]);
+bool mfma_verdict(pcr_ctx* ctx, bool f16);     // cached per context; runs the short self-test on first use
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool in_loop);
 int launch_nn1_brute_list(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, const uint32_t* qlist, const uint32_t* qcount, uint32_t qcap);
 // cap2: the caller only uses neighbours with d2 < cap2 (ICP's max_corres_dist gate) — the walk may stop once no such target can exist

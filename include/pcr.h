@@ -247,9 +247,10 @@ int pcr_ransac_global_f32(pcr_ctx* ctx, const float* src_xyz, size_t n_src, cons
                           float R[9], float t[3], uint32_t* best_count, int64_t* winner, uint32_t* counts);
 
 /* ---- multi-GPU: one process per GPU, sources sharded, targets replicated ------------------------------
- * Exactly one collective per ICP iteration: all-reduce(sum) of 16 f64 (+2 bookkeeping words). */
+ * Exactly one collective per ICP iteration: all-reduce(sum) of 56 + 2 * nranks f64 (wire format below; 104 at PCR_MAX_RANKS —
+ * a pcr_allreduce_fn must accept n up to 128). */
 #define PCR_COMM_ID_BYTES 128
-#define PCR_MAX_RANKS 24      /* one node has 8 GPUs; the per-iteration reduce buffer is 16 + 2 * nranks <= 64 f64 */
+#define PCR_MAX_RANKS 24      /* one node has 8 GPUs; the per-iteration reduce buffer holds 56 + 2 * nranks <= 128 f64 */
 int pcr_comm_unique_id(char id[PCR_COMM_ID_BYTES]);                     /* rank 0; broadcast it out of band */
 int pcr_comm_init_rccl(pcr_ctx* ctx, int nranks, int rank, const char id[PCR_COMM_ID_BYTES]);
 /* alternative transport: a host callback that sums buf[0..n) over ranks in place and returns 0
@@ -279,15 +280,32 @@ int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* t
 /* diagnostics of the last grid search launched with tune "grid_stats" = 1:
  * out = { candidates evaluated, fine x-rows opened, coarse rows tested, far stages run } summed over the queries */
 int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4]);
-/* Checks on THIS device the arithmetic the default exhaustive 1-NN filter (bf16 matrix cores, csrc/nn1_brute.hip BTRACK) relies on:
- * `trials` random 32 x 32 tiles per mode through the kernel's own pair of v_mfma_f32_32x32x16_bf16.
- *   worst[0] = max |D - exact| / (2^-24 sum |a_k b_k|) over operands with exponents spread over 2^-20 .. 2^20   (the bound's analysis assumes <= 16)
- *   worst[1] = max |G - (w - 2 r.t)| / (2^-24 (|r|^2 + |t|^2)) in the kernel's three-piece operand layout        (assumes <= 34.2) */
-int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[2]);
-/* The same for the f16 form the default filter uses when the target's coordinates fit f16's range after per-tile scaling (HTRACK):
- *   worst[0] = max |D - exact| / (2^-24 sum |a_k b_k|) of one v_mfma_f32_32x32x16_f16 on random f16 operands          (assumed <= 16)
- *   worst[1] = max |G - (w - 2 r.t)| / (2^-24 (|r|^2 + |t|^2)) with the operands built by the kernel's own two-piece code (assumed <= 82) */
-int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[2]);
+/* all eight diagnostics words of the last 1-NN launch made with tune "grid_stats" = 1.  Grid search: [0..3] as pcr_grid_stats.
+ * Matrix-core exhaustive search (HTRACK / BTRACK): [2] = (wave, query group) pairs that were filtered a second time, [4] = shader
+ * cycles (s_memtime) and [5] = 100 MHz real-time ticks (s_memrealtime) summed over the workgroups: [4] / [5] x 100 MHz is the shader
+ * clock the chip held under that launch (bench.py: the clock-corrected roofline). */
+int pcr_nn1_stats(pcr_ctx* ctx, uint64_t out[8]);
+/* Checks on THIS device the arithmetic the matrix-core forms of the exhaustive 1-NN filter rely on (csrc/nn1_brute.hip: BTRACK = two
+ * v_mfma_f32_32x32x16_bf16 per tile, three-piece operands; HTRACK = one v_mfma_f32_32x32x16_f16, two-piece scaled operands — the default).
+ * `trials` random tiles per mode plus 4 structured (cancellation across K-slots, alternating signs, subnormal pieces, maximal exponent
+ * spread) and 8 underflow-regime tiles, through the kernel's own MFMA(s) and operand code; u = 2^-24:
+ *   worst[0] = max |D - exact| / (u sum |a_k b_k|), random operands                                   (the bounds assume <= 16)
+ *   worst[1] = max (|G - (w - 2 r.t)| - 2 u) / (u (|r|^2 + |t|^2)), the kernel's operand layout       (assume <= 34.2 bf16 / <= 82 f16)
+ *   worst[2] = max |G - (w - 2 r.t)| / u over pairs with |r|^2 + |t|^2 <= 2^-6 (f16 underflow regime)  (HTRACK subtracts 4 u)
+ *   worst[3] = as worst[0] on the structured tiles                                                    (<= 16) */
+int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[4]);
+int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[4]);
+/* The library runs a short form of the two self-tests ITSELF, once per context, before it first picks a matrix-core kernel, and only
+ * uses a form whose four figures stay within HALF of what its bound assumes (f16 -> bf16 -> the f32 filters, whose bounds need IEEE
+ * arithmetic only).  This reports the verdicts (-1 = not run yet; run_now != 0 runs them), the figures, the host time the checks
+ * took, and which 1-NN kernel family served the last search ("htrack", "btrack", "etrack", "ftrack", "track", "grid"). */
+typedef struct {
+    int32_t f16_ok, bf16_ok;
+    double f16_worst[4], bf16_worst[4];
+    double check_ms;
+    char last_nn1_kernel[16];
+} pcr_mfma_check;
+int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
 /* tuning / diagnostic knobs by name (value 0 = library default, except "prof"): "nn_method" 1 brute force / 2 exact grid,
  * "nn1_variant", "knn_method", "radius_method", "icp_pipeline", "prof", ... — the names are listed where they are read (csrc/) */
 int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value);

@@ -40,15 +40,101 @@ def random_cloud32(rng, n, kind):
 def test_bf16_matrix_core_arithmetic_is_within_the_bound_the_filter_assumes(ctx):
     """BTRACK's lower bound (csrc/nn1_brute.hip) assumes: bf16 x bf16 products exact in f32 and an accumulation error of the two
     v_mfma_f32_32x32x16_bf16 of at most 16 x 2^-24 x sum |a b|; its three-piece operand layout then reproduces w - 2 r.t to within
-    34.2 x 2^-24 (|r|^2 + |t|^2).  Measured here on the device under test (the library's own MFMA pair, adversarial exponents), with a
-    factor two of head-room on both."""
-    acc, filt = ctx.selftest_mfma_bf16(96)
+    34.2 x 2^-24 (|r|^2 + |t|^2).  Measured here on the device under test (the library's own MFMA pair, adversarial exponents, and the
+    structured tiles: cancellation across K-slots, alternating signs, smallest pieces, maximal exponent spread), with a factor two of
+    head-room on every figure — the same pass marks the library applies to itself before it first picks the kernel (mfma_verdict)."""
+    acc, filt, small, struct = ctx.selftest_mfma_bf16(96)
     assert 0.0 < acc <= 8.0, acc
+    assert 0.0 <= struct <= 8.0, struct
     assert 0.0 < filt <= 17.0, filt
-    # the f16 form (HTRACK, the default where the cloud fits f16's range): accumulation <= 16 assumed, filter value <= 82 assumed
-    acc16, filt16 = ctx.selftest_mfma_f16(96)
+    assert 0.0 <= small <= 2.0, small
+    # the f16 form (HTRACK, the default where the cloud fits f16's range): accumulation <= 16 assumed, filter value <= 82 assumed, and
+    # in the regime where the second f16 piece underflows (|r|, |t| both below 2^-3 after scaling) an absolute 4 x 2^-24
+    acc16, filt16, small16, struct16 = ctx.selftest_mfma_f16(96)
     assert 0.0 < acc16 <= 8.0, acc16
+    assert 0.0 <= struct16 <= 8.0, struct16
     assert 0.0 < filt16 <= 41.0, filt16
+    assert 0.0 < small16 <= 2.0, small16
+
+
+def test_library_checks_the_matrix_core_arithmetic_itself_and_falls_back(ctx, orc, synth):
+    """The dispatcher consults a once-per-context verdict before it first uses a matrix-core kernel; a failing verdict (forced here
+    with the tune key) moves the search to the next form — f16 -> bf16 -> the f32 filters — with the same bits out."""
+    src, tgt = synth.kitti_like_pair(9000, seed_target=91, seed_pair=92)
+    oi, od = orc.nn1_f32(tgt, src)
+    ctx.tune("nn_method", 1)
+    chk = ctx.mfma_check(run_now=True)
+    assert chk["f16_ok"] == 1 and chk["bf16_ok"] == 1, chk
+    assert 0.0 < chk["check_ms"] < 20.0, chk                # both forms, once per context (measured: profiles/)
+    assert ctx.mfma_check(run_now=True)["check_ms"] == chk["check_ms"]         # cached: not run again
+    want = {0: ("htrack",), 1: ("btrack",), 2: ("htrack",), 3: ("ftrack", "etrack")}
+    for force in (0, 1, 2, 3, 3):
+        ctx.tune("mfma_force_fail", force)
+        ct, cs = ctx.cloud(tgt), ctx.cloud(src)
+        idx, d2 = ctx.nn1(ct, cs)
+        got = ctx.mfma_check()
+        assert got["last_nn1_kernel"] in want[force], (force, got)
+        assert got["f16_ok"] == (0 if force & 1 else 1) and got["bf16_ok"] == (0 if force & 2 else 1)
+        assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), force
+        # and inside a loop (seeded searches): the fallback of a failed verdict there is the f32 filter on the chunked index
+        T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=3, eps=1e-8)
+        if force == 3:
+            assert ctx.mfma_check()["last_nn1_kernel"] == "etrack"
+        if force == 0:
+            T0 = T
+        assert np.array_equal(T, T0), force
+        ct.free(); cs.free()
+    ctx.tune("mfma_force_fail", 0)
+    ctx.tune("nn_method", 0)
+
+
+def _ulp_step(a, k):
+    """a stepped by k units in the last place (per element)"""
+    b = np.ascontiguousarray(a, np.float32).copy()
+    i = b.view(np.int32)
+    i += np.where(b >= 0, k, -k).astype(np.int32)
+    return b
+
+
+@pytest.mark.parametrize("sps", [0, 1])
+def test_nn1_near_duplicates_next_to_a_super_tile_centre(ctx, orc, sps):
+    """with the query ON a target (d2 = 0) and |r|, |t''| of 1e-3 .. 3e-2 after HTRACK's per-super-tile scaling, the
+    second f16 piece of an operand underflows and the filter value misses by an absolute 2^-24 — more than the relative slack
+    2^-17 (Q + W) provides there; near-duplicate targets a few ulps apart in other chunks / slices could then hide the true
+    neighbour.  Clusters of 256 points = one super-tile each: 108 mirrored pairs within 1 m of the centre (so the centre of the
+    super-tile is the cluster centre to a few ulps and the scale is 2^7) and 40 near-duplicates within 8 ulps of the centre in every
+    coordinate; queries ON the near-duplicates and 1-2 ulps off them.  Every kernel against the oracle, bit for bit."""
+    rng = np.random.default_rng(2026)
+    M = 48
+    cen = rng.uniform(-60, 60, (3, M)).astype(np.float32)
+    tg, qs = [], []
+    for j in range(M):
+        c = cen[:, j:j + 1]
+        v = rng.uniform(-1, 1, (3, 108)).astype(np.float32)
+        dup = np.concatenate([_ulp_step(np.repeat(c, 40, 1)[k:k + 1], rng.integers(-8, 9, 40)) for k in range(3)], 0)
+        tg += [c + v, c - v, dup]
+        qs += [dup, np.concatenate([_ulp_step(dup[k:k + 1], rng.integers(-2, 3, 40)) for k in range(3)], 0), c + v[:, :8] * 0.5]
+    tgt = np.ascontiguousarray(np.concatenate(tg, 1), np.float32)
+    src = np.ascontiguousarray(np.concatenate(qs, 1), np.float32)
+    perm = rng.permutation(tgt.shape[1])
+    tgt = np.ascontiguousarray(tgt[:, perm])
+    oi, od = orc.nn1_f32(tgt, src)
+    assert (od == 0).sum() >= 40 * M                      # the coincident queries
+    ctx.tune("nn_method", 1)
+    ctx.tune("nn1_supers_per_slice", sps)                 # 1: every cluster its own slice (settled through the published bound)
+    for variant in (2, 7, 6, 0):
+        ctx.tune("nn1_variant", variant)
+        ct, cs = ctx.cloud(tgt), ctx.cloud(src)
+        idx, d2 = ctx.nn1(ct, cs)
+        assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (variant, sps, int((idx != oi).sum()))
+        ctx.tune("nn1_async_in_loop", 1)                  # and seeded by its own previous answer / by a stale one
+        for _ in range(2):
+            ctx.nn1_async(ct, cs)
+            idx, d2 = ctx.nn1_fetch(src.shape[1])
+            assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (variant, sps, "warm")
+        ctx.tune("nn1_async_in_loop", 0)
+        ct.free(); cs.free()
+    ctx.tune("nn1_variant", 0); ctx.tune("nn1_supers_per_slice", 0); ctx.tune("nn_method", 0)
 
 
 def test_nn1_randomised_sweep_every_kernel(ctx, orc):
