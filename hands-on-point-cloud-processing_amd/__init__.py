@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "pcr_nn1_f32", "pcr_nn1_f32_async", "pcr_nn1_fetch", "pcr_transform_f32", "pcr_kabsch_sums", "pcr_kabsch_solve", "pcr_kabsch_grid_exponent", "pcr_kabsch_limbs_to_sums",
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
-    "pcr_prof_reset", "pcr_prof_get", "pcr_tune_set",
+    "pcr_prof_reset", "pcr_prof_get", "pcr_prof_get_each", "pcr_tune_set",
     "pcr_grid_stats", "pcr_nn1_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_ctx_mfma_check", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_match_inter_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
 ]
@@ -117,6 +117,7 @@ def lib():
     L.pcr_shard_range.argtypes = [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]
     L.pcr_prof_reset.argtypes = [vp]
     L.pcr_prof_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    L.pcr_prof_get_each.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]
     L.pcr_tune_set.argtypes = [vp, C.c_char_p, C.c_int64]
     L.pcr_grid_stats.argtypes = [vp, vp]
     L.pcr_nn1_stats.argtypes = [vp, vp]
@@ -342,8 +343,8 @@ class Context:
         return {"candidates": out[0], "fine_rows": out[1], "coarse_rows": out[2], "far_stages": out[3]}
 
     def nn1_stats(self):
-        """the eight diagnostics words of the last 1-NN launch made with tune grid_stats = 1 (include/pcr.h)"""
-        out = (C.c_uint64 * 8)()
+        """the sixteen diagnostics words of the last 1-NN launch made with tune grid_stats = 1 (include/pcr.h)"""
+        out = (C.c_uint64 * 16)()
         self._ck(lib().pcr_nn1_stats(self.h, out))
         return [int(v) for v in out]
 
@@ -375,6 +376,13 @@ class Context:
         n, ms = C.c_uint64(), C.c_double()
         self._ck(lib().pcr_prof_get(self.h, kernel.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def prof_get_each(self, kernel: str):
+        """the individual durations (ms) of the named scope since the last prof_reset, in launch order"""
+        buf = np.zeros(4096, np.float64)
+        n = C.c_size_t()
+        self._ck(lib().pcr_prof_get_each(self.h, kernel.encode(), buf.ctypes.data, buf.size, C.byref(n)))
+        return buf[: min(n.value, buf.size)].copy()
 
     # ---- clouds
     def cloud(self, xyz: np.ndarray, layout: int = PCR_SOA) -> Cloud:

@@ -96,6 +96,7 @@ void prof_flush(pcr_ctx* ctx)
             if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
                 kv.second.launches++;
                 kv.second.total_ms += ms;
+                if (kv.second.each_ms.size() < 4096) kv.second.each_ms.push_back(ms);
             }
             hipEventDestroy(ev.first);
             hipEventDestroy(ev.second);
@@ -447,6 +448,17 @@ int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* t
     return PCR_OK;
 }
 
+int pcr_prof_get_each(pcr_ctx* ctx, const char* kernel, double* ms, size_t cap, size_t* n)
+{
+    if (!ctx || !kernel || !n || (cap && !ms)) return PCR_ERR_ARG;
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_flush(ctx);
+    auto it = ctx->prof.find(kernel);
+    *n = it == ctx->prof.end() ? 0 : it->second.each_ms.size();
+    for (size_t k = 0; k < *n && k < cap; k++) ms[k] = (double)it->second.each_ms[k];
+    return PCR_OK;
+}
+
 int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[4])
 {
     if (!ctx || !worst || trials < 0 || trials > 4096) return PCR_ERR_ARG;
@@ -478,22 +490,22 @@ int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4])
     if (!ctx || !out) return PCR_ERR_ARG;
     for (int k = 0; k < 4; k++) out[k] = 0;
     if (!ctx->grid_stats_dev) return PCR_OK;
-    unsigned long long h[8];
+    unsigned long long h[PCR_NSTATS];
     PCR_HIP(ctx, hipMemcpyAsync(h, ctx->grid_stats_dev, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 4; k++) out[k] = h[k];
     return PCR_OK;
 }
 
-int pcr_nn1_stats(pcr_ctx* ctx, uint64_t out[8])
+int pcr_nn1_stats(pcr_ctx* ctx, uint64_t out[16])
 {
     if (!ctx || !out) return PCR_ERR_ARG;
-    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (int k = 0; k < PCR_NSTATS; k++) out[k] = 0;
     if (!ctx->grid_stats_dev) return PCR_OK;
-    unsigned long long h[8];
+    unsigned long long h[PCR_NSTATS];
     PCR_HIP(ctx, hipMemcpyAsync(h, ctx->grid_stats_dev, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 8; k++) out[k] = h[k];
+    for (int k = 0; k < PCR_NSTATS; k++) out[k] = h[k];
     return PCR_OK;
 }
 

@@ -96,9 +96,29 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v)      // 3 bits -> bits 0
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
 }
 
-// MORTON: the low key word is (9-bit Morton code of the point's 8 x 8 x 8 sub-cell) << 23 | (x bits >> 9): consecutive records of
-// a cell are neighbours in space, which keeps the bounding spheres of 16-record runs small.  Still a pure function of the
-// point (ties resolve by original index: the radix sort is stable).
+// 8 bits -> bits 0, 3, 6, ..., 21
+__device__ __forceinline__ uint32_t spread8(uint32_t v)
+{
+    v &= 0xFFu;
+    v = (v | (v << 8)) & 0x00F00Fu;
+    v = (v | (v << 4)) & 0x0C30C3u;
+    v = (v | (v << 2)) & 0x249249u;
+    return v;
+}
+
+// 24-bit Morton code of a point's position INSIDE its cell (8 bits per axis: 1 / 256 of the cell edge); the top nine bits are the
+// 8 x 8 x 8 sub-cell code of round 2.  frac = (coordinate - lo) * inv_h - cell, clamped (a query outside the grid box).
+__device__ __forceinline__ uint32_t morton24_in_cell(float fx, float fy, float fz)
+{
+    const uint32_t sx = (uint32_t)fminf(fmaxf(fx * 256.0f, 0.0f), 255.0f), sy = (uint32_t)fminf(fmaxf(fy * 256.0f, 0.0f), 255.0f),
+                   sz = (uint32_t)fminf(fmaxf(fz * 256.0f, 0.0f), 255.0f);
+    return spread8(sx) | (spread8(sy) << 1) | (spread8(sz) << 2);
+}
+
+// MORTON: the low key word is the 24-bit Morton code of the point's position inside its cell (<< 8): consecutive records of a cell are
+// neighbours in space down to 1 / 256 of the cell edge (round 2: an 8 x 8 x 8 sub-cell code, then x), which keeps the bounding spheres of
+// 16-record runs small along any direction a scan line takes.  Still a pure function of the point (ties resolve by original index:
+// the radix sort is stable).
 template <bool MORTON>
 __global__ __launch_bounds__(GR_BLOCK) void record_keys_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
                                                                GridParams g, const uint32_t* __restrict__ cell_of, unsigned long long* __restrict__ keys,
@@ -114,11 +134,9 @@ __global__ __launch_bounds__(GR_BLOCK) void record_keys_kernel(const float* __re
         uint32_t m = 0;
         if (finite3(px, py, pz)) {
             const float fx = (px - g.lo[0]) * g.inv_h, fy = (py - g.lo[1]) * g.inv_h, fz = (pz - g.lo[2]) * g.inv_h;
-            const int sx = min(max((int)((fx - floorf(fx)) * 8.0f), 0), 7), sy = min(max((int)((fy - floorf(fy)) * 8.0f), 0), 7),
-                      sz = min(max((int)((fz - floorf(fz)) * 8.0f), 0), 7);
-            m = spread3((uint32_t)sx) | (spread3((uint32_t)sy) << 1) | (spread3((uint32_t)sz) << 2);
+            m = morton24_in_cell(fx - floorf(fx), fy - floorf(fy), fz - floorf(fz));
         }
-        u = (m << 23) | (u >> 9);
+        u = m << 8;
     }
     keys[i] = ((unsigned long long)cell_of[i] << 32) | u;
     vals[i] = i;
@@ -685,280 +703,329 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t run)
 // the best-distance window in x.  MODE 2 (SPH, G = 16): rows are walked as runs of 16 records whose bounding spheres are
 // tested first — the variant for large / dense targets (a LiDAR ring packs hundreds of points into one cell at 10 M points;
 // almost all of them lie outside the ball of the current best).
-template <int G, bool STATS, int MODE>
-__global__ __launch_bounds__(GR_BLOCK) void nn1_grid_kernel(
+// waves per SIMD of the list-mode instance (unbounded: 77 VGPRs = 6 waves; 7 waves: 71 VGPRs, nothing spilled; 8 waves: 64 VGPRs with
+// eight registers in scratch — as fast, but 115 MB of scratch traffic per search at 10 M)
+#ifndef PCR_LIST_WAVES
+#define PCR_LIST_WAVES 7
+#endif
+template <int G, bool STATS, int MODE, bool LIST = false>
+__global__ __launch_bounds__(GR_BLOCK, (LIST && !STATS) ? PCR_LIST_WAVES : 1) void nn1_grid_kernel(
     const float4* __restrict__ records, const float4* __restrict__ spheres, const uint32_t* __restrict__ cell_start,
     GridParams g, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     const uint32_t* __restrict__ perm, uint32_t ns, unsigned long long* __restrict__ keys, const int* __restrict__ stop,
     unsigned long long* __restrict__ stats, const float* __restrict__ tx, const float* __restrict__ ty,
     const float* __restrict__ tz, uint32_t nt, int warm_start, float cap2,
     uint32_t* __restrict__ far_list, uint32_t* __restrict__ far_count, uint32_t far_cap,
-    uint32_t* __restrict__ wpos, uint32_t xcd_run)
+    uint32_t* __restrict__ wpos, uint32_t xcd_run, const uint32_t* __restrict__ list_count, uint32_t list_segs)
 {
     // pipelined ICP: once the loop has ended the enqueued tail is a no-op.  The flags are REQUESTED here and tested below, after the
     // query's own loads have been issued: one memory round trip of every launch's serial chain less.
     const int stopv = stop ? (stop[0] | stop[1]) : 0;
     constexpr bool CLIP = MODE == 1, SPH = MODE == 2;
     static_assert(!SPH || G == 16, "the sphere walk scans one 16-record run per sub-group");
-    unsigned long long st_cand = 0, st_rows = 0, st_stages = 0, st_sph = 0;   // diagnostics (STATS builds only)
     const uint32_t vb = xcd_run ? xcd_block(blockIdx.x, xcd_run) : blockIdx.x;
-    const uint32_t gt = vb * GR_BLOCK + threadIdx.x;
-    if ((unsigned long long)vb * GR_BLOCK >= (unsigned long long)ns * G) return;   // a surplus workgroup of the padded launch
-    const uint32_t t = min(gt / G, ns - 1);          // clamp: surplus sub-groups redo the last query (same value written)
-    const int l = (int)(threadIdx.x % G);
-    const uint32_t i = perm ? perm[t] : t;
-    const float qx = sx[i], qy = sy[i], qz = sz[i];
-    const uint32_t pp0 = (warm_start >= 2) ? wpos[i] : 0xFFFFFFFFu;
-    if (stopv) return;
-    // The caller discards every neighbour with d2 >= cap2 (the ICP gate), so cap2 itself is a bound the walk may prune with from
-    // the start: the search begins with the pseudo-candidate (cap2, no index).  Rows and cells outside the cap2 ball are never
-    // opened, runs whose sphere lies outside it are never scanned, and a query with no target inside it ends with "none"
-    // (what the gate would have made of any farther neighbour).  A real candidate replaces it as soon as one is closer.
-    const unsigned long long bound0 = (cap2 > 0.0f && cap2 < 1e30f) ? (((unsigned long long)__float_as_uint(cap2) << 32) | 0xFFFFFFFFull) : KEY_NONE;
-    unsigned long long best = bound0;
-    uint32_t bestp = 0;
-    uint32_t seed_run = 0xFFFFFFFFu;             // the run scanned ahead of the walk (warm_start 3), which then skips it
-    if (finite3(qx, qy, qz)) {
-        if (SPH && warm_start == 3 && pp0 < nt) {
-            // The previous winner's whole RUN (its 16 Morton neighbours, one coalesced 256-byte load, a record per lane) instead of the
-            // winner alone: while the pose still moves by centimetres per iteration, one of the neighbours is often the new nearest
-            // point or close to it, and the ball every later sphere test and row clip works with is that much smaller.
-            seed_run = pp0 / GRID_CHUNK;
-            scan_run16(records, seed_run, l, qx, qy, qz, best, bestp);
-            group_min<16>(best, bestp);
-        } else if (warm_start >= 2) {
-            // ICP, from the second search of a loop on: wpos[] holds the record position of this query's previous winner.
-            // That target, evaluated exactly against the moved query, is a genuine candidate: it bounds the search from the
-            // first stage on (the radius jumps straight to the proving one, rows are clipped to its ball) without changing
-            // the result.  One 16-byte load that neighbouring queries share, instead of three 4-byte gathers.
-            const uint32_t pp = pp0;
-            if (pp < nt) {
-                const float4 rec = records[pp];
-                const float dx = qx - rec.x, dy = qy - rec.y, dz = qz - rec.z;
-                const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
-                const unsigned long long kk = ((unsigned long long)d << 32) | __float_as_uint(rec.w);
-                if (d < 0x7F7FFFFFu && kk < best) { best = kk; bestp = pp; }
-            }
-        } else if (warm_start == 1) {
-            // the same from keys[] (original index) when no record positions were kept
-            const uint32_t pj = (uint32_t)(keys[i] & 0xFFFFFFFFull);
-            if (pj < nt) {
-                const float dx = qx - tx[pj], dy = qy - ty[pj], dz = qz - tz[pj];
-                const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
-                const unsigned long long kk = ((unsigned long long)d << 32) | pj;
-                if (d < 0x7F7FFFFFu && kk < best) best = kk;
-            }
+    // LIST MODE (template LIST, G = 16): the queries the tile search deferred (grid_tile.hpp).  perm[] is a SEGMENTED list — segment s =
+    // the deferred queries of the 32-query group s of the sorted working cloud, list_count[s] of them at perm[32 s ...] — so the list is
+    // in the order of the working cloud however the tile kernel's waves were scheduled.  A fixed number of workgroups serves it: every
+    // wave owns `list_segs` consecutive segments (16: at most 512 queries — small enough for the hardware's dispatch order to balance
+    // the load, which a fixed split over 8 192 resident waves did not: the deferred queries are the expensive ones and cluster in
+    // space; runs of 32 workgroups share an XCD, like the query blocks of the plain launch), lays their entries out as one index space
+    // (counts -> inclusive scan -> LDS) and deals them to its four sub-groups.  (Its own instantiation: as a run-time mode the loop
+    // cost the plain form a wave of occupancy — 69 against 63 VGPRs.)
+    if (!LIST && (unsigned long long)vb * GR_BLOCK >= (unsigned long long)ns * G) return;   // a surplus workgroup of the padded launch
+    if (LIST && stopv) return;
+    __shared__ uint32_t seg_off[LIST ? GR_BLOCK / 64 : 1][LIST ? 65 : 1];
+    const uint32_t n_seg = LIST ? (ns + 31u) / 32u : 0u;
+    const uint32_t lb = LIST ? ((gridDim.x % 256u == 0u) ? xcd_block(blockIdx.x, 32u) : blockIdx.x) : 0u;
+    const uint32_t wv = LIST ? lb * (GR_BLOCK / 64) + (threadIdx.x >> 6) : 0u;
+    const uint32_t seg0 = wv * list_segs, seg1 = min(n_seg, seg0 + list_segs);
+    for (uint32_t cs = seg0; LIST ? cs < seg1 : true; cs += 64) {
+    uint32_t total = 0;
+    if (LIST) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t c = cs + lane < seg1 ? min(list_count[cs + lane], 32u) : 0u;
+        uint32_t inc = row_scan16(c);
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31),
+                       t2 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 47), t3 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        inc += lane >= 48 ? t0 + t1 + t2 : lane >= 32 ? t0 + t1 : lane >= 16 ? t0 : 0u;
+        total = t0 + t1 + t2 + t3;
+        seg_off[LIST ? threadIdx.x >> 6 : 0][LIST ? lane : 0] = inc - c;             // first entry of segment cs + lane
+        if (lane == 0) seg_off[LIST ? threadIdx.x >> 6 : 0][LIST ? 64 : 0] = total;
+    }
+    for (uint32_t slot = LIST ? (threadIdx.x & 63u) / G : (vb * GR_BLOCK + threadIdx.x) / G; LIST ? slot < total : true; slot += 64 / G) {
+        const uint32_t n_eff = ns;
+        uint32_t list_pos = 0;
+        if (LIST) {
+            const uint32_t* off = seg_off[LIST ? threadIdx.x >> 6 : 0];
+            int sg = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (off[LIST ? sg + step : 0] <= slot) sg += step;                    // the last segment whose first entry is <= slot
+            list_pos = (cs + (uint32_t)sg) * 32u + (slot - off[LIST ? sg : 0]);
         }
-        const int ux = cell_coord(qx, g.lo[0], g.inv_h), uy = cell_coord(qy, g.lo[1], g.inv_h), uz = cell_coord(qz, g.lo[2], g.inv_h);
-        // Chebyshev distance (in cells) from the query's cell to the grid box: smaller cubes hold no cell
-        const int r0 = max(max(max(-ux, ux - (g.n[0] - 1)), max(-uy, uy - (g.n[1] - 1))), max(max(-uz, uz - (g.n[2] - 1)), 0));
-        int r = max(r0, 1);
-        // a query farther from the grid box than the caller's gate (cap2) has no admissible neighbour at all
-        const float out_reach = ((float)r0 - 1.0f - g.slack) * g.h;
-        bool done = r0 > 1 && out_reach > TRUST && out_reach * out_reach * 0.99999f >= cap2;
-        if (r == 1 && SPH) {
-            // ---- stage 1, sphere walk: one row per lane
-            stage1_sph<STATS>(records, spheres, cell_start, g, ux, uy, uz, l, qx, qy, qz, best, bestp, st_cand, st_sph, st_rows, seed_run);
-            group_min<G>(best, bestp);
-            const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
-                                (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
-            const float reach = (1.0f - g.slack) * g.h;
-            done = covers || (reach > TRUST && (reach * reach * 0.99999f >= cap2 ||
-                                                (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f)));
-            r = 2;
-        } else if (r == 1) {
-            // ---- stage 1: static 3 x 3 rows, bounds first
-            const int xlo = max(ux - 1, 0), xhi = min(ux + 1, g.n[0] - 1);
-            uint32_t rb[9], re[9];
-            // with a seed (the previous correspondence, re-evaluated) only the rows and cells its ball reaches can matter: at the
-            // converged pose that is the query's own cell and the odd neighbour instead of all 27 (measured: DESIGN.md 5b)
-            const bool bounded = best != KEY_NONE;
-            const float clip2s = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f;
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const int cy = uy + (k % 3) - 1, cz = uz + (k / 3) - 1;
-                bool ok = (cy >= 0) && (cy < g.n[1]) && (cz >= 0) && (cz < g.n[2]) && (xlo <= xhi);
-                int xa = xlo, xb = xhi;
-                if (ok && bounded) {
-                    const float gy = axis_gap(qy, g.lo[1], g.h, cy, uy, g.slack), gz = axis_gap(qz, g.lo[2], g.h, cz, uz, g.slack);
-                    const float rem2 = clip2s - (gy * gy + gz * gz) * 0.9999f;
-                    if (rem2 < 0.0f) ok = false;
-                    else { ball_x_cells(g, qx, rem2, xa, xb); ok = xa <= xb; }
+        const bool live = LIST || slot < n_eff;
+        const uint32_t t = LIST ? list_pos : min(slot, n_eff - 1);         // clamp: surplus sub-groups redo the last query (same value written)
+        const int l = (int)(threadIdx.x % G);
+        const uint32_t i = perm ? perm[t] : t;
+        const float qx = sx[i], qy = sy[i], qz = sz[i];
+        const uint32_t pp0 = (warm_start >= 2) ? wpos[i] : 0xFFFFFFFFu;
+        if (stopv) return;
+        // The caller discards every neighbour with d2 >= cap2 (the ICP gate), so cap2 itself is a bound the walk may prune with from
+        // the start: the search begins with the pseudo-candidate (cap2, no index).  Rows and cells outside the cap2 ball are never
+        // opened, runs whose sphere lies outside it are never scanned, and a query with no target inside it ends with "none"
+        // (what the gate would have made of any farther neighbour).  A real candidate replaces it as soon as one is closer.
+        unsigned long long st_cand = 0, st_rows = 0, st_stages = 0, st_sph = 0;   // diagnostics (STATS builds only)
+        const unsigned long long bound0 = (cap2 > 0.0f && cap2 < 1e30f) ? (((unsigned long long)__float_as_uint(cap2) << 32) | 0xFFFFFFFFull) : KEY_NONE;
+        unsigned long long best = bound0;
+        uint32_t bestp = 0;
+        uint32_t seed_run = 0xFFFFFFFFu;             // the run scanned ahead of the walk (warm_start 3), which then skips it
+        if (finite3(qx, qy, qz)) {
+            if (SPH && warm_start == 3 && pp0 < nt) {
+                // The previous winner's whole RUN (its 16 Morton neighbours, one coalesced 256-byte load, a record per lane) instead of the
+                // winner alone: while the pose still moves by centimetres per iteration, one of the neighbours is often the new nearest
+                // point or close to it, and the ball every later sphere test and row clip works with is that much smaller.
+                seed_run = pp0 / GRID_CHUNK;
+                scan_run16(records, seed_run, l, qx, qy, qz, best, bestp);
+                group_min<16>(best, bestp);
+            } else if (warm_start >= 2) {
+                // ICP, from the second search of a loop on: wpos[] holds the record position of this query's previous winner.
+                // That target, evaluated exactly against the moved query, is a genuine candidate: it bounds the search from the
+                // first stage on (the radius jumps straight to the proving one, rows are clipped to its ball) without changing
+                // the result.  One 16-byte load that neighbouring queries share, instead of three 4-byte gathers.
+                const uint32_t pp = pp0;
+                if (pp < nt) {
+                    const float4 rec = records[pp];
+                    const float dx = qx - rec.x, dy = qy - rec.y, dz = qz - rec.z;
+                    const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                    const unsigned long long kk = ((unsigned long long)d << 32) | __float_as_uint(rec.w);
+                    if (d < 0x7F7FFFFFu && kk < best) { best = kk; bestp = pp; }
                 }
-                const uint32_t row = ok ? (uint32_t)((cz * g.n[1] + cy) * g.n[0]) : 0u;
-                rb[k] = ok ? cell_start[row + xa] : 0u;
-                re[k] = ok ? cell_start[row + xb + 1] : 0u;
-                if (STATS && l == 0 && ok) st_rows++;
+            } else if (warm_start == 1) {
+                // the same from keys[] (original index) when no record positions were kept
+                const uint32_t pj = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+                if (pj < nt) {
+                    const float dx = qx - tx[pj], dy = qy - ty[pj], dz = qz - tz[pj];
+                    const uint32_t d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                    const unsigned long long kk = ((unsigned long long)d << 32) | pj;
+                    if (d < 0x7F7FFFFFu && kk < best) best = kk;
+                }
             }
-            if (CLIP) {
-                uint32_t total = 0;
+            const int ux = cell_coord(qx, g.lo[0], g.inv_h), uy = cell_coord(qy, g.lo[1], g.inv_h), uz = cell_coord(qz, g.lo[2], g.inv_h);
+            // Chebyshev distance (in cells) from the query's cell to the grid box: smaller cubes hold no cell
+            const int r0 = max(max(max(-ux, ux - (g.n[0] - 1)), max(-uy, uy - (g.n[1] - 1))), max(max(-uz, uz - (g.n[2] - 1)), 0));
+            int r = max(r0, 1);
+            // a query farther from the grid box than the caller's gate (cap2) has no admissible neighbour at all
+            const float out_reach = ((float)r0 - 1.0f - g.slack) * g.h;
+            bool done = r0 > 1 && out_reach > TRUST && out_reach * out_reach * 0.99999f >= cap2;
+            if (r == 1 && SPH) {
+                // ---- stage 1, sphere walk: one row per lane
+                stage1_sph<STATS>(records, spheres, cell_start, g, ux, uy, uz, l, qx, qy, qz, best, bestp, st_cand, st_sph, st_rows, seed_run);
+                group_min<G>(best, bestp);
+                const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
+                                    (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
+                const float reach = (1.0f - g.slack) * g.h;
+                done = covers || (reach > TRUST && (reach * reach * 0.99999f >= cap2 ||
+                                                    (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f)));
+                r = 2;
+            } else if (r == 1) {
+                // ---- stage 1: static 3 x 3 rows, bounds first
+                const int xlo = max(ux - 1, 0), xhi = min(ux + 1, g.n[0] - 1);
+                uint32_t rb[9], re[9];
+                // with a seed (the previous correspondence, re-evaluated) only the rows and cells its ball reaches can matter: at the
+                // converged pose that is the query's own cell and the odd neighbour instead of all 27 (measured: DESIGN.md 5b)
+                const bool bounded = best != KEY_NONE;
+                const float clip2s = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f;
 #pragma unroll
-                for (int k = 0; k < 9; k++) total += re[k] - rb[k];
-                // dense neighbourhood without a warm-start candidate: the query's own row first, its best distance then
-                // cuts the other rows
-                if (!has_index(best) && total > 512u) {
-                    scan_range<G>(records, rb[4], re[4], l, qx, qy, qz, best, bestp);
-                    if (STATS && l == 0) st_cand += re[4] - rb[4];
-                    rb[4] = re[4] = 0;
-                    group_min<G>(best, bestp);
-                }
-                if (best != KEY_NONE && total > 48u) {
-                    float lo, hi;
-                    x_window(qx, fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f, lo, hi);
-                    if (G >= 9) {
-                        // one row per lane: the nine binary searches run side by side (one chain of ~12 dependent loads
-                        // instead of nine), the results travel back through shuffles
-                        uint32_t cb = 0, ce = 0;
-#pragma unroll
-                        for (int k = 0; k < 9; k++) if (l == k) { cb = rb[k]; ce = re[k]; }
-                        if (l < 9) clip_range_x(records, cb, ce, lo, hi);
-#pragma unroll
-                        for (int k = 0; k < 9; k++) { rb[k] = __shfl(cb, k, G); re[k] = __shfl(ce, k, G); }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 9; k++) clip_range_x(records, rb[k], re[k], lo, hi);
+                for (int k = 0; k < 9; k++) {
+                    const int cy = uy + (k % 3) - 1, cz = uz + (k / 3) - 1;
+                    bool ok = (cy >= 0) && (cy < g.n[1]) && (cz >= 0) && (cz < g.n[2]) && (xlo <= xhi);
+                    int xa = xlo, xb = xhi;
+                    if (ok && bounded) {
+                        const float gy = axis_gap(qy, g.lo[1], g.h, cy, uy, g.slack), gz = axis_gap(qz, g.lo[2], g.h, cz, uz, g.slack);
+                        const float rem2 = clip2s - (gy * gy + gz * gz) * 0.9999f;
+                        if (rem2 < 0.0f) ok = false;
+                        else { ball_x_cells(g, qx, rem2, xa, xb); ok = xa <= xb; }
                     }
+                    const uint32_t row = ok ? (uint32_t)((cz * g.n[1] + cy) * g.n[0]) : 0u;
+                    rb[k] = ok ? cell_start[row + xa] : 0u;
+                    re[k] = ok ? cell_start[row + xb + 1] : 0u;
+                    if (STATS && l == 0 && ok) st_rows++;
                 }
-            }
-            {
                 if (CLIP) {
-                    scan_flat9<G>(records, rb, re, l, qx, qy, qz, best, bestp);      // dense rows: 8.1 -> 6.9 ms at 10 M (costs 15 % at 120 k)
-                } else {
+                    uint32_t total = 0;
 #pragma unroll
-                    for (int k = 0; k < 9; k++) scan_range<G>(records, rb[k], re[k], l, qx, qy, qz, best, bestp);
-                }
-                if (STATS && l == 0) { for (int k = 0; k < 9; k++) st_cand += re[k] - rb[k]; }
-            }
-            group_min<G>(best, bestp);
-            const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
-                                (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
-            const float reach = (1.0f - g.slack) * g.h;
-            // (cap2: the caller discards neighbours with d2 >= cap2, so a cube that no closer target can lie outside of ends the search)
-            done = covers || (reach > TRUST && (reach * reach * 0.99999f >= cap2 ||
-                                                (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f)));
-            r = 2;
-        }
-        // ---- later stages.  rp = radius of the cube already scanned (0: none).  The next radius is the smallest one
-        // that can PROVE the current best (best < LB(r)), or 2 * r when nothing was found yet.  Inside the new cube,
-        // cells of the old cube are skipped, and so are cells that lie farther from the query than the current best
-        // (ball clipping, conservative by one cell + slack; such cells cannot hold a better or equal candidate).
-        // |u| <= 2^22 and every grid dimension is <= 4002, so a cube of radius 2^23 covers the grid from any query:
-        // the radius at least doubles whenever nothing is proven, so `covers` holds after <= 24 steps; the step bound
-        // makes termination unconditional.
-        int rp = (r == 2) ? 1 : 0;
-        for (int step = 0; step < 28 && !done; step++) {
-            const bool have = best != KEY_NONE;
-            const float bestf = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2);   // never reason below the trusted range
-            if (have) {
-                // smallest r with ((r - slack) h)^2 * 0.99999 > best; with only the gate as a bound the radius keeps doubling
-                // (near shells first: a real candidate tightens the ball for the far ones) but never beyond the gate's radius
-                const int need = (int)fminf(sqrtf(bestf * 1.00002f) * g.inv_h + g.slack, 16777215.0f) + 1;
-                r = max(min(has_index(best) ? need : min(r, need), 1 << 24), rp + 1);
-            }
-            const int xlo = max(ux - r, 0), xhi = min(ux + r, g.n[0] - 1);
-            const int ylo = max(uy - r, 0), yhi = min(uy + r, g.n[1] - 1);
-            const int zlo = max(uz - r, 0), zhi = min(uz + r, g.n[2] - 1);
-            const float clip2 = bestf * 1.0001f;
-            float wlo = 0.0f, whi = 0.0f;
-            if (CLIP && have) x_window(qx, clip2, wlo, whi);
-            if (xlo <= xhi && ylo <= yhi && zlo <= zhi) {
-                // Far searches open many x-rows, most of them short.  Rows are taken G at a time: every lane resolves
-                // ONE row (clipping + its cell_start bounds: G independent loads in flight per query), then the whole
-                // sub-group scans the G ranges one after the other with coalesced 16-byte loads.
-                const int ny_rows = yhi - ylo + 1;
-                const int n_rows = ny_rows * (zhi - zlo + 1);
-                // A far query (no target anywhere near: partial overlap in an unbounded search): once the next shell would open
-                // more rows than the target has points / FAR_DIV, the query is handed to the exhaustive kernel (one tiled pass over
-                // the target shared by hundreds of such queries) with what it has found so far; if the list is full it walks on.
-                if (far_list && (uint32_t)n_rows > nt / FAR_DIV + 256u) {
-                    int ok = 0;
-                    if (l == 0 && gt / G < ns) {
-                        const uint32_t pos = atomicAdd(far_count, 1u);
-                        if (pos < far_cap) { far_list[pos] = i; ok = 1; }
+                    for (int k = 0; k < 9; k++) total += re[k] - rb[k];
+                    // dense neighbourhood without a warm-start candidate: the query's own row first, its best distance then
+                    // cuts the other rows
+                    if (!has_index(best) && total > 512u) {
+                        scan_range<G>(records, rb[4], re[4], l, qx, qy, qz, best, bestp);
+                        if (STATS && l == 0) st_cand += re[4] - rb[4];
+                        rb[4] = re[4] = 0;
+                        group_min<G>(best, bestp);
                     }
-                    ok = __shfl(ok, 0, G);
-                    if (gt / G >= ns) ok = 1;               // surplus sub-groups of the last workgroup: nothing to do
-                    if (ok) { done = true; break; }
-                }
-                for (int k0 = 0; k0 < n_rows; k0 += G) {
-                    const int k = k0 + l;
-                    uint32_t b1 = 0, e1 = 0, b2 = 0, e2 = 0;       // up to two pieces per row
-                    if (k < n_rows) {
-                        const int cy = ylo + k % ny_rows, cz = zlo + k / ny_rows;
-                        const int ady = abs(cy - uy), adz = abs(cz - uz);
-                        int xa = xlo, xb = xhi;
-                        bool open = true;
-                        if (best != KEY_NONE) {
-                            // (the bound of THIS batch of rows: candidates found in the earlier batches of the stage already count)
-                            const float clip2k = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f;
-                            const float fy = axis_gap(qy, g.lo[1], g.h, cy, uy, g.slack), fz = axis_gap(qz, g.lo[2], g.h, cz, uz, g.slack);
-                            const float rem2 = clip2k - (fy * fy + fz * fz) * 0.9999f;
-                            if (rem2 < 0.0f) open = false;                     // the whole row is outside the ball
-                            else ball_x_cells(g, qx, rem2, xa, xb);
-                        }
-                        if (open && xa <= xb) {
-                            const uint32_t row = (uint32_t)((cz * g.n[1] + cy) * g.n[0]);
-                            if (ady <= rp && adz <= rp) {
-                                // this row crossed the old cube: only the two end pieces are new
-                                const int la = xa, lb = min(xb, ux - rp - 1);
-                                const int ra = max(xa, ux + rp + 1), rb2 = xb;
-                                if (la <= lb) { b1 = cell_start[row + la]; e1 = cell_start[row + lb + 1]; }
-                                if (ra <= rb2) { b2 = cell_start[row + ra]; e2 = cell_start[row + rb2 + 1]; }
-                            } else {
-                                b1 = cell_start[row + xa]; e1 = cell_start[row + xb + 1];
-                            }
-                            if (CLIP && have) {                            // x-sorted rows: keep only |x - qx| <= best
-                                clip_range_x(records, b1, e1, wlo, whi);
-                                clip_range_x(records, b2, e2, wlo, whi);
-                            }
-                            if (STATS) { st_rows++; if (!SPH) st_cand += (e1 - b1) + (e2 - b2); }
+                    if (best != KEY_NONE && total > 48u) {
+                        float lo, hi;
+                        x_window(qx, fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f, lo, hi);
+                        if (G >= 9) {
+                            // one row per lane: the nine binary searches run side by side (one chain of ~12 dependent loads
+                            // instead of nine), the results travel back through shuffles
+                            uint32_t cb = 0, ce = 0;
+#pragma unroll
+                            for (int k = 0; k < 9; k++) if (l == k) { cb = rb[k]; ce = re[k]; }
+                            if (l < 9) clip_range_x(records, cb, ce, lo, hi);
+#pragma unroll
+                            for (int k = 0; k < 9; k++) { rb[k] = __shfl(cb, k, G); re[k] = __shfl(ce, k, G); }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 9; k++) clip_range_x(records, rb[k], re[k], lo, hi);
                         }
                     }
-                    if (SPH) {
-                        // the runs of the (up to) 2 x 16 pieces as one index space: dense batches of 16 sphere tests
-                        if (__ballot((b1 < e1) || (b2 < e2)) >> ((threadIdx.x & 63) / 16 * 16) & 0xFFFFull)
-                            scan_pieces_sph<STATS>(records, spheres, b1, e1, b2, e2, l, qx, qy, qz, best, bestp, st_cand, st_sph, seed_run);
+                }
+                {
+                    if (CLIP) {
+                        scan_flat9<G>(records, rb, re, l, qx, qy, qz, best, bestp);      // dense rows: 8.1 -> 6.9 ms at 10 M (costs 15 % at 120 k)
                     } else {
-                        // visit only the lanes that hold a non-empty piece (far searches are mostly empty space)
-                        const unsigned long long any = __ballot((b1 < e1) || (b2 < e2));
-                        unsigned long long mine = (any >> ((threadIdx.x & 63) / G * G)) & (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull));
-                        while (mine) {
-                            const int j = __builtin_ctzll(mine);
-                            mine &= mine - 1;
-                            const uint32_t jb1 = __shfl(b1, j, G), je1 = __shfl(e1, j, G);
-                            const uint32_t jb2 = __shfl(b2, j, G), je2 = __shfl(e2, j, G);
-                            if (jb1 < je1) scan_range<G>(records, jb1, je1, l, qx, qy, qz, best, bestp);
-                            if (jb2 < je2) scan_range<G>(records, jb2, je2, l, qx, qy, qz, best, bestp);
+#pragma unroll
+                        for (int k = 0; k < 9; k++) scan_range<G>(records, rb[k], re[k], l, qx, qy, qz, best, bestp);
+                    }
+                    if (STATS && l == 0) { for (int k = 0; k < 9; k++) st_cand += re[k] - rb[k]; }
+                }
+                group_min<G>(best, bestp);
+                const bool covers = (ux - 1 <= 0) && (ux + 1 >= g.n[0] - 1) && (uy - 1 <= 0) && (uy + 1 >= g.n[1] - 1) &&
+                                    (uz - 1 <= 0) && (uz + 1 >= g.n[2] - 1);
+                const float reach = (1.0f - g.slack) * g.h;
+                // (cap2: the caller discards neighbours with d2 >= cap2, so a cube that no closer target can lie outside of ends the search)
+                done = covers || (reach > TRUST && (reach * reach * 0.99999f >= cap2 ||
+                                                    (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f)));
+                r = 2;
+            }
+            // ---- later stages.  rp = radius of the cube already scanned (0: none).  The next radius is the smallest one
+            // that can PROVE the current best (best < LB(r)), or 2 * r when nothing was found yet.  Inside the new cube,
+            // cells of the old cube are skipped, and so are cells that lie farther from the query than the current best
+            // (ball clipping, conservative by one cell + slack; such cells cannot hold a better or equal candidate).
+            // |u| <= 2^22 and every grid dimension is <= 4002, so a cube of radius 2^23 covers the grid from any query:
+            // the radius at least doubles whenever nothing is proven, so `covers` holds after <= 24 steps; the step bound
+            // makes termination unconditional.
+            int rp = (r == 2) ? 1 : 0;
+            for (int step = 0; step < 28 && !done; step++) {
+                const bool have = best != KEY_NONE;
+                const float bestf = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2);   // never reason below the trusted range
+                if (have) {
+                    // smallest r with ((r - slack) h)^2 * 0.99999 > best; with only the gate as a bound the radius keeps doubling
+                    // (near shells first: a real candidate tightens the ball for the far ones) but never beyond the gate's radius
+                    const int need = (int)fminf(sqrtf(bestf * 1.00002f) * g.inv_h + g.slack, 16777215.0f) + 1;
+                    r = max(min(has_index(best) ? need : min(r, need), 1 << 24), rp + 1);
+                }
+                const int xlo = max(ux - r, 0), xhi = min(ux + r, g.n[0] - 1);
+                const int ylo = max(uy - r, 0), yhi = min(uy + r, g.n[1] - 1);
+                const int zlo = max(uz - r, 0), zhi = min(uz + r, g.n[2] - 1);
+                const float clip2 = bestf * 1.0001f;
+                float wlo = 0.0f, whi = 0.0f;
+                if (CLIP && have) x_window(qx, clip2, wlo, whi);
+                if (xlo <= xhi && ylo <= yhi && zlo <= zhi) {
+                    // Far searches open many x-rows, most of them short.  Rows are taken G at a time: every lane resolves
+                    // ONE row (clipping + its cell_start bounds: G independent loads in flight per query), then the whole
+                    // sub-group scans the G ranges one after the other with coalesced 16-byte loads.
+                    const int ny_rows = yhi - ylo + 1;
+                    const int n_rows = ny_rows * (zhi - zlo + 1);
+                    // A far query (no target anywhere near: partial overlap in an unbounded search): once the next shell would open
+                    // more rows than the target has points / FAR_DIV, the query is handed to the exhaustive kernel (one tiled pass over
+                    // the target shared by hundreds of such queries) with what it has found so far; if the list is full it walks on.
+                    if (far_list && (uint32_t)n_rows > nt / FAR_DIV + 256u) {
+                        int ok = 0;
+                        if (l == 0 && live) {
+                            const uint32_t pos = atomicAdd(far_count, 1u);
+                            if (pos < far_cap) { far_list[pos] = i; ok = 1; }
+                        }
+                        ok = __shfl(ok, 0, G);
+                        if (!live) ok = 1;               // surplus sub-groups of the last workgroup: nothing to do
+                        if (ok) { done = true; break; }
+                    }
+                    for (int k0 = 0; k0 < n_rows; k0 += G) {
+                        const int k = k0 + l;
+                        uint32_t b1 = 0, e1 = 0, b2 = 0, e2 = 0;       // up to two pieces per row
+                        if (k < n_rows) {
+                            const int cy = ylo + k % ny_rows, cz = zlo + k / ny_rows;
+                            const int ady = abs(cy - uy), adz = abs(cz - uz);
+                            int xa = xlo, xb = xhi;
+                            bool open = true;
+                            if (best != KEY_NONE) {
+                                // (the bound of THIS batch of rows: candidates found in the earlier batches of the stage already count)
+                                const float clip2k = fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f;
+                                const float fy = axis_gap(qy, g.lo[1], g.h, cy, uy, g.slack), fz = axis_gap(qz, g.lo[2], g.h, cz, uz, g.slack);
+                                const float rem2 = clip2k - (fy * fy + fz * fz) * 0.9999f;
+                                if (rem2 < 0.0f) open = false;                     // the whole row is outside the ball
+                                else ball_x_cells(g, qx, rem2, xa, xb);
+                            }
+                            if (open && xa <= xb) {
+                                const uint32_t row = (uint32_t)((cz * g.n[1] + cy) * g.n[0]);
+                                if (ady <= rp && adz <= rp) {
+                                    // this row crossed the old cube: only the two end pieces are new
+                                    const int la = xa, lb = min(xb, ux - rp - 1);
+                                    const int ra = max(xa, ux + rp + 1), rb2 = xb;
+                                    if (la <= lb) { b1 = cell_start[row + la]; e1 = cell_start[row + lb + 1]; }
+                                    if (ra <= rb2) { b2 = cell_start[row + ra]; e2 = cell_start[row + rb2 + 1]; }
+                                } else {
+                                    b1 = cell_start[row + xa]; e1 = cell_start[row + xb + 1];
+                                }
+                                if (CLIP && have) {                            // x-sorted rows: keep only |x - qx| <= best
+                                    clip_range_x(records, b1, e1, wlo, whi);
+                                    clip_range_x(records, b2, e2, wlo, whi);
+                                }
+                                if (STATS) { st_rows++; if (!SPH) st_cand += (e1 - b1) + (e2 - b2); }
+                            }
+                        }
+                        if (SPH) {
+                            // the runs of the (up to) 2 x 16 pieces as one index space: dense batches of 16 sphere tests
+                            if (__ballot((b1 < e1) || (b2 < e2)) >> ((threadIdx.x & 63) / 16 * 16) & 0xFFFFull)
+                                scan_pieces_sph<STATS>(records, spheres, b1, e1, b2, e2, l, qx, qy, qz, best, bestp, st_cand, st_sph, seed_run);
+                        } else {
+                            // visit only the lanes that hold a non-empty piece (far searches are mostly empty space)
+                            const unsigned long long any = __ballot((b1 < e1) || (b2 < e2));
+                            unsigned long long mine = (any >> ((threadIdx.x & 63) / G * G)) & (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull));
+                            while (mine) {
+                                const int j = __builtin_ctzll(mine);
+                                mine &= mine - 1;
+                                const uint32_t jb1 = __shfl(b1, j, G), je1 = __shfl(e1, j, G);
+                                const uint32_t jb2 = __shfl(b2, j, G), je2 = __shfl(e2, j, G);
+                                if (jb1 < je1) scan_range<G>(records, jb1, je1, l, qx, qy, qz, best, bestp);
+                                if (jb2 < je2) scan_range<G>(records, jb2, je2, l, qx, qy, qz, best, bestp);
+                            }
                         }
                     }
                 }
+                if (STATS && l == 0) st_stages++;
+                group_min<G>(best, bestp);
+                const bool covers = (ux - r <= 0) && (ux + r >= g.n[0] - 1) && (uy - r <= 0) && (uy + r >= g.n[1] - 1) &&
+                                    (uz - r <= 0) && (uz + r >= g.n[2] - 1);
+                // every target outside the cube is farther than (r - slack) * h in some axis
+                const float reach = ((float)r - g.slack) * g.h;
+                // (cap2: the caller discards neighbours with d2 >= cap2, so a cube that no closer target can lie outside of ends the search)
+                done = covers || (reach > TRUST && (reach * reach * 0.99999f >= cap2 ||
+                                                    (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f)));
+                rp = r;
+                r = min(r * 2, 1 << 24);
             }
-            if (STATS && l == 0) st_stages++;
-            group_min<G>(best, bestp);
-            const bool covers = (ux - r <= 0) && (ux + r >= g.n[0] - 1) && (uy - r <= 0) && (uy + r >= g.n[1] - 1) &&
-                                (uz - r <= 0) && (uz + r >= g.n[2] - 1);
-            // every target outside the cube is farther than (r - slack) * h in some axis
-            const float reach = ((float)r - g.slack) * g.h;
-            // (cap2: the caller discards neighbours with d2 >= cap2, so a cube that no closer target can lie outside of ends the search)
-            done = covers || (reach > TRUST && (reach * reach * 0.99999f >= cap2 ||
-                                                (best != KEY_NONE && __uint_as_float((uint32_t)(best >> 32)) < reach * reach * 0.99999f)));
-            rp = r;
-            r = min(r * 2, 1 << 24);
         }
+        if (STATS && live) {
+            if (st_cand) atomicAdd(&stats[0], st_cand);
+            if (st_rows) atomicAdd(&stats[1], st_rows);
+            if (st_sph) atomicAdd(&stats[2], st_sph);
+            if (st_stages) atomicAdd(&stats[3], st_stages);
+        }
+        if (l == 0 && live) {
+            const uint32_t bidx = (uint32_t)(best & 0xFFFFFFFFull);
+            const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : (uint32_t)(best >> 32);
+            keys[i] = ((unsigned long long)bits << 32) | bidx;
+            if (wpos) wpos[i] = bidx == 0xFFFFFFFFu ? 0xFFFFFFFFu : bestp;
+        }
+        if (!LIST) break;
     }
-    if (STATS && gt / G < ns) {
-        if (st_cand) atomicAdd(&stats[0], st_cand);
-        if (st_rows) atomicAdd(&stats[1], st_rows);
-        if (st_sph) atomicAdd(&stats[2], st_sph);
-        if (st_stages) atomicAdd(&stats[3], st_stages);
-    }
-    if (l == 0 && gt / G < ns) {
-        const uint32_t bidx = (uint32_t)(best & 0xFFFFFFFFull);
-        const uint32_t bits = (bidx == 0xFFFFFFFFu) ? 0x7F800000u : (uint32_t)(best >> 32);
-        keys[i] = ((unsigned long long)bits << 32) | bidx;
-        if (wpos) wpos[i] = bidx == 0xFFFFFFFFu ? 0xFFFFFFFFu : bestp;
+    if (!LIST) break;
     }
 }
+
+#include "grid_tile.hpp"
 
 __global__ __launch_bounds__(GR_BLOCK) void count_nonzero_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ out)
 {
@@ -1224,8 +1291,9 @@ static int sort_queries(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
     return PCR_OK;
 }
 
-// key of a query in the ORDER OF THE RECORDS: (cell of the target's grid, clamped << 9) | Morton code of the 8 x 8 x 8 sub-cell.
-// Non-finite queries go last.
+// key of a query in the ORDER OF THE RECORDS: (cell of the target's grid, clamped) << 24 | 24-bit Morton code of the position inside the
+// cell (morton24_in_cell: what the records of a Morton-ordered index are sorted by).  Non-finite queries go last.
+constexpr int QKEY_SUB_BITS = 24;
 __global__ __launch_bounds__(GR_BLOCK) void query_keys_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
                                                               GridParams g, uint32_t n_cells, unsigned long long* __restrict__ keys,
                                                               uint32_t* __restrict__ vals)
@@ -1233,18 +1301,17 @@ __global__ __launch_bounds__(GR_BLOCK) void query_keys_kernel(const float* __res
     const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float px = x[i], py = y[i], pz = z[i];
-    unsigned long long key = (unsigned long long)n_cells << 9;
+    unsigned long long key = (unsigned long long)n_cells << QKEY_SUB_BITS;
     if (finite3(px, py, pz)) {
         const float p[3] = { px, py, pz };
-        int c[3], s[3];
+        int c[3];
+        float f[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             c[k] = min(max(cell_coord(p[k], g.lo[k], g.inv_h), 0), g.n[k] - 1);
-            const float f = ((p[k] - g.lo[k]) * g.inv_h - (float)c[k]) * 8.0f;     // < 0 or >= 8 for a query outside the grid box
-            s[k] = (int)fminf(fmaxf(f, 0.0f), 7.0f);
+            f[k] = (p[k] - g.lo[k]) * g.inv_h - (float)c[k];                       // < 0 or >= 1 for a query outside the grid box (clamped below)
         }
-        const uint32_t m = spread3((uint32_t)s[0]) | (spread3((uint32_t)s[1]) << 1) | (spread3((uint32_t)s[2]) << 2);
-        key = ((unsigned long long)((c[2] * g.n[1] + c[1]) * g.n[0] + c[0]) << 9) | m;
+        key = ((unsigned long long)((c[2] * g.n[1] + c[1]) * g.n[0] + c[0]) << QKEY_SUB_BITS) | morton24_in_cell(f[0], f[1], f[2]);
     }
     keys[i] = key;
     vals[i] = i;
@@ -1260,7 +1327,7 @@ static int sort_queries_fine(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
     int key_bits = 1;
     while (((size_t)1 << key_bits) < g->n_cells + 1) key_bits++;
     size_t temp_bytes = 0;
-    sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, key_bits + 9, ctx->stream);
+    sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, key_bits + QKEY_SUB_BITS, ctx->stream);
     const size_t a4 = (n * 4 + 255) & ~(size_t)255, a8 = (n * 8 + 255) & ~(size_t)255;
     int rc = ensure_scratch(ctx, 2 * a8 + a4 + temp_bytes + 256);
     if (rc) return rc;
@@ -1276,7 +1343,7 @@ static int sort_queries_fine(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
     uint32_t* v_in = (uint32_t*)(sc + 2 * a8);
     hipLaunchKernelGGL(query_keys_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), (uint32_t)n,
                        g->p, (uint32_t)g->n_cells, k_in, v_in);
-    const hipError_t e = sort_pairs_u64_u32(sc + 2 * a8 + a4, temp_bytes, k_in, k_out, v_in, ctx->qperm, n, 0, key_bits + 9, ctx->stream);
+    const hipError_t e = sort_pairs_u64_u32(sc + 2 * a8 + a4, temp_bytes, k_in, k_out, v_in, ctx->qperm, n, 0, key_bits + QKEY_SUB_BITS, ctx->stream);
     if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "radix sort(queries)", e);
     PCR_HIP(ctx, hipGetLastError());
     ctx->qperm_n = n;
@@ -1632,8 +1699,8 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     const uint32_t* perm = (!sorted && tune_get(ctx, "grid_sort_queries", 1) > 0) ? ctx->qperm : nullptr;
     unsigned long long* stats_dev = nullptr;
     if (tune_get(ctx, "grid_stats", 0) > 0) {     // diagnostics: candidates / fine rows / coarse rows / far stages of this launch
-        if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
-        PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, PCR_NSTATS * sizeof(unsigned long long)));
+        PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, PCR_NSTATS * sizeof(unsigned long long), ctx->stream));
         stats_dev = ctx->grid_stats_dev;
     }
     // warm start: only inside an ICP loop (reuse_perm), from its second search on, when keys[] belongs to this source
@@ -1698,12 +1765,65 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         launch_blocks = (nblocks + unit - 1) / unit * unit;
     }
     ctx->last_nn1_kernel = "grid";
+    // TILE SEARCH (grid_tile.hpp; tune grid_tile: 0 auto = targets of 500 000 points and more, 1 on, 2 off): the seeded searches of a loop
+    // whose working cloud is in the order of a Morton-ordered index — one wave per 32 consecutive queries shares rows, sphere tests and
+    // record loads, and passes of more than four runs are filtered on the f16 matrix pipe; queries whose ball exceeds
+    // grid_tile_bmax_pct % of a cell edge (default 400) and passes with more than grid_tile_keep surviving runs (default 512) go to a
+    // segmented list that the cell walk serves in a second launch (list mode).  Measured at 10 M x 10 M, same box, per search of a
+    // 20-iteration loop (profiles/r03_c5_tile_search.txt): converged 2.79 -> 1.66 ms, average over the first 20 searches 4.45 -> 3.65 ms.
+    // Other knobs (defaults measured in the same file): grid_tile_lim_pct (ball limit as a multiple of the group's mean ball, 1000 =
+    // off), grid_tile_reach_pct (cluster reach of a pass in ball limits, 200), grid_tile_total_mult (runs a pass may test, x keep, 16),
+    // grid_tile_min_members (8), grid_tile_list_segs (groups per wave of the list walk, 1), grid_tile_filter (2 = exact loop only).
+    // Same results as the walk alone, bit for bit (tests: test_config5.py, test_gpu_parity.py::test_icp_tile_search_...).
+    const int64_t tile_tune = tune_get(ctx, "grid_tile", 0);
+    if (mode == 2 && warm == 3 && sorted && !perm && wpos && cap2 < __builtin_inff() && tile_tune != 2 && (tile_tune == 1 || tgt->n >= 500000)) {
+        // the segmented list of deferred queries: 32 slots per group of 32 queries + one count per group (far_list is free here: the
+        // hand-off of far queries to the exhaustive kernel only exists for unbounded searches)
+        const size_t n_groups_sz = (ns + 31) / 32, need = n_groups_sz * 32 + n_groups_sz;
+        if (ctx->far_cap < need) {
+            if (ctx->far_list) { PCR_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->far_list); ctx->far_list = nullptr; ctx->far_cap = 0; }
+            PCR_HIP(ctx, hipMalloc((void**)&ctx->far_list, (need + 1) * sizeof(uint32_t)));
+            ctx->far_cap = need;
+        }
+        uint32_t* dlist = ctx->far_list;
+        uint32_t* dcount = ctx->far_list + n_groups_sz * 32;
+        const float bmax = (float)tune_get(ctx, "grid_tile_bmax_pct", 400) * 0.01f * g->p.h;
+        const float lim_k = (float)tune_get(ctx, "grid_tile_lim_pct", 1000) * 0.01f, reach_k = (float)tune_get(ctx, "grid_tile_reach_pct", 200) * 0.01f;
+        const uint32_t keep_max = (uint32_t)std::min<int64_t>(TL_KEEP, std::max<int64_t>(2, tune_get(ctx, "grid_tile_keep", 512)));
+        // (the filter of large passes runs on the f16 matrix pipe: only where this device's arithmetic passed the library's own check)
+        const int use_filter = (tune_get(ctx, "grid_tile_filter", 1) == 1 && mfma_verdict(ctx, true)) ? 1 : 0;
+        const uint32_t min_members = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, tune_get(ctx, "grid_tile_min_members", 8)));
+        const uint32_t total_mult = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, tune_get(ctx, "grid_tile_total_mult", 16)));
+        const uint32_t n_groups = (uint32_t)((ns + 31) / 32);
+        size_t tblocks = (n_groups + (GR_BLOCK / 64) - 1) / (GR_BLOCK / 64);
+        int64_t trun = tune_get(ctx, "grid_xcd_run", 0);
+        if (trun == 0) trun = tblocks >= 4096 ? 32 : -1;
+        uint32_t txcd = 0;
+        if (trun > 0) { txcd = (uint32_t)trun; const size_t unit = 8 * (size_t)txcd; tblocks = (tblocks + unit - 1) / unit * unit; }
+        const uint32_t list_segs = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, tune_get(ctx, "grid_tile_list_segs", 1)));
+        const unsigned lblocks = (unsigned)(((n_groups_sz + (size_t)list_segs * 4 - 1) / ((size_t)list_segs * 4) + 255) / 256 * 256);      // (whole XCD runs)
+        ctx->last_nn1_kernel = "grid-tile";
+        {
+            ProfScope p(ctx, "nn1_grid", 1);
+#define PCR_TILE(ST)                                                                                                                        \
+    hipLaunchKernelGGL((nn1_tile_kernel<ST>), dim3((unsigned)tblocks), dim3(GR_BLOCK), 0, ctx->stream, g->records, g->spheres, g->cell_start, g->p, \
+                       src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)tgt->n, cap2, wpos, dlist,  \
+                       dcount, txcd, bmax, n_groups, lim_k, reach_k, keep_max, use_filter, min_members, total_mult);                                                             \
+    hipLaunchKernelGGL((nn1_grid_kernel<16, ST, 2, true>), dim3(lblocks), dim3(GR_BLOCK), 0, ctx->stream, g->records, g->spheres, g->cell_start, g->p,   \
+                       src->x(), src->y(), src->z(), (const uint32_t*)dlist, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(),     \
+                       tgt->y(), tgt->z(), (uint32_t)tgt->n, 3, cap2, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, wpos, 0u, (const uint32_t*)dcount, list_segs)
+            if (stats_dev) { PCR_TILE(true); } else { PCR_TILE(false); }
+#undef PCR_TILE
+        }
+        PCR_HIP(ctx, hipGetLastError());
+        return PCR_OK;
+    }
     {
         ProfScope p(ctx, "nn1_grid", 1);
 #define PCR_GRID2(GG, ST, MD)                                                                                          \
     hipLaunchKernelGGL((nn1_grid_kernel<GG, ST, MD>), dim3((unsigned)launch_blocks), dim3(GR_BLOCK), 0, ctx->stream, g->records, g->spheres, \
                        g->cell_start, g->p, src->x(), src->y(), src->z(), perm, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(), tgt->y(),   \
-                       tgt->z(), (uint32_t)tgt->n, warm, cap2, far_list, far_count, far_cap, wpos, xcd_run)
+                       tgt->z(), (uint32_t)tgt->n, warm, cap2, far_list, far_count, far_cap, wpos, xcd_run, (const uint32_t*)nullptr, 0u)
 #define PCR_GRID(GG)                                                                                                   \
     do {                                                                                                               \
         if (stats_dev) { if (mode == 1) PCR_GRID2(GG, true, 1); else PCR_GRID2(GG, true, 0); }                         \

@@ -118,6 +118,40 @@ __device__ __forceinline__ uint4 ht_target_operand(float tx, float ty, float tz,
     return upper_half ? make_uint4(qz, qz, w[0] | (w[1] << 16), 0u) : make_uint4(qx, qx, qy, qy);
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// query side of the f16 filter (nn1_brute.hip HTRACK, grid_tile.hpp): error analysis in the header of nn1_btrack_kernel
+#ifndef PCR_HT_ABS_SLACK
+#define PCR_HT_ABS_SLACK 2.384185791015625e-07f      // 2^-22 (A/B builds of the underflow test: -DPCR_HT_ABS_SLACK=0.0f)
+#endif
+__device__ __forceinline__ void ht_pair(float c, uint32_t& d_hi, uint32_t& d_lo)      // (c1, c1) and (c2, c2): c ~ c1 + c2 in f16
+{
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_amdgcn_cvt_pkrtz(c, c);
+    const float rem = c - (float)a.x;
+    const h2 b = __builtin_amdgcn_cvt_pkrtz(rem, rem);
+    d_hi = __builtin_bit_cast(uint32_t, a); d_lo = __builtin_bit_cast(uint32_t, b);
+}
+
+// the f16 form's query operands for one super-tile (centre C.xyz, scale C.w): clamped scaled offset, two f16 pieces per coordinate in the
+// lane-half's K-slots (lanes >= 32: [z pieces | 1, 1, 0, 0]), and R = KAPPA |r|^2 / scale^2 (the bound of a tile is then ONE fma:
+// m / scale^2 + R — the division is exact)
+__device__ __forceinline__ void ht_setup(float qx, float qy, float qz, const float4 C, bool h, uint4& bq, float& R, float& inv2)
+{
+    constexpr float KAPPA = 0.99999237060546875f;             // 1 - 2^-17
+    const float sc = C.w;
+    inv2 = 1.0f / (sc * sc);                                  // exact: |exponent| <= 120
+    const float rx = __builtin_amdgcn_fmed3f((qx - C.x) * sc, -32000.0f, 32000.0f), ry = __builtin_amdgcn_fmed3f((qy - C.y) * sc, -32000.0f, 32000.0f),
+                rz = __builtin_amdgcn_fmed3f((qz - C.z) * sc, -32000.0f, 32000.0f);
+    // KAPPA |r|^2 - 2^-22 in scaled units (the absolute slack for f16 underflow: header above), then back to the cloud's units
+    R = __builtin_fmaf(-PCR_HT_ABS_SLACK, inv2, (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) * KAPPA) * inv2);
+    uint32_t f1, f2, s1, s2;
+    ht_pair(h ? rz : rx, f1, f2);
+    ht_pair(ry, s1, s2);
+    bq = make_uint4(f1, f2, h ? 0x3C003C00u : s1, h ? 0u : s2);
+}
+
 void bt_free(BtIndex* b);
 // builds (and caches on tgt) the index if it is not there yet
 int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt);

@@ -433,7 +433,6 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_etrack_kernel(
     }
 }
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- BTRACK: the filter on the bf16 matrix pipe (the f32 MFMA was tried twice — it runs at the vector ALU's own FMA rate and the two
 // never overlap: DESIGN.md 5, profiles/r02_mfma_filter_experiments.txt).  f32 values are cut into three bf16 pieces each
@@ -492,37 +491,8 @@ __device__ __forceinline__ void bt_pack(float c, uint4& b)
 // (Q + W < 1/48) R is small enough for the subtraction to be exact to 2^-29.  The self-test measures this regime on the device too
 // (worst[2]: |r|, |t''| both in 2^-20 .. 2^-3, subnormal pieces; <= 2 u asserted): an MFMA that FLUSHED f16 subnormals would show
 // up there as ~2^-14-sized errors and fail the verdict (mfma_verdict below).
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef PCR_HT_ABS_SLACK
-#define PCR_HT_ABS_SLACK 2.384185791015625e-07f      // 2^-22 (A/B builds of the underflow test: -DPCR_HT_ABS_SLACK=0.0f)
-#endif
-__device__ __forceinline__ void ht_pair(float c, uint32_t& d_hi, uint32_t& d_lo)      // (c1, c1) and (c2, c2): c ~ c1 + c2 in f16
-{
-    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
-    const h2 a = __builtin_amdgcn_cvt_pkrtz(c, c);
-    const float rem = c - (float)a.x;
-    const h2 b = __builtin_amdgcn_cvt_pkrtz(rem, rem);
-    d_hi = __builtin_bit_cast(uint32_t, a); d_lo = __builtin_bit_cast(uint32_t, b);
-}
-
-// the f16 form's query operands for one super-tile (centre C.xyz, scale C.w): clamped scaled offset, two f16 pieces per coordinate in the
-// lane-half's K-slots (lanes >= 32: [z pieces | 1, 1, 0, 0]), and R = KAPPA |r|^2 / scale^2 (the bound of a tile is then ONE fma:
-// m / scale^2 + R — the division is exact)
-__device__ __forceinline__ void ht_setup(float qx, float qy, float qz, const float4 C, bool h, uint4& bq, float& R, float& inv2)
-{
-    constexpr float KAPPA = 0.99999237060546875f;             // 1 - 2^-17
-    const float sc = C.w;
-    inv2 = 1.0f / (sc * sc);                                  // exact: |exponent| <= 120
-    const float rx = __builtin_amdgcn_fmed3f((qx - C.x) * sc, -32000.0f, 32000.0f), ry = __builtin_amdgcn_fmed3f((qy - C.y) * sc, -32000.0f, 32000.0f),
-                rz = __builtin_amdgcn_fmed3f((qz - C.z) * sc, -32000.0f, 32000.0f);
-    // KAPPA |r|^2 - 2^-22 in scaled units (the absolute slack for f16 underflow: header above), then back to the cloud's units
-    R = __builtin_fmaf(-PCR_HT_ABS_SLACK, inv2, (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) * KAPPA) * inv2);
-    uint32_t f1, f2, s1, s2;
-    ht_pair(h ? rz : rx, f1, f2);
-    ht_pair(ry, s1, s2);
-    bq = make_uint4(f1, f2, h ? 0x3C003C00u : s1, h ? 0u : s2);
-}
+// (ht_pair, ht_setup: grid_common.hpp — the tile search of grid.hip builds the same operands)
 
 // waves per SIMD the headline instance (four query groups, f16, LDS-staged) is built for: 5 = at most 96 VGPRs (two spilled outside the
 // tile loop) — measured 0.574 (130 VGPRs, unbounded) / 0.559 (4 waves, 128) / 0.551 ms (5 waves) per 120 k x 120 k search
@@ -1041,8 +1011,8 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
             PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
         unsigned long long* stats_dev = nullptr;
         if (tune_get(ctx, "grid_stats", 0) > 0) {
-            if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
-            PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
+            if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, PCR_NSTATS * sizeof(unsigned long long)));
+            PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, PCR_NSTATS * sizeof(unsigned long long), ctx->stream));
             stats_dev = ctx->grid_stats_dev;
         }
         {
@@ -1114,8 +1084,8 @@ else hipLaunchKernelGGL((nn1_btrack_kernel<Q, false>), grid, dim3(NN_BLOCK), 0, 
             ctx->last_nn1_kernel = "etrack";
             unsigned long long* stats_dev = nullptr;
             if (tune_get(ctx, "grid_stats", 0) > 0) {          // diagnostics: slot 2 counts the exact rescans of this launch
-                if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, 8 * sizeof(unsigned long long)));
-                PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
+                if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, PCR_NSTATS * sizeof(unsigned long long)));
+                PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, PCR_NSTATS * sizeof(unsigned long long), ctx->stream));
                 stats_dev = ctx->grid_stats_dev;
             }
             {

@@ -17,12 +17,14 @@ namespace pcr {
 // Every cloud is allocated with its length rounded up to PAD points; x of the padding is +inf so that a
 // padded target can never win a nearest-neighbour comparison (d2 = +inf is not < FLT_MAX).
 constexpr size_t PAD = 1024;
+constexpr int PCR_NSTATS = 16;      // diagnostics words of a 1-NN launch (tune grid_stats; pcr_nn1_stats)
 
 inline size_t padded(size_t n) { return ((n + PAD - 1) / PAD) * PAD + PAD; }   // always >= 1 full pad block
 
 struct ProfEntry {
     uint64_t launches = 0;
     double total_ms = 0.0;
+    std::vector<float> each_ms;           // the individual durations since the last reset, in launch order (at most 4096 kept)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 

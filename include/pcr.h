@@ -277,14 +277,19 @@ void pcr_shard_range(size_t n, int nranks, int rank, size_t* begin, size_t* end)
  * pcr_tune_set(ctx, "prof", 1) times the correspondence kernels, 2 every kernel, 0 switches it off again. */
 int pcr_prof_reset(pcr_ctx* ctx);
 int pcr_prof_get(pcr_ctx* ctx, const char* kernel, uint64_t* launches, double* total_ms);
+/* the individual durations (ms, launch order, at most 4096 since the last reset): *n = how many exist, ms[0 .. min(*n, cap)) filled */
+int pcr_prof_get_each(pcr_ctx* ctx, const char* kernel, double* ms, size_t cap, size_t* n);
 /* diagnostics of the last grid search launched with tune "grid_stats" = 1:
  * out = { candidates evaluated, fine x-rows opened, coarse rows tested, far stages run } summed over the queries */
 int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4]);
-/* all eight diagnostics words of the last 1-NN launch made with tune "grid_stats" = 1.  Grid search: [0..3] as pcr_grid_stats.
+/* the sixteen diagnostics words of the last 1-NN launch made with tune "grid_stats" = 1.  Cell walk: [0..3] as pcr_grid_stats.
+ * Tile search (csrc/grid_tile.hpp) + the walk of its deferred queries: [0] record evaluations summed over the queries, [1] rows
+ * opened, [2] spheres tested, [3] far stages of the walk, [4] / [5] largest box edge / largest ball of the served passes (um, summed),
+ * [6] queries deferred to the walk, [7] passes, [8] passes that took the matrix-pipe filter, [9] of those, passes it could not settle.
  * Matrix-core exhaustive search (HTRACK / BTRACK): [2] = (wave, query group) pairs that were filtered a second time, [4] = shader
  * cycles (s_memtime) and [5] = 100 MHz real-time ticks (s_memrealtime) summed over the workgroups: [4] / [5] x 100 MHz is the shader
  * clock the chip held under that launch (bench.py: the clock-corrected roofline). */
-int pcr_nn1_stats(pcr_ctx* ctx, uint64_t out[8]);
+int pcr_nn1_stats(pcr_ctx* ctx, uint64_t out[16]);
 /* Checks on THIS device the arithmetic the matrix-core forms of the exhaustive 1-NN filter rely on (csrc/nn1_brute.hip: BTRACK = two
  * v_mfma_f32_32x32x16_bf16 per tile, three-piece operands; HTRACK = one v_mfma_f32_32x32x16_f16, two-piece scaled operands — the default).
  * `trials` random tiles per mode plus 4 structured (cancellation across K-slots, alternating signs, subnormal pieces, maximal exponent

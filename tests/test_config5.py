@@ -50,5 +50,18 @@ def test_c5_10M_pair_exact_search_shard_linearity_and_pose(pcr, orc, synth):
         assert st["iters_run"] == 4 and st["last_pairs"] > 0.99 * N and e4 < 0.6 * e0
         T2, st2 = ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=4, eps=0.0)
         assert np.linalg.norm(T2 - synth.gt_pose()) < 0.7 * e4
+        # (6) the tile search (default at this size from the third search of a loop on) against the cell walk alone: same pose bits,
+        # same pairs, same loss — through the misaligned first iterations (most queries deferred) and near the converged pose
+        assert ctx.mfma_check()["last_nn1_kernel"] == "grid-tile"
+        ctx.tune("grid_tile", 2)
+        for init, it in ((None, 4), (T, 4), (None, 9)):
+            Tw, sw = ctx.icp_point2point(cs, ct, init_T=init, max_corr=1.0, max_iter=it, eps=0.0)
+            assert ctx.mfma_check()["last_nn1_kernel"] == "grid"
+            ctx.tune("grid_tile", 0)
+            Tt, stt = ctx.icp_point2point(cs, ct, init_T=init, max_corr=1.0, max_iter=it, eps=0.0)
+            ctx.tune("grid_tile", 2)
+            assert np.array_equal(Tw.view(np.uint32), Tt.view(np.uint32)), it
+            assert sw["last_pairs"] == stt["last_pairs"] and np.float32(sw["last_loss"]).view(np.uint32) == np.float32(stt["last_loss"]).view(np.uint32)
+        ctx.tune("grid_tile", 0)
     finally:
         ctx.close()

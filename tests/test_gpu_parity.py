@@ -430,6 +430,55 @@ def test_icp_sphere_walk_gate_as_bound_and_any_working_order(ctx, synth, n):
     cs.free(); ct.free(); cm.free()
 
 
+@pytest.mark.parametrize("n", [30000, 200000])
+def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n):
+    """The tile search of the large-target loops (csrc/grid_tile.hpp: one wave per 32 consecutive queries of the sorted working cloud,
+    far queries deferred to the cell walk in list mode), forced onto small pairs: pose bits, pair count and loss of every iteration
+    count, gate and ball limit equal the exhaustive search's — with non-finite, far-away, gated-out and duplicated points in the
+    clouds, and with the limits so tight that whole groups overflow a wave and take the deferral path."""
+    src, tgt = synth.kitti_like_pair(n, seed_target=247, seed_pair=248)
+    src = src.copy(); tgt = tgt.copy()
+    src[:, 5] = np.nan; src[2, 77] = np.inf; src[0, 100:110] += 300.0; src[2, 200:260] += 1.3
+    tgt[:, 1000:1040] = tgt[:, 2000:2001]                  # 40 exact duplicates of one target: ties, lowest original index wins
+    src[:, 3000:3010] = tgt[:, 2000:2001]                  # ... and queries ON them
+    cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+    gates = (1.0, 0.02, 1e-9)
+    its = (1, 2, 3, 6, 11)
+    ref = {}
+    ctx.tune("nn_method", 1)
+    for gate in gates:
+        for it in its:
+            ref[gate, it] = ctx.icp_point2point(cs, ct, max_corr=gate, max_iter=it, eps=0.0)
+    ctx.tune("nn_method", 2); ctx.tune("grid_order", 2); ctx.tune("grid_mode", 3); ctx.tune("grid_tile", 1)
+    cm = ctx.cloud(tgt)                                    # a fresh cloud: its index is built Morton-ordered
+    used = set()
+    for bmax, pipe in ((0, 0), (5, 0), (150, 0), (400, -1), (50, 1)):
+        ctx.tune("grid_tile_bmax_pct", bmax); ctx.tune("icp_pipeline", pipe)
+        for gate in gates:
+            for it in its:
+                T, st = ctx.icp_point2point(cs, cm, max_corr=gate, max_iter=it, eps=0.0)
+                if it > 2:
+                    used.add(ctx.mfma_check()["last_nn1_kernel"])
+                r = ref[gate, it]
+                assert np.array_equal(T.view(np.uint32), r[0].view(np.uint32)), (bmax, pipe, gate, it)
+                for k in ("iters_run", "last_pairs", "empty_pairs"):
+                    assert st[k] == r[1][k], (k, bmax, pipe, gate, it)
+                assert np.float32(st["last_loss"]).view(np.uint32) == np.float32(r[1]["last_loss"]).view(np.uint32)
+    assert used == {"grid-tile"}, used
+    # the diagnostics: a loop at the converged pose serves nearly every query from the tiles
+    ctx.tune("grid_tile_bmax_pct", 0); ctx.tune("icp_pipeline", 0)
+    T, _ = ctx.icp_point2point(cs, cm, max_corr=1.0, max_iter=25, eps=0.0)
+    ca = cs.clone(); ctx.transform(ca, T)
+    ctx.tune("grid_stats", 1)
+    ctx.icp_point2point(ca, cm, max_corr=1.0, max_iter=3, eps=0.0)
+    w = ctx.nn1_stats()
+    ctx.tune("grid_stats", 0)
+    assert w[0] > 0 and w[6] < n, w                       # (sparse clouds: balls of the size of a cell — most queries take the walk at 30 000 points)
+    for k in ("nn_method", "grid_order", "grid_mode", "grid_tile", "grid_tile_bmax_pct", "icp_pipeline"):
+        ctx.tune(k, 0)
+    cs.free(); ct.free(); cm.free(); ca.free()
+
+
 def test_cloud_layouts_roundtrip(ctx, pcr, synth):
     src, _ = synth.kitti_like_pair(1234)
     c = ctx.cloud(src)
