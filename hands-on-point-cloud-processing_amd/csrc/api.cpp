@@ -339,6 +339,7 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
     if (ctx && ctx->keys_src == c) ctx->keys_src = nullptr;
     if (ctx && ctx->keys_tgt == c) { ctx->keys_tgt = nullptr; ctx->keys_warm = false; ctx->wpos_valid = false; }
     if (ctx && ctx->work_orig_src == c) ctx->work_orig_src = nullptr;
+    if (ctx && (ctx->keys_seed_src == c || ctx->keys_seed_tgt == c)) { ctx->keys_seeded = false; ctx->keys_seed_src = ctx->keys_seed_tgt = nullptr; }
     cloud_modified(c);
     if (c->base) hipFree(c->base);
     delete c;

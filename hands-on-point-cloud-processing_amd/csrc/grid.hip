@@ -1685,6 +1685,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     const size_t ns = src->n;
     if (ns == 0) { ctx->keys_n = 0; ctx->wpos_valid = false; return PCR_OK; }
     if (ns > 0xFFFFFFF0ull || tgt->n > 0xFFFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "cloud too large for u32 indices");
+    ctx->keys_seeded = false;             // (seeds written for an exhaustive search: the walk re-evaluates its own)
     int rc = ensure_keys(ctx, ns);
     if (rc) return rc;
     ctx->keys_n = ns;

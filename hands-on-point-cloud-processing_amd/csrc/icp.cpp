@@ -35,6 +35,7 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
     pcr_icp_stats st;
     memset(&st, 0, sizeof st);
     const LoopHint hint(ctx, prm->max_iter);
+    ctx->keys_seeded = false;            // (seeds a move of an earlier loop left behind describe positions that no longer exist)
 
     // prof bookkeeping: report only this call's nn1 time
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -141,6 +142,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     pcr_icp_stats st;
     memset(&st, 0, sizeof st);
     const LoopHint hint(ctx, prm->max_iter);
+    ctx->keys_seeded = false;            // (seeds a move of an earlier loop left behind describe positions that no longer exist)
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_flush(ctx);
     const uint64_t nn_l0 = ctx->prof["nn1_brute"].launches + ctx->prof["nn1_grid"].launches;
@@ -184,7 +186,12 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     const bool force_slots = tune_get(ctx, "icp_force_slots", 0) > 0;
     // small clouds on one rank: the solve and the move share a launch (kabsch.hip icp_update_move_kernel; tune icp_fused_move: 2 = off);
     // the state then alternates between dev[0] and dev[1]: iteration k reads dev[k & 1] and writes dev[(k + 1) & 1]
-    const bool fused = nranks == 1 && !force_slots && work->n > 0 && work->n <= 32768 && tune_get(ctx, "icp_fused_move", 1) == 1;
+    // (round 3: up to 262 144 points — with the seed of the next search folded in as well, the chain of a 120 k iteration is search ->
+    // sums -> solve + move + seed: three launches instead of five)
+    const int64_t fused_max = tune_get(ctx, "icp_fused_max", 262144);
+    const bool fused = nranks == 1 && !force_slots && work->n > 0 && work->n <= (size_t)fused_max && tune_get(ctx, "icp_fused_move", 1) == 1;
+    // exhaustive searches of a loop seed themselves from the previous correspondences: the move writes those seeds (tune icp_seed_in_move: 2 = off)
+    const pcr_cloud* seed_tgt = (!icp_uses_grid(ctx, tgt) && tune_get(ctx, "icp_seed_in_move", 1) == 1 && tune_get(ctx, "nn1_warm_start", 1) == 1) ? tgt : nullptr;
     uint64_t enq = 0, chunks = 0;
     bool stopped = false;
     while (rc == PCR_OK && !stopped && enq < prm->max_iter) {
@@ -195,7 +202,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
             uint32_t blocks = 0;
             if (work->n && (rc = launch_kabsch_partial(ctx, tgt, work, prm->max_corr, plan, &blocks))) break;   // :936-940,:964-985
             if (fused) {
-                if ((rc = launch_icp_update_move(ctx, blocks, cur, dev + ((enq + 1) & 1), plan, work))) break;   // :948-1003
+                if ((rc = launch_icp_update_move(ctx, blocks, cur, dev + ((enq + 1) & 1), plan, work, seed_tgt))) break;   // :948-1003
                 continue;
             }
             if (nranks == 1 && work->n && !force_slots) {
@@ -205,7 +212,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
                 if ((rc = comm_allreduce_f64_device(ctx, ctx->dev_out, nred))) break;       // the ONE collective
                 if ((rc = launch_icp_update_from_sums(ctx, nranks, dev, plan))) break;
             }
-            if ((rc = launch_transform_state(ctx, work, dev))) break;                       // :1003
+            if ((rc = launch_transform_state(ctx, work, dev, seed_tgt))) break;             // :1003
         }
         ctx->stop_flag_dev = nullptr;
         if (rc) break;

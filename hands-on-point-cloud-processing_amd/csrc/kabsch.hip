@@ -483,6 +483,30 @@ __global__ __launch_bounds__(KF_BLOCK) void icp_update_kernel(const double* __re
     }
 }
 
+// The seed of the NEXT exhaustive search, computed where the point moves (round 3: one launch less per iteration than nn1_seed_kernel
+// in front of every warm search, nn1_brute.hip): keys[] holds this iteration's correspondence of point i; that target, evaluated with
+// the exact A1 arithmetic against the point's NEW position, is a genuine candidate of the next search and therefore an upper bound of
+// its answer from the first instruction on.  Same values as nn1_seed_kernel writes (a correspondence that is not acceptable any more,
+// or none at all, leaves "no claim").
+struct SeedArgs {
+    const float* tx; const float* ty; const float* tz;     // the target cloud (nullptr: no seeding)
+    unsigned long long* keys;
+    uint32_t nt;
+};
+
+__device__ __forceinline__ void seed_next_search(const SeedArgs& sd, uint32_t i, uint32_t n, float x, float y, float z)
+{
+    if (i >= n) return;
+    const uint32_t j = (uint32_t)(sd.keys[i] & 0xFFFFFFFFull);
+    unsigned long long key = ~0ull;
+    if (j < sd.nt) {
+        const float dx = x - sd.tx[j], dy = y - sd.ty[j], dz = z - sd.tz[j];
+        const uint32_t e = __float_as_uint((dx * dx + dy * dy) + dz * dz);       // A1, unfused (nanoflann.hpp:403-406)
+        if (e < 0x7F7FFFFFu) key = ((unsigned long long)e << 32) | j;              // FLT_MAX gate, nanoflann.hpp:163,1360
+    }
+    sd.keys[i] = key;
+}
+
 // Small clouds, single rank: the solve AND the move in one launch — one link less in the latency chain of an iteration
 // (search -> sums -> solve -> move), which is all an iteration is at hw9's own size.  Every workgroup repeats the reduce and the 3 x 3
 // solve on its own LDS copy of the state it read from st_in (deterministic arithmetic on the same rows: all of them arrive at the
@@ -492,7 +516,7 @@ __global__ __launch_bounds__(KF_BLOCK) void icp_update_kernel(const double* __re
 // into stop without a move, a step that stops (converged, no pair, overflow) does not move, any other step moves.
 __global__ __launch_bounds__(KF_BLOCK) void icp_update_move_kernel(const double* __restrict__ partials, uint32_t n_blocks, int e, const IcpState* __restrict__ st_in,
                                                                    IcpState* __restrict__ st_out, double* __restrict__ out, float* __restrict__ x,
-                                                                   float* __restrict__ y, float* __restrict__ z, uint32_t n, uint32_t n4)
+                                                                   float* __restrict__ y, float* __restrict__ z, uint32_t n, uint32_t n4, SeedArgs sd)
 {
     __shared__ double red[KF_GROUPS][64];
     __shared__ double row[KB_ROW];
@@ -539,6 +563,10 @@ __global__ __launch_bounds__(KF_BLOCK) void icp_update_move_kernel(const double*
     reinterpret_cast<float4*>(x)[i] = ox;
     reinterpret_cast<float4*>(y)[i] = oy;
     reinterpret_cast<float4*>(z)[i] = oz;
+    if (sd.tx) {
+        seed_next_search(sd, base + 0, n, ox.x, oy.x, oz.x); seed_next_search(sd, base + 1, n, ox.y, oy.y, oz.y);
+        seed_next_search(sd, base + 2, n, ox.z, oy.z, oz.z); seed_next_search(sd, base + 3, n, ox.w, oy.w, oz.w);
+    }
 }
 
 // multi rank, step 1: reduce the block rows into the all-reduce buffer
@@ -593,7 +621,7 @@ __global__ __launch_bounds__(64) void icp_update_from_sums_kernel(double* __rest
 }
 
 __global__ __launch_bounds__(256) void transform_state_kernel(float* __restrict__ x, float* __restrict__ y,
-                                                              float* __restrict__ z, uint32_t n, uint32_t n4, IcpState* st)
+                                                              float* __restrict__ z, uint32_t n, uint32_t n4, IcpState* st, SeedArgs sd)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
@@ -627,6 +655,10 @@ __global__ __launch_bounds__(256) void transform_state_kernel(float* __restrict_
     reinterpret_cast<float4*>(x)[i] = ox;
     reinterpret_cast<float4*>(y)[i] = oy;
     reinterpret_cast<float4*>(z)[i] = oz;
+    if (sd.tx) {
+        seed_next_search(sd, base + 0, n, ox.x, oy.x, oz.x); seed_next_search(sd, base + 1, n, ox.y, oy.y, oz.y);
+        seed_next_search(sd, base + 2, n, ox.z, oy.z, oz.z); seed_next_search(sd, base + 3, n, ox.w, oy.w, oz.w);
+    }
 }
 
 int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev, const KabschPlan& plan)
@@ -639,13 +671,26 @@ int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev, const K
     return PCR_OK;
 }
 
-int launch_icp_update_move(pcr_ctx* ctx, uint32_t n_blocks, const IcpState* st_in, IcpState* st_out, const KabschPlan& plan, pcr_cloud* c)
+// seed_tgt != nullptr: the move also seeds the next exhaustive search against that target (seed_next_search) and says so on the context
+static SeedArgs seed_args(pcr_ctx* ctx, const pcr_cloud* c, const pcr_cloud* seed_tgt)
+{
+    SeedArgs sd = { nullptr, nullptr, nullptr, nullptr, 0u };
+    ctx->keys_seeded = false;
+    if (seed_tgt && ctx->keys && ctx->keys_n == c->n && c->n) {
+        sd = SeedArgs{ seed_tgt->x(), seed_tgt->y(), seed_tgt->z(), ctx->keys, (uint32_t)seed_tgt->n };
+        ctx->keys_seeded = true; ctx->keys_seed_src = c; ctx->keys_seed_tgt = seed_tgt;
+    }
+    return sd;
+}
+
+int launch_icp_update_move(pcr_ctx* ctx, uint32_t n_blocks, const IcpState* st_in, IcpState* st_out, const KabschPlan& plan, pcr_cloud* c, const pcr_cloud* seed_tgt)
 {
     const uint32_t n4 = (uint32_t)((c->n + 3) / 4);
+    const SeedArgs sd = seed_args(ctx, c, seed_tgt);
     {
         ProfScope p(ctx, "icp_update");
         hipLaunchKernelGGL(icp_update_move_kernel, dim3((n4 + KF_BLOCK - 1) / KF_BLOCK), dim3(KF_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, plan.e, st_in,
-                           st_out, ctx->dev_out, c->x(), c->y(), c->z(), (uint32_t)c->n, n4);
+                           st_out, ctx->dev_out, c->x(), c->y(), c->z(), (uint32_t)c->n, n4, sd);
     }
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
@@ -666,13 +711,14 @@ int launch_icp_update_from_sums(pcr_ctx* ctx, int nranks, IcpState* st_dev, cons
     return PCR_OK;
 }
 
-int launch_transform_state(pcr_ctx* ctx, pcr_cloud* c, IcpState* st_dev)
+int launch_transform_state(pcr_ctx* ctx, pcr_cloud* c, IcpState* st_dev, const pcr_cloud* seed_tgt)
 {
     if (c->n) {
         const uint32_t n4 = (uint32_t)((c->n + 3) / 4);
+        const SeedArgs sd = seed_args(ctx, c, seed_tgt);
         ProfScope p(ctx, "transform");
         hipLaunchKernelGGL(transform_state_kernel, dim3((n4 + 255) / 256), dim3(256), 0, ctx->stream, c->x(), c->y(), c->z(),
-                           (uint32_t)c->n, n4, st_dev);
+                           (uint32_t)c->n, n4, st_dev, sd);
     }
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;

@@ -937,6 +937,9 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     // keys[] still holds this source's correspondences of the previous ICP iteration?
     const bool warm = in_loop && ctx->keys_warm && (ctx->keys_src == src || ctx->keys_tgt == tgt) && ctx->keys_warm_n == ns &&
                       tune_get(ctx, "nn1_warm_start", 1) == 1;
+    // ... and the move of the previous iteration already turned them into this search's seeds (kabsch.hip seed_next_search)?
+    const bool pre_seeded = warm && ctx->keys_seeded && ctx->keys_seed_src == src && ctx->keys_seed_tgt == tgt && ctx->keys_n == ns;
+    ctx->keys_seeded = false;
     int rc = ensure_keys(ctx, ns);
     if (rc) return rc;
     ctx->keys_n = ns;
@@ -1004,7 +1007,8 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
         // a cold, sliced search seeds itself from the nearest super-tile (tune nn1_cold_seed: 1 on (default), 2 off)
         const bool cold_seed = !warm && slices > 1 && tune_get(ctx, "nn1_cold_seed", 1) == 1;
         const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
-        if (warm)
+        if (warm && pre_seeded) { /* keys[] holds the seeds already */ }
+        else if (warm)
             hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
                                (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
         else if (merge_atomic && !cold_seed)
@@ -1075,7 +1079,8 @@ else hipLaunchKernelGGL((nn1_btrack_kernel<Q, false>), grid, dim3(NN_BLOCK), 0, 
             uint32_t slices = (uint32_t)((g->n_chunks + cps - 1) / cps);
             if (slices > 65535) { slices = 65535; cps = (g->n_chunks + slices - 1) / slices; slices = (uint32_t)((g->n_chunks + cps - 1) / cps); }
             const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
-            if (warm)
+            if (warm && pre_seeded) { /* keys[] holds the seeds already */ }
+            else if (warm)
                 hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
                                    (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
             else if (merge_atomic)

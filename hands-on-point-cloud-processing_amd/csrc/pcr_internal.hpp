@@ -102,6 +102,11 @@ struct pcr_ctx {
     const pcr_cloud* keys_src = nullptr;  // its source (identity only; reset when the cloud is destroyed)
     const pcr_cloud* keys_tgt = nullptr;  // its target (identity only; reset when the cloud is destroyed)
     size_t keys_warm_n = 0;               // number of queries of that search
+    // the last move of an ICP loop already turned keys[] into the seeds of the next exhaustive search of (keys_seed_src, keys_seed_tgt):
+    // launch_nn1_brute then skips its own seed kernel (consumed by the next search, whatever it is)
+    bool keys_seeded = false;
+    const pcr_cloud* keys_seed_src = nullptr;
+    const pcr_cloud* keys_seed_tgt = nullptr;
     uint32_t* qperm = nullptr;            // queries grouped by target-grid cell (grid NN)
     size_t qperm_cap = 0;
     size_t qperm_n = 0;
@@ -223,9 +228,11 @@ int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev, const K
 int launch_icp_reduce_slots(pcr_ctx* ctx, uint32_t n_blocks, int nranks, int rank, bool have_points);
 int launch_icp_update_from_sums(pcr_ctx* ctx, int nranks, IcpState* st_dev, const KabschPlan& plan);
 inline int icp_nred(int nranks) { return 56 + 2 * nranks; }
-int launch_transform_state(pcr_ctx* ctx, pcr_cloud* c, IcpState* st_dev);
+// seed_tgt != nullptr: the move also writes the seeds of the next exhaustive search into keys[] (kabsch.hip seed_next_search)
+int launch_transform_state(pcr_ctx* ctx, pcr_cloud* c, IcpState* st_dev, const pcr_cloud* seed_tgt = nullptr);
 // small clouds, one rank: icp_update + transform_state in one launch; the state alternates between the two buffers st_in / st_out
-int launch_icp_update_move(pcr_ctx* ctx, uint32_t n_blocks, const IcpState* st_in, IcpState* st_out, const KabschPlan& plan, pcr_cloud* c);
+int launch_icp_update_move(pcr_ctx* ctx, uint32_t n_blocks, const IcpState* st_in, IcpState* st_out, const KabschPlan& plan, pcr_cloud* c,
+                           const pcr_cloud* seed_tgt = nullptr);
 int comm_allreduce_f64_device(pcr_ctx* ctx, double* dev_buf, int n);   // RCCL on the ctx stream, no host round trip
 int launch_plane_count(pcr_ctx* ctx, const pcr_cloud* pts, const double* planes4_dev, size_t n_planes,
                        double thr, unsigned long long* counts_dev);
