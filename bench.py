@@ -166,9 +166,8 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] block of the default line")
     ap.add_argument("--no-extras", action="store_true", help="only the timed loop and its roofline (profiling runs)")
     ap.add_argument("--c5-points", type=int, default=10_000_000)
-    ap.add_argument("--qpl", type=int, default=0)
     ap.add_argument("--tiles-per-slice", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=0, help="nn1 kernel variant (0 = library default; 2 = exact TRACK; 3 = exact TRACK through LDS tiles)")
+    ap.add_argument("--variant", type=int, default=0, help="nn1 kernel variant (0 = library default; 1 FTRACK, 2 exact TRACK, 4 ETRACK, 6 BTRACK, 7 HTRACK)")
     ap.add_argument("--nn", choices=["brute", "grid"], default="brute",
                     help="correspondence search of the c2 headline: brute = BASELINE configs[1] (exhaustive), grid = exact grid index")
     args = ap.parse_args()
@@ -213,8 +212,6 @@ def main():
         k, v = kv.split("=")
         ctx.tune(k.strip(), int(v))
         tunes_env[k.strip()] = int(v)
-    if args.qpl:
-        ctx.tune("nn1_qpl", args.qpl)
     if args.tiles_per_slice:
         ctx.tune("nn1_tiles_per_slice", args.tiles_per_slice)
     if args.variant:
@@ -358,7 +355,7 @@ def main():
         kern_s = nn_ms / 1e3 / max(nn_launches, 1)
         n_q, n_t = src.shape[1], tgt.shape[1]
         pairs = float(n_q) * float(n_t)
-        default_kernels = not (args.qpl or args.variant)
+        default_kernels = not args.variant
         extras = not args.no_extras
         bd = kernel_breakdown(cs, ct, main_method, min(args.steps, 10)) if extras else {}
 
@@ -396,7 +393,7 @@ def main():
                 return ms / max(k, 1)
             ms_exact = time_search(ct, 5, nn1_variant=2)
             tf = OPS_PER_PAIR * pairs / (ms_exact / 1e3) / 1e12
-            exact_line = {"kernel": "pcr::nn1_track_kernel<2, 16, true> (nn1_variant 2: the exact unfused arithmetic for every pair, no filter)",
+            exact_line = {"kernel": "pcr::nn1_track_kernel<2, 16> (nn1_variant 2: the exact unfused arithmetic for every pair, no filter)",
                           "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TOPS_NOFMA, "unit": "T lane-ops/s", "frac": tf / VALU_PEAK_TOPS_NOFMA,
                           "avg_launch_ms": ms_exact, "kernel_M_corr_per_s": n_q / ms_exact / 1e3,
                           "algorithmic": f"{OPS_PER_PAIR} f32 lane-ops per (query, target) pair (SURVEY.md 8d: 3 sub + 3 mul + 2 add + 1 compare) x {pairs:.3e} "
@@ -490,7 +487,7 @@ def main():
                     "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
                                      f"kernel with this very libpcr_hip.so (sha {sha}), {pmc['source']}") if pmc else
                                     "null: PMC counters need a rocprofv3 wrapper (tools/gpu_check.sh); none was collected with the library loaded now",
-                    "kernel": (("pcr::nn1_btrack_kernel<4, true, true> = HTRACK, operands staged through LDS per workgroup (exhaustive scan of every (query, 16-target chunk): the expanded-form lower "
+                    "kernel": (("pcr::nn1_btrack_kernel<4, true> = HTRACK, operands staged through LDS per workgroup (exhaustive scan of every (query, 16-target chunk): the expanded-form lower "
                                 "bound of ALL pairs on the f16 matrix pipe — operands scaled per 256-target super-tile and cut into two f16 pieces each, "
                                 "every piece product exact in f32, ONE v_mfma_f32_32x32x16_f16 per 32 queries x 32 targets; the vector ALU takes the "
                                 "minimum of the 16 accumulators per lane (8 v_min3) and tracks first / second minimum branch-free; only the winning "
@@ -505,7 +502,7 @@ def main():
                                ("pcr::nn1_etrack_kernel<4> (exhaustive scan of every (query, 16-target chunk); chunk-centred targets broadcast through the "
                                 "scalar cache; expanded-form lower bound = 3 FMAs per pair (v_pk_fma_f32), min-tree + first/second minimum tracked "
                                 "branch-free; only the winning chunk is evaluated with the exact unfused arithmetic; the previous correspondence of "
-                                "each query, re-evaluated exactly, seeds the bound)")) if default_kernels else f"nn1 variant={args.variant} qpl={args.qpl}",
+                                "each query, re-evaluated exactly, seeds the bound)")) if default_kernels else f"nn1 variant={args.variant}",
                     "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
                     "algorithmic": (f"{flops_pp} {'f16' if f16 else 'bf16'} flop per (query, target) pair ({flops_pp // 2} piece products that carry data, of "
                                     f"the {16 if f16 else 32} K-slots executed) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16 / bf16.  On this chip "
@@ -551,8 +548,8 @@ def main():
                                     "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
                                     "note": "compulsory bytes (32 B/point); brute force is VALU-bound, see DESIGN.md"}}
                 workload = (f"point-to-point ICP iteration = exhaustive 1-NN correspondence of ONE {n} x {n_t} pair + Kabsch + transform; BASELINE.json "
-                            "configs[1]/[2] ('LDS-tiled brute force': the default kernels broadcast the target through the scalar cache, faster than "
-                            "the LDS-tiled variant, which --variant 3 selects; same results)")
+                            "configs[1]/[2] ('LDS-tiled brute force': the default kernel stages the target's matrix-core operands through LDS, one "
+                            "256-target super-tile per workgroup and barrier)")
             else:
                 roofline, workload = grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha), \
                     f"point-to-point ICP iteration on ONE {n_t} x {n} pair = exact grid 1-NN + Kabsch + transform"

@@ -41,8 +41,8 @@ namespace pcr {
 constexpr int NN_BLOCK = 256;
 constexpr int NN_TILE = 1024;   // targets per LDS tile: 3 * 4 KiB
 constexpr bool NN_F16_DEFAULT = true;      // measured: 0.72 against 0.88 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
-constexpr bool NN_PAIR_CHUNKS = true;      // LDS-staged f16 form: first / second minimum tracked per pair of tiles (chunks of 32 records)
-constexpr int NN_LDS_OPS_DEFAULT = 1;      // matrix-core operands staged through LDS per workgroup (tune nn1_lds_ops: 1 on, 2 off): 0.706 against 0.737 ms per 120k x 120k search
+// (the f16 form stages its operands through LDS per workgroup — 0.706 against 0.737 ms per 120k x 120k search — and tracks first / second
+// minimum per pair of tiles = chunks of 32 records: both were switches in round 2, both are what the kernel is since round 3)
 constexpr int NN_XCD_DEFAULT = 4;          // XCD-aware launch of the matrix-core kernels (tune nn1_xcd; nn1_btrack_kernel): 24.6 against 68.5 MiB fetched per 120k x 120k launch, same time
 constexpr bool NN_BF16_DEFAULT = true;     // measured: 0.90 against 1.30 ms per warm 120k x 120k search (profiles/r02_mfma_filter_experiments.txt)
 
@@ -104,17 +104,13 @@ struct TrackLane {
     }
 };
 
-template <int QPL, int CH, bool SGPR>
+template <int QPL, int CH>
 __global__ __launch_bounds__(NN_BLOCK) void nn1_track_kernel(
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
     const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
     uint32_t ns, uint32_t n_tiles, uint32_t tiles_per_slice,
     unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop)
 {
-    __shared__ float4 lx[SGPR ? 1 : NN_TILE / 4];
-    __shared__ float4 ly[SGPR ? 1 : NN_TILE / 4];
-    __shared__ float4 lz[SGPR ? 1 : NN_TILE / 4];
-
     if (stop && (stop[0] | stop[1])) return;      // pipelined ICP: the loop has ended, the enqueued tail is a no-op
     const uint32_t tid = threadIdx.x;
     const uint32_t qbase = blockIdx.x * (NN_BLOCK * QPL);
@@ -128,49 +124,23 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_track_kernel(
     }
     const uint32_t tile0 = blockIdx.y * tiles_per_slice;
     const uint32_t tile1 = min(tile0 + tiles_per_slice, n_tiles);
-    if (SGPR) {
-        const uint32_t j_begin = tile0 * NN_TILE, j_end = tile1 * NN_TILE;
+    // the targets are wave-uniform data: s_load_dwordx4 of the SoA arrays through the scalar cache — operands arrive in SGPRs, no LDS,
+    // no barriers (round 1 also carried an LDS-tiled transport of the same loop: 3-4 % slower, retired in round 3; since round 2 the
+    // LDS-staged kernel of this file is the matrix-core one, nn1_btrack_kernel)
+    const uint32_t j_begin = tile0 * NN_TILE, j_end = tile1 * NN_TILE;
 #pragma unroll 2
-        for (uint32_t j0 = j_begin; j0 < j_end; j0 += CH) {
-            float X[CH], Y[CH], Z[CH];
+    for (uint32_t j0 = j_begin; j0 < j_end; j0 += CH) {
+        float X[CH], Y[CH], Z[CH];
 #pragma unroll
-            for (int g = 0; g < CH / 4; g++) {
-                const float4 a = *reinterpret_cast<const float4*>(tx + j0 + 4 * g);
-                const float4 b = *reinterpret_cast<const float4*>(ty + j0 + 4 * g);
-                const float4 c = *reinterpret_cast<const float4*>(tz + j0 + 4 * g);
-                X[4 * g] = a.x; X[4 * g + 1] = a.y; X[4 * g + 2] = a.z; X[4 * g + 3] = a.w;
-                Y[4 * g] = b.x; Y[4 * g + 1] = b.y; Y[4 * g + 2] = b.z; Y[4 * g + 3] = b.w;
-                Z[4 * g] = c.x; Z[4 * g + 1] = c.y; Z[4 * g + 2] = c.z; Z[4 * g + 3] = c.w;
-            }
-            L.chunk(X, Y, Z, j0);
+        for (int g = 0; g < CH / 4; g++) {
+            const float4 a = *reinterpret_cast<const float4*>(tx + j0 + 4 * g);
+            const float4 b = *reinterpret_cast<const float4*>(ty + j0 + 4 * g);
+            const float4 c = *reinterpret_cast<const float4*>(tz + j0 + 4 * g);
+            X[4 * g] = a.x; X[4 * g + 1] = a.y; X[4 * g + 2] = a.z; X[4 * g + 3] = a.w;
+            Y[4 * g] = b.x; Y[4 * g + 1] = b.y; Y[4 * g + 2] = b.z; Y[4 * g + 3] = b.w;
+            Z[4 * g] = c.x; Z[4 * g + 1] = c.y; Z[4 * g + 2] = c.z; Z[4 * g + 3] = c.w;
         }
-    } else if (tile0 < tile1) {
-        const float4* gx = reinterpret_cast<const float4*>(tx) + (size_t)tile0 * (NN_TILE / 4);
-        const float4* gy = reinterpret_cast<const float4*>(ty) + (size_t)tile0 * (NN_TILE / 4);
-        const float4* gz = reinterpret_cast<const float4*>(tz) + (size_t)tile0 * (NN_TILE / 4);
-        float4 rx = gx[tid], ry = gy[tid], rz = gz[tid];
-        for (uint32_t tile = tile0; tile < tile1; tile++) {
-            lx[tid] = rx; ly[tid] = ry; lz[tid] = rz;
-            __syncthreads();
-            if (tile + 1 < tile1) {     // prefetch the next tile while this one is consumed
-                gx += NN_TILE / 4; gy += NN_TILE / 4; gz += NN_TILE / 4;
-                rx = gx[tid]; ry = gy[tid]; rz = gz[tid];
-            }
-            const uint32_t jbase = tile * NN_TILE;
-#pragma unroll 2
-            for (int c = 0; c < NN_TILE / CH; c++) {
-                float X[CH], Y[CH], Z[CH];
-#pragma unroll
-                for (int g = 0; g < CH / 4; g++) {
-                    const float4 a = lx[(CH / 4) * c + g], b = ly[(CH / 4) * c + g], cc = lz[(CH / 4) * c + g];
-                    X[4 * g] = a.x; X[4 * g + 1] = a.y; X[4 * g + 2] = a.z; X[4 * g + 3] = a.w;
-                    Y[4 * g] = b.x; Y[4 * g + 1] = b.y; Y[4 * g + 2] = b.z; Y[4 * g + 3] = b.w;
-                    Z[4 * g] = cc.x; Z[4 * g + 1] = cc.y; Z[4 * g + 2] = cc.z; Z[4 * g + 3] = cc.w;
-                }
-                L.chunk(X, Y, Z, jbase + CH * c);
-            }
-            __syncthreads();
-        }
+        L.chunk(X, Y, Z, j0);
     }
     // once per query: which target of the remembered chunk attained the minimum (lowest index first)
 #pragma unroll
@@ -499,8 +469,8 @@ __device__ __forceinline__ void bt_pack(float c, uint4& b)
 #ifndef PCR_BT_WAVES
 #define PCR_BT_WAVES 5
 #endif
-template <int QG, bool F16, bool LDSA = false>
-__global__ __launch_bounds__(NN_BLOCK, (F16 && LDSA && QG == 4) ? PCR_BT_WAVES : 1) void nn1_btrack_kernel(
+template <int QG, bool F16>
+__global__ __launch_bounds__(NN_BLOCK, (F16 && QG == 4) ? PCR_BT_WAVES : 1) void nn1_btrack_kernel(
     const float4* __restrict__ centres, const uint4* __restrict__ ops, const float4* __restrict__ records, uint32_t n_rec, uint32_t n_super,
     uint32_t supers_per_slice, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
     unsigned long long* __restrict__ keys, int merge_atomic, const int* __restrict__ stop, unsigned long long* __restrict__ stats,
@@ -515,12 +485,13 @@ __global__ __launch_bounds__(NN_BLOCK, (F16 && LDSA && QG == 4) ? PCR_BT_WAVES :
     // (query block, slice) of this workgroup.  xq = 0: the plain 2-D launch — workgroups go to the 8 XCDs round-robin, so every XCD's
     // L2 pulls in ALL operands and ALL queries.  xq = 1 / 2 / 4: a 1-D launch in which XCD k = id % 8 owns the query blocks = k % xq
     // (mod xq) and the slices = k / xq (mod 8 / xq): its L2 holds 1 / xq of the queries and xq / 8 of the operands.
-    // lds (template LDSA; tune nn1_lds_ops: 1 = the f16 form (default), 3 = both forms, 2 = off): the four waves of a workgroup scan the SAME tiles for different queries; instead of
-    // four per-wave streams of 16-byte loads from L1 / L2, the workgroup stages the operands of one super-tile (8 KB; bf16: 16 KB) in LDS, the next
-    // one prefetched into registers a whole super-tile ahead, one barrier per super-tile.  (A wave beyond the queries then stays for
-    // the barriers: it repeats the last query and stores nothing.)
-    constexpr bool lds = LDSA;
-    constexpr bool PAIR = F16 && LDSA && NN_PAIR_CHUNKS;      // chunks of 32 records (two tiles), see the f16 loop
+    // The f16 form stages its operands through LDS: the four waves of a workgroup scan the SAME tiles for different queries; instead of
+    // four per-wave streams of 16-byte loads from L1 / L2, the workgroup holds the operands of one super-tile (8 KB) in LDS, the next
+    // one prefetched into registers a whole super-tile ahead, one barrier per super-tile (a wave beyond the queries then stays for the
+    // barriers: it repeats the last query and stores nothing).  The bf16 form (two MFMAs per tile, 16 KB per super-tile) measured the
+    // same either way and keeps the per-wave loads.  (Round 2 carried both transports for both forms as template / tune switches.)
+    constexpr bool lds = F16;
+    constexpr bool PAIR = F16;                                // chunks of 32 records (two tiles), see the f16 loop
     uint32_t qb = blockIdx.x, sl = blockIdx.y;
     if (xq) {
         const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, xs = 8u / xq, qb_per = (qblocks + xq - 1) / xq;
@@ -553,18 +524,16 @@ __global__ __launch_bounds__(NN_BLOCK, (F16 && LDSA && QG == 4) ? PCR_BT_WAVES :
 #pragma unroll
     for (int j = 0; j < 16; j++) zero[j] = 0.0f;
     if (F16) {
-        __shared__ uint4 sA[lds ? 2 : 1][lds ? TPS * 64 : 1];      // (lds) the operands of two super-tiles: 16 KB
-        uint4 an = make_uint4(0, 0, 0, 0), pre0 = an, pre1 = an;
-        if (lds) {
-            if (sb < se) {
-                sA[0][lds ? threadIdx.x : 0] = ops[(size_t)sb * TPS * 64 + threadIdx.x];
-                sA[0][lds ? NN_BLOCK + threadIdx.x : 0] = ops[(size_t)sb * TPS * 64 + NN_BLOCK + threadIdx.x];
-            }
-            __syncthreads();
-        } else if (sb < se) an = ops[(size_t)sb * TPS * 64 + lane];
+        __shared__ uint4 sA[2][TPS * 64];                     // the operands of two super-tiles: 16 KB
+        uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0;
+        if (sb < se) {
+            sA[0][threadIdx.x] = ops[(size_t)sb * TPS * 64 + threadIdx.x];
+            sA[0][NN_BLOCK + threadIdx.x] = ops[(size_t)sb * TPS * 64 + NN_BLOCK + threadIdx.x];
+        }
+        __syncthreads();
         for (uint32_t S = sb; S < se; S++) {
             const uint32_t buf = (S - sb) & 1u;
-            if (lds && S + 1 < se) {                          // the next super-tile: in flight during this one's eight tiles
+            if (S + 1 < se) {                                 // the next super-tile: in flight during this one's eight tiles
                 pre0 = ops[(size_t)(S + 1) * TPS * 64 + threadIdx.x];
                 pre1 = ops[(size_t)(S + 1) * TPS * 64 + NN_BLOCK + threadIdx.x];
             }
@@ -574,126 +543,75 @@ __global__ __launch_bounds__(NN_BLOCK, (F16 && LDSA && QG == 4) ? PCR_BT_WAVES :
             float R[QG];
 #pragma unroll
             for (int g = 0; g < QG; g++) ht_setup(qx[g], qy[g], qz[g], C, h, bq[g], R[g], inv2);
-            if (PAIR) {
-                // chunks of 32: the minimum chain of a lane runs on through the two tiles of a pair (the second tile's chain starts from the
-                // first tile's minimum), and first / second minimum and the winning chunk are tracked once per PAIR — 3 of the 22 vector
-                // issue slots of a tile less.  Chunk 2 P + h = the records of half-lane h in tiles 2 P and 2 P + 1 (two runs of 16).
-                static_assert(TPS % 2 == 0, "pairs of tiles must not straddle super-tiles");
+            // chunks of 32: the minimum chain of a lane runs on through the two tiles of a pair (the second tile's chain starts from the
+            // first tile's minimum), and first / second minimum and the winning chunk are tracked once per PAIR — 3 of the 22 vector
+            // issue slots of a tile less.  Chunk 2 P + h = the records of half-lane h in tiles 2 P and 2 P + 1 (two runs of 16).
+            static_assert(TPS % 2 == 0, "pairs of tiles must not straddle super-tiles");
 #pragma unroll 1
-                for (int tp = 0; tp < TPS / 2; tp++) {
-                    const uint32_t Pr = (S * TPS) / 2 + tp;
-                    const uint4 A0 = sA[lds ? buf : 0][lds ? (2 * tp) * 64 + lane : 0], A1 = sA[lds ? buf : 0][lds ? (2 * tp + 1) * 64 + lane : 0];
-                    const uint32_t c = 2 * Pr + (h ? 1u : 0u);
-#pragma unroll
-                    for (int g = 0; g < QG; g++) {
-                        const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A0), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
-                        float m = big;
-#pragma unroll
-                        for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc0[j]), acc0[j + 1]);
-                        const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A1), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
-#pragma unroll
-                        for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc1[j]), acc1[j + 1]);
-                        const float L = __builtin_fmaf(m, inv2, R[g]);
-                        m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], L);
-                        const bool better = L < m1[g];
-                        m1[g] = better ? L : m1[g];
-                        c1[g] = better ? c : c1[g];
-                    }
-                }
-            } else {
-#pragma unroll 1
-            for (int tt = 0; tt < TPS; tt++) {
-                const uint32_t T = S * TPS + tt;
-                uint4 A;
-                if (lds) A = sA[lds ? buf : 0][lds ? tt * 64 + lane : 0];
-                else {
-                    A = an;
-                    if (tt + 1 < TPS || S + 1 < se) an = ops[(size_t)(T + 1) * 64 + lane];
-                }
-                const uint32_t c = 2 * T + (h ? 1u : 0u);
+            for (int tp = 0; tp < TPS / 2; tp++) {
+                const uint32_t Pr = (S * TPS) / 2 + tp;
+                const uint4 A0 = sA[buf][(2 * tp) * 64 + lane], A1 = sA[buf][(2 * tp + 1) * 64 + lane];
+                const uint32_t c = 2 * Pr + (h ? 1u : 0u);
 #pragma unroll
                 for (int g = 0; g < QG; g++) {
-                    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
+                    // minimum of the accumulators: v_min3 chains starting from an opaque +inf (a plain two-operand fminf of two MFMA
+                    // results is first canonicalised: three half-rate instructions instead of one).  (No inline-asm v_min3 on the
+                    // accumulators themselves: the compiler would not know to wait for the MFMA before it — measured: wrong minima.)
+                    const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A0), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
+                    float m = big;
+#pragma unroll
+                    for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc0[j]), acc0[j + 1]);
+                    const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A1), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc1[j]), acc1[j + 1]);
+                    const float L = __builtin_fmaf(m, inv2, R[g]);
+                    m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], L);
+                    const bool better = L < m1[g];            // (false for a NaN L: a non-finite query is rescanned exactly anyway)
+                    m1[g] = better ? L : m1[g];
+                    c1[g] = better ? c : c1[g];
+                }
+            }
+            if (S + 1 < se) { sA[buf ^ 1u][threadIdx.x] = pre0; sA[buf ^ 1u][NN_BLOCK + threadIdx.x] = pre1; }
+            __syncthreads();
+        }
+    } else {
+        uint4 a0n = make_uint4(0, 0, 0, 0), a1n = a0n;
+        if (sb < se) { a0n = ops[(size_t)sb * TPS * 128 + lane]; a1n = ops[(size_t)sb * TPS * 128 + 64 + lane]; }
+        for (uint32_t S = sb; S < se; S++) {
+            const float4 C = centres[S];                      // wave-uniform: scalar load
+            uint4 b0[QG], b1[QG];
+            float R[QG];
+#pragma unroll
+            for (int g = 0; g < QG; g++) {
+                const float rx = qx[g] - C.x, ry = qy[g] - C.y, rz = qz[g] - C.z;
+                R[g] = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
+                bt_pack(h ? ry : rx, b0[g]);
+                bt_pack(h ? 1.0f : rz, b1[g]);
+            }
+#pragma unroll 1
+            for (int tt = 0; tt < TPS; tt++) {                // (not unrolled: the scheduler would keep all 16 accumulator tiles alive)
+                const uint32_t T = S * TPS + tt;
+                const uint4 A0 = a0n, A1 = a1n;
+                if (tt + 1 < TPS || S + 1 < se) { a0n = ops[(size_t)(T + 1) * 128 + lane]; a1n = ops[(size_t)(T + 1) * 128 + 64 + lane]; }   // next tile in flight
+                const uint32_t c = 2 * T + (h ? 1u : 0u);
+                // (Tried: reducing the PREVIOUS group's accumulators between the two MFMAs of the current one, in program order enforced with
+                // sched_group_barrier — 0.892 against 0.900 ms.  On this chip the bf16 MFMA and the vector instructions of one SIMD's waves
+                // take turns rather than overlap in this loop: tools/ubench/mfma_filter.hip part C, profiles/r02_mfma_filter_experiments.txt.)
+#pragma unroll
+                for (int g = 0; g < QG; g++) {
+                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), __builtin_bit_cast(bf16x8, b0[g]), zero, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1), __builtin_bit_cast(bf16x8, b1[g]), acc, 0, 0, 0);
                     float m = big;
 #pragma unroll
                     for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc[j]), acc[j + 1]);
-                    const float L = __builtin_fmaf(m, inv2, R[g]);
+                    const float L = __builtin_fmaf(R[g], KAPPA, m);
                     m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], L);
                     const bool better = L < m1[g];
                     m1[g] = better ? L : m1[g];
                     c1[g] = better ? c : c1[g];
                 }
             }
-            }
-            if (lds) {
-                if (S + 1 < se) { sA[lds ? buf ^ 1u : 0][lds ? threadIdx.x : 0] = pre0; sA[lds ? buf ^ 1u : 0][lds ? NN_BLOCK + threadIdx.x : 0] = pre1; }
-                __syncthreads();
-            }
         }
-    } else {
-    __shared__ uint4 sB[lds ? 2 : 1][lds ? TPS * 128 : 1];     // (lds) the operands of two super-tiles: 32 KB
-    uint4 a0n = make_uint4(0, 0, 0, 0), a1n = a0n, pre[4] = { a0n, a0n, a0n, a0n };
-    if (lds) {
-        if (sb < se) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) sB[0][lds ? j * NN_BLOCK + threadIdx.x : 0] = ops[(size_t)sb * TPS * 128 + j * NN_BLOCK + threadIdx.x];
-        }
-        __syncthreads();
-    } else if (sb < se) { a0n = ops[(size_t)sb * TPS * 128 + lane]; a1n = ops[(size_t)sb * TPS * 128 + 64 + lane]; }
-    for (uint32_t S = sb; S < se; S++) {
-        const uint32_t buf = (S - sb) & 1u;
-        if (lds && S + 1 < se) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) pre[j] = ops[(size_t)(S + 1) * TPS * 128 + j * NN_BLOCK + threadIdx.x];
-        }
-        const float4 C = centres[S];                          // wave-uniform: scalar load
-        uint4 b0[QG], b1[QG];
-        float R[QG];
-#pragma unroll
-        for (int g = 0; g < QG; g++) {
-            const float rx = qx[g] - C.x, ry = qy[g] - C.y, rz = qz[g] - C.z;
-            R[g] = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
-            bt_pack(h ? ry : rx, b0[g]);
-            bt_pack(h ? 1.0f : rz, b1[g]);
-        }
-#pragma unroll 1
-        for (int tt = 0; tt < TPS; tt++) {                    // (not unrolled: the scheduler would keep all 16 accumulator tiles alive)
-            const uint32_t T = S * TPS + tt;
-            uint4 A0, A1;
-            if (lds) { A0 = sB[lds ? buf : 0][lds ? tt * 128 + lane : 0]; A1 = sB[lds ? buf : 0][lds ? tt * 128 + 64 + lane : 0]; }
-            else {
-                A0 = a0n; A1 = a1n;
-                if (tt + 1 < TPS || S + 1 < se) { a0n = ops[(size_t)(T + 1) * 128 + lane]; a1n = ops[(size_t)(T + 1) * 128 + 64 + lane]; }   // next tile in flight
-            }
-            const uint32_t c = 2 * T + (h ? 1u : 0u);
-            // (Tried: reducing the PREVIOUS group's accumulators between the two MFMAs of the current one, in program order enforced with
-            // sched_group_barrier — 0.892 against 0.900 ms.  On this chip the bf16 MFMA and the vector instructions of one SIMD's waves
-            // take turns rather than overlap in this loop: tools/ubench/mfma_filter.hip part C, profiles/r02_mfma_filter_experiments.txt.)
-#pragma unroll
-            for (int g = 0; g < QG; g++) {
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), __builtin_bit_cast(bf16x8, b0[g]), zero, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1), __builtin_bit_cast(bf16x8, b1[g]), acc, 0, 0, 0);
-                // minimum of the 16 accumulators: eight v_min3 starting from an opaque +inf (a plain two-operand fminf of two MFMA
-                // results is first canonicalised: three half-rate instructions instead of one).  (No inline-asm v_min3 on the
-                // accumulators themselves: the compiler would not know to wait for the MFMA before it — measured: wrong minima.)
-                float m = big;
-#pragma unroll
-                for (int j = 0; j + 1 < CH; j += 2) m = fminf(fminf(m, acc[j]), acc[j + 1]);
-                const float L = __builtin_fmaf(R[g], KAPPA, m);
-                m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], L);
-                const bool better = L < m1[g];                // (false for a NaN L: a non-finite query is rescanned exactly anyway)
-                m1[g] = better ? L : m1[g];
-                c1[g] = better ? c : c1[g];
-            }
-        }
-        if (lds) {
-            if (S + 1 < se) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) sB[lds ? buf ^ 1u : 0][lds ? j * NN_BLOCK + threadIdx.x : 0] = pre[j];
-            }
-            __syncthreads();
-        }
-    }
     }
 #pragma unroll
     for (int g = 0; g < QG; g++) {
@@ -898,35 +816,153 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
     }
 }
 
-template <int CH, bool SGPR>
-static void launch_track(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t ns,
-                         uint32_t n_tiles, uint32_t tps, int merge_atomic)
+// ---------------------------------------------------------------------------------------------------------------- dispatcher
+// Which kernel serves an exhaustive search (tune nn1_variant forces one; 0 = this table):
+//
+//   target                          search                                   kernel
+//   ------------------------------  ---------------------------------------  -----------------------------------------------------------
+//   >= 8 192 points, fits f16       any (cold ones seed themselves)          HTRACK  nn1_btrack_kernel<4 | 2, true>   (variant 7)
+//   >= 8 192 points, beyond f16     any                                      BTRACK  nn1_btrack_kernel<4 | 2, false>  (variant 6)
+//   either form failing the device check (mfma_verdict), or nn1_bf16 = 2     the two rows below
+//   >= 2 048 points                 inside a loop / index exists / 2nd search ETRACK  nn1_etrack_kernel<4>             (variant 4)
+//   anything else                   (first one-shot search, small targets)   FTRACK  nn1_ftrack_kernel<2, 16>         (variant 1)
+//   —                               only on request                          TRACK   nn1_track_kernel<2, 16>          (variant 2: exact arithmetic
+//                                                                            for every pair — the on-device reference of the others)
+// (Targets below 2 048 points inside loops, and one-shot searches with queries x targets > 2e9, never get here: api.cpp nn1_auto_grid
+// sends them to the exact grid.)  Tune keys read here — every one 0 = default:
+//   nn1_variant (above) · nn1_bf16 (1 force / 2 forbid the matrix-core forms) · nn1_f16 (1 / 2 the same for the f16 form) ·
+//   nn1_btrack_qg (query groups of 32 per wave: 2 or 4; default 2 up to 49 152 queries) · nn1_supers_per_slice / nn1_btrack_blocks
+//   (slice length of the matrix-core launch directly / via the workgroup count, default 14 336) · nn1_xcd (XCD-aware launch: 1 / 2 / 4
+//   query-block groups per 8 XCDs, -1 plain 2-D launch; default 4) · nn1_cold_seed (2 = off) · nn1_warm_start (2 = off) ·
+//   nn1_chunks_per_slice / nn1_etrack_blocks (ETRACK, default 32 768 workgroups) · nn1_tiles_per_slice / nn1_target_blocks (FTRACK / TRACK,
+//   default 16 384) · mfma_force_fail (tests) · grid_stats (diagnostics launch).  Retired in round 3 with the kernels they selected:
+//   nn1_qpl, nn1_chunk, nn1_etrack_qpl, nn1_lds_ops, variant 3 (LDS-tiled TRACK).
+
+// slices of `n_units` units such that about `want_blocks` workgroups exist; returns units per slice, *slices = how many (<= 65 535)
+static uint32_t slice_plan(uint32_t n_units, uint32_t qblocks, int64_t per_slice_tune, int64_t want_blocks, uint32_t* slices)
 {
-#define PCR_TRACK(Q)                                                                                               \
-    hipLaunchKernelGGL((nn1_track_kernel<Q, CH, SGPR>), grid, dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(),    \
-                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic, ctx->stop_flag_dev)
-    switch (qpl) {
-    case 1: PCR_TRACK(1); break;
-    case 4: PCR_TRACK(4); break;
-    default: PCR_TRACK(2); break;
+    int64_t per = per_slice_tune;
+    if (per <= 0) {
+        const int64_t s = std::max<int64_t>(1, (want_blocks + qblocks - 1) / std::max<uint32_t>(qblocks, 1u));
+        per = std::max<int64_t>(1, ((int64_t)n_units + s - 1) / s);
     }
-#undef PCR_TRACK
+    uint32_t ns = n_units ? (uint32_t)((n_units + per - 1) / per) : 1u;
+    if (ns > 65535u) { ns = 65535u; per = (n_units + ns - 1) / ns; ns = (uint32_t)((n_units + per - 1) / per); }
+    *slices = ns;
+    return (uint32_t)per;
 }
 
-template <int CH>
-static void launch_ftrack(int qpl, pcr_ctx* ctx, dim3 grid, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t ns,
-                          uint32_t n_tiles, uint32_t tps, int merge_atomic)
+static int stats_buffer(pcr_ctx* ctx, unsigned long long** out)
 {
-#define PCR_FTRACK(Q)                                                                                              \
-    hipLaunchKernelGGL((nn1_ftrack_kernel<Q, CH>), grid, dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(),         \
-                       tgt->z(), src->x(), src->y(), src->z(), ns, n_tiles, tps, ctx->keys, merge_atomic, ctx->stop_flag_dev, \
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u)
-    switch (qpl) {
-    case 1: PCR_FTRACK(1); break;
-    case 4: PCR_FTRACK(4); break;
-    default: PCR_FTRACK(2); break;
+    *out = nullptr;
+    if (tune_get(ctx, "grid_stats", 0) <= 0) return PCR_OK;
+    if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, PCR_NSTATS * sizeof(unsigned long long)));
+    PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, PCR_NSTATS * sizeof(unsigned long long), ctx->stream));
+    *out = ctx->grid_stats_dev;
+    return PCR_OK;
+}
+
+// the seeds of a warm search: keys[] <- the previous correspondences re-evaluated exactly (unless the last move wrote them already)
+static void seed_warm(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool pre_seeded)
+{
+    if (pre_seeded) return;
+    hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((src->n + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
+                       (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)src->n, ctx->keys);
+}
+
+// HTRACK / BTRACK over the target's Morton-ordered operands (bt_ensure)
+static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool f16, bool warm, bool pre_seeded)
+{
+    const BtIndex* g = tgt->bt;
+    const size_t ns = src->n;
+    ctx->last_nn1_kernel = f16 ? "htrack" : "btrack";
+    // query groups (of 32) per wave: four amortise the per-tile operand loads best on a full batch; a source shard of a strong-scaling run
+    // (15-30 k queries against the whole target) fills the chip better with two — measured, per ICP iteration: 15 k queries 0.158 -> 0.137
+    // ms, 30 k 0.241 -> 0.218, 60 k 0.378 / 0.375, 120 k 0.664 -> 0.723
+    const int qg = tune_get(ctx, "nn1_btrack_qg", ns <= 49152 ? 2 : 4) == 2 ? 2 : 4;
+    const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                          // queries per workgroup
+    const uint32_t qblocks = (uint32_t)((ns + qpb - 1) / qpb);
+    const uint32_t n_super = (uint32_t)(g->n_tiles / (BT_SUPER / 32));
+    // (120 k: 8 super-tiles per slice, the measured optimum of both forms since their unsettled queries are filtered again)
+    uint32_t slices = 1;
+    const uint32_t sps = slice_plan(n_super, qblocks, tune_get(ctx, "nn1_supers_per_slice", 0), tune_get(ctx, "nn1_btrack_blocks", 14336), &slices);
+    // a cold, sliced search seeds itself from the nearest super-tile (tune nn1_cold_seed: 2 = off)
+    const bool cold_seed = !warm && slices > 1 && tune_get(ctx, "nn1_cold_seed", 1) == 1;
+    const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
+    if (warm) seed_warm(ctx, tgt, src, pre_seeded);
+    else if (merge_atomic && !cold_seed) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
+    unsigned long long* stats_dev = nullptr;
+    int rc = stats_buffer(ctx, &stats_dev);
+    if (rc) return rc;
+    {
+        ProfScope p(ctx, "nn1_brute", 1);
+        if (cold_seed)                                                              // (inside the timed scope: it is part of the cold search)
+            hipLaunchKernelGGL(bt_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->records, n_super,
+                               std::max<uint32_t>(1u, n_super / 1024u), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
+        // XCD-aware launch (tune nn1_xcd: 1 / 2 / 4 = query-block groups per 8 XCDs, -1 = the plain 2-D launch): see the kernel
+        int64_t xq = tune_get(ctx, "nn1_xcd", NN_XCD_DEFAULT);
+        if ((xq != 1 && xq != 2 && xq != 4) || slices < 8 || (uint64_t)qblocks * slices >= (1ull << 27)) xq = 0;
+        const dim3 grid = xq ? dim3(8u * ((qblocks + (uint32_t)xq - 1) / (uint32_t)xq) * ((slices + 8u / (uint32_t)xq - 1) / (8u / (uint32_t)xq)), 1) : dim3(qblocks, slices);
+#define PCR_BTRACK(Q, H, OPS)                                                                                                              \
+    hipLaunchKernelGGL((nn1_btrack_kernel<Q, H>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, OPS, g->records, n_super * BT_SUPER, n_super, sps,  \
+                       src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices)
+        if (f16) { if (qg == 2) PCR_BTRACK(2, true, g->ops16); else PCR_BTRACK(4, true, g->ops16); }
+        else { if (qg == 2) PCR_BTRACK(2, false, g->ops); else PCR_BTRACK(4, false, g->ops); }
+#undef PCR_BTRACK
     }
-#undef PCR_FTRACK
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+// ETRACK over the chunked, centred copy of the target's grid index (build_target_grid)
+static int launch_etrack(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool warm, bool pre_seeded)
+{
+    const Grid* g = tgt->grid;
+    const size_t ns = src->n;
+    ctx->last_nn1_kernel = "etrack";
+    constexpr int EQ = 4;                          // queries per lane: the filter is bound by the scalar operand path (272 B per chunk per wave)
+    const uint32_t qblocks = (uint32_t)((ns + (size_t)NN_BLOCK * EQ - 1) / ((size_t)NN_BLOCK * EQ));
+    uint32_t slices = 1;
+    const uint32_t cps = slice_plan((uint32_t)g->n_chunks, qblocks, tune_get(ctx, "nn1_chunks_per_slice", 0), tune_get(ctx, "nn1_etrack_blocks", 32768), &slices);
+    const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
+    if (warm) seed_warm(ctx, tgt, src, pre_seeded);
+    else if (merge_atomic) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
+    unsigned long long* stats_dev = nullptr;               // diagnostics: slot 2 counts the exact rescans of this launch
+    int rc = stats_buffer(ctx, &stats_dev);
+    if (rc) return rc;
+    {
+        ProfScope p(ctx, "nn1_brute", 1);
+        hipLaunchKernelGGL((nn1_etrack_kernel<EQ>), dim3(qblocks, slices), dim3(NN_BLOCK), 0, ctx->stream, g->chunks, g->records, (uint32_t)tgt->n, (uint32_t)g->n_chunks,
+                           cps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev);
+    }
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
+// FTRACK (exact = false) / TRACK (exact = true) straight over the SoA target: no index at all
+static int launch_plain(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool exact)
+{
+    const size_t ns = src->n;
+    ctx->last_nn1_kernel = exact ? "track" : "ftrack";
+    constexpr int QPL = 2;
+    const uint32_t n_tiles = (uint32_t)((tgt->n + NN_TILE - 1) / NN_TILE);
+    const uint32_t qblocks = (uint32_t)((ns + (size_t)NN_BLOCK * QPL - 1) / ((size_t)NN_BLOCK * QPL));
+    // enough workgroups to balance 256 CUs x 8 resident blocks over several rounds
+    uint32_t slices = 1;
+    const uint32_t tps = slice_plan(n_tiles, qblocks, tune_get(ctx, "nn1_tiles_per_slice", 0), tune_get(ctx, "nn1_target_blocks", 16384), &slices);
+    const int merge_atomic = slices > 1;
+    if (merge_atomic) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
+    {
+        ProfScope p(ctx, "nn1_brute", 1);
+        if (exact)
+            hipLaunchKernelGGL((nn1_track_kernel<QPL, 16>), dim3(qblocks, slices), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(), src->x(), src->y(),
+                               src->z(), (uint32_t)ns, n_tiles, tps, ctx->keys, merge_atomic, ctx->stop_flag_dev);
+        else
+            hipLaunchKernelGGL((nn1_ftrack_kernel<QPL, 16>), dim3(qblocks, slices), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(), src->x(), src->y(),
+                               src->z(), (uint32_t)ns, n_tiles, tps, ctx->keys, merge_atomic, ctx->stop_flag_dev, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+    }
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
 }
 
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool in_loop)
@@ -949,210 +985,42 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     ctx->keys_src = src;
     ctx->keys_tgt = tgt;
 
-    int qpl = (int)tune_get(ctx, "nn1_qpl", 2);
-    if (qpl != 1 && qpl != 4) qpl = 2;
-    // variant 4 = ETRACK: needs the target's grid index (cell-sorted records + the chunked, centred copy)
-    // nn1_variant unset: ETRACK when a warm-start bound exists or the target's index does (profiles/r01_tune_nn1_etrack.txt),
-    // FTRACK otherwise; 4 forces ETRACK, 1-3 the kernels below
-    const int64_t variant_tune = tune_get(ctx, "nn1_variant", 0);
-    // BTRACK (variant 6, tune nn1_bf16: 1 on, 2 off): the filter on the bf16 matrix pipe, from a target's FIRST search on — its index
-    // (operands in Morton order, bt_ensure) costs one bounding-box round trip and ~0.2 ms at 120 k points, less than the kernel saves
-    // (small targets stay on ETRACK: 44 against 53 us per ICP iteration at 4 000 points, 114 against 72 at 20 000 — profiles/r02_mfma_filter_experiments.txt)
-    const int64_t bf16_tune = tune_get(ctx, "nn1_bf16", 0);
-    const bool want_bf16 = variant_tune == 6 || variant_tune == 7 ||
-                           (variant_tune == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)));
-    if (want_bf16) {
+    const int64_t variant = tune_get(ctx, "nn1_variant", 0), bf16_tune = tune_get(ctx, "nn1_bf16", 0), f16_tune = tune_get(ctx, "nn1_f16", 0);
+    // The matrix-core forms, from a target's FIRST search on: the index (operands in Morton order, bt_ensure) costs one bounding-box
+    // round trip and ~0.2 ms at 120 k points, less than the kernel saves (small targets stay on the f32 filters: 44 against 53 us per
+    // ICP iteration at 4 000 points, 114 against 72 at 20 000 — profiles/r02_mfma_filter_experiments.txt)
+    if (variant == 6 || variant == 7 || (variant == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)))) {
         rc = bt_ensure(ctx, tgt);
         if (rc) return rc;
-    }
-    // HTRACK (variant 7, tune nn1_f16: 1 on, 2 off): one f16 MFMA per tile instead of two bf16 ones, when the cloud fits f16's range
-    bool f16 = false, matrix = false;
-    if (want_bf16 && tgt->bt->safe && tgt->bt->n_tiles) {
-        const int64_t f16_tune = tune_get(ctx, "nn1_f16", 0);
-        f16 = variant_tune == 7 || (variant_tune == 0 && f16_tune != 2 && (f16_tune == 1 || NN_F16_DEFAULT));
-        if (f16 && tgt->bt->bad16_host < 0) {                                      // the flag of the operand build, read once
-            int flag = 1;
-            PCR_HIP(ctx, hipMemcpyAsync(&flag, tgt->bt->bad16, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            tgt->bt->bad16_host = flag;
-        }
-        if (f16 && tgt->bt->bad16_host != 0) f16 = false;
-        // The bounds of both matrix-core forms assume how the pipe accumulates (header of nn1_btrack_kernel) — measured ON THIS DEVICE
-        // before either form is first chosen (mfma_verdict: once per context, cached): a form whose measured error exceeds half of
-        // what its bound budgets is not used here; the f32 filters below (bounds from IEEE arithmetic alone) answer instead.
-        if (f16 && !mfma_verdict(ctx, true)) f16 = false;
-        matrix = f16 || mfma_verdict(ctx, false);
-    }
-    if (matrix) {
-        const BtIndex* g = tgt->bt;
-        ctx->last_nn1_kernel = f16 ? "htrack" : "btrack";
-        // query groups (of 32) per wave: four amortise the per-tile operand loads best on a full batch; a source shard of a
-        // strong-scaling run (15-30 k queries against the whole target) fills the chip better with two — measured, per ICP iteration:
-        // 15 k queries 0.158 -> 0.137 ms, 30 k 0.241 -> 0.218, 60 k 0.378 / 0.375, 120 k 0.664 -> 0.723
-        int qg = (int)tune_get(ctx, "nn1_btrack_qg", ns <= 49152 ? 2 : 4);
-        if (qg != 1 && qg != 2) qg = 4;                                           // (8 groups per wave: hipcc 7.2 crashes on the instantiation)
-        const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                      // queries per workgroup
-        const uint32_t qblocks = (uint32_t)((ns + qpb - 1) / qpb);
-        const size_t n_super = g->n_tiles / (BT_SUPER / 32);
-        int64_t sps = tune_get(ctx, "nn1_supers_per_slice", 0);
-        if (sps <= 0) {
-            // (120 k: 8 super-tiles per slice, the measured optimum of both forms since their unsettled queries are filtered again instead
-            // of rescanned exactly: 3 (f16) / 4 (bf16) super-tiles per slice before that)
-            const int64_t want_blocks = tune_get(ctx, "nn1_btrack_blocks", 14336);
-            const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
-            sps = std::max<int64_t>(1, ((int64_t)n_super + slices - 1) / slices);
-        }
-        uint32_t slices = (uint32_t)((n_super + sps - 1) / sps);
-        if (slices > 65535) { slices = 65535; sps = (n_super + slices - 1) / slices; slices = (uint32_t)((n_super + sps - 1) / sps); }
-        // a cold, sliced search seeds itself from the nearest super-tile (tune nn1_cold_seed: 1 on (default), 2 off)
-        const bool cold_seed = !warm && slices > 1 && tune_get(ctx, "nn1_cold_seed", 1) == 1;
-        const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
-        if (warm && pre_seeded) { /* keys[] holds the seeds already */ }
-        else if (warm)
-            hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
-                               (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
-        else if (merge_atomic && !cold_seed)
-            PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
-        unsigned long long* stats_dev = nullptr;
-        if (tune_get(ctx, "grid_stats", 0) > 0) {
-            if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, PCR_NSTATS * sizeof(unsigned long long)));
-            PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, PCR_NSTATS * sizeof(unsigned long long), ctx->stream));
-            stats_dev = ctx->grid_stats_dev;
-        }
-        {
-            ProfScope p(ctx, "nn1_brute", 1);
-            if (cold_seed)                                                          // (inside the timed scope: it is part of the cold search)
-                hipLaunchKernelGGL(bt_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->records,
-                                   (uint32_t)n_super, (uint32_t)std::max<size_t>(1, n_super / 1024), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
-            // XCD-aware launch (tune nn1_xcd: 1 / 2 / 4 = query-block groups per 8 XCDs, -1 = the plain 2-D launch): see the kernel
-            int64_t xq = tune_get(ctx, "nn1_xcd", NN_XCD_DEFAULT);
-            if (xq != 1 && xq != 2 && xq != 4) xq = 0;
-            if (slices < 8 || (uint64_t)qblocks * slices >= (1ull << 27)) xq = 0;
-            dim3 grid(qblocks, slices);
-            // (the f16 form by default; the bf16 form — two MFMAs per tile, more matrix time per byte — measured 0.933 ms either way: tune 3 stages it too)
-            const int64_t lds_tune = tune_get(ctx, "nn1_lds_ops", NN_LDS_OPS_DEFAULT);
-            const uint32_t lds_flag = (lds_tune == 3 || (lds_tune == 1 && f16)) ? 1u : 0u;
-            if (xq) grid = dim3(8u * ((qblocks + (uint32_t)xq - 1) / (uint32_t)xq) * ((slices + 8u / (uint32_t)xq - 1) / (8u / (uint32_t)xq)), 1);
-#define PCR_BTRACK(Q)                                                                                                                   \
-if (f16 && lds_flag) hipLaunchKernelGGL((nn1_btrack_kernel<Q, true, true>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records, \
-                   (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
-                   merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices);                                         \
-else if (f16) hipLaunchKernelGGL((nn1_btrack_kernel<Q, true>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records,    \
-                   (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
-                   merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices);                                         \
-else if (lds_flag) hipLaunchKernelGGL((nn1_btrack_kernel<Q, false, true>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops, g->records, \
-                   (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
-                   merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices);                                         \
-else hipLaunchKernelGGL((nn1_btrack_kernel<Q, false>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops, g->records,              \
-                   (uint32_t)(n_super * BT_SUPER), (uint32_t)n_super, (uint32_t)sps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys,  \
-                   merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices)
-            switch (qg) {
-            case 1: PCR_BTRACK(1); break;
-            case 2: PCR_BTRACK(2); break;
-            default: PCR_BTRACK(4); break;
+        if (tgt->bt->safe && tgt->bt->n_tiles) {
+            // HTRACK: one f16 MFMA per tile instead of two bf16 ones, when the cloud fits f16's range (the flag of the operand build, read once)
+            bool f16 = variant == 7 || (variant == 0 && f16_tune != 2 && (f16_tune == 1 || NN_F16_DEFAULT));
+            if (f16 && tgt->bt->bad16_host < 0) {
+                int flag = 1;
+                PCR_HIP(ctx, hipMemcpyAsync(&flag, tgt->bt->bad16, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                tgt->bt->bad16_host = flag;
             }
-#undef PCR_BTRACK
+            if (f16 && tgt->bt->bad16_host != 0) f16 = false;
+            // The bounds of both forms assume how the matrix pipe accumulates (header of nn1_btrack_kernel) — measured ON THIS DEVICE before
+            // either is first chosen (mfma_verdict: once per context, cached): a form whose measured error exceeds half of what its bound
+            // budgets is not used here; the f32 filters below (bounds from IEEE arithmetic alone) answer instead.
+            if (f16 && !mfma_verdict(ctx, true)) f16 = false;
+            if (f16 || mfma_verdict(ctx, false)) return launch_matrix(ctx, tgt, src, f16, warm, pre_seeded);
         }
-        PCR_HIP(ctx, hipGetLastError());
-        return PCR_OK;
     }
-    // The f32 kernels: ETRACK needs the cell index (chunked, centred copy of the target): cold searches take it when that index exists
-    // or will be needed anyway (inside an ICP loop), or on a target's second search; its FIRST one-shot search stays on FTRACK, which
-    // needs no index at all
+    // ETRACK needs the cell index (chunked, centred copy of the target): cold searches take it when that index exists or will be needed
+    // anyway (inside an ICP loop), or on a target's second search; its FIRST one-shot search stays on FTRACK, which needs no index at all
     const bool reused = tgt->grid == nullptr && tgt->brute_searches++ >= 1;
-    if (variant_tune == 4 || (variant_tune == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid || reused))) {
+    if (variant == 4 || (variant == 0 && tgt->n >= 2048 && (warm || in_loop || tgt->grid || reused))) {
         rc = build_target_grid(ctx, tgt);
         if (rc) return rc;
-        const Grid* g = tgt->grid;
-        if (g->chunk_safe && g->n_chunks) {
-            // queries per lane: the filter is bound by the scalar operand path (272 B per chunk per wave), more queries per lane
-            // amortise it — measured: profiles/r01_tune_nn1_etrack.txt
-            int eq = (int)tune_get(ctx, "nn1_etrack_qpl", 4);
-            if (eq != 1 && eq != 2 && eq != 8) eq = 4;
-            const uint32_t qblocks = (uint32_t)((ns + (size_t)NN_BLOCK * eq - 1) / ((size_t)NN_BLOCK * eq));
-            int64_t cps = tune_get(ctx, "nn1_chunks_per_slice", 0);
-            if (cps <= 0) {
-                const int64_t want_blocks = tune_get(ctx, "nn1_etrack_blocks", 32768);
-                const int64_t slices = std::max<int64_t>(1, (want_blocks + qblocks - 1) / qblocks);
-                cps = std::max<int64_t>(1, ((int64_t)g->n_chunks + slices - 1) / slices);
-            }
-            uint32_t slices = (uint32_t)((g->n_chunks + cps - 1) / cps);
-            if (slices > 65535) { slices = 65535; cps = (g->n_chunks + slices - 1) / slices; slices = (uint32_t)((g->n_chunks + cps - 1) / cps); }
-            const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
-            if (warm && pre_seeded) { /* keys[] holds the seeds already */ }
-            else if (warm)
-                hipLaunchKernelGGL(nn1_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
-                                   (uint32_t)tgt->n, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
-            else if (merge_atomic)
-                PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
-            const dim3 grid(qblocks, slices);
-            ctx->last_nn1_kernel = "etrack";
-            unsigned long long* stats_dev = nullptr;
-            if (tune_get(ctx, "grid_stats", 0) > 0) {          // diagnostics: slot 2 counts the exact rescans of this launch
-                if (!ctx->grid_stats_dev) PCR_HIP(ctx, hipMalloc((void**)&ctx->grid_stats_dev, PCR_NSTATS * sizeof(unsigned long long)));
-                PCR_HIP(ctx, hipMemsetAsync(ctx->grid_stats_dev, 0, PCR_NSTATS * sizeof(unsigned long long), ctx->stream));
-                stats_dev = ctx->grid_stats_dev;
-            }
-            {
-                ProfScope p(ctx, "nn1_brute", 1);
-#define PCR_ETRACK(Q)                                                                                                                   \
-    hipLaunchKernelGGL((nn1_etrack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->chunks, g->records, (uint32_t)tgt->n, (uint32_t)g->n_chunks, \
-                       (uint32_t)cps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev)
-                switch (eq) {
-                case 1: PCR_ETRACK(1); break;
-                case 2: PCR_ETRACK(2); break;
-                case 8: PCR_ETRACK(8); break;
-                default: PCR_ETRACK(4); break;
-                }
-#undef PCR_ETRACK
-            }
-            PCR_HIP(ctx, hipGetLastError());
-            return PCR_OK;
-        }
-        // non-finite or astronomically large coordinates: the exact-filter kernels below handle them
+        if (tgt->grid->chunk_safe && tgt->grid->n_chunks) return launch_etrack(ctx, tgt, src, warm, pre_seeded);
+        // (non-finite or astronomically large coordinates: the kernels below handle them)
     }
-    // variant: 1 = FTRACK (default: fused-filter tracking + exact decision, targets through the scalar cache);
-    //          2 = TRACK (exact arithmetic only, scalar cache); 3 (or any other value) = TRACK with targets through LDS tiles
-    const int variant = variant_tune == 0 ? 1 : (int)variant_tune;   // cold default FTRACK: fastest measured (profiles/r01_tune_nn1_ftrack.txt)
-    const int chunk = (int)tune_get(ctx, "nn1_chunk", 16);
-    const uint32_t n_tiles = (uint32_t)((tgt->n + NN_TILE - 1) / NN_TILE);
-    const uint32_t qblocks = (uint32_t)((ns + (size_t)NN_BLOCK * qpl - 1) / ((size_t)NN_BLOCK * qpl));
-    // enough workgroups to balance 256 CUs x 8 resident blocks over several rounds
-    int64_t tps = tune_get(ctx, "nn1_tiles_per_slice", 0);
-    if (tps <= 0) {
-        const int64_t want_blocks = tune_get(ctx, "nn1_target_blocks", 16384);
-        int64_t slices = (want_blocks + qblocks - 1) / qblocks;
-        if (slices < 1) slices = 1;
-        tps = n_tiles ? (n_tiles + slices - 1) / slices : 1;
-        if (tps < 1) tps = 1;
-    }
-    uint32_t slices = n_tiles ? (uint32_t)((n_tiles + tps - 1) / tps) : 1;
-    if (slices > 65535) { slices = 65535; tps = (n_tiles + slices - 1) / slices; slices = (uint32_t)((n_tiles + tps - 1) / tps); }
-    const int merge_atomic = slices > 1;
-    if (merge_atomic) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
-
-    dim3 grid(qblocks, slices);
-    ctx->last_nn1_kernel = variant == 1 ? "ftrack" : "track";
-    {
-        ProfScope p(ctx, "nn1_brute", 1);
-        switch (variant) {
-        case 1:
-            if (chunk == 16) launch_ftrack<16>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
-            else launch_ftrack<8>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
-            break;
-        case 2:
-            if (chunk == 16) launch_track<16, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
-            else launch_track<8, true>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
-            break;
-        default:
-            if (chunk == 16) launch_track<16, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
-            else launch_track<8, false>(qpl, ctx, grid, tgt, src, (uint32_t)ns, n_tiles, (uint32_t)tps, merge_atomic);
-            break;
-        }
-    }
-    PCR_HIP(ctx, hipGetLastError());
-    return PCR_OK;
+    return launch_plain(ctx, tgt, src, variant == 2);
 }
+
 
 // exhaustive search of the listed queries only (count on the device, at most qcap), merged into keys[] (grid.hip hands its far
 // queries over: one tiled pass over the target per ~512 of them instead of a cube walk to a neighbour tens of metres away)

@@ -311,8 +311,27 @@ typedef struct {
     char last_nn1_kernel[16];
 } pcr_mfma_check;
 int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
-/* tuning / diagnostic knobs by name (value 0 = library default, except "prof"): "nn_method" 1 brute force / 2 exact grid,
- * "nn1_variant", "knn_method", "radius_method", "icp_pipeline", "prof", ... — the names are listed where they are read (csrc/) */
+/* Tuning / diagnostic knobs by name.  A value of 0 means "library default" for every key except "prof"; results never depend on a knob
+ * (the parity tests run the switches against each other), only speed and which kernel serves a call.  Defaults in brackets.
+ *  dispatch    nn_method [0 auto: api.cpp nn1_auto_grid] 1 exhaustive / 2 exact grid · nn1_variant [0: table above launch_nn1_brute,
+ *              csrc/nn1_brute.hip] 1 FTRACK, 2 TRACK (exact arithmetic only), 4 ETRACK, 6 BTRACK, 7 HTRACK · nn1_bf16, nn1_f16 [on]
+ *              1 force / 2 forbid the matrix-core forms · mfma_force_fail 1 f16 / 2 bf16 / 3 both (tests: a failing device check) ·
+ *              knn_method, radius_method [auto] 1 exhaustive / 2 grid · nn1_async_in_loop [off] 1 = pcr_nn1_f32_async calls of one
+ *              caller-side loop seed each other as the searches inside pcr_icp_p2p_f32 do
+ *  exhaustive  nn1_btrack_qg [2 up to 49 152 queries, else 4] · nn1_supers_per_slice [from nn1_btrack_blocks = 14 336] ·
+ *              nn1_xcd [4] 1 / 2 / 4, -1 plain launch · nn1_cold_seed, nn1_warm_start [on] 2 = off · nn1_chunks_per_slice [from
+ *              nn1_etrack_blocks = 32 768] · nn1_tiles_per_slice [from nn1_target_blocks = 16 384] · bt_sort_work [on] 2 = off
+ *  exact grid  grid_order [0: Morton from 500 000 points] 1 x-sorted / 2 Morton · grid_mode [by index] 1 plain / 2 x-window / 3 spheres ·
+ *              grid_lanes [16] · grid_cell_um, grid_cell_scale_x100 [150 for Morton], grid_occupancy_x10 [20], grid_max_cells ·
+ *              grid_sort_queries, grid_sort_work, grid_warm_start, grid_wpos, grid_seed_run, grid_far_brute [on] 2 = off ·
+ *              grid_sort_fine [auto] 1 / 2 · grid_query_bins_log2 [22], grid_query_bin_min [2] · grid_xcd_run [32 from 4 096 blocks]
+ *              -1 = identity · grid_tile [0: from 500 000 points] 1 on / 2 off, grid_tile_bmax_pct [400], grid_tile_keep [512],
+ *              grid_tile_lim_pct [1000], grid_tile_reach_pct [200], grid_tile_total_mult [16], grid_tile_min_members [8],
+ *              grid_tile_list_segs [1], grid_tile_filter [on] 2 = off (csrc/grid.hip launch_nn1_grid) · knn_cell_scale_x100, knn_slices
+ *  ICP loop    icp_pipeline [0 = 1 device-resident] -1 synchronous · icp_chunk [4] · icp_bounded_search [on] 2 = off ·
+ *              icp_fused_move [on] 2 = off, icp_fused_max [262 144] · icp_seed_in_move [on] 2 = off · icp_force_slots (tests) ·
+ *              kabsch_bfly [on], kabsch_records [on], kabsch_one_pair_blocks [128], kabsch_max_blocks [1 024]
+ *  other       iss_lanes [32] · radius_fused [on] 2 = off · grid_stats 1 = the next 1-NN launch fills pcr_nn1_stats · prof 0 / 1 / 2 */
 int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

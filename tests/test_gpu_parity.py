@@ -138,7 +138,7 @@ def test_nn1_near_duplicates_next_to_a_super_tile_centre(ctx, orc, sps):
 
 
 def test_nn1_randomised_sweep_every_kernel(ctx, orc):
-    """120 random problems x {FTRACK, TRACK scalar, TRACK LDS, ETRACK, BTRACK (matrix cores), exact grid (plain / x-window / bounding-sphere kernels on the
+    """120 random problems x {FTRACK, TRACK, ETRACK, BTRACK (matrix cores), exact grid (plain / x-window / bounding-sphere kernels on the
     x-sorted index, plain / bounding-sphere kernels on the Morton-ordered index)}: indices and d2 bits equal to the oracle."""
     rng = np.random.default_rng(77)
     for trial in range(120):
@@ -149,7 +149,7 @@ def test_nn1_randomised_sweep_every_kernel(ctx, orc):
             src[:, : min(ns, nt) // 2] = tgt[:, : min(ns, nt) // 2]
         oi, od = orc.nn1_f32(tgt, src)
         ct, cs = ctx.cloud(tgt), ctx.cloud(src)
-        for method, variant, mode in ((1, 1, 0), (1, 2, 0), (1, 3, 0), (1, 4, 0), (1, 6, 0), (1, 7, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)):
+        for method, variant, mode in ((1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 6, 0), (1, 7, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)):
             ctx.tune("nn_method", method)
             ctx.tune("nn1_variant", variant)
             ctx.tune("grid_mode", mode)                # 1 plain, 2 x-window, 3 bounding spheres (0: by target size)
@@ -187,23 +187,22 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
     cs.free(); ct.free()
 
 
-# variant 1: FTRACK (default: fused-filter tracking, exact decision); 2: TRACK (exact only), scalar-cache targets; 3: TRACK, LDS tiles
-# (4 exact, 5 fused filter, 6/7 the same with scalar-load targets); chunk = targets per min-tree
-VARIANTS = [(1, 8), (1, 16), (2, 8), (2, 16), (3, 8), (3, 16), (4, 16), (6, 16), (7, 16)]   # 4 = ETRACK (expanded-form filter on the grid's chunked target copy), 6 = BTRACK (the filter on the bf16 matrix cores, three-piece operands), 7 = HTRACK (one f16 MFMA per tile, two-piece scaled operands)
+# nn1_variant: 1 FTRACK (fused-filter tracking, exact decision; no index), 2 TRACK (the exact arithmetic for every pair: the on-device
+# reference), 4 ETRACK (expanded-form f32 filter on the grid's chunked target copy), 6 BTRACK (the filter on the bf16 matrix cores,
+# three-piece operands), 7 HTRACK (one f16 MFMA per tile, two-piece scaled operands) — csrc/nn1_brute.hip, table above launch_nn1_brute
+VARIANTS = [1, 2, 4, 6, 7]
 
 
-def set_variant(ctx, vc):
-    v, ch = vc
+def set_variant(ctx, v):
     ctx.tune("nn_method", 1)                  # brute force (auto would pick the grid for large targets)
     ctx.tune("nn1_variant", v)
-    ctx.tune("nn1_chunk", ch)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-@pytest.mark.parametrize("qpl", [1, 2, 4])
+@pytest.mark.parametrize("qpl", [2, 4])
 @pytest.mark.parametrize("ns,nt", [(1, 1), (63, 5), (257, 1023), (1000, 1025), (3001, 7000), (5000, 2049)])
 def test_nn1_ragged_sizes_vs_oracle(ctx, orc, synth, qpl, ns, nt, variant):
-    ctx.tune("nn1_qpl", qpl); ctx.tune("nn1_btrack_qg", qpl)
+    ctx.tune("nn1_btrack_qg", qpl)            # query groups of 32 per wave of the matrix-core kernels
     set_variant(ctx, variant)
     src, _ = synth.kitti_like_pair(max(ns, 64), seed_target=7 + ns, seed_pair=11 + nt)
     tgt = synth.kitti_like_scan(max(nt, 64), seed=13 + nt)
@@ -213,7 +212,7 @@ def test_nn1_ragged_sizes_vs_oracle(ctx, orc, synth, qpl, ns, nt, variant):
     oidx, od2 = orc.nn1_f32(tgt, src)
     assert np.array_equal(idx, oidx) and np.array_equal(bits32(d2), bits32(od2))
     cs.free(); ct.free()
-    ctx.tune("nn1_qpl", 0); ctx.tune("nn1_btrack_qg", 0)
+    ctx.tune("nn1_btrack_qg", 0)
     ctx.tune("nn1_variant", 0)
     ctx.tune("nn_method", 0)
 
@@ -623,10 +622,11 @@ def test_icp_state_machine_matches_oracle(ctx, orc, synth):
 
 
 def test_matrix_core_search_switches_change_no_bit(ctx, synth):
-    """The launch / staging / ordering switches of the matrix-core brute-force search are speed only: LDS-staged operands on / off / for
-    both forms (nn1_lds_ops), XCD-aware launch off / 1 / 2 / 4 (nn1_xcd), the loop's sorted working cloud off (bt_sort_work), slice length
-    (nn1_supers_per_slice), query groups per wave (nn1_btrack_qg), each for the f16 and the bf16 form — same keys as the exact-only kernel
-    for a one-shot search, same pose / statistics / loss for a 10-iteration loop."""
+    """The launch / ordering switches of the matrix-core brute-force search are speed only: XCD-aware launch off / 1 / 2 / 4 (nn1_xcd), the
+    loop's sorted working cloud off (bt_sort_work), the seed of the next search written by the move or by its own kernel
+    (icp_seed_in_move), solve + move in one launch or two (icp_fused_move), slice length (nn1_supers_per_slice), query groups per wave
+    (nn1_btrack_qg), each for the f16 and the bf16 form — same keys as the exact-only kernel for a one-shot search, same pose /
+    statistics / loss for a 10-iteration loop."""
     n = 21000                                                       # > 8 192: the matrix-core kernels answer; 83 super-tiles
     src, tgt = synth.kitti_like_pair(n, seed_target=601, seed_pair=602)
     ctx.tune("nn_method", 1)
@@ -635,9 +635,10 @@ def test_matrix_core_search_switches_change_no_bit(ctx, synth):
     ref_idx, ref_d2 = ctx.nn1(ct, cs)
     ctx.tune("nn1_variant", 0)
     T0, st0 = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=10, eps=0.0)
-    switches = [dict(nn1_lds_ops=2), dict(nn1_lds_ops=3), dict(nn1_xcd=-1), dict(nn1_xcd=1), dict(nn1_xcd=2), dict(bt_sort_work=2),
-                dict(nn1_supers_per_slice=1), dict(nn1_supers_per_slice=5), dict(nn1_supers_per_slice=40), dict(nn1_btrack_qg=2), dict(nn1_btrack_qg=1),
-                dict(nn1_f16=2), dict(nn1_f16=2, nn1_lds_ops=3), dict(nn1_f16=2, nn1_lds_ops=2, nn1_supers_per_slice=2)]
+    switches = [dict(nn1_xcd=-1), dict(nn1_xcd=1), dict(nn1_xcd=2), dict(bt_sort_work=2), dict(icp_seed_in_move=2), dict(icp_fused_move=2),
+                dict(icp_seed_in_move=2, icp_fused_move=2), dict(icp_fused_max=4096),
+                dict(nn1_supers_per_slice=1), dict(nn1_supers_per_slice=5), dict(nn1_supers_per_slice=40), dict(nn1_btrack_qg=2), dict(nn1_btrack_qg=4),
+                dict(nn1_f16=2), dict(nn1_f16=2, nn1_btrack_qg=4), dict(nn1_f16=2, icp_seed_in_move=2, nn1_supers_per_slice=2)]
     for sw in switches:
         for k, v in sw.items():
             ctx.tune(k, v)

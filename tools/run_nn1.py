@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch the brute-force 1-NN kernel a few times on the BASELINE pair (for rocprofv3 runs).
-usage: run_nn1.py [n] [launches] [variant] [qpl] [tiles_per_slice] [order: scan|shuffle]"""
+usage: run_nn1.py [n] [launches] [variant] [unused] [tiles_per_slice] [order: scan|shuffle]"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -20,8 +20,6 @@ if order == "shuffle":
 ctx = pcr.Context(0)
 if variant is not None:
     ctx.tune("nn1_variant", variant)
-ctx.tune("nn1_chunk", int(os.environ.get("NN1_CHUNK", "0")))
-ctx.tune("nn1_qpl", qpl)
 ctx.tune("nn1_tiles_per_slice", tps)
 method = int(os.environ.get("NN_METHOD", "1"))     # 1 = brute force, 2 = exact grid
 ctx.tune("nn_method", method)
