@@ -713,6 +713,24 @@ def bench_c4(ctx, pcr, synth, np, args):
     rc = L.pcr_db64_radius(ctx.h, d.h, db.ctypes.data, n, C.c_double(1.0), row.ctypes.data, idx.ctypes.data, dist.ctypes.data)
     full_call_ms = (time.perf_counter() - t0) * 1e3
     assert rc == 0
+    # the same search with its rows kept in HBM (pcr_rows) and REDUCED there: what a consumer that only needs neighbour counts / sums /
+    # moments pays at the boundary — the search, m + 1 offsets and m doubles over PCIe instead of 12 B per neighbour
+    R = d.radius_rows(None, 1.0); R.free()                               # (code objects, allocator warm-up)
+    t0 = time.perf_counter()
+    R = d.radius_rows(None, 1.0)
+    rows_search_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    cnt_r = R.reduce(R.COUNT); sum_r = R.reduce(R.SUM_DIST)
+    rows_reduce_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    R.moments()
+    rows_moments_ms = (time.perf_counter() - t0) * 1e3
+    assert R.total == total and np.array_equal(cnt_r, np.diff(row).astype(np.float64))
+    assert np.allclose(sum_r[:64], [dist[row[i]:row[i + 1]].sum() for i in range(64)], rtol=1e-12)
+    t0 = time.perf_counter()
+    blk_i, blk_d = R.fetch(0, min(n, 2048), row)                         # a bounded block of rows (the iterate access)
+    rows_block_ms = (time.perf_counter() - t0) * 1e3
+    R.free()
     kern = {}
     for name in ("radius_grid_build", "radius_count", "radius_emit", "radius_fill", "radius_sort", "radius_dist"):
         k, ms = ctx.prof_get(name)
@@ -737,6 +755,12 @@ def bench_c4(ctx, pcr, synth, np, args):
         "radius": {"kernel_ms": kern, "kernels_total_ms": radius_kernel_ms, "M_queries_per_s": n / radius_kernel_ms / 1e3,
                    "G_neighbours_per_s": total / radius_kernel_ms / 1e6, "count_only_call_ms": count_call_ms, "full_call_ms_incl_d2h": full_call_ms,
                    "result_bytes": out_bytes, "result_GB/s_of_kernels": out_bytes / radius_kernel_ms / 1e6,
+                   "rows_handle": {"search_call_ms": rows_search_ms, "reduce_count_and_sum_ms": rows_reduce_ms, "moments_ms": rows_moments_ms,
+                                   "search_plus_reduce_ms": rows_search_ms + rows_reduce_ms,
+                                   "vs_kernels": (rows_search_ms + rows_reduce_ms) / radius_kernel_ms if radius_kernel_ms else None,
+                                   "fetch_block_of_2048_rows_ms": rows_block_ms, "block_bytes": int(12 * blk_i.size),
+                                   "note": "pcr_db64_radius_rows (self-query, the CSR stays in HBM) + pcr_rows_reduce x 2: wall time of the calls "
+                                           "against the kernels' 'kernels_total_ms'; the full D2H of the rows is 'full_call_ms_incl_d2h'"},
                    "note": "results are 12 B per reported neighbour (i32 index + f64 distance): the call is D2H-bound at this boundary; kernels: grid build, "
                            "count, fill, per-row ascending-index sort, distances"},
         "roofline": {"bound": "hbm", "achieved": out_bytes / radius_kernel_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -61,6 +61,7 @@ ABI_SYMBOLS = [
     "pcr_prof_reset", "pcr_prof_get", "pcr_prof_get_each", "pcr_tune_set",
     "pcr_grid_stats", "pcr_nn1_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_ctx_mfma_check", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_match_inter_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
+    "pcr_db64_radius_rows", "pcr_rows_destroy", "pcr_rows_info", "pcr_rows_row_ptr", "pcr_rows_fetch", "pcr_rows_reduce", "pcr_rows_moments",
 ]
 
 
@@ -108,6 +109,13 @@ def lib():
     L.pcr_db64_size.argtypes = [vp]
     L.pcr_db64_knn.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, vp, vp]
     L.pcr_db64_radius.argtypes = [vp, vp, vp, sz, C.c_double, vp, vp, vp]
+    L.pcr_db64_radius_rows.argtypes = [vp, vp, vp, sz, C.c_double, C.POINTER(vp)]
+    L.pcr_rows_destroy.argtypes = [vp, vp]
+    L.pcr_rows_info.argtypes = [vp, C.POINTER(sz), C.POINTER(C.c_uint64)]
+    L.pcr_rows_row_ptr.argtypes = [vp, vp]
+    L.pcr_rows_fetch.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.pcr_rows_reduce.argtypes = [vp, vp, C.c_int, vp]
+    L.pcr_rows_moments.argtypes = [vp, vp, vp, vp]
     L.pcr_comm_unique_id.argtypes = [vp]
     L.pcr_comm_init_rccl.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pcr_comm_init_callback.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp]
@@ -272,10 +280,66 @@ class Db64:
                                                idx.ctypes.data, dist.ctypes.data))
         return row, idx[:total], dist[:total]
 
+    def radius_rows(self, q, r: float) -> "Rows":
+        """The same search with its rows kept in HBM (q = None: every point of the database queries the database)."""
+        h = C.c_void_p()
+        if q is None:
+            self.ctx._ck(lib().pcr_db64_radius_rows(self.ctx.h, self.h, None, 0, r, C.byref(h)))
+        else:
+            q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+            self.ctx._ck(lib().pcr_db64_radius_rows(self.ctx.h, self.h, q.ctypes.data, q.shape[0], r, C.byref(h)))
+        return Rows(self.ctx, h, self)
+
     def free(self):
         if self.h and self.ctx.h:
             lib().pcr_db64_destroy(self.ctx.h, self.h)
         self.h = None
+
+
+class Rows:
+    """Device-resident CSR rows of a radius search (include/pcr.h pcr_rows): reduce them on the GPU or fetch them block by block."""
+    COUNT, SUM_DIST, MAX_DIST = 0, 1, 2
+
+    def __init__(self, ctx: "Context", handle, db: "Db64"):
+        self.ctx, self.h, self.db = ctx, handle, db          # (db kept alive: the indices refer to it)
+        ctx._handles.add(self)
+        m, total = C.c_size_t(), C.c_uint64()
+        lib().pcr_rows_info(self.h, C.byref(m), C.byref(total))
+        self.m, self.total = m.value, total.value
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:   # noqa: BLE001
+            pass
+
+    def row_ptr(self):
+        row = np.zeros(self.m + 1, np.int64)
+        self.ctx._ck(lib().pcr_rows_row_ptr(self.h, row.ctypes.data))
+        return row
+
+    def fetch(self, row_begin: int, row_end: int, row_ptr=None):
+        row = self.row_ptr() if row_ptr is None else row_ptr
+        cnt = int(row[row_end] - row[row_begin])
+        idx, dist = np.zeros(max(cnt, 1), np.int32), np.zeros(max(cnt, 1), np.float64)
+        self.ctx._ck(lib().pcr_rows_fetch(self.ctx.h, self.h, row_begin, row_end, idx.ctypes.data, dist.ctypes.data))
+        return idx[:cnt], dist[:cnt]
+
+    def reduce(self, op: int):
+        out = np.zeros(self.m, np.float64)
+        self.ctx._ck(lib().pcr_rows_reduce(self.ctx.h, self.h, int(op), out.ctypes.data))
+        return out
+
+    def moments(self):
+        mean, cov = np.zeros((self.m, 3), np.float64), np.zeros((self.m, 6), np.float64)
+        self.ctx._ck(lib().pcr_rows_moments(self.ctx.h, self.h, mean.ctypes.data, cov.ctypes.data))
+        return mean, cov
+
+    def free(self):
+        if self.h and self.ctx.h:
+            lib().pcr_rows_destroy(self.ctx.h, self.h)
+        self.h = None
+        self.ctx._handles.discard(self)
 
 
 def read_kitti_bin(path: str, floats_per_point: int = 4) -> np.ndarray:

@@ -187,8 +187,9 @@ int launch_nn1_brute_list(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* s
 // cap2: the caller only uses neighbours with d2 < cap2 (ICP's max_corres_dist gate) — the walk may stop once no such target can exist
 int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2);
 // grid radius search with the hw2 contract (radius_grid.hip); *used = false -> the caller runs the exhaustive kernels
+struct RadiusRowsDev { uint32_t* rows_dev = nullptr; int32_t* idx_dev = nullptr; double* dist_dev = nullptr; uint64_t total = 0; };
 int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r, double r2max, int64_t* row_ptr_host, int32_t* idx_host, double* dist_host,
-                bool* used);
+                bool* used, RadiusRowsDev* keep = nullptr);
 // exact grid k-NN between resident clouds (knn_grid.hip); host outputs idx/val [m x k], found [m] (optional)
 int cloud_knn_host(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k, double cap_s, bool squared, double empty_val, int32_t empty_idx,
                    int32_t* idx, double* val, uint32_t* found);

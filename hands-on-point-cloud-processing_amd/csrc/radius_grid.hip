@@ -300,10 +300,13 @@ struct DevBuf {
 }  // namespace
 
 // *used = false: the caller falls back to the exhaustive kernels (radius too large for a useful grid, 2^31 neighbours, ...)
+// keep != nullptr: the rows stay in HBM — the fill runs whether or not host arrays were given, nothing but the counts crosses PCIe,
+// and the caller owns keep->rows_dev (m + 1 u32 offsets), idx_dev, dist_dev afterwards (hipFree; all null when there is no neighbour)
 int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r, double r2max, int64_t* row_ptr_host, int32_t* idx_host, double* dist_host,
-                bool* used)
+                bool* used, RadiusRowsDev* keep)
 {
     *used = false;
+    if (keep) *keep = RadiusRowsDev();
     const size_t n = db->n, m = q->n;
     if (n == 0 || m == 0 || !(r > 0.0) || !std::isfinite(r) || r2max < 0.0) return PCR_OK;
     // the index with cell edge 1.01 r is kept on the database cloud (one slot: the radius of the last search), so that a driver
@@ -360,7 +363,7 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
     row_ptr_host[m] = (int64_t)acc;
     if (acc >= 0x7FFFFFF0ull) return PCR_OK;                   // 32-bit offsets / item counts: exhaustive path (which redoes the counts)
     *used = true;
-    if (!idx_host || acc == 0) return PCR_OK;
+    if ((!idx_host && !keep) || acc == 0) return PCR_OK;
     const size_t total = (size_t)acc;
     std::vector<uint32_t> hr(m + 1);
     for (size_t i = 0; i <= m; i++) hr[i] = (uint32_t)row_ptr_host[i];
@@ -425,10 +428,13 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
         PCR_HIP(ctx, hipGetLastError());
         int herr = 0;
         PCR_HIP(ctx, hipMemcpyAsync(&herr, errbuf.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP(ctx, hipMemcpyAsync(idx_host, idx_b.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP(ctx, hipMemcpyAsync(dist_host, dist.p, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (idx_host) {
+            PCR_HIP(ctx, hipMemcpyAsync(idx_host, idx_b.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP(ctx, hipMemcpyAsync(dist_host, dist.p, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
         PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (herr) return fail(ctx, PCR_ERR_STATE, "radius_emit: a row changed between the count and the fill pass");
+        if (keep) { keep->rows_dev = (uint32_t*)rows.p; keep->idx_dev = (int32_t*)idx_b.p; keep->dist_dev = (double*)dist.p; keep->total = total; rows.p = idx_b.p = dist.p = nullptr; }
         return PCR_OK;
     }
     // rows longer than the LDS of a workgroup: fill unsorted, device-wide segmented sort, distance pass
@@ -454,9 +460,12 @@ int radius_grid(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, double r,
                            (const uint32_t*)rows.p, (const int32_t*)idx_b.p, (double*)dist.p);
     }
     PCR_HIP(ctx, hipGetLastError());
-    PCR_HIP(ctx, hipMemcpyAsync(idx_host, idx_b.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PCR_HIP(ctx, hipMemcpyAsync(dist_host, dist.p, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (idx_host) {
+        PCR_HIP(ctx, hipMemcpyAsync(idx_host, idx_b.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP(ctx, hipMemcpyAsync(dist_host, dist.p, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (keep) { keep->rows_dev = (uint32_t*)rows.p; keep->idx_dev = (int32_t*)idx_b.p; keep->dist_dev = (double*)dist.p; keep->total = total; rows.p = idx_b.p = dist.p = nullptr; }
     return PCR_OK;
 }
 

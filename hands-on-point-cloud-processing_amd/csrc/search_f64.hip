@@ -513,3 +513,231 @@ extern "C" int pcr_radius_f64(pcr_ctx* ctx, const double* db, size_t n, const do
     pcr_db64_destroy(ctx, h);
     return rc;
 }
+
+// ================================================================================================ device-resident radius rows (round 3)
+// The rows of a radius search are 12 bytes per reported neighbour: 2.84 GB for every point of a 120 000-point scan at r = 1 — 1.9 ms of
+// kernels and 170 ms of PCIe at the pcr_db64_radius boundary.  A consumer that REDUCES the rows (neighbour counts, ISS-style weights,
+// neighbourhood moments for normals: Homework7/hw7/src/iss_detector.cpp:48-76, Homework1 pca_normal.py:89-103) or walks them a block at
+// a time (the self-query protocol of Homework2/hw2/include/benchmark.hpp:66-70) does not need them on the host at once: pcr_rows keeps
+// the CSR in HBM, only the m + 1 row offsets cross PCIe with the search.
+struct pcr_rows {
+    size_t m = 0;
+    uint64_t total = 0;
+    uint32_t* rows_dev = nullptr;       // m + 1 offsets (the grid route caps a search below 2^31 neighbours)
+    int32_t* idx_dev = nullptr;         // ascending index inside a row (the canonical order of pcr_radius_f64)
+    double* dist_dev = nullptr;
+    const pcr_db64* db = nullptr;       // the database the indices refer to (must outlive the rows)
+    std::vector<int64_t> row_ptr;       // host copy of the offsets
+};
+
+namespace pcr {
+namespace {
+
+constexpr int RR_BLOCK = 256;
+
+// one wave per row: out[row] = count | sum of distances | largest distance (0 for an empty row).  The sum adds the lanes' partial sums
+// (lane l holds entries l, l + 64, ... in row order) with a shuffle tree: deterministic, but not the left-to-right sum of a host loop.
+__global__ __launch_bounds__(RR_BLOCK) void rows_reduce_kernel(const uint32_t* __restrict__ rows, const double* __restrict__ dist, uint32_t m, int op,
+                                                               double* __restrict__ out)
+{
+    const uint32_t row = blockIdx.x * (RR_BLOCK / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= m) return;
+    const uint32_t b = rows[row], e = rows[row + 1];
+    double acc = 0.0;
+    if (op == PCR_ROWS_SUM_DIST) {
+        for (uint32_t p = b + lane; p < e; p += 64) acc += dist[p];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    } else if (op == PCR_ROWS_MAX_DIST) {
+        for (uint32_t p = b + lane; p < e; p += 64) acc = fmax(acc, dist[p]);
+        for (int o = 32; o > 0; o >>= 1) acc = fmax(acc, __shfl_xor(acc, o, 64));
+    } else {
+        acc = (double)(e - b);
+    }
+    if (lane == 0) out[row] = acc;
+}
+
+// one wave per row: mean[3] and the six distinct entries of the scatter matrix sum (p - mean)(p - mean)^T / count of the row's
+// neighbours, f64, two passes over the row (mean first: the centred products do not cancel); xx xy xz yy yz zz
+__global__ __launch_bounds__(RR_BLOCK) void rows_moments_kernel(const uint32_t* __restrict__ rows, const int32_t* __restrict__ idx, uint32_t m,
+                                                                const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                                                                double* __restrict__ mean, double* __restrict__ cov)
+{
+    const uint32_t row = blockIdx.x * (RR_BLOCK / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= m) return;
+    const uint32_t b = rows[row], e = rows[row + 1];
+    double s[3] = { 0.0, 0.0, 0.0 };
+    for (uint32_t p = b + lane; p < e; p += 64) { const int32_t j = idx[p]; s[0] += x[j]; s[1] += y[j]; s[2] += z[j]; }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        for (int o = 32; o > 0; o >>= 1) s[c] += __shfl_xor(s[c], o, 64);
+    const double cnt = (double)(e - b), inv = e > b ? 1.0 / cnt : 0.0;
+    const double mx = s[0] * inv, my = s[1] * inv, mz = s[2] * inv;
+    double c6[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    for (uint32_t p = b + lane; p < e; p += 64) {
+        const int32_t j = idx[p];
+        const double dx = x[j] - mx, dy = y[j] - my, dz = z[j] - mz;
+        c6[0] += dx * dx; c6[1] += dx * dy; c6[2] += dx * dz; c6[3] += dy * dy; c6[4] += dy * dz; c6[5] += dz * dz;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+        for (int o = 32; o > 0; o >>= 1) c6[c] += __shfl_xor(c6[c], o, 64);
+    if (lane == 0) {
+        mean[3 * (size_t)row] = mx; mean[3 * (size_t)row + 1] = my; mean[3 * (size_t)row + 2] = mz;
+        for (int c = 0; c < 6; c++) cov[6 * (size_t)row + c] = c6[c] * inv;
+    }
+}
+
+}  // namespace
+}  // namespace pcr
+
+extern "C" int pcr_rows_destroy(pcr_ctx* ctx, pcr_rows* rows)
+{
+    if (!rows) return PCR_OK;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (rows->rows_dev) hipFree(rows->rows_dev);
+    if (rows->idx_dev) hipFree(rows->idx_dev);
+    if (rows->dist_dev) hipFree(rows->dist_dev);
+    delete rows;
+    return PCR_OK;
+}
+
+extern "C" int pcr_db64_radius_rows(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, double r, pcr_rows** out)
+{
+    if (!ctx || !db || !out) return fail(ctx, PCR_ERR_ARG, "pcr_db64_radius_rows");
+    *out = nullptr;
+    const bool self = q == nullptr;                 // every point of the database queries the database
+    if (self) m = db->n;
+    if (m > 0x7FFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "pcr_db64_radius_rows: too many queries");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    pcr_rows* h = new (std::nothrow) pcr_rows();
+    if (!h) return fail(ctx, PCR_ERR_NOMEM, "pcr_db64_radius_rows");
+    h->m = m; h->db = db;
+    h->row_ptr.assign(m + 1, 0);
+    if (m == 0) { *out = h; return PCR_OK; }
+    int rc = PCR_OK;
+    bool used = false;
+    // the grid route leaves its rows where they are (radius_grid.hip, keep)
+    if (db->twin && tune_get(ctx, "radius_method", 0) != 1) {
+        RadiusRowsDev keep;
+        const double r2max = radius_sq_bound(r);
+        if (self) {
+            rc = radius_grid(ctx, db->twin, db->twin, r, r2max, h->row_ptr.data(), nullptr, nullptr, &used, &keep);
+        } else {
+            std::vector<float> qf;
+            if (f32_exact(q, m, qf)) {
+                pcr_cloud* qc = nullptr;
+                rc = pcr_cloud_create(ctx, qf.data(), m, PCR_AOS3, &qc);
+                if (rc == PCR_OK) { rc = radius_grid(ctx, db->twin, qc, r, r2max, h->row_ptr.data(), nullptr, nullptr, &used, &keep); pcr_cloud_destroy(ctx, qc); }
+            }
+        }
+        prof_flush(ctx);
+        if (rc) { delete h; return rc; }
+        if (used) { h->rows_dev = keep.rows_dev; h->idx_dev = keep.idx_dev; h->dist_dev = keep.dist_dev; h->total = (uint64_t)h->row_ptr[m]; }
+    }
+    if (!used) {
+        // any other database / query set: the host-boundary search, its result uploaded once (the exhaustive route has no 2^31 cap,
+        // the handle has: its offsets are 32-bit)
+        std::vector<double> qself;
+        if (self) {
+            qself.resize(3 * m);
+            std::vector<double> soa(3 * db->cap);
+            hipError_t e = hipMemcpy(soa.data(), db->dev, 3 * db->cap * sizeof(double), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { delete h; return fail(ctx, PCR_ERR_HIP, "rows: database download", e); }
+            for (size_t i = 0; i < m; i++) { qself[3 * i] = soa[i]; qself[3 * i + 1] = soa[db->cap + i]; qself[3 * i + 2] = soa[2 * db->cap + i]; }
+            q = qself.data();
+        }
+        rc = pcr_db64_radius(ctx, db, q, m, r, h->row_ptr.data(), nullptr, nullptr);
+        if (rc) { delete h; return rc; }
+        const uint64_t total = (uint64_t)h->row_ptr[m];
+        if (total >= 0x7FFFFFF0ull) { delete h; return fail(ctx, PCR_ERR_ARG, "pcr_db64_radius_rows: 2^31 neighbours or more"); }
+        h->total = total;
+        if (total) {
+            std::vector<int32_t> idx(total);
+            std::vector<double> dist(total);
+            rc = pcr_db64_radius(ctx, db, q, m, r, h->row_ptr.data(), idx.data(), dist.data());
+            std::vector<uint32_t> r32(m + 1);
+            for (size_t i = 0; i <= m; i++) r32[i] = (uint32_t)h->row_ptr[i];
+            hipError_t e = rc ? hipSuccess : hipMalloc((void**)&h->rows_dev, (m + 1) * 4);
+            if (!rc && e == hipSuccess) e = hipMalloc((void**)&h->idx_dev, total * 4);
+            if (!rc && e == hipSuccess) e = hipMalloc((void**)&h->dist_dev, total * 8);
+            if (!rc && e == hipSuccess) e = hipMemcpy(h->rows_dev, r32.data(), (m + 1) * 4, hipMemcpyHostToDevice);
+            if (!rc && e == hipSuccess) e = hipMemcpy(h->idx_dev, idx.data(), total * 4, hipMemcpyHostToDevice);
+            if (!rc && e == hipSuccess) e = hipMemcpy(h->dist_dev, dist.data(), total * 8, hipMemcpyHostToDevice);
+            if (rc || e != hipSuccess) { pcr_rows_destroy(ctx, h); return rc ? rc : fail(ctx, PCR_ERR_HIP, "rows: upload", e); }
+        }
+    }
+    *out = h;
+    return PCR_OK;
+}
+
+extern "C" int pcr_rows_info(const pcr_rows* rows, size_t* m, uint64_t* total)
+{
+    if (!rows) return PCR_ERR_ARG;
+    if (m) *m = rows->m;
+    if (total) *total = rows->total;
+    return PCR_OK;
+}
+
+extern "C" int pcr_rows_row_ptr(const pcr_rows* rows, int64_t* row_ptr)
+{
+    if (!rows || !row_ptr) return PCR_ERR_ARG;
+    memcpy(row_ptr, rows->row_ptr.data(), (rows->m + 1) * sizeof(int64_t));
+    return PCR_OK;
+}
+
+extern "C" int pcr_rows_fetch(pcr_ctx* ctx, const pcr_rows* rows, size_t row_begin, size_t row_end, int32_t* idx, double* dist)
+{
+    if (!ctx || !rows || row_begin > row_end || row_end > rows->m) return fail(ctx, PCR_ERR_ARG, "pcr_rows_fetch");
+    const size_t b = (size_t)rows->row_ptr[row_begin], e = (size_t)rows->row_ptr[row_end];
+    if (e == b) return PCR_OK;
+    if (!idx && !dist) return fail(ctx, PCR_ERR_ARG, "pcr_rows_fetch: no output array");
+    if (idx) PCR_HIP(ctx, hipMemcpyAsync(idx, rows->idx_dev + b, (e - b) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (dist) PCR_HIP(ctx, hipMemcpyAsync(dist, rows->dist_dev + b, (e - b) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+extern "C" int pcr_rows_reduce(pcr_ctx* ctx, const pcr_rows* rows, int op, double* out)
+{
+    if (!ctx || !rows || (rows->m && !out) || op < PCR_ROWS_COUNT || op > PCR_ROWS_MAX_DIST) return fail(ctx, PCR_ERR_ARG, "pcr_rows_reduce");
+    const size_t m = rows->m;
+    if (m == 0) return PCR_OK;
+    if (op == PCR_ROWS_COUNT || rows->total == 0) {                        // (the offsets are on the host already)
+        for (size_t i = 0; i < m; i++) out[i] = op == PCR_ROWS_COUNT ? (double)(rows->row_ptr[i + 1] - rows->row_ptr[i]) : 0.0;
+        return PCR_OK;
+    }
+    int rc = ensure_scratch(ctx, m * sizeof(double));
+    if (rc) return rc;
+    {
+        ProfScope p(ctx, "rows_reduce", 1);
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)((m + RR_BLOCK / 64 - 1) / (RR_BLOCK / 64))), dim3(RR_BLOCK), 0, ctx->stream, rows->rows_dev,
+                           rows->dist_dev, (uint32_t)m, op, (double*)ctx->scratch);
+    }
+    PCR_HIP(ctx, hipGetLastError());
+    PCR_HIP(ctx, hipMemcpyAsync(out, ctx->scratch, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+extern "C" int pcr_rows_moments(pcr_ctx* ctx, const pcr_rows* rows, double* mean, double* cov)
+{
+    if (!ctx || !rows || !rows->db || (rows->m && (!mean || !cov))) return fail(ctx, PCR_ERR_ARG, "pcr_rows_moments");
+    const size_t m = rows->m;
+    if (m == 0) return PCR_OK;
+    if (rows->total == 0) { memset(mean, 0, 3 * m * sizeof(double)); memset(cov, 0, 6 * m * sizeof(double)); return PCR_OK; }
+    int rc = ensure_scratch(ctx, 9 * m * sizeof(double));
+    if (rc) return rc;
+    double* dmean = (double*)ctx->scratch;
+    double* dcov = dmean + 3 * m;
+    const pcr_db64* db = rows->db;
+    {
+        ProfScope p(ctx, "rows_moments", 1);
+        hipLaunchKernelGGL(rows_moments_kernel, dim3((unsigned)((m + RR_BLOCK / 64 - 1) / (RR_BLOCK / 64))), dim3(RR_BLOCK), 0, ctx->stream, rows->rows_dev,
+                           rows->idx_dev, (uint32_t)m, db->dev, db->dev + db->cap, db->dev + 2 * db->cap, dmean, dcov);
+    }
+    PCR_HIP(ctx, hipGetLastError());
+    PCR_HIP(ctx, hipMemcpyAsync(mean, dmean, 3 * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipMemcpyAsync(cov, dcov, 6 * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}

@@ -148,6 +148,23 @@ int pcr_db64_knn(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, in
 int pcr_db64_radius(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, double r,
                     int64_t* row_ptr, int32_t* idx, double* dist);
 
+/* ---- device-resident radius rows: the CSR of a radius search kept in HBM (12 B per neighbour never cross PCIe unless asked for) --------
+ * What the batched consumers of the reference do with radius rows is reduce them — neighbour counts and 1 / count weights
+ * (Homework7/hw7/src/iss_detector.cpp:48-76), neighbourhood moments for normals (Homework1 pca_normal.py:89-103) — or walk them in query
+ * order (the self-query loop of Homework2/hw2/include/benchmark.hpp:66-70).  q == NULL: every point of db queries db (m is ignored).
+ * Same rows as pcr_db64_radius, bit for bit (ascending index inside a row, d <= r inclusive).  The database must outlive the handle. */
+typedef struct pcr_rows pcr_rows;
+int pcr_db64_radius_rows(pcr_ctx* ctx, const pcr_db64* db, const double* q, size_t m, double r, pcr_rows** out);
+int pcr_rows_destroy(pcr_ctx* ctx, pcr_rows* rows);
+int pcr_rows_info(const pcr_rows* rows, size_t* m, uint64_t* total);            /* queries, reported neighbours */
+int pcr_rows_row_ptr(const pcr_rows* rows, int64_t* row_ptr);                   /* the m + 1 offsets (host copy, no GPU work) */
+/* rows [row_begin, row_end) -> idx / dist (either may be NULL), (row_ptr[row_end] - row_ptr[row_begin]) entries: iterate in bounded blocks */
+int pcr_rows_fetch(pcr_ctx* ctx, const pcr_rows* rows, size_t row_begin, size_t row_end, int32_t* idx, double* dist);
+enum pcr_rows_op { PCR_ROWS_COUNT = 0, PCR_ROWS_SUM_DIST = 1, PCR_ROWS_MAX_DIST = 2 };
+int pcr_rows_reduce(pcr_ctx* ctx, const pcr_rows* rows, int op, double* out);    /* out[m]; an empty row gives 0 */
+/* per row: mean (m x 3) and scatter matrix sum (p - mean)(p - mean)^T / count as xx xy xz yy yz zz (m x 6) of its neighbours' coordinates */
+int pcr_rows_moments(pcr_ctx* ctx, const pcr_rows* rows, double* mean, double* cov);
+
 /* Registration::ICPpoint2plane (registration.hpp:195-202, registration.cpp:710-860): the point-to-plane variant on the same
  * 1-NN loop.  tgt_normals: one normal per target point (a cloud whose x/y/z are normal_x/y/z; e.g. floats 3..5 of hw9's .bin
  * rows).  Rows A = [n x p, n], b = n.q - n.p in f32 as written (:807-814); normal equations in f64; update R_delta = I + [x]_x,

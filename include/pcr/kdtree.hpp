@@ -14,7 +14,9 @@
 // microseconds) against the reference's ~2 us per query, so:
 //   * a query that is bit-identical to a database point (the benchmark protocol, benchmark.hpp:59-66: every point queries its
 //     own cloud) is served from ONE batched self-query of the whole database, computed at the first such call for that
-//     k / radius (one k and one radius are kept: a different one replaces it);
+//     k / radius (one k and one radius are kept: a different one replaces it).  The radius rows stay IN HBM (pcr_rows: 2.8 GB for
+//     radius 1 on a 120 k scan) and reach the host through a bounded window — at most 64 MB at a time, grown while the caller walks
+//     the points in order, a single row for a caller that jumps around;
 //   * any other query costs one small launch (measured beside the reference: INTEGRATION.md);
 //   * callers that have their queries at hand use the EXTENSIONS KDTreeKNNSearchBatch / KDTreeRadiusNNSearchBatch below: one
 //     launch for all of them, well under a microsecond per query.
@@ -95,8 +97,17 @@ struct TreeEntry {
     // memoised self-queries: ONE k and ONE radius (a batch over the whole database is n x k entries, or — radius 1 on a
     // 120 k scan — 2.8 GB: a new k / radius replaces the old one instead of piling up)
     std::map<int, std::pair<std::vector<int32_t>, std::vector<double>>> self_knn;          // k -> (idx, dist), n x k
-    struct Csr { std::vector<int64_t> row; std::vector<int32_t> idx; std::vector<double> dist; };
-    std::map<double, Csr> self_radius;                          // radius -> CSR over all database points
+    // the self-query rows of ONE radius: device-resident (pcr_rows), the host holds the offsets and a window of whole rows
+    struct RadiusMemo {
+        bool valid = false;
+        double r = 0.0;
+        pcr_rows* rows = nullptr;
+        std::vector<int64_t> row;                               // n + 1 offsets
+        size_t win_b = 0, win_e = 0;                            // rows [win_b, win_e) are in idx / dist
+        size_t win_entries = 1u << 14;                          // entries the next window may hold: doubles while the access is sequential
+        std::vector<int32_t> idx;
+        std::vector<double> dist;
+    } self_radius;
 };
 
 inline std::unordered_map<const Node*, TreeEntry>& registry()
@@ -206,23 +217,30 @@ inline void KDTreeRadiusNNSearch(Node*& root, std::vector<std::vector<double>>& 
     const double r = result_set.getWorstDist();
     auto hit = e.first_index.find(key_of(query.data()));
     if (hit != e.first_index.end()) {
-        auto it = e.self_radius.find(r);
-        if (it == e.self_radius.end()) {
-            e.self_radius.clear();      // one radius at a time
-            TreeEntry::Csr csr;
-            csr.row.resize(e.n + 1);
-            pcr::check(pcr_db64_radius(pcr::default_ctx(), e.db, e.flat.data(), e.n, r, csr.row.data(), nullptr, nullptr),
-                       "pcr_db64_radius(count)");
-            csr.idx.resize((size_t)csr.row[e.n] + 1);
-            csr.dist.resize((size_t)csr.row[e.n] + 1);
-            if (csr.row[e.n] > 0)
-                pcr::check(pcr_db64_radius(pcr::default_ctx(), e.db, e.flat.data(), e.n, r, csr.row.data(), csr.idx.data(),
-                                           csr.dist.data()), "pcr_db64_radius(fill)");
-            it = e.self_radius.emplace(r, std::move(csr)).first;
+        TreeEntry::RadiusMemo& mm = e.self_radius;
+        if (!mm.valid || mm.r != r) {                           // first self-query for this radius (one radius at a time)
+            if (mm.rows) pcr_rows_destroy(pcr::default_ctx(), mm.rows);
+            mm = TreeEntry::RadiusMemo();
+            pcr::check(pcr_db64_radius_rows(pcr::default_ctx(), e.db, nullptr, 0, r, &mm.rows), "pcr_db64_radius_rows(self)");
+            mm.row.resize(e.n + 1);
+            pcr::check(pcr_rows_row_ptr(mm.rows, mm.row.data()), "pcr_rows_row_ptr");
+            mm.r = r; mm.valid = true;
         }
-        const TreeEntry::Csr& c = it->second;
-        const int64_t b = c.row[hit->second], en = c.row[hit->second + 1];
-        result_set.assign(&c.dist[b], &c.idx[b], (size_t)(en - b), (int)(en - b));
+        const size_t i = (size_t)hit->second;
+        if (i < mm.win_b || i >= mm.win_e) {
+            // a new window of whole rows starting at row i: at most 5.3 M entries (64 MB of idx + dist); its budget doubles while the
+            // caller continues where the last window ended (benchmark.hpp:66-70 walks the cloud in order) and starts small otherwise
+            constexpr size_t cap = ((size_t)64 << 20) / 12;
+            mm.win_entries = (i == mm.win_e && mm.win_e != 0) ? std::min(cap, mm.win_entries * 2) : (size_t)(1u << 14);
+            size_t e_row = i + 1;
+            while (e_row < e.n && (size_t)(mm.row[e_row + 1] - mm.row[i]) <= mm.win_entries) e_row++;
+            const size_t cnt = (size_t)(mm.row[e_row] - mm.row[i]);
+            mm.idx.resize(cnt + 1); mm.dist.resize(cnt + 1);
+            pcr::check(pcr_rows_fetch(pcr::default_ctx(), mm.rows, i, e_row, mm.idx.data(), mm.dist.data()), "pcr_rows_fetch");
+            mm.win_b = i; mm.win_e = e_row;
+        }
+        const int64_t b = mm.row[i] - mm.row[mm.win_b], en = mm.row[i + 1] - mm.row[mm.win_b];
+        result_set.assign(&mm.dist[b], &mm.idx[b], (size_t)(en - b), (int)(en - b));
         return;
     }
     int64_t row[2] = { 0, 0 };
@@ -268,7 +286,10 @@ inline int TreeDepth(Node*& root)
 inline void KDTreeDestruction()
 {
     using namespace pcr::dropin;
-    for (auto& kv : registry()) pcr_db64_destroy(pcr::default_ctx(), kv.second.db);
+    for (auto& kv : registry()) {
+        if (kv.second.self_radius.rows) pcr_rows_destroy(pcr::default_ctx(), kv.second.self_radius.rows);
+        pcr_db64_destroy(pcr::default_ctx(), kv.second.db);
+    }
     registry().clear();
     for (Node* n : Node::address_set_ref()) delete n;
     Node::address_set_ref().clear();   // unlike the reference, a second call is harmless

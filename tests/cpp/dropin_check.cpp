@@ -101,6 +101,24 @@ int main(int argc, char** argv)
         auto query = db[i];
         dump_query(out, root, db, query, (int)k, r, mat_index);
     }
+    // the self-query rows live in HBM and reach the host through a bounded window: a caller that jumps around the cloud (every window
+    // re-fetched) must see the rows a batch of the same points gets
+    {
+        const int64_t jumps = n < 48 ? n : 48;
+        my_vector_of_vectors_t jq;
+        for (int64_t t = 0; t < jumps; t++) jq.push_back(db[(size_t)((t * 7919 + 13) % n)]);
+        std::vector<RadiusNNResultSet> rs((size_t)jumps, RadiusNNResultSet(r));
+        KDTreeRadiusNNSearchBatch(root, db, rs, jq);
+        for (int64_t t = 0; t < jumps; t++) {
+            RadiusNNResultSet oner(r);
+            KDTreeRadiusNNSearch(root, db, oner, jq[t]);
+            if (oner.size() != rs[t].size()) { fprintf(stderr, "window/radius count mismatch at %lld\n", (long long)t); return 7; }
+            for (size_t s2 = 0; s2 < oner.distIndexList.size(); s2++)
+                if (oner.distIndexList[s2].index != rs[t].distIndexList[s2].index || oner.distIndexList[s2].distance != rs[t].distIndexList[s2].distance) {
+                    fprintf(stderr, "window/radius mismatch at %lld\n", (long long)t); return 7;
+                }
+        }
+    }
     int depth = TreeDepth(root);
     fwrite(&depth, 4, 1, out);
     KDTreeDestruction();
