@@ -221,6 +221,8 @@ int pcr_ctx_destroy(pcr_ctx* ctx)
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->aux) hipFree(ctx->aux);
     if (ctx->host_stage) hipHostFree(ctx->host_stage);
+    if (ctx->coop_host) hipHostFree(ctx->coop_host);
+    if (ctx->coop_ticket) hipFree(ctx->coop_ticket);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return PCR_OK;

@@ -17,6 +17,8 @@
 #include "grid_common.hpp"
 #include "eig3.hpp"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <vector>
 
@@ -174,6 +176,148 @@ __global__ __launch_bounds__(KG_BLOCK) void knn_grid_kernel(const float4* __rest
     if (found_out) found_out[row] = found;
 }
 
+// ---- ONE WAVE PER QUERY (round 3): the same search for a handful of queries — the one-question-at-a-time calls of the reference API
+// (KDTreeKNNSearch, kdtree.hpp:329; nanoflann findNeighbors, nanoflann.hpp:1222).  With one LANE per query a single call is one lane's
+// serial walk (~30 us of a 71 us call); here the 64 lanes stride the records of every opened row (coalesced loads), each keeping its own
+// top-k of what it saw; after every cube the lists are merged — k rounds of "smallest head over the wave" — into the exact global
+// top-k, which decides termination as in the serial walk (and bounds the next shell).  Every record is seen by exactly one lane and
+// every comparison is on (value, index): the result is the canonical one, bit for bit that of knn_grid_kernel.
+// Completion is signalled through host memory: results (zero-copy) -> system-scope fence -> the last wave stores `done`; the host polls
+// that word instead of paying the interrupt + wake-up of a stream synchronisation.
+struct CoopQueries { float x[16], y[16], z[16]; };       // the queries travel as kernel arguments: no read over PCIe in front of the walk
+
+template <int K, bool SQ>
+__global__ __launch_bounds__(64) void knn_grid_coop_kernel(const float4* __restrict__ records, const uint32_t* __restrict__ cell_start, GridParams g,
+                                                            CoopQueries qs, uint32_t m, int k_out, double cap_s, double empty_val, int32_t empty_idx,
+                                                            int32_t* __restrict__ idx_out, double* __restrict__ val_out, uint32_t* __restrict__ done,
+                                                            uint32_t done_value, uint32_t* __restrict__ ticket)
+{
+#pragma clang fp contract(off)
+    const uint32_t row = blockIdx.x, lane = threadIdx.x;
+    if (row >= m) return;
+    const float fx = qs.x[row], fy = qs.y[row], fz = qs.z[row];
+    TopK<K> t;                          // this lane's candidates
+    double mv[K];                       // the merged global top-k (the same in every lane)
+    int32_t mi[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) { t.v[s] = INFINITY; t.i[s] = 0x7FFFFFFF; mv[s] = INFINITY; mi[s] = 0x7FFFFFFF; }
+    double kth_s = INFINITY;            // s-domain bound of the global k-th entry (from the last merge)
+    if (finite3(fx, fy, fz)) {
+        const double qx = fx, qy = fy, qz = fz;
+        const int ux = cell_coord(fx, g.lo[0], g.inv_h), uy = cell_coord(fy, g.lo[1], g.inv_h), uz = cell_coord(fz, g.lo[2], g.inv_h);
+        const int r0 = max(max(max(-ux, ux - (g.n[0] - 1)), max(-uy, uy - (g.n[1] - 1))), max(max(-uz, uz - (g.n[2] - 1)), 0));
+        int r = max(r0, 1), rp = -1;
+        const double h = g.h, slack = g.slack;
+        for (int step = 0; step < 40; step++) {
+            const int xlo = max(ux - r, 0), xhi = min(ux + r, g.n[0] - 1);
+            const int ylo = max(uy - r, 0), yhi = min(uy + r, g.n[1] - 1);
+            const int zlo = max(uz - r, 0), zhi = min(uz + r, g.n[2] - 1);
+            const double lim0 = fmin(kth_s, cap_s);                                        // (uniform: the bound of the last merge)
+            double my_kth = kth_s;                                                         // tightened by this lane's own list
+            auto consider = [&](const float4 rec) {
+                const double dx = (double)rec.x - qx, dy = (double)rec.y - qy, dz = (double)rec.z - qz;   // t - q, kdtree.hpp:343
+                const double s = (dx * dx + dy * dy) + dz * dz;
+                if (!(s < cap_s) || !(s <= my_kth)) return;
+                const int32_t j = (int32_t)__float_as_uint(rec.w);
+                const double val = SQ ? s : sqrt(s);
+                if (lex_less(val, j, t.v[K - 1], t.i[K - 1])) {
+                    topk_insert<K>(t, val, j);
+                    const double w = t.v[K - 1];                                           // (a lane's own k-th bounds the global k-th from above)
+                    my_kth = fmin(my_kth, SQ ? w : w * w * (1.0 + 1e-12));
+                }
+            };
+            if (xlo <= xhi && ylo <= yhi && zlo <= zhi) {
+                // The rows of the shell, 64 at a time, ONE ROW PER LANE: every lane resolves its row (pruning against the k-th ball, the
+                // cell_start bounds of its one or two pieces — all 64 x 2..4 loads in flight together instead of one dependent pair per
+                // row), an inclusive scan lays the pieces out as one index space, and the wave strides that space: candidate f belongs to
+                // the lane whose offset is the last one <= f (six shuffle steps).
+                const int ny_rows = yhi - ylo + 1, n_rows = ny_rows * (zhi - zlo + 1);
+                for (int k0 = 0; k0 < n_rows; k0 += 64) {
+                    const int kk = k0 + (int)lane;
+                    uint32_t b1 = 0, c1 = 0, b2 = 0, c2 = 0;
+                    if (kk < n_rows) {
+                        const int cy = ylo + kk % ny_rows, cz = zlo + kk / ny_rows;
+                        const int ady = abs(cy - uy), adz = abs(cz - uz);
+                        const double fy2 = fmax((double)ady - 1.0 - slack, 0.0) * h, fz2 = fmax((double)adz - 1.0 - slack, 0.0) * h;
+                        if (!(fy2 * fy2 + fz2 * fz2 > lim0 * 1.0001)) {                    // (else: the whole row is outside the k-th ball)
+                            const uint32_t rowbase = (uint32_t)((cz * g.n[1] + cy) * g.n[0]);
+                            if (ady <= rp && adz <= rp) {                                  // crosses the old cube: two end pieces
+                                const int lb = min(xhi, ux - rp - 1), ra = max(xlo, ux + rp + 1);
+                                if (xlo <= lb) { b1 = cell_start[rowbase + xlo]; c1 = cell_start[rowbase + lb + 1] - b1; }
+                                if (ra <= xhi) { b2 = cell_start[rowbase + ra]; c2 = cell_start[rowbase + xhi + 1] - b2; }
+                            } else {
+                                b1 = cell_start[rowbase + xlo]; c1 = cell_start[rowbase + xhi + 1] - b1;
+                            }
+                        }
+                    }
+                    uint32_t inc = c1 + c2;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, o, 64); if ((int)lane >= o) inc += up; }
+                    const uint32_t off = inc - (c1 + c2), total = (uint32_t)__shfl((int)inc, 63, 64);
+                    for (uint32_t f = lane; f < total + 63u - (total + 63u) % 64u; f += 64) {     // (whole trips: the shuffles need every lane)
+                        int owner = 0;
+#pragma unroll
+                        for (int step = 32; step > 0; step >>= 1)
+                            if ((uint32_t)__shfl((int)off, owner + step, 64) <= f) owner += step;
+                        const uint32_t rel = f - (uint32_t)__shfl((int)off, owner, 64);
+                        const uint32_t ob1 = (uint32_t)__shfl((int)b1, owner, 64), oc1 = (uint32_t)__shfl((int)c1, owner, 64), ob2 = (uint32_t)__shfl((int)b2, owner, 64);
+                        if (f < total) consider(records[rel < oc1 ? ob1 + rel : ob2 + (rel - oc1)]);
+                    }
+                }
+            }
+            // merge: K rounds, each takes the smallest head over the wave (the lane that owns it pops it); the previous merged list
+            // takes part through lane 0, which holds it as its own list from the second stage on
+#pragma unroll
+            for (int s = 0; s < K; s++) {
+                double hv = t.v[0];
+                int32_t hi = t.i[0];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double ov = __shfl_xor(hv, o, 64);
+                    const int32_t oi = __shfl_xor(hi, o, 64);
+                    if (lex_less(ov, oi, hv, hi)) { hv = ov; hi = oi; }
+                }
+                mv[s] = hv; mi[s] = hi;
+                if (t.i[0] == hi && t.v[0] == hv && hi != 0x7FFFFFFF) {                    // mine: pop
+#pragma unroll
+                    for (int u = 0; u + 1 < K; u++) { t.v[u] = t.v[u + 1]; t.i[u] = t.i[u + 1]; }
+                    t.v[K - 1] = INFINITY; t.i[K - 1] = 0x7FFFFFFF;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < K; s++) { t.v[s] = lane == 0 ? mv[s] : INFINITY; t.i[s] = lane == 0 ? mi[s] : 0x7FFFFFFF; }
+            const double w = mv[K - 1];
+            kth_s = SQ ? w : w * w * (1.0 + 1e-12);                                        // INFINITY while fewer than K were seen
+            const bool covers = (ux - r <= 0) && (ux + r >= g.n[0] - 1) && (uy - r <= 0) && (uy + r >= g.n[1] - 1) && (uz - r <= 0) && (uz + r >= g.n[2] - 1);
+            const double reach = ((double)r - slack) * h;
+            const double lim = fmin(kth_s, cap_s);                                         // nothing at or beyond `lim` can enter
+            if (covers || lim < reach * reach * 0.99999) break;
+            rp = r;
+            if (lim < INFINITY) {
+                const double need = fmin(sqrt(lim * 1.00002) * (double)g.inv_h + slack + 1.0, 16777216.0);
+                r = max((int)need, rp + 1);
+            } else {
+                r = min(r * 2, 1 << 24);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        if (s < k_out && (int)lane == s) {
+            const bool have = mi[s] != 0x7FFFFFFF;
+            idx_out[(size_t)row * k_out + s] = have ? mi[s] : empty_idx;
+            val_out[(size_t)row * k_out + s] = have ? mv[s] : empty_val;
+        }
+    }
+    // results -> system-scope fence -> a ticket in device memory; the wave that draws the last ticket (every other wave's results are
+    // fenced by then) publishes the completion word in host memory: ONE transaction over PCIe per call, not one per query
+    __threadfence_system();
+    if (lane == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old % m == m - 1) __hip_atomic_store(done, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // normals[i] = eigenvector of the smallest eigenvalue of the scatter matrix of point i's neighbours (pca_normal.py:17-36,
 // :96-103): centre = sum / n, XTX = sum (p - c)(p - c)^T in neighbour order (ascending distance); zeros when fewer than 3
 __global__ __launch_bounds__(KG_BLOCK) void normals_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
@@ -290,6 +434,64 @@ int knn_grid_device(pcr_ctx* ctx, const pcr_cloud* db, const pcr_cloud* q, int k
 // rows there (zero-copy over PCIe: a few hundred bytes per query); the widened grid of db is cached on the cloud.
 // A driver that asks one question at a time (KDTreeKNNSearch per query, nanoflann findNeighbors) pays a launch + a wake-up
 // per call instead of the 13 ms single-lane scan of the exhaustive kernel.
+// a handful of queries (<= KNN_COOP_MAX): one wave per query, completion polled in host memory (tune knn_coop: 2 = off)
+constexpr size_t KNN_COOP_MAX = 16;
+
+static int cloud_knn_coop(pcr_ctx* ctx, const Grid* g, const float* q_rows, size_t m, int k, double cap_s, bool squared, double empty_val, int32_t empty_idx,
+                          int32_t* idx, double* val)
+{
+    // a small coherent (fine-grained) host buffer of its own: [done word | values | indices], and a ticket word in device memory
+    constexpr size_t OFF_V = 256, OFF_I = OFF_V + KNN_COOP_MAX * 32 * 8, TOTAL = OFF_I + KNN_COOP_MAX * 32 * 4;
+    if (!ctx->coop_host) {
+        PCR_HIP(ctx, hipHostMalloc(&ctx->coop_host, TOTAL, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(ctx->coop_host, 0, TOTAL);
+        PCR_HIP(ctx, hipMalloc((void**)&ctx->coop_ticket, 256));
+        PCR_HIP(ctx, hipMemset(ctx->coop_ticket, 0, 256));
+    }
+    char* st = (char*)ctx->coop_host;
+    volatile uint32_t* done = (volatile uint32_t*)st;
+    CoopQueries qs;
+    for (size_t i = 0; i < KNN_COOP_MAX; i++) { const size_t j = i < m ? i : 0; qs.x[i] = q_rows[3 * j]; qs.y[i] = q_rows[3 * j + 1]; qs.z[i] = q_rows[3 * j + 2]; }
+    double* val_p = (double*)(st + OFF_V);
+    int32_t* idx_p = (int32_t*)(st + OFF_I);
+    // the ticket counts waves modulo m: a call must find it at a multiple of m (the previous call used another m: reset it, in stream order)
+    if (ctx->coop_m != m) { PCR_HIP(ctx, hipMemsetAsync(ctx->coop_ticket, 0, 4, ctx->stream)); ctx->coop_m = m; }
+    const uint32_t target = ++ctx->coop_seq;
+#define PCR_KC(KK)                                                                                                                          \
+    do {                                                                                                                                    \
+        if (squared)                                                                                                                        \
+            hipLaunchKernelGGL((knn_grid_coop_kernel<KK, true>), dim3((unsigned)m), dim3(64), 0, ctx->stream, g->records, g->cell_start, g->p, qs, \
+                               (uint32_t)m, k, cap_s, empty_val, empty_idx, idx_p, val_p, (uint32_t*)st, target, ctx->coop_ticket);          \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((knn_grid_coop_kernel<KK, false>), dim3((unsigned)m), dim3(64), 0, ctx->stream, g->records, g->cell_start, g->p, qs, \
+                               (uint32_t)m, k, cap_s, empty_val, empty_idx, idx_p, val_p, (uint32_t*)st, target, ctx->coop_ticket);          \
+    } while (0)
+    if (k <= 1) PCR_KC(1);
+    else if (k <= 4) PCR_KC(4);
+    else if (k <= 8) PCR_KC(8);
+    else if (k <= 16) PCR_KC(16);
+    else PCR_KC(32);
+#undef PCR_KC
+    PCR_HIP(ctx, hipGetLastError());
+    // poll the completion word (a few microseconds after the last wave's store); a stream synchronisation settles it if it does not
+    // show up in time — correctness never depends on the poll
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (uint32_t spin = 0; ; spin++) {
+        if (*done == target) { seen = true; break; }
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) {
+        // (a wave count the ticket did not expect, a failed launch ...: the stream settles it; the ticket restarts from zero)
+        PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PCR_HIP(ctx, hipMemsetAsync(ctx->coop_ticket, 0, 4, ctx->stream));
+    }
+    memcpy(idx, idx_p, m * (size_t)k * 4);
+    memcpy(val, val_p, m * (size_t)k * 8);
+    return PCR_OK;
+}
+
 int cloud_knn_small(pcr_ctx* ctx, const pcr_cloud* db, const float* q_rows, size_t m, int k, double cap_s, bool squared, double empty_val,
                     int32_t empty_idx, int32_t* idx, double* val)
 {
@@ -298,6 +500,7 @@ int cloud_knn_small(pcr_ctx* ctx, const pcr_cloud* db, const float* q_rows, size
     bool owned = false;
     int rc = knn_grid_for(ctx, db, k, &g, &owned);
     if (rc) return rc;
+    if (m <= KNN_COOP_MAX && !owned && tune_get(ctx, "knn_coop", 1) == 1) return cloud_knn_coop(ctx, g, q_rows, m, k, cap_s, squared, empty_val, empty_idx, idx, val);
     const size_t mp = (m + 63) & ~(size_t)63;
     const size_t off_val = (3 * mp * 4 + 255) & ~(size_t)255, off_idx = off_val + ((m * (size_t)k * 8 + 255) & ~(size_t)255),
                  off_found = off_idx + ((m * (size_t)k * 4 + 255) & ~(size_t)255), total = off_found + m * 4 + 256;

@@ -129,6 +129,10 @@ struct pcr_ctx {
     size_t scratch_cap = 0;
     void* host_stage = nullptr;           // pinned staging for uploads / downloads
     size_t host_stage_cap = 0;
+    void* coop_host = nullptr;            // small coherent host buffer of the one-wave-per-query k-NN (knn_grid.hip): completion word, results
+    uint32_t* coop_ticket = nullptr;      // its wave ticket (device memory)
+    uint32_t coop_seq = 0;                // value the completion word takes at the end of the next call
+    size_t coop_m = 0;                    // queries of the last call (the ticket counts modulo m)
     void* aux = nullptr;                  // second device scratch (partial results of sliced searches), grows on demand
     size_t aux_cap = 0;
     pcr::IcpState* icp_state_dev = nullptr;    // pipelined ICP: device state, pinned snapshots, snapshot events

@@ -266,3 +266,33 @@ def test_gpu_kat_query5_open3d_squared_distances(pcr, golden):
         ctx.tune("knn_method", 0)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 3, 8, 16, 32])
+def test_one_wave_per_query_kernel_equals_the_batch_kernel(pcr, synth, k):
+    """One question at a time (KDTreeKNNSearch, kdtree.hpp:329; nanoflann findNeighbors): calls of up to 16 queries take the
+    one-wave-per-query kernel (csrc/knn_grid.hip knn_grid_coop_kernel: 64 lanes stride every opened row, per-lane top-k lists merged
+    after every cube, completion polled in host memory).  Same values and indices, bit for bit, as the one-lane-per-query kernel a large
+    batch takes — near, duplicate, far-away, non-finite queries, both distance contracts."""
+    rng = np.random.default_rng(100 + k)
+    scan = synth.kitti_like_scan(30000, seed=77)
+    db = np.ascontiguousarray(scan.T.astype(np.float64))
+    q = np.concatenate([db[rng.integers(0, 30000, 40)], db[rng.integers(0, 30000, 40)] + rng.normal(0, 0.3, (40, 3)).astype(np.float32),
+                        np.array([[500.0, -300.0, 40.0], [0.0, 0.0, 0.0], [np.nan, 1.0, 2.0], [1e6, 1e6, 1e6]])]).astype(np.float32).astype(np.float64)
+    ctx = pcr.Context(0)
+    try:
+        d = ctx.db64(db)
+        for squared in (False, True):
+            ctx.tune("knn_coop", 2)
+            bi, bd = d.knn(q, k, squared)                       # the one-lane-per-query kernel (what a batch takes)
+            ctx.tune("knn_coop", 0)
+            for a in range(0, q.shape[0], 7):                   # calls of 7 queries, then single queries
+                ci, cd = d.knn(q[a:a + 7], k, squared)
+                assert np.array_equal(ci, bi[a:a + 7]) and np.array_equal(cd.view(np.uint64), bd[a:a + 7].view(np.uint64)), (k, squared, a)
+            for a in (0, 41, 80, 81, 82, 83):
+                ci, cd = d.knn(q[a:a + 1], k, squared)
+                assert np.array_equal(ci, bi[a:a + 1]) and np.array_equal(cd.view(np.uint64), bd[a:a + 1].view(np.uint64)), (k, squared, a)
+        d.free()
+    finally:
+        ctx.close()

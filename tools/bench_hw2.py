@@ -25,6 +25,23 @@ for npts in (10000, 100000):
     for _ in range(3):
         t0 = time.perf_counter(); row, ri, rd = h.radius(db, 1.0); tr = min(tr, time.perf_counter() - t0)
     print(f"     radius r=1.0 of all points {tr*1e3:.2f} ms ({tr*1e3/db.shape[0]:.6f} ms/query), {row[-1]} neighbours ({row[-1]*12/1e6:.0f} MB of results over PCIe)")
+    # ONE arbitrary query per call (KDTreeKNNSearch / findNeighbors with a query that is not a database point): wall time per call
+    rng = np.random.default_rng(3)
+    qs = (db[rng.integers(0, db.shape[0], 400)] + rng.normal(0, 0.2, (400, 3))).astype(np.float32).astype(np.float64)
+    for coop in (1, 2):
+        ctx.tune("knn_coop", coop)
+        h.knn(qs[:1], 8)
+        t0 = time.perf_counter()
+        for i in range(400):
+            h.knn(qs[i:i + 1], 8)
+        t1 = (time.perf_counter() - t0) / 400
+        t0 = time.perf_counter()
+        for i in range(0, 400, 8):
+            h.knn(qs[i:i + 8], 8)
+        t8 = (time.perf_counter() - t0) / 50
+        print(f"     one 8-NN query per call: {t1*1e3:.4f} ms per call; eight per call: {t8*1e3:.4f} ms per call "
+              f"({'one wave per query, completion polled' if coop == 1 else 'one lane per query, stream synchronisation (round 2)'}; incl. the Python / ctypes call)")
+    ctx.tune("knn_coop", 0)
     try:
         import orc
         if orc.have_ref():
