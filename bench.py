@@ -631,45 +631,54 @@ def main():
 
 
 def grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha):
-    """steady state of the exact grid search: the source at the final pose, a few launches timed with HIP events, one more launch
-    with the diagnostics counters for the algorithmic bytes (SURVEY.md 8d "1-NN exact grid")"""
-    ca = cs.clone()
-    ctx.transform(ca, T)
-    # searches of a loop that has converged: each is seeded by the previous result (nn1_async_in_loop = what pcr_icp_p2p_f32 does)
-    ctx.tune("nn_method", 2); ctx.tune("prof", 1); ctx.tune("nn1_async_in_loop", 1)
-    ctx.nn1_async(ct, ca); ctx.nn1_async(ct, ca); ctx.sync(); ctx.prof_reset()
-    for _ in range(5):
-        ctx.nn1_async(ct, ca)
-    gl, gms = ctx.prof_get("nn1_grid")
-    ctx.tune("grid_stats", 1); ctx.nn1_async(ct, ca); ctx.sync(); gs = ctx.grid_stats(); ctx.tune("grid_stats", 0)
-    ctx.tune("nn1_async_in_loop", 0)
-    ca.free()
-    ctx.tune("prof", 0)
-    steady_s = gms / 1e3 / max(gl, 1)
+    """steady state of the exact grid search: the searches of an ICP loop that STARTS at the final pose (HIP-event duration of every
+    search of the loop: the cold first one and the first seeded one are skipped), and one more loop with the diagnostics counters for
+    the algorithmic bytes (SURVEY.md 8d "1-NN exact grid").  Large targets take the tile search (csrc/grid_tile.hpp), which needs the
+    loop's sorted working cloud — a bare sequence of pcr_nn1_f32_async calls would measure the cell walk alone."""
+    ctx.tune("nn_method", 2); ctx.tune("prof", 1); ctx.prof_reset()
+    ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=8, eps=0.0)
+    each = ctx.prof_get_each("nn1_grid")
+    family = ctx.mfma_check()["last_nn1_kernel"]
+    steady = each[2:] if each.size > 2 else each
+    gl, steady_s = int(steady.size), float(steady.mean()) / 1e3
+    ctx.tune("grid_stats", 1)
+    ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=3, eps=0.0)
+    w = ctx.nn1_stats()
+    ctx.tune("grid_stats", 0); ctx.tune("prof", 0)
+    tile = family == "grid-tile"
     gpmc = load_pmc("latest_pmc_grid.json", sha)
     if gpmc and (gpmc.get("n") != n_t or n_q != n_t):
         gpmc = None
-    alg_bytes = n_q * (12.0 + 4.0 + 8.0) + 8.0 * gs["fine_rows"] + 16.0 * gs["candidates"] + 16.0 * gs["coarse_rows"]
+    # bytes the search has to move through L2: per query its point, winner position and key; per opened x-row two bounds; per tested
+    # sphere 16 B; per record LOADED 16 B — the tile search loads a record once for the (up to 32) queries of its pass, the cell walk
+    # once per query that visits it
+    rec_loads = w[10] if tile else w[0]                  # (tile: the walk's loads for the few deferred queries are not in [10])
+    alg_bytes = n_q * (12.0 + 4.0 + 8.0) + 8.0 * w[1] + 16.0 * w[2] + 16.0 * rec_loads + (16.0 * 16.0 * n_q if tile else 0.0)
     L2_PEAK_GBS = 34500.0    # aggregate L2 bandwidth measured on MI355X (MI355X_MICROARCH.md, L2 section)
     return {
         "bound": "l2-gather", "achieved": alg_bytes / steady_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
         "frac": alg_bytes / steady_s / 1e9 / L2_PEAK_GBS,
         "traffic": (gpmc["fetch_bytes_per_launch_corrected_x2"] + gpmc["write_bytes_per_launch"]) if gpmc else None,
-        "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
-                         f"kernel at {gpmc['n']} x {gpmc['n']} with this very library (sha {sha}), {gpmc['source']}") if gpmc
-                        else "null: no PMC pass of this kernel at this size with the library loaded now (tools/gpu_pmc_grid.sh)",
+        "traffic_note": (f"HBM-side bytes per search (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, summed over the launches of a search) from separate "
+                         f"rocprofv3 --pmc passes at {gpmc['n']} x {gpmc['n']} with this very library (sha {sha}), {gpmc['source']}") if gpmc
+                        else "null: no PMC pass of this search at this size with the library loaded now (tools/gpu_pmc_grid.sh)",
         "compulsory_bytes": n_q * 24.0 + n_t * 16.0,
         "vs_hbm_stream_peak": alg_bytes / steady_s / 1e9 / HBM_PEAK_GBS,
-        "kernel": "pcr::nn1_grid_kernel (exact uniform-grid 1-NN) at the converged pose, seeded by the previous correspondences as inside the loop",
-        "launches": int(gl), "avg_launch_ms": steady_s * 1e3, "kernel_M_corr_per_s": n_q / steady_s / 1e6,
+        "compulsory_vs_hbm_peak": (n_q * 24.0 + n_t * 16.0) / steady_s / 1e9 / HBM_PEAK_GBS,
+        "kernel": ("pcr::nn1_tile_kernel (one wave per 32 consecutive queries of the sorted working cloud: shared rows, sphere tests and record loads; passes of "
+                   "more than four runs filtered on the f16 matrix pipe) + pcr::nn1_grid_kernel<16, false, 2, true> (the cell walk over the list of deferred "
+                   "queries), at the converged pose, seeded by the previous winners") if tile else
+                  "pcr::nn1_grid_kernel (exact uniform-grid 1-NN, cell walk) at the converged pose, seeded by the previous correspondences as inside the loop",
+        "kernel_family": family,
+        "launches": gl, "avg_launch_ms": steady_s * 1e3, "kernel_M_corr_per_s": n_q / steady_s / 1e6,
         "avg_launch_ms_over_the_timed_icp": kern_s * 1e3,
-        "candidates_per_query": gs["candidates"] / max(n_q, 1), "rows_per_query": gs["fine_rows"] / max(n_q, 1),
-        "sphere_tests_per_query": gs["coarse_rows"] / max(n_q, 1),
-        "algorithmic": f"per query 12 B point + 4 B order + 8 B key, 8 B per opened x-row ({gs['fine_rows'] / max(n_q, 1):.1f}/query), 16 B per "
-                       f"bounding sphere tested ({gs['coarse_rows'] / max(n_q, 1):.1f}/query) and "
-                       f"16 B per visited candidate ({gs['candidates'] / max(n_q, 1):.1f}/query), counted by the kernel's diagnostics "
-                       "build.  Neighbouring queries visit the same cells, so most candidate records are served by L2: the bound is the "
-                       "L2 gather rate"}
+        "pair_evaluations_per_query": w[0] / max(n_q, 1), "rows_per_query": w[1] / max(n_q, 1), "sphere_tests_per_query": w[2] / max(n_q, 1),
+        "records_loaded_per_query": rec_loads / max(n_q, 1), "deferred_to_the_walk_frac": w[6] / max(n_q, 1) if tile else None,
+        "algorithmic": f"per query 12 B point + 4 B winner position + 8 B key, 8 B per opened x-row ({w[1] / max(n_q, 1):.2f}/query), 16 B per bounding "
+                       f"sphere tested ({w[2] / max(n_q, 1):.1f}/query), 16 B per record loaded ({rec_loads / max(n_q, 1):.1f}/query; every loaded record is "
+                       f"evaluated against up to 32 queries: {w[0] / max(n_q, 1):.0f} lower-bound / exact pair evaluations per query) and 256 B for the exact "
+                       "evaluation of the winning run, counted by the kernels' diagnostics build.  Neighbouring groups need the same records: the bound is the "
+                       "L2 gather rate; the search is bound by dependent L2 round trips and vector issue, not by bandwidth (profiles/r03_grid_pmc.md)"}
 
 
 def bench_c4(ctx, pcr, synth, np, args):

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_TILE_WAVES) void nn1_tile
     const float lim = lim_k * mean;
     const bool member = near && rho <= lim;
     bool deferred = valid && !member;
-    unsigned long long st_cand = 0, st_rows = 0, st_sph = 0, st_ext = 0, st_rho = 0, st_filt = 0, st_fall = 0;  // diagnostics (STATS builds only; wave totals, lane 0)
+    unsigned long long st_cand = 0, st_rows = 0, st_sph = 0, st_ext = 0, st_rho = 0, st_filt = 0, st_fall = 0, st_load = 0;  // diagnostics (STATS builds only; wave totals, lane 0)
 
     // A pass serves the remaining members that lie within two ball limits (Chebyshev) of the first remaining member: where the sorted
     // order jumps — from one octant of a cell to the next, from a cell to its neighbour, across the cloud at the end of a row of cells —
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_TILE_WAVES) void nn1_tile
         if (!ok) { deferred = deferred || in; continue; }     // too many rows / runs for one wave: the walk takes these queries
         if (STATS) {
             st_cand += (uint64_t)nk * GRID_CHUNK * (uint64_t)__popc(inmask);
+            st_load += (uint64_t)nk * GRID_CHUNK;                     // records the pass loads ONCE for all its queries
             st_ext += (uint64_t)(fmaxf(fmaxf(bhi[0] - blo[0], bhi[1] - blo[1]), bhi[2] - blo[2]) * 1e6f);      // um
             st_rho += (uint64_t)(rho_max * 1e6f);
         }
@@ -346,5 +347,6 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_TILE_WAVES) void nn1_tile
         if (st_rho) atomicAdd(&stats[5], st_rho);
         if (st_filt) atomicAdd(&stats[8], st_filt);                                   // [8]: passes through the matrix-pipe filter, [9]: of those, not settled by it
         if (st_fall) atomicAdd(&stats[9], st_fall);
+        if (st_load) atomicAdd(&stats[10], st_load);                                  // [10]: records loaded by the passes (shared by their queries)
     }
 }

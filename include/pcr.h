@@ -302,7 +302,8 @@ int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4]);
 /* the sixteen diagnostics words of the last 1-NN launch made with tune "grid_stats" = 1.  Cell walk: [0..3] as pcr_grid_stats.
  * Tile search (csrc/grid_tile.hpp) + the walk of its deferred queries: [0] record evaluations summed over the queries, [1] rows
  * opened, [2] spheres tested, [3] far stages of the walk, [4] / [5] largest box edge / largest ball of the served passes (um, summed),
- * [6] queries deferred to the walk, [7] passes, [8] passes that took the matrix-pipe filter, [9] of those, passes it could not settle.
+ * [6] queries deferred to the walk, [7] passes, [8] passes that took the matrix-pipe filter, [9] of those, passes it could not settle, [10] records the passes loaded
+ * (each once for all queries of its pass).
  * Matrix-core exhaustive search (HTRACK / BTRACK): [2] = (wave, query group) pairs that were filtered a second time, [4] = shader
  * cycles (s_memtime) and [5] = 100 MHz real-time ticks (s_memrealtime) summed over the workgroups: [4] / [5] x 100 MHz is the shader
  * clock the chip held under that launch (bench.py: the clock-corrected roofline). */

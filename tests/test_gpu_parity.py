@@ -464,6 +464,20 @@ def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n):
                     assert st[k] == r[1][k], (k, bmax, pipe, gate, it)
                 assert np.float32(st["last_loss"]).view(np.uint32) == np.float32(r[1]["last_loss"]).view(np.uint32)
     assert used == {"grid-tile"}, used
+    # the exits of the state machine with the tile search's two launches in the enqueued tail: convergence at the 16th iteration
+    # (registration.cpp:948-958 with eps large), no pair at all (the loop stops at once), max_iter 0
+    ctx.tune("grid_tile_bmax_pct", 0)
+    for pipe in (0, -1):
+        ctx.tune("icp_pipeline", pipe)
+        for kw in (dict(max_corr=1.0, max_iter=40, eps=1e30), dict(max_corr=1e-12, max_iter=9, eps=0.0), dict(max_corr=1.0, max_iter=0, eps=0.0)):
+            ctx.tune("nn_method", 1)
+            Tb, sb = ctx.icp_point2point(cs, ct, **kw)
+            ctx.tune("nn_method", 2)
+            Tt, stt = ctx.icp_point2point(cs, cm, **kw)
+            assert np.array_equal(Tt.view(np.uint32), Tb.view(np.uint32)), (pipe, kw)
+            for k in ("iters_run", "converged", "empty_pairs", "last_pairs"):
+                assert stt[k] == sb[k], (k, pipe, kw)
+    assert sb["iters_run"] == 0
     # the diagnostics: a loop at the converged pose serves nearly every query from the tiles
     ctx.tune("grid_tile_bmax_pct", 0); ctx.tune("icp_pipeline", 0)
     T, _ = ctx.icp_point2point(cs, cm, max_corr=1.0, max_iter=25, eps=0.0)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off soak of the correspondence kernels on random inputs: the default path (FTRACK on a target's first search, the bf16
-matrix-core filters HTRACK / BTRACK from 8 192 target points on), the cold ETRACK, BTRACK and HTRACK searches and the exact grid search must give
-the bits of the exact-only brute-force kernel (nn1_variant = 2) on every input.
+matrix-core filters HTRACK / BTRACK from 8 192 target points on), the cold ETRACK, BTRACK and HTRACK searches, the exact grid search and the tile
+search of large-target loops (forced onto these pairs, with its default limits and with limits so tight that most passes overflow and are
+deferred) must give the bits of the exact-only brute-force kernel (nn1_variant = 2) on every input.
 usage: soak_nn1.py [cases=60] [seed0=1]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -50,7 +51,9 @@ for case in range(cases):
     rng = np.random.default_rng(seed0 + case)
     kind, t, s, scale = make(rng)
     res = {}
-    for name, tunes in (("exact", {"nn1_variant": 2}), ("default", {}), ("etrack_cold", {"nn1_variant": 4}), ("btrack_cold", {"nn1_variant": 6}), ("htrack_cold", {"nn1_variant": 7}), ("grid", {"nn_method": 2})):
+    for name, tunes in (("exact", {"nn1_variant": 2}), ("default", {}), ("etrack_cold", {"nn1_variant": 4}), ("btrack_cold", {"nn1_variant": 6}), ("htrack_cold", {"nn1_variant": 7}), ("grid", {"nn_method": 2}),
+                        ("grid_tile", {"nn_method": 2, "grid_order": 2, "grid_mode": 3, "grid_tile": 1}),
+                        ("grid_tile_tight", {"nn_method": 2, "grid_order": 2, "grid_mode": 3, "grid_tile": 1, "grid_tile_bmax_pct": 30, "grid_tile_keep": 6, "grid_tile_filter": 2})):
         ctx = pcr.Context(0)
         ctx.tune("nn_method", 1)
         for k, v in tunes.items():
@@ -63,7 +66,7 @@ for case in range(cases):
             out.append(T.view(np.uint32).copy()); out.append(np.array([st["iters_run"], st["last_pairs"]]))
         res[name] = out
         ctx.close()
-    for name in ("default", "etrack_cold", "btrack_cold", "htrack_cold", "grid"):
+    for name in ("default", "etrack_cold", "btrack_cold", "htrack_cold", "grid", "grid_tile", "grid_tile_tight"):
         ok = all(np.array_equal(a, b) for a, b in zip(res["exact"], res[name]))
         if not ok:
             bad += 1
