@@ -1208,6 +1208,17 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, i
     rc = exclusive_scan_u32(ctx, count, g->cell_start, ncell, totals, totals + nb);
     if (rc) { grid_free(g); return rc; }
     if (n) {
+        // occupied cells of the final grid (the tile search compares the working cloud's density with the target's: launch_nn1_grid).
+        // totals[nb + 1] is a free word of the scan's workspace; the value reaches the host with the next synchronisation.
+        uint32_t* nzf = totals + nb + 1;
+        e = hipMemsetAsync(nzf, 0, 4, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(count_nonzero_kernel, dim3(256), dim3(GR_BLOCK), 0, ctx->stream, count, (uint32_t)cells, nzf);
+            e = hipMemcpyAsync(&g->occupied, nzf, 4, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "grid occupancy", e); }
+    }
+    if (n) {
         g->x_sorted = order != GRID_ORDER_MORTON;
         if (g->x_sorted)
             hipLaunchKernelGGL(record_keys_kernel<false>, gridn, dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)n, g->p, cell_of, k_in, v_in);
@@ -1249,6 +1260,7 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, i
 // 30.6 -> 26.0 ms per search with 2^22 instead of 2^17 bins, profiles/r01_c5_10M_single_gpu.txt).  perm[] goes to ctx->qperm.
 static int sort_queries(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
 {
+    ctx->work_cells = 0;                  // (coarse bins: the density of the order is unknown)
     GridParams cp = g->p;
     int f = (int)tune_get(ctx, "grid_query_bin_min", 2);
     for (;;) {
@@ -1317,6 +1329,16 @@ __global__ __launch_bounds__(GR_BLOCK) void query_keys_kernel(const float* __res
     vals[i] = i;
 }
 
+// number of distinct values of key >> shift in a sorted key array
+__global__ __launch_bounds__(GR_BLOCK) void count_key_runs_kernel(const unsigned long long* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ out)
+{
+    uint32_t c = 0;
+    for (uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x; i < n; i += gridDim.x * GR_BLOCK) c += (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 // perm[] (-> ctx->qperm) = the queries in the order of the target's records: consecutive queries are neighbours in space at the
 // resolution of an eighth of a cell, so that the 16 queries of a workgroup open the same rows, test the same spheres and scan
 // the same runs (the coarse bins of sort_queries leave the order inside a bin to the atomics).  One radix sort of the whole
@@ -1343,9 +1365,16 @@ static int sort_queries_fine(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
     uint32_t* v_in = (uint32_t*)(sc + 2 * a8);
     hipLaunchKernelGGL(query_keys_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, src->x(), src->y(), src->z(), (uint32_t)n,
                        g->p, (uint32_t)g->n_cells, k_in, v_in);
-    const hipError_t e = sort_pairs_u64_u32(sc + 2 * a8 + a4, temp_bytes, k_in, k_out, v_in, ctx->qperm, n, 0, key_bits + QKEY_SUB_BITS, ctx->stream);
+    hipError_t e = sort_pairs_u64_u32(sc + 2 * a8 + a4, temp_bytes, k_in, k_out, v_in, ctx->qperm, n, 0, key_bits + QKEY_SUB_BITS, ctx->stream);
     if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "radix sort(queries)", e);
     PCR_HIP(ctx, hipGetLastError());
+    // how many cells of the target's grid the queries occupy (-> ctx->work_cells with the caller's next synchronisation; the sort's
+    // input keys are dead by now: their first word is the counter)
+    uint32_t* runs = (uint32_t*)k_in;
+    ctx->work_cells = 0;
+    PCR_HIP(ctx, hipMemsetAsync(runs, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(count_key_runs_kernel, dim3(256), dim3(GR_BLOCK), 0, ctx->stream, k_out, (uint32_t)n, QKEY_SUB_BITS, runs);
+    PCR_HIP(ctx, hipMemcpyAsync(&ctx->work_cells, runs, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->qperm_n = n;
     ctx->qperm_src = src;
     return PCR_OK;
@@ -1777,7 +1806,14 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     // grid_tile_min_members (8), grid_tile_list_segs (groups per wave of the list walk, 1), grid_tile_filter (2 = exact loop only).
     // Same results as the walk alone, bit for bit (tests: test_config5.py, test_gpu_parity.py::test_icp_tile_search_...).
     const int64_t tile_tune = tune_get(ctx, "grid_tile", 0);
-    if (mode == 2 && warm == 3 && sorted && !perm && wpos && cap2 < __builtin_inff() && tile_tune != 2 && (tile_tune == 1 || tgt->n >= 500000)) {
+    // auto: large targets, and a working cloud about as dense as the target where it lies — 32 consecutive queries of a SPARSE subset (a
+    // uniformly drawn 1 / 8 shard of a multi-GPU run) span eight times the region, their pass needs eight times the records per query, and the
+    // cell walk (whose cost per query does not depend on the other queries) wins: 0.40 against 0.61 ms per converged search of a 1 / 8 shard of
+    // the 10 M pair, 1.44 against 1.04 ms (tile ahead) at 1 / 2 — profiles/r03_c5_tile_search.txt.  Density = queries per occupied cell of
+    // the target's grid against targets per occupied cell; a spatially compact shard keeps its local density and the tile search.
+    const bool dense = ctx->work_cells > 0 && g->occupied > 0 &&
+                       (double)ns / (double)ctx->work_cells >= 0.4 * (double)tgt->n / (double)g->occupied;
+    if (mode == 2 && warm == 3 && sorted && !perm && wpos && cap2 < __builtin_inff() && tile_tune != 2 && (tile_tune == 1 || (tgt->n >= 500000 && dense))) {
         // the segmented list of deferred queries: 32 slots per group of 32 queries + one count per group (far_list is free here: the
         // hand-off of far queries to the exhaustive kernel only exists for unbounded searches)
         const size_t n_groups_sz = (ns + 31) / 32, need = n_groups_sz * 32 + n_groups_sz;

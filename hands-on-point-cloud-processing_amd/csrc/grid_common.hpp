@@ -19,6 +19,7 @@ struct Grid {
     GridParams p;
     size_t n_points = 0;
     size_t n_cells = 0;
+    uint32_t occupied = 0;            // non-empty cells (copied back asynchronously at build time: valid after the next stream synchronisation)
     float4* records = nullptr;        // n_points, sorted by (cell, x): every x-row of cells is one x-sorted range
     uint32_t* cell_start = nullptr;   // n_cells + 2 (cell n_cells holds the non-finite points, never visited)
     // chunked, centred copy of the records for the expanded-form brute-force filter (nn1_brute.hip, ETRACK): per chunk of

@@ -121,6 +121,7 @@ struct pcr_ctx {
     size_t work_orig_cap = 0;
     size_t work_orig_n = 0;
     const pcr_cloud* work_orig_src = nullptr;
+    uint32_t work_cells = 0;              // distinct target-grid cells the sorted working cloud occupies (0: unknown); valid after the sort's synchronisation
     double* partials = nullptr;           // block rows of the Kabsch pass (8192 x 58 doubles)
     size_t partials_cap = 0;
     double* dev_out = nullptr;            // 128 doubles: reduced sums / limbs + bookkeeping

@@ -343,7 +343,7 @@ int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
  *              grid_lanes [16] · grid_cell_um, grid_cell_scale_x100 [150 for Morton], grid_occupancy_x10 [20], grid_max_cells ·
  *              grid_sort_queries, grid_sort_work, grid_warm_start, grid_wpos, grid_seed_run, grid_far_brute [on] 2 = off ·
  *              grid_sort_fine [auto] 1 / 2 · grid_query_bins_log2 [22], grid_query_bin_min [2] · grid_xcd_run [32 from 4 096 blocks]
- *              -1 = identity · grid_tile [0: from 500 000 points] 1 on / 2 off, grid_tile_bmax_pct [400], grid_tile_keep [512],
+ *              -1 = identity · grid_tile [0: targets from 500 000 points, working cloud about as dense as the target] 1 on / 2 off, grid_tile_bmax_pct [400], grid_tile_keep [512],
  *              grid_tile_lim_pct [1000], grid_tile_reach_pct [200], grid_tile_total_mult [16], grid_tile_min_members [8],
  *              grid_tile_list_segs [1], grid_tile_filter [on] 2 = off (csrc/grid.hip launch_nn1_grid) · knn_cell_scale_x100, knn_slices
  *  ICP loop    icp_pipeline [0 = 1 device-resident] -1 synchronous · icp_chunk [4] · icp_bounded_search [on] 2 = off ·
