@@ -47,6 +47,7 @@ VALU_PEAK_TOPS_NOFMA = 78.6     # the same issue rate counted one op per lane-sl
 HBM_PEAK_GBS = 8000.0
 OPS_PER_PAIR = 9                # 3 sub + 3 mul + 2 add + 1 compare per (query, target) pair — the exact kernel's work
 ETRACK_FLOPS_PER_PAIR = 6       # the f32 filter's algorithm: 3 FMAs per (query, target) pair (csrc/nn1_brute.hip, ETRACK)
+STRACK_FLOPS_PER_PAIR = 32      # the sign form of the f16 filter: all 16 K-slots carry data (HTRACK's 14 + the two pieces of the query's threshold)
 HTRACK_FLOPS_PER_PAIR = 28      # the f16 filter's algorithm: 14 f16 multiply-adds per pair that carry data (3 coordinates x 4 piece products + 2 pieces of
                                 # |t''|^2) of the 16 K-slots ONE v_mfma_f32_32x32x16_f16 provides (csrc/nn1_brute.hip, HTRACK)
 BTRACK_FLOPS_PER_PAIR = 54      # the bf16 filter's algorithm: 27 bf16 multiply-adds per pair that carry data (3 coordinates x 8 piece products + 3 pieces
@@ -362,7 +363,7 @@ def main():
         # ---- the shader clock the chip holds under the headline kernel's own load: s_memtime / s_memrealtime stamps of a diagnostics
         # launch (tune grid_stats) that follows 40 back-to-back launches of the same seeded search; median of 3
         clock_mhz = None
-        if extras and args.nn == "brute" and family in ("htrack", "btrack"):
+        if extras and args.nn == "brute" and family in ("strack", "htrack", "btrack"):
             ca = cs.clone(); ctx.transform(ca, T)
             ctx.tune("nn_method", 1); ctx.tune("prof", 0); ctx.tune("nn1_async_in_loop", 1)
             clocks = []
@@ -472,10 +473,11 @@ def main():
         if rank == 0:
             gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
             if args.nn == "brute":
-                f16 = family == "htrack"
-                bf16 = family in ("htrack", "btrack")
+                sign = family == "strack"
+                f16 = family in ("strack", "htrack")
+                bf16 = family in ("strack", "htrack", "btrack")
                 slots_pp = 32 if f16 else 64                 # flop per pair of ALL K-slots the matrix instruction(s) execute (16 / 2 x 16 multiply-adds)
-                flops_pp = HTRACK_FLOPS_PER_PAIR if f16 else BTRACK_FLOPS_PER_PAIR if bf16 else ETRACK_FLOPS_PER_PAIR
+                flops_pp = STRACK_FLOPS_PER_PAIR if sign else HTRACK_FLOPS_PER_PAIR if f16 else BTRACK_FLOPS_PER_PAIR if bf16 else ETRACK_FLOPS_PER_PAIR
                 peak_tf = MFMA_BF16_PEAK_TFLOPS if bf16 else VALU_PEAK_TFLOPS
                 achieved_tflops = flops_pp * pairs / kern_s / 1e12
                 compulsory_bytes = 12.0 * n_t + 12.0 * n_q + 8.0 * n_q        # targets + sources + (idx, d2) key
@@ -487,7 +489,15 @@ def main():
                     "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
                                      f"kernel with this very libpcr_hip.so (sha {sha}), {pmc['source']}") if pmc else
                                     "null: PMC counters need a rocprofv3 wrapper (tools/gpu_check.sh); none was collected with the library loaded now",
-                    "kernel": (("pcr::nn1_btrack_kernel<4, true> = HTRACK, operands staged through LDS per workgroup (exhaustive scan of every (query, 16-target chunk): the expanded-form lower "
+                    "kernel": (("pcr::nn1_strack_kernel<4> = STRACK, the SIGN form of the f16 matrix-core filter, operands staged through LDS per workgroup "
+                                "(exhaustive: the expanded-form lower bound of ALL (query, target) pairs from ONE v_mfma_f32_32x32x16_f16 per 32 queries "
+                                "x 32 targets — operands scaled per 256-target super-tile and cut into two f16 pieces, every piece product exact in f32 — "
+                                "with the query's threshold (the exact distance of its best candidate so far: the previous correspondence re-evaluated, "
+                                "then whatever the scan finds) folded into the two remaining K-slots, so that an accumulator is bound - threshold and "
+                                "its SIGN says whether the record can matter; the vector ALU ORs the 16 accumulators of a lane (8 full-rate v_or3_b32) "
+                                "and the wave tests one word per tile; a lane whose sign is set evaluates its chunk of 16 records with the exact unfused "
+                                "arithmetic and lowers the threshold in its operand at once)") if sign else
+                               ("pcr::nn1_btrack_kernel<4, true> = HTRACK, operands staged through LDS per workgroup (exhaustive scan of every (query, 16-target chunk): the expanded-form lower "
                                 "bound of ALL pairs on the f16 matrix pipe — operands scaled per 256-target super-tile and cut into two f16 pieces each, "
                                 "every piece product exact in f32, ONE v_mfma_f32_32x32x16_f16 per 32 queries x 32 targets; the vector ALU takes the "
                                 "minimum of the 16 accumulators per lane (8 v_min3) and tracks first / second minimum branch-free; only the winning "
@@ -504,7 +514,11 @@ def main():
                                 "branch-free; only the winning chunk is evaluated with the exact unfused arithmetic; the previous correspondence of "
                                 "each query, re-evaluated exactly, seeds the bound)")) if default_kernels else f"nn1 variant={args.variant}",
                     "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
-                    "algorithmic": (f"{flops_pp} {'f16' if f16 else 'bf16'} flop per (query, target) pair ({flops_pp // 2} piece products that carry data, of "
+                    "algorithmic": ((f"{flops_pp} f16 flop per (query, target) pair (all 16 K-slots of the one MFMA carry data: 14 piece products + the two "
+                                     f"pieces of the threshold) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16.  Per 1024 pairs: one MFMA "
+                                     "(32 cycles of the SIMD's matrix pipe) and 9 vector instructions (8 v_or3_b32 + the share of one compare per tile)")
+                                    if sign else
+                                    f"{flops_pp} {'f16' if f16 else 'bf16'} flop per (query, target) pair ({flops_pp // 2} piece products that carry data, of "
                                     f"the {16 if f16 else 32} K-slots executed) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16 / bf16.  On this chip "
                                     "the matrix instructions and the vector instructions of one SIMD's waves take turns in this loop (measured: "
                                     "tools/ubench/mfma_filter.hip, profiles/r02_mfma_filter_experiments.txt), so the launch time is MFMA time "

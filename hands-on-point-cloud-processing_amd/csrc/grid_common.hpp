@@ -107,6 +107,7 @@ __device__ __forceinline__ void ht_split(float v, uint32_t& p1, uint32_t& p2)
     p1 = __builtin_bit_cast(uint32_t, a) & 0xFFFFu; p2 = __builtin_bit_cast(uint32_t, b) & 0xFFFFu;
 }
 
+constexpr uint32_t HT_THETA_CONSTS = 0x54007800u;      // f16 (2^15, 2^6) in K-slots (14, 15) of every target row
 __device__ __forceinline__ uint4 ht_target_operand(float tx, float ty, float tz, bool finite, bool upper_half)
 {
     uint32_t t[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } }, w[2] = { 0x7C00u, 0 };                  // padding / non-finite: w = +inf
@@ -116,7 +117,9 @@ __device__ __forceinline__ uint4 ht_target_operand(float tx, float ty, float tz,
         ht_split(fminf(ww, 65000.0f), w[0], w[1]);
     }
     const uint32_t qx = t[0][0] | (t[0][1] << 16), qy = t[1][0] | (t[1][1] << 16), qz = t[2][0] | (t[2][1] << 16);
-    return upper_half ? make_uint4(qz, qz, w[0] | (w[1] << 16), 0u) : make_uint4(qx, qx, qy, qy);
+    // K-slots 14 / 15 of the upper half: the constants 2^15 and 2^6 (f16 0x7800, 0x5400).  The minimum-tracking kernels keep zeros on the
+    // query side there (products 0); the sign filter (st_theta below) puts the two pieces of its threshold against them.
+    return upper_half ? make_uint4(qz, qz, w[0] | (w[1] << 16), HT_THETA_CONSTS) : make_uint4(qx, qx, qy, qy);
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -151,6 +154,58 @@ __device__ __forceinline__ void ht_setup(float qx, float qy, float qz, const flo
     ht_pair(h ? rz : rx, f1, f2);
     ht_pair(ry, s1, s2);
     bq = make_uint4(f1, f2, h ? 0x3C003C00u : s1, h ? 0u : s2);
+}
+
+// ---- query side of the SIGN filter (STRACK, nn1_brute.hip).  The filter value of a (query, record) pair, G = w - 2 r.t'' (scaled units),
+// bounds the exact distance from below: d2 scale^2 >= Rs + G with Rs = KAPPA |r|^2 - 2^-22 (header of nn1_btrack_kernel).  A record can
+// only matter to a query whose best candidate so far lies at thr if d2 <= thr, i.e. if G <= theta := thr scale^2 - Rs.  The two K-slots
+// the f16 form leaves free carry -theta (two f16 pieces against the constants 2^15 and 2^6 of the target rows, HT_THETA_CONSTS), so the
+// accumulator of the pair is  E = G - theta_hat  and its SIGN BIT is the answer: the vector ALU ORs the sixteen sign bits of a lane
+// (v_or3_b32, full rate) instead of taking minima (v_min3_f32, half rate) and tracking first / second minimum and their chunk.
+// Exactness.  Let S be the exact sum of the 14 data products and theta_hat = hi 2^15 + lo 2^6 the value the pieces represent.  The one
+// assumption of the f16 form — the matrix pipe accumulates with an error <= 16 u sum |a b| (u = 2^-24; measured on the device by
+// mfma_verdict: <= 8 u or the form is not used) — gives  E <= S - theta_hat + 16 u (sum_data |a b| + 1.01 |theta_hat|),  and the existing
+// bound says  d2 scale^2 >= Rs + S + 16 u sum_data |a b|.  Hence  d2 <= thr  =>  E <= theta - theta_hat + 16.2 u |theta_hat|,  which is
+// negative as soon as  theta_hat >= theta (1 + 17 u) + eps:  st_theta rounds the f32 value of theta (one fma: within u |theta|) up by
+// 2^-19 |theta| = 32 u |theta|, cuts it with the first piece rounded toward zero and the second rounded UP (by 2^-9 of itself + 2^-23:
+// an f16 conversion toward zero loses < 2^-10 of a normal value, < 2^-24 of a subnormal one), and clamps it to +-65 000 x 2^15: beyond
+// that every |S| <= 2.5e7 is decided by the clamped value's sign alone (a huge threshold flags everything, a hugely negative one
+// nothing).  A flag that is raised needlessly costs one exact evaluation of 16 records; a flag that is missed cannot happen.
+// A query without finite coordinates or without a candidate gets thr = -inf (theta at its lower limit: no flag, ever); the caller scans
+// such a query's slice exactly.
+// the two threshold slots of the upper half-lane: f16 (-hi, -lo) with hi 2^15 + lo 2^6 >= theta (1 + 2^-19) (see above); thr in the
+// cloud's units (a finite d2, or -inf for "never"), sc2 = scale^2
+__device__ __forceinline__ uint32_t st_theta(float thr, float sc2, float Rs)
+{
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    constexpr float LIM = 2129920000.0f;                      // 65 000 x 2^15
+    float th = __builtin_amdgcn_fmed3f(__builtin_fmaf(thr, sc2, -Rs), -LIM, LIM);            // (+-inf products land on the limits)
+    th = __builtin_fmaf(fabsf(th), 1.9073486328125e-06f, th);                                // + 2^-19 |theta|
+    const h2 a = __builtin_amdgcn_cvt_pkrtz(th * 3.0517578125e-05f, 0.0f);                    // hi = rtz(theta / 2^15)
+    const float rem = __builtin_fmaf(-(float)a.x, 32768.0f, th);                              // exact
+    float lo = rem * 0.015625f;
+    lo = __builtin_fmaf(fabsf(lo), 0.001953125f, lo) + 1.1920928955078125e-07f;              // up: 2^-9 of itself + 2^-23
+    const h2 b = __builtin_amdgcn_cvt_pkrtz(lo, 0.0f);
+    return ((__builtin_bit_cast(uint32_t, a) ^ 0x8000u) & 0xFFFFu) | ((__builtin_bit_cast(uint32_t, b) ^ 0x8000u) << 16);
+}
+
+// One lane builds the WHOLE operand of one (query, super-tile): the words the lower half-lane of the query's column feeds the MFMA
+// (P: x pieces, y pieces) and the upper half-lane's (Q: z pieces, the ones against w's pieces, the threshold slots).  The kernel lets
+// lane (n, h) do this for query n of group 2 p + h and exchanges the halves with four v_permlane32_swap_b32 — one setup per query and
+// super-tile instead of two that each computed everything and kept half.  The query must be finite (the kernel replaces others by 0
+// and gives them thr = -inf).
+__device__ __forceinline__ void st_setup(float qx, float qy, float qz, const float4 C, float thr, float sc2, uint32_t P[4], uint32_t Q[4])
+{
+    constexpr float KAPPA = 0.99999237060546875f;             // 1 - 2^-17
+    const float sc = C.w;
+    const float rx = __builtin_amdgcn_fmed3f((qx - C.x) * sc, -32000.0f, 32000.0f), ry = __builtin_amdgcn_fmed3f((qy - C.y) * sc, -32000.0f, 32000.0f),
+                rz = __builtin_amdgcn_fmed3f((qz - C.z) * sc, -32000.0f, 32000.0f);
+    const float Rs = __builtin_fmaf(__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)), KAPPA, -PCR_HT_ABS_SLACK);
+    ht_pair(rx, P[0], P[1]);
+    ht_pair(ry, P[2], P[3]);
+    ht_pair(rz, Q[0], Q[1]);
+    Q[2] = 0x3C003C00u;
+    Q[3] = st_theta(thr, sc2, Rs);
 }
 
 void bt_free(BtIndex* b);

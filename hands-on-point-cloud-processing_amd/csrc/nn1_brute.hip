@@ -758,6 +758,216 @@ __global__ __launch_bounds__(NN_BLOCK, (F16 && QG == 4) ? PCR_BT_WAVES : 1) void
     }
 }
 
+// ---- STRACK: the SIGN form of the f16 filter (round 3, second session).  HTRACK's launch is vector time plus matrix time: per 32 x 32
+// pairs one MFMA (32 cycles) and ~22 vector instructions, eight of them half-rate v_min3 — the vector side is the larger share and the
+// two pipes take turns.  Every search this kernel serves starts from a genuine candidate per query (keys[]: the previous correspondence
+// re-evaluated by the move / nn1_seed_kernel, or bt_seed_kernel's for a cold search), so the question per pair is not "what is the
+// minimum" but "can this record matter": with the query's threshold folded into the two free K-slots the accumulator is
+// bound - threshold and its sign bit answers (st_setup / st_theta, grid_common.hpp: error analysis there).  Per (query group, tile)
+// the vector ALU ORs 16 accumulators (8 full-rate v_or3_b32) and the wave tests ONE word per tile; no minimum, no chunk tracking, no
+// second pass.  A set sign = "the 16 records of this half-lane's chunk may hold one at or below the query's threshold": the lane notes
+// (chunk, query) in a wave-private LDS list and the scan goes on; at the end of a super-tile (and when the list is full) the wave
+// evaluates the listed chunks TOGETHER — 16 lanes per chunk, one record each, one coalesced 256-byte load, A1 arithmetic, canonical
+// (d2, index) minimum by DPP and a 64-bit LDS minimum per query — and the queries' thresholds fall to what was found before the next
+// super-tile's operands are built.  (First form: the flagged lane evaluated its 16 records itself, one dependent load after the
+// other, the other 63 lanes waiting — one such visit per query and slice-with-a-candidate: 0.59 ms against HTRACK's 0.50.)
+// Same keys bit for bit: a record at or below a query's final answer always raises its flag, the exact evaluation decides.
+#ifndef PCR_ST_WAVES
+#define PCR_ST_WAVES 4
+#endif
+#ifndef PCR_ST_UNROLL
+#define PCR_ST_UNROLL 2
+#endif
+constexpr int ST_CAP = 128;                                   // entries of a wave's list
+template <int QG>
+struct StWaveLds {
+    float4 q[QG * 32];                                        // the wave's queries (the evaluating lanes are not the owning ones)
+    unsigned long long best[QG * 32];                         // (d2 bits << 32 | index) found so far, ~0 = nothing
+    uint32_t list[ST_CAP];                                    // (chunk relative to the slice << 7) | query slot
+};
+
+// the listed chunks against their queries: four per step, 16 lanes each
+template <int QG>
+__device__ __forceinline__ void st_flush(StWaveLds<QG>& L, uint32_t cnt, uint32_t chunk0, const float4* __restrict__ records, uint32_t lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (uint32_t e0 = 0; e0 < cnt; e0 += 4) {
+        const uint32_t e = e0 + (lane >> 4);
+        const bool valid = e < cnt;
+        const uint32_t ent = L.list[valid ? e : 0], slot = ent & 127u;
+        const float4 q = L.q[slot];
+        const float4 rec = records[(size_t)(chunk0 + (ent >> 7)) * 16 + (lane & 15)];          // (padding records: x = +inf, never accepted)
+        const uint32_t d = d2_exact_bits(q.x, q.y, q.z, rec.x, rec.y, rec.z);
+        unsigned long long key = (valid && d < 0x7F7FFFFFu) ? (((unsigned long long)d << 32) | __float_as_uint(rec.w)) : ~0ull;   // FLT_MAX gate
+#define PCR_ST_MIN(CTRL) { const unsigned long long w = ((unsigned long long)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(key >> 32), CTRL, 0xF, 0xF, false) << 32) | \
+                                                      (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)key, CTRL, 0xF, 0xF, false);                              \
+                           key = w < key ? w : key; }
+        PCR_ST_MIN(0xB1) PCR_ST_MIN(0x4E) PCR_ST_MIN(0x141) PCR_ST_MIN(0x140)                 // quad xor 1, xor 2, half-row mirror, row mirror
+#undef PCR_ST_MIN
+        if ((lane & 15) == 0 && key != ~0ull) atomicMin(&L.best[slot], key);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+template <int QG>
+__global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
+    const float4* __restrict__ centres, const uint4* __restrict__ ops, const float4* __restrict__ records, uint32_t n_rec, uint32_t n_super,
+    uint32_t supers_per_slice, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
+    unsigned long long* __restrict__ keys, const int* __restrict__ stop, unsigned long long* __restrict__ stats,
+    uint32_t xq, uint32_t qblocks, uint32_t slices, uint32_t flush_at)
+{
+    const int stopv = stop ? (stop[0] | stop[1]) : 0;
+    constexpr int TPS = BT_SUPER / 32;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = lane & 31;
+    const bool h = lane >= 32;
+    uint32_t qb = blockIdx.x, sl = blockIdx.y;                // (query block, slice): as nn1_btrack_kernel
+    if (xq) {
+        const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, xs = 8u / xq, qb_per = (qblocks + xq - 1) / xq;
+        qb = (j % qb_per) * xq + k % xq;
+        sl = (j / qb_per) * xs + k / xq;
+        if (qb >= qblocks || sl >= slices) return;
+    }
+    __shared__ uint4 sA[2][TPS * 64];                         // the operands of two super-tiles: 16 KB
+    __shared__ StWaveLds<QG> lds_all[NN_BLOCK / 64];
+    StWaveLds<QG>& L = lds_all[wave];
+    const uint32_t qbase = (qb * (NN_BLOCK / 64) + wave) * (32 * QG);
+    // lane (n, h) owns query n of the groups 2 p + h: it builds their operands (st_setup) and carries their thresholds; the other
+    // half-lane of the column gets its half of the operand by v_permlane32_swap.  The flush reads the queries from LDS.
+    static_assert(QG % 2 == 0, "groups come in pairs");
+    float qx[QG / 2], qy[QG / 2], qz[QG / 2], thr[QG / 2];
+    bool ok[QG / 2];
+    bool okg[QG];                                             // per group: every query of it served by the filter (wave-uniform)
+#pragma unroll
+    for (int p = 0; p < QG / 2; p++) {
+        const uint32_t slot = (2 * p + (h ? 1 : 0)) * 32 + n, i = min(qbase + slot, ns - 1);
+        qx[p] = sx[i]; qy[p] = sy[i]; qz[p] = sz[i];
+        const uint32_t cb = (uint32_t)(__atomic_load_n(&keys[i], __ATOMIC_RELAXED) >> 32);      // the candidate's d2 (or what other slices published)
+        // a query the filter can serve: finite coordinates and a finite candidate (else: exact scan of the slice below)
+        ok[p] = fabsf(qx[p]) < 1e18f && fabsf(qy[p]) < 1e18f && fabsf(qz[p]) < 1e18f && cb < 0x7F7FFFFFu;
+        thr[p] = ok[p] ? __uint_as_float(cb) : -INFINITY;
+        L.q[slot] = make_float4(qx[p], qy[p], qz[p], 0.0f);
+        L.best[slot] = ~0ull;
+        if (!ok[p]) { qx[p] = 0.0f; qy[p] = 0.0f; qz[p] = 0.0f; }                                // (finite operands; thr = -inf: no flag, ever)
+        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok[p]);
+        okg[2 * p] = (uint32_t)okm == 0xFFFFFFFFu; okg[2 * p + 1] = (uint32_t)(okm >> 32) == 0xFFFFFFFFu;
+    }
+    if (stopv) return;
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (stats) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    uint32_t st_flushes = 0, st_eval = 0;
+    const uint32_t sb = sl * supers_per_slice, se = min(sb + supers_per_slice, n_super);
+    f32x16 zero;
+#pragma unroll
+    for (int j = 0; j < 16; j++) zero[j] = 0.0f;
+    uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0;
+    if (sb < se) {
+        sA[0][threadIdx.x] = ops[(size_t)sb * TPS * 64 + threadIdx.x];
+        sA[0][NN_BLOCK + threadIdx.x] = ops[(size_t)sb * TPS * 64 + NN_BLOCK + threadIdx.x];
+    }
+    __syncthreads();
+    uint32_t cnt = 0;                                         // entries in the wave's list (wave-uniform)
+    for (uint32_t S = sb; S < se; S++) {
+        const uint32_t buf = (S - sb) & 1u;
+        if (S + 1 < se) {                                     // the next super-tile: in flight during this one's eight tiles
+            pre0 = ops[(size_t)(S + 1) * TPS * 64 + threadIdx.x];
+            pre1 = ops[(size_t)(S + 1) * TPS * 64 + NN_BLOCK + threadIdx.x];
+        }
+        const float4 C = centres[S];                          // wave-uniform: scalar load; .w = the super-tile's scale (a power of two)
+        const float sc2 = C.w * C.w;                          // exact: |exponent| <= 120
+        uint4 A = sA[buf][lane];                              // the first tile's operand: on its way while the query side is built
+        uint4 bq[QG];
+#pragma unroll
+        for (int p = 0; p < QG / 2; p++) {
+            uint32_t P[4], Q[4];
+            st_setup(qx[p], qy[p], qz[p], C, thr[p], sc2, P, Q);
+            // P: what the lower half-lane of my column feeds the MFMA, Q: the upper half-lane's.  Swapping P's upper 32 lanes with Q's
+            // lower 32 leaves group 2 p complete in P and group 2 p + 1 complete in Q.
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const auto r = __builtin_amdgcn_permlane32_swap(P[j], Q[j], false, false);
+                P[j] = r[0]; Q[j] = r[1];
+            }
+            bq[2 * p] = make_uint4(P[0], P[1], P[2], P[3]);
+            bq[2 * p + 1] = make_uint4(Q[0], Q[1], Q[2], Q[3]);
+        }
+#pragma unroll PCR_ST_UNROLL
+        for (int tt = 0; tt < TPS; tt++) {
+            const uint4 An = sA[buf][min(tt + 1, TPS - 1) * 64 + lane];       // the next tile's operand, one tile ahead
+            uint32_t o[QG], any = 0;
+#pragma unroll
+            for (int g = 0; g < QG; g++) {
+                const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
+                uint32_t v = __float_as_uint(acc[0]) | __float_as_uint(acc[1]) | __float_as_uint(acc[2]);
+#pragma unroll
+                for (int j = 3; j + 1 < 16; j += 2) v = v | __float_as_uint(acc[j]) | __float_as_uint(acc[j + 1]);
+                o[g] = v | __float_as_uint(acc[15]);
+                any |= o[g];
+            }
+            if (__builtin_amdgcn_ballot_w64((int)any < 0)) {
+                // rare: some half-lane's chunk (records 32 T + 16 h ...) may hold a record at or below its query's threshold
+                const uint32_t crel = (((S - sb) * TPS + (uint32_t)tt) * 2 + (h ? 1u : 0u)) << 7;
+#pragma unroll
+                for (int g = 0; g < QG; g++) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64((int)o[g] < 0);
+                    if (!m) continue;
+                    const uint32_t k = (uint32_t)__popcll(m);
+                    if (cnt + k > (uint32_t)ST_CAP) { st_flush<QG>(L, cnt, sb * TPS * 2, records, lane); st_flushes++; st_eval += cnt; cnt = 0; }
+                    if ((int)o[g] < 0) L.list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = crel | (uint32_t)(g * 32) | n;
+                    cnt += k;
+                }
+            }
+            A = An;
+        }
+        if (cnt >= flush_at || (cnt && S + 1 == se)) {
+            // the chunks flagged so far, evaluated together; the thresholds of their queries fall before the next operands are built.
+            // (Not after every super-tile: a flush is a dependent global round trip, longer than a super-tile's 32 MFMAs, and the other
+            // three waves of the workgroup wait for it at the barrier below — 0.54 against 0.50 ms per search.)
+            st_flush<QG>(L, cnt, sb * TPS * 2, records, lane); st_flushes++; st_eval += cnt; cnt = 0;
+#pragma unroll
+            for (int p = 0; p < QG / 2; p++) {
+                const uint32_t fb = (uint32_t)(L.best[(2 * p + (h ? 1 : 0)) * 32 + n] >> 32);   // (~0 >> 32 is a NaN pattern: fminf keeps thr)
+                thr[p] = ok[p] ? fminf(thr[p], __uint_as_float(fb)) : thr[p];
+            }
+        }
+        if (S + 1 < se) { sA[buf ^ 1u][threadIdx.x] = pre0; sA[buf ^ 1u][NN_BLOCK + threadIdx.x] = pre1; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < QG; g++) {
+        unsigned long long kbest = L.best[g * 32 + n];
+        if (!okg[g] && sb < se) {
+            // a query without finite coordinates or without a candidate: the wave scans the slice exactly for this group, each half-lane
+            // one half of it (rare: NaN / inf queries, a seed kernel that found nothing acceptable)
+            const float4 q = L.q[g * 32 + n];
+            const uint32_t r0 = sb * BT_SUPER, r1 = min(se * BT_SUPER, n_rec), mid = r0 + (r1 - r0) / 2;
+            for (uint32_t j = h ? mid : r0; j < (h ? r1 : mid); j++) {
+                const float4 rec = records[j];
+                const uint32_t e = d2_exact_bits(q.x, q.y, q.z, rec.x, rec.y, rec.z);
+                const unsigned long long key = ((unsigned long long)e << 32) | __float_as_uint(rec.w);
+                if (e < 0x7F7FFFFFu && key < kbest) kbest = key;
+            }
+            const unsigned long long ko = ((unsigned long long)(uint32_t)__shfl_xor((int)(kbest >> 32), 32, 64) << 32) |
+                                          (uint32_t)__shfl_xor((int)(uint32_t)kbest, 32, 64);
+            kbest = ko < kbest ? ko : kbest;
+            // "no neighbour" is the key (+inf, no index), as every other kernel writes it (a seed kernel that found nothing left ~0 behind)
+            if (kbest == ~0ull) kbest = 0x7F800000FFFFFFFFull;
+        }
+        const uint32_t i = qbase + g * 32 + n;
+        if (!h && i < ns && kbest != ~0ull) merge_key(&keys[i], kbest);
+    }
+    if (stats) {
+        if (lane == 0) {
+            if (st_flushes) atomicAdd(&stats[2], (unsigned long long)st_flushes);                 // joint evaluations (wave level)
+            if (st_eval) atomicAdd(&stats[6], (unsigned long long)st_eval);                       // (query, chunk) pairs evaluated exactly
+        }
+        if (threadIdx.x == 0) {
+            atomicAdd(&stats[4], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0);
+            atomicAdd(&stats[5], (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt0);
+        }
+    }
+}
+
 // ICP iterations after the first: the previous correspondence, re-evaluated exactly against the moved query, is a genuine
 // candidate and therefore an upper bound of the new answer from the first instruction on (ETRACK settles every far slice with it).
 __global__ __launch_bounds__(NN_BLOCK) void nn1_seed_kernel(const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, uint32_t nt,
@@ -821,7 +1031,8 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
 //
 //   target                          search                                   kernel
 //   ------------------------------  ---------------------------------------  -----------------------------------------------------------
-//   >= 8 192 points, fits f16       any (cold ones seed themselves)          HTRACK  nn1_btrack_kernel<4 | 2, true>   (variant 7)
+//   >= 8 192 points, fits f16       seeded by the previous iteration's move  STRACK  nn1_strack_kernel<4 | 2>         (variant 8: every seeded search)
+//   >= 8 192 points, fits f16       any other (cold ones seed themselves)    HTRACK  nn1_btrack_kernel<4 | 2, true>   (variant 7)
 //   >= 8 192 points, beyond f16     any                                      BTRACK  nn1_btrack_kernel<4 | 2, false>  (variant 6)
 //   either form failing the device check (mfma_verdict), or nn1_bf16 = 2     the two rows below
 //   >= 2 048 points                 inside a loop / index exists / 2nd search ETRACK  nn1_etrack_kernel<4>             (variant 4)
@@ -831,6 +1042,8 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
 // (Targets below 2 048 points inside loops, and one-shot searches with queries x targets > 2e9, never get here: api.cpp nn1_auto_grid
 // sends them to the exact grid.)  Tune keys read here — every one 0 = default:
 //   nn1_variant (above) · nn1_bf16 (1 force / 2 forbid the matrix-core forms) · nn1_f16 (1 / 2 the same for the f16 form) ·
+//   nn1_sign (STRACK: 1 = every warm search, 2 = never, 3 = cold seeded searches too) · nn1_sign_flush (list entries from which the end
+//   of a super-tile evaluates them, default 64) ·
 //   nn1_btrack_qg (query groups of 32 per wave: 2 or 4; default 2 up to 49 152 queries) · nn1_supers_per_slice / nn1_btrack_blocks
 //   (slice length of the matrix-core launch directly / via the workgroup count, default 14 336) · nn1_xcd (XCD-aware launch: 1 / 2 / 4
 //   query-block groups per 8 XCDs, -1 plain 2-D launch; default 4) · nn1_cold_seed (2 = off) · nn1_warm_start (2 = off) ·
@@ -871,11 +1084,10 @@ static void seed_warm(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, 
 }
 
 // HTRACK / BTRACK over the target's Morton-ordered operands (bt_ensure)
-static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool f16, bool warm, bool pre_seeded)
+static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool f16, bool warm, bool pre_seeded, bool force_sign)
 {
     const BtIndex* g = tgt->bt;
     const size_t ns = src->n;
-    ctx->last_nn1_kernel = f16 ? "htrack" : "btrack";
     // query groups (of 32) per wave: four amortise the per-tile operand loads best on a full batch; a source shard of a strong-scaling run
     // (15-30 k queries against the whole target) fills the chip better with two — measured, per ICP iteration: 15 k queries 0.158 -> 0.137
     // ms, 30 k 0.241 -> 0.218, 60 k 0.378 / 0.375, 120 k 0.664 -> 0.723
@@ -887,8 +1099,17 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     uint32_t slices = 1;
     const uint32_t sps = slice_plan(n_super, qblocks, tune_get(ctx, "nn1_supers_per_slice", 0), tune_get(ctx, "nn1_btrack_blocks", 14336), &slices);
     // a cold, sliced search seeds itself from the nearest super-tile (tune nn1_cold_seed: 2 = off)
-    const bool cold_seed = !warm && slices > 1 && tune_get(ctx, "nn1_cold_seed", 1) == 1;
-    const int merge_atomic = (slices > 1 || warm) ? 1 : 0;
+    const bool cold_seed = !warm && (slices > 1 || force_sign) && tune_get(ctx, "nn1_cold_seed", 1) == 1;
+    const int merge_atomic = (slices > 1 || warm || cold_seed) ? 1 : 0;
+    // STRACK, the sign form of the f16 filter, serves the searches that start from a GOOD candidate per query in keys[]: those whose
+    // seeds the move of the previous iteration of the same loop wrote (kabsch.hip seed_next_search: the pose moved by one ICP step).
+    // A cold search's own seeds (bt_seed_kernel: the best of 32 records of the nearest super-tile) and the correspondences of an
+    // EARLIER loop re-evaluated at a new start pose are decimetres off: 6.6 chunks flagged per query instead of 1.0-2.4, 0.88 ms
+    // against HTRACK's 0.50.  Tune nn1_sign: 1 = every warm search, 2 = never, 3 = cold seeded searches too; nn1_variant 8 = every
+    // search that has or can make itself a seed (the parity tests' way to put the kernel in front of every input).
+    const int64_t sign_tune = tune_get(ctx, "nn1_sign", 0);
+    const bool sign = force_sign ? (warm || cold_seed) : f16 && sign_tune != 2 && (pre_seeded || (warm && sign_tune == 1) || (cold_seed && sign_tune == 3));
+    ctx->last_nn1_kernel = sign ? "strack" : f16 ? "htrack" : "btrack";
     if (warm) seed_warm(ctx, tgt, src, pre_seeded);
     else if (merge_atomic && !cold_seed) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
     unsigned long long* stats_dev = nullptr;
@@ -900,14 +1121,21 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
             hipLaunchKernelGGL(bt_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->records, n_super,
                                std::max<uint32_t>(1u, n_super / 1024u), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
         // XCD-aware launch (tune nn1_xcd: 1 / 2 / 4 = query-block groups per 8 XCDs, -1 = the plain 2-D launch): see the kernel
+        // STRACK: entries in a wave's list from which the end of a super-tile evaluates them (tune nn1_sign_flush; the end of the slice always does)
+        const uint32_t st_flush_at = (uint32_t)std::min<int64_t>(std::max<int64_t>(tune_get(ctx, "nn1_sign_flush", 64), 1), 1 << 20);
         int64_t xq = tune_get(ctx, "nn1_xcd", NN_XCD_DEFAULT);
         if ((xq != 1 && xq != 2 && xq != 4) || slices < 8 || (uint64_t)qblocks * slices >= (1ull << 27)) xq = 0;
         const dim3 grid = xq ? dim3(8u * ((qblocks + (uint32_t)xq - 1) / (uint32_t)xq) * ((slices + 8u / (uint32_t)xq - 1) / (8u / (uint32_t)xq)), 1) : dim3(qblocks, slices);
 #define PCR_BTRACK(Q, H, OPS)                                                                                                              \
     hipLaunchKernelGGL((nn1_btrack_kernel<Q, H>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, OPS, g->records, n_super * BT_SUPER, n_super, sps,  \
                        src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices)
-        if (f16) { if (qg == 2) PCR_BTRACK(2, true, g->ops16); else PCR_BTRACK(4, true, g->ops16); }
+#define PCR_STRACK(Q)                                                                                                                      \
+    hipLaunchKernelGGL((nn1_strack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records, n_super * BT_SUPER, n_super, sps,  \
+                       src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices, st_flush_at)
+        if (sign) { if (qg == 2) PCR_STRACK(2); else PCR_STRACK(4); }
+        else if (f16) { if (qg == 2) PCR_BTRACK(2, true, g->ops16); else PCR_BTRACK(4, true, g->ops16); }
         else { if (qg == 2) PCR_BTRACK(2, false, g->ops); else PCR_BTRACK(4, false, g->ops); }
+#undef PCR_STRACK
 #undef PCR_BTRACK
     }
     PCR_HIP(ctx, hipGetLastError());
@@ -989,12 +1217,12 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     // The matrix-core forms, from a target's FIRST search on: the index (operands in Morton order, bt_ensure) costs one bounding-box
     // round trip and ~0.2 ms at 120 k points, less than the kernel saves (small targets stay on the f32 filters: 44 against 53 us per
     // ICP iteration at 4 000 points, 114 against 72 at 20 000 — profiles/r02_mfma_filter_experiments.txt)
-    if (variant == 6 || variant == 7 || (variant == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)))) {
+    if (variant == 6 || variant == 7 || variant == 8 || (variant == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)))) {
         rc = bt_ensure(ctx, tgt);
         if (rc) return rc;
         if (tgt->bt->safe && tgt->bt->n_tiles) {
             // HTRACK: one f16 MFMA per tile instead of two bf16 ones, when the cloud fits f16's range (the flag of the operand build, read once)
-            bool f16 = variant == 7 || (variant == 0 && f16_tune != 2 && (f16_tune == 1 || NN_F16_DEFAULT));
+            bool f16 = variant == 7 || variant == 8 || (variant == 0 && f16_tune != 2 && (f16_tune == 1 || NN_F16_DEFAULT));
             if (f16 && tgt->bt->bad16_host < 0) {
                 int flag = 1;
                 PCR_HIP(ctx, hipMemcpyAsync(&flag, tgt->bt->bad16, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1006,7 +1234,7 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
             // either is first chosen (mfma_verdict: once per context, cached): a form whose measured error exceeds half of what its bound
             // budgets is not used here; the f32 filters below (bounds from IEEE arithmetic alone) answer instead.
             if (f16 && !mfma_verdict(ctx, true)) f16 = false;
-            if (f16 || mfma_verdict(ctx, false)) return launch_matrix(ctx, tgt, src, f16, warm, pre_seeded);
+            if (f16 || mfma_verdict(ctx, false)) return launch_matrix(ctx, tgt, src, f16, warm, pre_seeded, f16 && variant == 8);
         }
     }
     // ETRACK needs the cell index (chunked, centred copy of the target): cold searches take it when that index exists or will be needed

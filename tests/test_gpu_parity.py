@@ -67,7 +67,7 @@ def test_library_checks_the_matrix_core_arithmetic_itself_and_falls_back(ctx, or
     assert chk["f16_ok"] == 1 and chk["bf16_ok"] == 1, chk
     assert 0.0 < chk["check_ms"] < 20.0, chk                # both forms, once per context (measured: profiles/)
     assert ctx.mfma_check(run_now=True)["check_ms"] == chk["check_ms"]         # cached: not run again
-    want = {0: ("htrack",), 1: ("btrack",), 2: ("htrack",), 3: ("ftrack", "etrack")}
+    want = {0: ("strack", "htrack"), 1: ("btrack",), 2: ("strack", "htrack"), 3: ("ftrack", "etrack")}
     for force in (0, 1, 2, 3, 3):
         ctx.tune("mfma_force_fail", force)
         ct, cs = ctx.cloud(tgt), ctx.cloud(src)
@@ -122,7 +122,7 @@ def test_nn1_near_duplicates_next_to_a_super_tile_centre(ctx, orc, sps):
     assert (od == 0).sum() >= 40 * M                      # the coincident queries
     ctx.tune("nn_method", 1)
     ctx.tune("nn1_supers_per_slice", sps)                 # 1: every cluster its own slice (settled through the published bound)
-    for variant in (2, 7, 6, 0):
+    for variant in (2, 7, 6, 8, 0):
         ctx.tune("nn1_variant", variant)
         ct, cs = ctx.cloud(tgt), ctx.cloud(src)
         idx, d2 = ctx.nn1(ct, cs)
@@ -137,6 +137,51 @@ def test_nn1_near_duplicates_next_to_a_super_tile_centre(ctx, orc, sps):
     ctx.tune("nn1_variant", 0); ctx.tune("nn1_supers_per_slice", 0); ctx.tune("nn_method", 0)
 
 
+def test_sign_filter_bad_seeds_nonfinite_queries_and_full_lists(ctx, orc, synth):
+    """STRACK (csrc/nn1_brute.hip: the sign form of the f16 filter) decides from a candidate per query.  Here the candidates are as bad
+    as they get — the correspondences of a DIFFERENT pose (metres away, rotated), a cold search's own seeds —, some queries are NaN /
+    inf / 10^6 m away, the target holds a lattice (ties) and exact duplicates, and the wave's list of flagged chunks is flushed after
+    every super-tile or only when it is full (it overflows with seeds this bad): every answer equals the exact-only kernel's, and the
+    oracle's for the first pose."""
+    n = 20000
+    src, tgt = synth.kitti_like_pair(n, seed_target=811, seed_pair=812)
+    tgt = tgt.copy(); src = src.copy()
+    tgt[:, :2000] = np.round(tgt[:, :2000] * 4) / 4                  # ties
+    tgt[:, 2000:2500] = tgt[:, 1500:2000]                            # exact duplicates: the lowest index must win
+    src[:, :500] = tgt[:, 1700:2200]                                 # queries ON targets
+    src[:, 5] = np.nan; src[0, 77] = np.inf; src[2, 78] = -np.inf; src[:, 100:110] = 1.0e6
+    c, s_ = np.float32(np.cos(0.7)), np.float32(np.sin(0.7))
+    Rz = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+    poses = [src, (src + np.array([[0.05], [-0.03], [0.01]], np.float32)).astype(np.float32), (Rz @ src + np.array([[4.0], [-7.0], [0.5]], np.float32)).astype(np.float32),
+             src, (src * np.float32(0.5)).astype(np.float32)]
+    poses = [np.ascontiguousarray(p_, np.float32) for p_ in poses]
+    ctx.tune("nn_method", 1)
+    ct = ctx.cloud(tgt)
+    clouds = [ctx.cloud(p_) for p_ in poses]
+    ctx.tune("nn1_variant", 2)
+    ref = [ctx.nn1(ct, c_) for c_ in clouds]
+    oi, od = orc.nn1_f32(tgt, poses[0])
+    assert np.array_equal(ref[0][0], oi) and np.array_equal(bits32(ref[0][1]), bits32(od))
+    for qg, flush, sps in ((4, 0, 0), (2, 1, 0), (4, 100000, 1), (2, 0, 3), (4, 1, 200), (4, 3, 0)):
+        ctx.tune("nn1_btrack_qg", qg); ctx.tune("nn1_sign_flush", flush); ctx.tune("nn1_supers_per_slice", sps)
+        ctx.tune("nn1_variant", 8)
+        ctx.tune("nn1_async_in_loop", 1)
+        fresh = ctx.cloud(tgt)                                       # the first search is cold: it seeds itself
+        for k, c_ in enumerate(clouds + clouds[:2]):
+            ctx.nn1_async(fresh, c_)
+            assert ctx.mfma_check()["last_nn1_kernel"] == "strack", (qg, flush, sps, k)
+            idx, d2 = ctx.nn1_fetch(n)
+            ri, rd = ref[k % len(clouds)]
+            assert np.array_equal(idx, ri) and np.array_equal(bits32(d2), bits32(rd)), (qg, flush, sps, k, int((idx != ri).sum()))
+        ctx.tune("nn1_async_in_loop", 0)
+        fresh.free()
+    for k_ in ("nn1_btrack_qg", "nn1_sign_flush", "nn1_supers_per_slice", "nn1_variant", "nn_method"):
+        ctx.tune(k_, 0)
+    for c_ in clouds:
+        c_.free()
+    ct.free()
+
+
 def test_nn1_randomised_sweep_every_kernel(ctx, orc):
     """120 random problems x {FTRACK, TRACK, ETRACK, BTRACK (matrix cores), exact grid (plain / x-window / bounding-sphere kernels on the
     x-sorted index, plain / bounding-sphere kernels on the Morton-ordered index)}: indices and d2 bits equal to the oracle."""
@@ -149,7 +194,7 @@ def test_nn1_randomised_sweep_every_kernel(ctx, orc):
             src[:, : min(ns, nt) // 2] = tgt[:, : min(ns, nt) // 2]
         oi, od = orc.nn1_f32(tgt, src)
         ct, cs = ctx.cloud(tgt), ctx.cloud(src)
-        for method, variant, mode in ((1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 6, 0), (1, 7, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)):
+        for method, variant, mode in ((1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 6, 0), (1, 7, 0), (1, 8, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)):
             ctx.tune("nn_method", method)
             ctx.tune("nn1_variant", variant)
             ctx.tune("grid_mode", mode)                # 1 plain, 2 x-window, 3 bounding spheres (0: by target size)
@@ -158,7 +203,7 @@ def test_nn1_randomised_sweep_every_kernel(ctx, orc):
         ct.free()
         ctx.tune("grid_order", 2)                      # the Morton-ordered index of large targets, forced on a fresh cloud
         cm = ctx.cloud(tgt)
-        for method, variant, mode in ((2, 1, 3), (2, 1, 1), (1, 4, 0), (1, 6, 0), (1, 7, 0)):
+        for method, variant, mode in ((2, 1, 3), (2, 1, 1), (1, 4, 0), (1, 6, 0), (1, 7, 0), (1, 8, 0)):
             ctx.tune("nn_method", method); ctx.tune("nn1_variant", variant); ctx.tune("grid_mode", mode)
             idx, d2 = ctx.nn1(cm, cs)
             assert np.array_equal(idx, oi) and np.array_equal(bits32(d2), bits32(od)), (trial, kind, nt, ns, method, variant, mode, "morton")
@@ -189,8 +234,9 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
 
 # nn1_variant: 1 FTRACK (fused-filter tracking, exact decision; no index), 2 TRACK (the exact arithmetic for every pair: the on-device
 # reference), 4 ETRACK (expanded-form f32 filter on the grid's chunked target copy), 6 BTRACK (the filter on the bf16 matrix cores,
-# three-piece operands), 7 HTRACK (one f16 MFMA per tile, two-piece scaled operands) — csrc/nn1_brute.hip, table above launch_nn1_brute
-VARIANTS = [1, 2, 4, 6, 7]
+# three-piece operands), 7 HTRACK (one f16 MFMA per tile, two-piece scaled operands), 8 STRACK (the sign form of the f16 filter for every
+# search that has or can make itself a seed; HTRACK where none exists) — csrc/nn1_brute.hip, table above launch_nn1_brute
+VARIANTS = [1, 2, 4, 6, 7, 8]
 
 
 def set_variant(ctx, v):
@@ -652,7 +698,12 @@ def test_matrix_core_search_switches_change_no_bit(ctx, synth):
     switches = [dict(nn1_xcd=-1), dict(nn1_xcd=1), dict(nn1_xcd=2), dict(bt_sort_work=2), dict(icp_seed_in_move=2), dict(icp_fused_move=2),
                 dict(icp_seed_in_move=2, icp_fused_move=2), dict(icp_fused_max=4096),
                 dict(nn1_supers_per_slice=1), dict(nn1_supers_per_slice=5), dict(nn1_supers_per_slice=40), dict(nn1_btrack_qg=2), dict(nn1_btrack_qg=4),
-                dict(nn1_f16=2), dict(nn1_f16=2, nn1_btrack_qg=4), dict(nn1_f16=2, icp_seed_in_move=2, nn1_supers_per_slice=2)]
+                dict(nn1_f16=2), dict(nn1_f16=2, nn1_btrack_qg=4), dict(nn1_f16=2, icp_seed_in_move=2, nn1_supers_per_slice=2),
+                # the sign form of the f16 filter (STRACK): never / every warm search / cold seeded searches too, its list flushed after
+                # every super-tile or only when full, one-super-tile and one-slice launches, two query groups per wave
+                dict(nn1_sign=2), dict(nn1_sign=1), dict(nn1_sign=3), dict(nn1_sign=3, nn1_sign_flush=1), dict(nn1_sign=3, nn1_sign_flush=100000),
+                dict(nn1_sign=3, nn1_supers_per_slice=1), dict(nn1_sign=3, nn1_supers_per_slice=100, nn1_btrack_qg=2), dict(nn1_sign=1, icp_seed_in_move=2),
+                dict(nn1_variant=8), dict(nn1_variant=8, nn1_xcd=-1, nn1_btrack_qg=2)]
     for sw in switches:
         for k, v in sw.items():
             ctx.tune(k, v)

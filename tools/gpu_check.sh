@@ -14,8 +14,13 @@ stage() {   # stage <name> <timeout> <logfile> <command...>
     echo "$name rc=$rc"; tail -4 "$log"
     return $rc
 }
+# a line a minute into gpurun_out/ while the stages run (a quiet stage — pytest writing to a block-buffered file — must not read as a hang;
+# every stage has its own timeout)
+( while true; do date +%T >> gpurun_out/heartbeat.log; sleep 60; done ) &
+HB=$!
+trap 'kill $HB 2>/dev/null' EXIT
 stage smoke 300 gpurun_out/smoke.log python -c "import __graft_entry__ as g; g.smoke()" || exit 1
-stage pytest 1000 gpurun_out/pytest_gpu.log python -m pytest tests -m gpu -q --timeout 600 || exit 1
+stage pytest 1000 gpurun_out/pytest_gpu.log python -u -m pytest tests -m gpu -q --timeout 600 || exit 1
 timeout -k 10 300 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; rc=$?
 echo "bench rc=$rc"; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err; [ $rc -eq 0 ] || exit 1
 cd /tmp || exit 1

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""STRACK (sign form of the f16 filter) against HTRACK (minimum tracking) on the BASELINE pair: duration of every search of a
+20-iteration ICP loop (HIP events), and the exact-branch statistics of a cold, a perturbed-warm and a converged-warm search.
+usage: run_strack.py [n] [iters]        env PCR_TUNE="key=value,..." applies to both arms"""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+pcr = importlib.import_module("hands-on-point-cloud-processing_amd")
+synth = importlib.import_module("hands-on-point-cloud-processing_amd.synth")
+a = sys.argv[1:]
+n = int(a[0]) if len(a) > 0 else 120000
+iters = int(a[1]) if len(a) > 1 else 20
+src, tgt = synth.kitti_like_pair(n)
+ctx = pcr.Context(0)
+ctx.tune("nn_method", 1)
+for kv in os.environ.get("PCR_TUNE", "").split(","):
+    if "=" in kv:
+        k_, v_ = kv.split("="); ctx.tune(k_, int(v_))
+cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=3, eps=0.0)            # index, code objects
+arms = [int(x) for x in os.environ.get("ARMS", "1,2").split(",")]
+# extra STRACK arms: CONFIGS="key=value,key=value;key=value" (each ';'-separated set is one more arm with nn1_sign = 1)
+configs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",") if "=" in kv) for c in os.environ.get("CONFIGS", "").split(";") if c]
+runs = [(f"nn1_sign={s_}", {"nn1_sign": s_}) for s_ in arms] + [("nn1_sign=1 " + str(c), dict(c, nn1_sign=1)) for c in configs]
+poses = {}
+for rep in range(2):
+    for label, tunes in runs:
+        for k_, v_ in tunes.items():
+            ctx.tune(k_, v_)
+        ctx.tune("prof", 1); ctx.prof_reset()
+        T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=iters, eps=0.0)
+        each = ctx.prof_get_each("nn1_brute")
+        poses[label] = T.tobytes()
+        fam = ctx.mfma_check()["last_nn1_kernel"]
+        print(f"rep {rep} {label} ({fam}): avg {each.mean():.4f} ms, last5 {each[-5:].mean():.4f}; each: " + " ".join(f"{v:.3f}" for v in each))
+        for k_ in tunes:
+            if k_ != "nn1_sign":
+                ctx.tune(k_, 0)
+if len(runs) > 1:
+    print("pose bits equal:", len(set(poses.values())) == 1)
+ctx.tune("prof", 0)
+
+
+def stats_of(label, c_src, warm_calls):
+    for sign in arms:
+        ctx.tune("nn1_sign", sign)
+        ctx.tune("nn1_async_in_loop", 1 if warm_calls else 0)
+        for _ in range(warm_calls):
+            ctx.nn1_async(ct, c_src)
+        ctx.tune("grid_stats", 1); ctx.nn1_async(ct, c_src); ctx.sync(); w = ctx.nn1_stats(); ctx.tune("grid_stats", 0)
+        ctx.tune("nn1_async_in_loop", 0)
+        clk = w[4] / w[5] * 100.0 if w[5] else 0.0
+        print(f"{label} nn1_sign={sign} ({ctx.mfma_check()['last_nn1_kernel']}): exact-branch visits {w[2]} ({w[2] / max(n / 128, 1):.1f} per wave-of-128-queries), "
+              f"chunk evaluations {w[6]} ({w[6] / n:.2f} per query), clock {clk:.0f} MHz")
+
+
+stats_of("cold, identity pose     ", cs, 0)
+ca = cs.clone(); ctx.transform(ca, synth.gt_pose().astype(np.float32))
+stats_of("warm, converged pose    ", ca, 2)
+# a warm search whose seeds come from a pose a few centimetres away (as between two early ICP iterations)
+d = np.eye(4, dtype=np.float32); d[:3, 3] = (0.05, -0.03, 0.01)
+for sign in arms:
+    ctx.tune("nn1_sign", sign); ctx.tune("nn1_async_in_loop", 1)
+    cb = cs.clone(); ctx.transform(cb, synth.gt_pose().astype(np.float32))
+    ctx.nn1_async(ct, cb); ctx.nn1_async(ct, cb)
+    ctx.transform(cb, d)
+    # (the transform dropped nothing of keys[]: the next in-loop search re-evaluates the previous correspondences against the moved queries)
+    ctx.tune("grid_stats", 1); ctx.nn1_async(ct, cb); ctx.sync(); w = ctx.nn1_stats(); ctx.tune("grid_stats", 0)
+    ctx.tune("nn1_async_in_loop", 0)
+    print(f"warm, moved by 6 cm      nn1_sign={sign} ({ctx.mfma_check()['last_nn1_kernel']}): exact-branch visits {w[2]}, chunk evaluations {w[6]} ({w[6] / n:.2f} per query)")
+    cb.free()
