@@ -176,6 +176,12 @@ def main():
     if args.gpus > 1 and not os.environ.get("WORLD_SIZE"):
         sys.exit(self_launch(args.gpus))                # before torch / HIP are even imported
 
+    # PCR_BENCH_WATCHDOG_S=<seconds>: a rank that is still running after that long dumps the Python stack of every thread to stderr and
+    # exits (a deadlocked multi-rank run then says WHERE each rank waits instead of hanging until the caller's timeout)
+    if os.environ.get("PCR_BENCH_WATCHDOG_S"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PCR_BENCH_WATCHDOG_S"]), exit=True)
+
     import numpy as np
     import torch   # device sync + torch.distributed (RCCL) plumbing; loaded BEFORE libpcr_hip.so so that the
                    # HIP runtime (libamdhip64.so.7) is shared
@@ -470,6 +476,8 @@ def main():
                     "scaling": "weak", "n_src_per_rank": n, "note": "every rank owns a different 120k-point shard of the source scan, target replicated"}
             cw.free()
 
+        # (grid_roofline runs ICP loops — collectives under world > 1 — so EVERY rank calls it, not only the one that prints)
+        groof_c2 = grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha) if args.nn == "grid" else None
         if rank == 0:
             gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
             if args.nn == "brute":
@@ -565,7 +573,7 @@ def main():
                             "configs[1]/[2] ('LDS-tiled brute force': the default kernel stages the target's matrix-core operands through LDS, one "
                             "256-target super-tile per workgroup and barrier)")
             else:
-                roofline, workload = grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha), \
+                roofline, workload = groof_c2, \
                     f"point-to-point ICP iteration on ONE {n_t} x {n} pair = exact grid 1-NN + Kabsch + transform"
             out = {
                 "metric": METRIC, "value": n * args.steps / dt / 1e6, "unit": "M corr/s", "icp_iter_per_s": args.steps / dt,
@@ -616,8 +624,9 @@ def main():
         gl, gms = ctx.prof_get("nn1_grid")
         kern_s = gms / 1e3 / max(gl, 1)
         bd = kernel_breakdown(cs, ct, 2, min(steps5, 5))
+        n_q, n_t = src.shape[1], tgt.shape[1]
+        groof = grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha)      # (every rank: its ICP loops are collective)
         if rank == 0:
-            n_q, n_t = src.shape[1], tgt.shape[1]
             c5 = {"metric": METRIC, "value": n5 * steps5 / dt / 1e6, "unit": "M corr/s", "icp_iter_per_s": steps5 / dt, "n_gpus": world, "steps": steps5,
                   "warmup": warm5, "ms_per_step": dt * 1e3 / steps5, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                   "data": "synthetic",
@@ -628,7 +637,7 @@ def main():
                              "pose_err_vs_gt_fro": float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose())),
                              "kept_pairs_last_iter": int(st["last_pairs"]), "lib_sha16": sha,
                              "pose_bits": "".join(f"{int(v):08x}" for v in np.ascontiguousarray(T, np.float32).view(np.uint32).ravel())},
-                  "roofline": grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha),
+                  "roofline": groof,
                   "kernels": stream_kernels(bd, n_q, int(st["last_pairs"]) * n_q // max(n5, 1))}
             if args.workload == "c5":
                 out = c5

@@ -790,6 +790,9 @@ struct StWaveLds {
 template <int QG>
 __device__ __forceinline__ void st_flush(StWaveLds<QG>& L, uint32_t cnt, uint32_t chunk0, const float4* __restrict__ records, uint32_t lane)
 {
+#ifdef PCR_ST_TIMING_NOFLUSH                                  // (timing builds only: what the joint evaluations cost — wrong answers)
+    return;
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (uint32_t e0 = 0; e0 < cnt; e0 += 4) {
         const uint32_t e = e0 + (lane >> 4);
@@ -867,6 +870,7 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
     }
     __syncthreads();
     uint32_t cnt = 0;                                         // entries in the wave's list (wave-uniform)
+    uint4 bq[QG];
     for (uint32_t S = sb; S < se; S++) {
         const uint32_t buf = (S - sb) & 1u;
         if (S + 1 < se) {                                     // the next super-tile: in flight during this one's eight tiles
@@ -876,7 +880,9 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
         const float4 C = centres[S];                          // wave-uniform: scalar load; .w = the super-tile's scale (a power of two)
         const float sc2 = C.w * C.w;                          // exact: |exponent| <= 120
         uint4 A = sA[buf][lane];                              // the first tile's operand: on its way while the query side is built
-        uint4 bq[QG];
+#ifdef PCR_ST_TIMING_NOSETUP                                  // (timing builds only: what the operand setup costs — wrong answers)
+        if (S == sb)
+#endif
 #pragma unroll
         for (int p = 0; p < QG / 2; p++) {
             uint32_t P[4], Q[4];
@@ -991,7 +997,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_seed_kernel(const float* __restr
 // iteration (0.95 -> ? ms per unseeded 120 k x 120 k search); without it every slice evaluates a chunk exactly and proves it.
 __global__ __launch_bounds__(NN_BLOCK) void bt_seed_kernel(const float4* __restrict__ centres, const float4* __restrict__ records, uint32_t n_super, uint32_t centre_step,
                                                            const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
-                                                           unsigned long long* __restrict__ keys)
+                                                           unsigned long long* __restrict__ keys, int merge)
 {
     const uint32_t i = blockIdx.x * NN_BLOCK + threadIdx.x;
     if (i >= ns) return;
@@ -1005,12 +1011,14 @@ __global__ __launch_bounds__(NN_BLOCK) void bt_seed_kernel(const float4* __restr
         if (d < bc) { bc = d; sc = S; }
     }
     unsigned long long key = ~0ull;
-    for (int j = 0; j < 32; j++) {
+    for (int j = 0; j < 32; j++) {                             // (64 / 128 / 256 samples: 6.1 / 5.5 / 5.1 instead of 6.9 flagged chunks per query, no faster)
         const float4 rec = records[(size_t)sc * BT_SUPER + (uint32_t)j * (BT_SUPER / 32) + (i & (BT_SUPER / 32 - 1))];
         const uint32_t e = d2_exact_bits(qx, qy, qz, rec.x, rec.y, rec.z);
         const unsigned long long k = ((unsigned long long)e << 32) | __float_as_uint(rec.w);
         if (e < 0x7F7FFFFFu && k < key) key = k;                                   // FLT_MAX gate; padding records have x = +inf
     }
+    // merge: keys[] already holds a candidate (a stale correspondence re-evaluated by nn1_seed_kernel) — the better of the two stays
+    if (merge) { const unsigned long long old = keys[i]; key = old < key ? old : key; }
     keys[i] = key;
 }
 
@@ -1031,8 +1039,8 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
 //
 //   target                          search                                   kernel
 //   ------------------------------  ---------------------------------------  -----------------------------------------------------------
-//   >= 8 192 points, fits f16       seeded by the previous iteration's move  STRACK  nn1_strack_kernel<4 | 2>         (variant 8: every seeded search)
-//   >= 8 192 points, fits f16       any other (cold ones seed themselves)    HTRACK  nn1_btrack_kernel<4 | 2, true>   (variant 7)
+//   >= 8 192 points, fits f16       any seeded one (cold ones seed themselves) STRACK  nn1_strack_kernel<4 | 2>       (variant 8: one-slice launches too)
+//   >= 8 192 points, fits f16       cold one-slice launches; nn1_sign = 2    HTRACK  nn1_btrack_kernel<4 | 2, true>   (variant 7)
 //   >= 8 192 points, beyond f16     any                                      BTRACK  nn1_btrack_kernel<4 | 2, false>  (variant 6)
 //   either form failing the device check (mfma_verdict), or nn1_bf16 = 2     the two rows below
 //   >= 2 048 points                 inside a loop / index exists / 2nd search ETRACK  nn1_etrack_kernel<4>             (variant 4)
@@ -1042,7 +1050,7 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
 // (Targets below 2 048 points inside loops, and one-shot searches with queries x targets > 2e9, never get here: api.cpp nn1_auto_grid
 // sends them to the exact grid.)  Tune keys read here — every one 0 = default:
 //   nn1_variant (above) · nn1_bf16 (1 force / 2 forbid the matrix-core forms) · nn1_f16 (1 / 2 the same for the f16 form) ·
-//   nn1_sign (STRACK: 1 = every warm search, 2 = never, 3 = cold seeded searches too) · nn1_sign_flush (list entries from which the end
+//   nn1_sign (STRACK: 2 = never) · nn1_sign_flush (list entries from which the end
 //   of a super-tile evaluates them, default 64) ·
 //   nn1_btrack_qg (query groups of 32 per wave: 2 or 4; default 2 up to 49 152 queries) · nn1_supers_per_slice / nn1_btrack_blocks
 //   (slice length of the matrix-core launch directly / via the workgroup count, default 14 336) · nn1_xcd (XCD-aware launch: 1 / 2 / 4
@@ -1101,14 +1109,15 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     // a cold, sliced search seeds itself from the nearest super-tile (tune nn1_cold_seed: 2 = off)
     const bool cold_seed = !warm && (slices > 1 || force_sign) && tune_get(ctx, "nn1_cold_seed", 1) == 1;
     const int merge_atomic = (slices > 1 || warm || cold_seed) ? 1 : 0;
-    // STRACK, the sign form of the f16 filter, serves the searches that start from a GOOD candidate per query in keys[]: those whose
-    // seeds the move of the previous iteration of the same loop wrote (kabsch.hip seed_next_search: the pose moved by one ICP step).
-    // A cold search's own seeds (bt_seed_kernel: the best of 32 records of the nearest super-tile) and the correspondences of an
-    // EARLIER loop re-evaluated at a new start pose are decimetres off: 6.6 chunks flagged per query instead of 1.0-2.4, 0.88 ms
-    // against HTRACK's 0.50.  Tune nn1_sign: 1 = every warm search, 2 = never, 3 = cold seeded searches too; nn1_variant 8 = every
-    // search that has or can make itself a seed (the parity tests' way to put the kernel in front of every input).
+    // STRACK, the sign form of the f16 filter, serves every search that starts from a candidate per query in keys[]: the searches seeded by
+    // the move of the previous iteration (kabsch.hip seed_next_search), the cold ones that seed themselves (bt_seed_kernel: 0.55 ms against
+    // HTRACK's 0.60), and the warm ones whose seeds are old correspondences re-evaluated by nn1_seed_kernel.  Those may stem from another
+    // loop's final pose — decimetres to metres off, 0.88 ms — so they are merged with the cold seed: every seed is then at least as good
+    // as a cold search's.  Tune nn1_sign: 2 = never (HTRACK's minimum tracking), nn1_variant 8 = also the one-slice launches of small
+    // targets (the parity tests' way to put the kernel in front of every input).
     const int64_t sign_tune = tune_get(ctx, "nn1_sign", 0);
-    const bool sign = force_sign ? (warm || cold_seed) : f16 && sign_tune != 2 && (pre_seeded || (warm && sign_tune == 1) || (cold_seed && sign_tune == 3));
+    const bool sign = force_sign ? (warm || cold_seed) : f16 && sign_tune != 2 && (warm || cold_seed);
+    const bool reseed = sign && warm && !pre_seeded && tune_get(ctx, "nn1_cold_seed", 1) == 1;
     ctx->last_nn1_kernel = sign ? "strack" : f16 ? "htrack" : "btrack";
     if (warm) seed_warm(ctx, tgt, src, pre_seeded);
     else if (merge_atomic && !cold_seed) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
@@ -1117,9 +1126,9 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     if (rc) return rc;
     {
         ProfScope p(ctx, "nn1_brute", 1);
-        if (cold_seed)                                                              // (inside the timed scope: it is part of the cold search)
+        if (cold_seed || reseed)                                                    // (inside the timed scope: it is part of the search)
             hipLaunchKernelGGL(bt_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->records, n_super,
-                               std::max<uint32_t>(1u, n_super / 1024u), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys);
+                               std::max<uint32_t>(1u, n_super / 1024u), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, reseed ? 1 : 0);
         // XCD-aware launch (tune nn1_xcd: 1 / 2 / 4 = query-block groups per 8 XCDs, -1 = the plain 2-D launch): see the kernel
         // STRACK: entries in a wave's list from which the end of a super-tile evaluates them (tune nn1_sign_flush; the end of the slice always does)
         const uint32_t st_flush_at = (uint32_t)std::min<int64_t>(std::max<int64_t>(tune_get(ctx, "nn1_sign_flush", 64), 1), 1 << 20);

@@ -306,7 +306,8 @@ int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4]);
  * (each once for all queries of its pass).
  * Matrix-core exhaustive search (HTRACK / BTRACK): [2] = (wave, query group) pairs that were filtered a second time, [4] = shader
  * cycles (s_memtime) and [5] = 100 MHz real-time ticks (s_memrealtime) summed over the workgroups: [4] / [5] x 100 MHz is the shader
- * clock the chip held under that launch (bench.py: the clock-corrected roofline). */
+ * clock the chip held under that launch (bench.py: the clock-corrected roofline).  STRACK (the sign form of the f16 filter): [2] =
+ * joint evaluations of a wave's list of flagged chunks, [6] = (query, 16-record chunk) pairs evaluated exactly, [4] / [5] as above. */
 int pcr_nn1_stats(pcr_ctx* ctx, uint64_t out[16]);
 /* Checks on THIS device the arithmetic the matrix-core forms of the exhaustive 1-NN filter rely on (csrc/nn1_brute.hip: BTRACK = two
  * v_mfma_f32_32x32x16_bf16 per tile, three-piece operands; HTRACK = one v_mfma_f32_32x32x16_f16, two-piece scaled operands — the default).
@@ -321,7 +322,8 @@ int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[4]);
 /* The library runs a short form of the two self-tests ITSELF, once per context, before it first picks a matrix-core kernel, and only
  * uses a form whose four figures stay within HALF of what its bound assumes (f16 -> bf16 -> the f32 filters, whose bounds need IEEE
  * arithmetic only).  This reports the verdicts (-1 = not run yet; run_now != 0 runs them), the figures, the host time the checks
- * took, and which 1-NN kernel family served the last search ("htrack", "btrack", "etrack", "ftrack", "track", "grid"). */
+ * took, and which 1-NN kernel family served the last search ("strack", "htrack", "btrack", "etrack", "ftrack", "track", "grid",
+ * "grid-tile"). */
 typedef struct {
     int32_t f16_ok, bf16_ok;
     double f16_worst[4], bf16_worst[4];
@@ -332,11 +334,14 @@ int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
 /* Tuning / diagnostic knobs by name.  A value of 0 means "library default" for every key except "prof"; results never depend on a knob
  * (the parity tests run the switches against each other), only speed and which kernel serves a call.  Defaults in brackets.
  *  dispatch    nn_method [0 auto: api.cpp nn1_auto_grid] 1 exhaustive / 2 exact grid · nn1_variant [0: table above launch_nn1_brute,
- *              csrc/nn1_brute.hip] 1 FTRACK, 2 TRACK (exact arithmetic only), 4 ETRACK, 6 BTRACK, 7 HTRACK · nn1_bf16, nn1_f16 [on]
- *              1 force / 2 forbid the matrix-core forms · mfma_force_fail 1 f16 / 2 bf16 / 3 both (tests: a failing device check) ·
+ *              csrc/nn1_brute.hip] 1 FTRACK, 2 TRACK (exact arithmetic only), 4 ETRACK, 6 BTRACK, 7 HTRACK, 8 STRACK for every search
+ *              that has or can make itself a seed (HTRACK otherwise) · nn1_bf16, nn1_f16 [on] 1 force / 2 forbid the matrix-core forms ·
+ *              nn1_sign [on: STRACK for every seeded search on a target that fits f16] 2 = never (HTRACK) ·
+ *              mfma_force_fail 1 f16 / 2 bf16 / 3 both (tests: a failing device check) ·
  *              knn_method, radius_method [auto] 1 exhaustive / 2 grid · nn1_async_in_loop [off] 1 = pcr_nn1_f32_async calls of one
  *              caller-side loop seed each other as the searches inside pcr_icp_p2p_f32 do
  *  exhaustive  nn1_btrack_qg [2 up to 49 152 queries, else 4] · nn1_supers_per_slice [from nn1_btrack_blocks = 14 336] ·
+ *              nn1_sign_flush [64: entries of a wave's list of flagged chunks from which the end of a super-tile evaluates them] ·
  *              nn1_xcd [4] 1 / 2 / 4, -1 plain launch · nn1_cold_seed, nn1_warm_start [on] 2 = off · nn1_chunks_per_slice [from
  *              nn1_etrack_blocks = 32 768] · nn1_tiles_per_slice [from nn1_target_blocks = 16 384] · bt_sort_work [on] 2 = off
  *  exact grid  grid_order [0: Morton from 500 000 points] 1 x-sorted / 2 Morton · grid_mode [by index] 1 plain / 2 x-window / 3 spheres ·

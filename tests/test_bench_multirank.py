@@ -6,6 +6,7 @@ moments are exact integer limbs: csrc/numerics.hpp) — north_star: "one RCCL al
 iteration", SURVEY.md 8(e)."""
 import json
 import os
+import signal
 import subprocess
 import sys
 
@@ -16,14 +17,27 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(gpus, *flags, timeout=900):
-    env = dict(os.environ, PCR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def run_bench(gpus, *flags, timeout=420):
+    # a rank that is still running after 300 s dumps its Python stacks and exits (bench.py PCR_BENCH_WATCHDOG_S): a deadlock says where;
+    # the launcher and its ranks form one process group that is killed as a whole if the call does not come back in time — no rank may
+    # outlive its test on the GPU (the box allows six processes on the card)
+    env = dict(os.environ, PCR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PCR_BENCH_WATCHDOG_S="300")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *flags]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints ONE line, the other ranks none
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    try:
+        stdout, stderr = p.communicate(timeout=timeout)
+    except BaseException:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        stdout, stderr = p.communicate()
+        raise AssertionError(f"bench.py --gpus {gpus} did not finish within {timeout} s\n" + stdout[-2000:] + "\n" + stderr[-6000:])
+    assert p.returncode == 0, stdout[-3000:] + "\n" + stderr[-3000:]
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]            # rank 0 prints ONE line, the other ranks none
     return json.loads(lines[0])
 
 

@@ -699,10 +699,10 @@ def test_matrix_core_search_switches_change_no_bit(ctx, synth):
                 dict(icp_seed_in_move=2, icp_fused_move=2), dict(icp_fused_max=4096),
                 dict(nn1_supers_per_slice=1), dict(nn1_supers_per_slice=5), dict(nn1_supers_per_slice=40), dict(nn1_btrack_qg=2), dict(nn1_btrack_qg=4),
                 dict(nn1_f16=2), dict(nn1_f16=2, nn1_btrack_qg=4), dict(nn1_f16=2, icp_seed_in_move=2, nn1_supers_per_slice=2),
-                # the sign form of the f16 filter (STRACK): never / every warm search / cold seeded searches too, its list flushed after
-                # every super-tile or only when full, one-super-tile and one-slice launches, two query groups per wave
-                dict(nn1_sign=2), dict(nn1_sign=1), dict(nn1_sign=3), dict(nn1_sign=3, nn1_sign_flush=1), dict(nn1_sign=3, nn1_sign_flush=100000),
-                dict(nn1_sign=3, nn1_supers_per_slice=1), dict(nn1_sign=3, nn1_supers_per_slice=100, nn1_btrack_qg=2), dict(nn1_sign=1, icp_seed_in_move=2),
+                # the sign form of the f16 filter (STRACK): never, its list flushed after every super-tile or only when full, no cold seed
+                # (cold searches then take HTRACK, stale seeds are not merged with a cold one), one-slice launches too (variant 8)
+                dict(nn1_sign=2), dict(nn1_sign_flush=1), dict(nn1_sign_flush=100000), dict(nn1_cold_seed=2), dict(nn1_cold_seed=2, icp_seed_in_move=2),
+                dict(nn1_sign_flush=1, nn1_supers_per_slice=1), dict(nn1_supers_per_slice=100, nn1_btrack_qg=2),
                 dict(nn1_variant=8), dict(nn1_variant=8, nn1_xcd=-1, nn1_btrack_qg=2)]
     for sw in switches:
         for k, v in sw.items():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""STRACK (sign form of the f16 filter) against HTRACK (minimum tracking) on the BASELINE pair: duration of every search of a
+"""STRACK (sign form of the f16 filter: the default, nn1_sign = 0) against HTRACK (minimum tracking, nn1_sign = 2) on the BASELINE pair: duration of every search of a
 20-iteration ICP loop (HIP events), and the exact-branch statistics of a cold, a perturbed-warm and a converged-warm search.
 usage: run_strack.py [n] [iters]        env PCR_TUNE="key=value,..." applies to both arms"""
 import importlib, os, sys
@@ -18,7 +18,7 @@ for kv in os.environ.get("PCR_TUNE", "").split(","):
         k_, v_ = kv.split("="); ctx.tune(k_, int(v_))
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
 ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=3, eps=0.0)            # index, code objects
-arms = [int(x) for x in os.environ.get("ARMS", "1,2").split(",")]
+arms = [int(x) for x in os.environ.get("ARMS", "0,2").split(",")]
 # extra STRACK arms: CONFIGS="key=value,key=value;key=value" (each ';'-separated set is one more arm with nn1_sign = 1)
 configs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",") if "=" in kv) for c in os.environ.get("CONFIGS", "").split(";") if c]
 runs = [(f"nn1_sign={s_}", {"nn1_sign": s_}) for s_ in arms] + [("nn1_sign=1 " + str(c), dict(c, nn1_sign=1)) for c in configs]

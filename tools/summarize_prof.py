@@ -45,7 +45,7 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_mfma", "pmc_fetch", "pmc_write"):
     agg = collections.defaultdict(list)
     rows = list(csv.DictReader(open(f)))
     # the dominant kernel of the profiled ICP loop: the warm-start kernel when it ran, else the cold one
-    want = next((w for w in ("nn1_btrack", "nn1_etrack") if any(w in r["Kernel_Name"] for r in rows)), "nn1_ftrack")
+    want = next((w for w in ("nn1_strack", "nn1_btrack", "nn1_etrack") if any(w in r["Kernel_Name"] for r in rows)), "nn1_ftrack")
     per_dispatch = collections.defaultdict(float)
     for r in rows:
         if want in r["Kernel_Name"]:

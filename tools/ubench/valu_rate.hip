@@ -105,6 +105,82 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* ticks, 
 #define X(i) asm volatile("v_min_i32 %0, %0, %1" : "+v"(a[i]) : "v"(v1));
                 REP8(X)
 #undef X
+            } else if (MODE == 20) {
+#define X(i) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(v1), "v"(v2));
+                REP8(X)
+#undef X
+            } else if (MODE == 21) {
+#define X(i) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(v1));
+                REP8(X)
+#undef X
+            } else if (MODE == 22) {
+#define X(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(v1), "v"(v2));
+                REP8(X)
+#undef X
+            } else if (MODE == 23) {
+#define X(i) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(v1), "v"(v2));
+                REP8(X)
+#undef X
+            } else if (MODE == 24) {
+#define X(i) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(v1));
+                REP8(X)
+#undef X
+            } else if (MODE == 25) {
+#define X(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(v1), "v"(v2));
+                REP8(X)
+#undef X
+            } else if (MODE == 26) {
+#define X(i) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(a[i]) : "v"(v1));
+                REP8(X)
+#undef X
+            } else if (MODE == 27) {
+#define X(i) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(a[i]) : "v"(v1), "v"(v2));
+                REP8(X)
+#undef X
+            } else if (MODE == 28) {
+#define X(i) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(v1), "v"(v2));
+                REP8(X)
+#undef X
+            } else if (MODE == 29) {
+#define X(i) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(v1), "v"(v2));
+                REP8(X)
+#undef X
+            } else if (MODE == 30) {
+#define X(i) asm volatile("v_sad_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(v1), "v"(v2));
+                REP8(X)
+#undef X
+            } else if (MODE == 31) {
+#define X(i) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(v1), "v"(v2));
+                REP8(X)
+#undef X
+            } else if (MODE == 32) {
+#define X(i) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(v1));
+                REP8(X)
+#undef X
+            } else if (MODE == 33) {
+#define X(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(v1));
+                REP8(X)
+#undef X
+            } else if (MODE == 34) {
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(v1));
+                REP8(X)
+#undef X
+            } else if (MODE == 35) {
+#define X(i) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(v1));
+                REP8(X)
+#undef X
+            } else if (MODE == 36) {
+#define X(i) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a[i]) : "v"(v1));
+                REP8(X)
+#undef X
+            } else if (MODE == 37) {
+#define X(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(v1) : "vcc");
+                REP8(X)
+#undef X
+            } else if (MODE == 38) {
+#define X(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_or_b64 s[20:21], s[20:21], vcc" : : "v"(a[i]), "v"(v1) : "vcc", "s20", "s21");
+                REP8(X)
+#undef X
             } else if (MODE == 11) {     // v_fma_f32 with an SGPR and dependent 3-chain
 #define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0\n v_fma_f32 %0, %2, %1, %0\n v_fma_f32 %0, %1, %1, %0" : "+v"(a[i]) : "s"(s1), "v"(v2));
                 REP8(X)
@@ -123,7 +199,7 @@ template <int MODE>
 static void run(const char* name, int per_instr_mult)
 {
     const int iters = 20000;
-    for (int w : { 1, 2, 4, 8 }) {
+    for (int w : { 1, 4, 8 }) {
         const int blocks = 256 * w;                       // w waves per SIMD (a 256-thread block = one wave per SIMD of its CU)
         float* out; unsigned long long* ticks;
         CK(hipMalloc(&out, (size_t)blocks * 256 * sizeof(float)));
@@ -166,5 +242,24 @@ int main()
     run<17>("v_cmp_lt_u32 + v_cndmask", 2);
     run<18>("v_add_f32", 1);
     run<19>("v_min_i32", 1);
+    run<20>("v_or3_b32", 1);
+    run<21>("v_or_b32", 1);
+    run<22>("v_and_or_b32", 1);
+    run<23>("v_add3_u32", 1);
+    run<24>("v_lshl_or_b32", 1);
+    run<25>("v_perm_b32", 1);
+    run<26>("v_pk_min_i16", 1);
+    run<27>("v_mad_u32_u24", 1);
+    run<28>("v_bfi_b32", 1);
+    run<29>("v_max3_i32", 1);
+    run<30>("v_sad_u32", 1);
+    run<31>("v_xad_u32", 1);
+    run<32>("v_lshl_add_u32", 1);
+    run<33>("v_add_u32", 1);
+    run<34>("v_mov_b32", 1);
+    run<35>("v_pk_add_u16", 1);
+    run<36>("v_alignbit_b32", 1);
+    run<37>("v_cmp_lt_f32 (vcc)", 1);
+    run<38>("v_cmp_lt_f32 + s_or_b64", 1);
     return 0;
 }
