@@ -434,18 +434,19 @@ def main():
             ctx.tune("nn_method", 1)
             ms_fresh_auto = sorted(walls_auto)[len(walls_auto) // 2]
             ms_indexed = time_search(ct, 5)
+            cold_family = ctx.mfma_check()["last_nn1_kernel"].upper()      # what the dispatcher took for the cold, self-seeded search
             one_shot = {"note": "BASELINE configs[1]: ONE 1-NN search of the pair with no earlier correspondences (no seed)",
                         "fresh_target": {"ms": ms_fresh, "M_corr_per_s": n_q / ms_fresh / 1e3, "kernel_ms": ms_fresh_kernel,
                                          "kernel": "the FIRST search of a target cloud, wall time of the call (median of 7, host launch + completion wait "
                                                    "included): the Morton-ordered bf16 operands are built (one bounding-box round trip, radix sort) and "
-                                                   "the default kernel (HTRACK) runs",
+                                                   f"the default kernel ({cold_family}, behind the cold seed of bt_seed_kernel) runs",
                                          "f32_kernels_ms": ms_fresh_f32,
                                          "f32_kernels": "the same call with nn1_bf16 = 2: pcr::nn1_ftrack_kernel<2, 16>, which needs no index",
                                          "auto_dispatch_ms": ms_fresh_auto,
                                          "auto_dispatch": "the same call with nn_method 0, the library's own choice: at this size (queries x targets > 2e9) "
                                                           "the exact grid — index build + search, same answers; NOT the brute-force workload of BASELINE configs[1]"},
                         "indexed_target": {"ms": ms_indexed, "M_corr_per_s": n_q / ms_indexed / 1e3,
-                                           "kernel": "the default kernel (HTRACK), cold — no earlier correspondences; the search seeds itself from the nearest super-tile (bt_seed_kernel, inside the timed scope) — kernel time (the target's operands exist: any earlier search built them)"}}
+                                           "kernel": f"the default kernel ({cold_family}), cold — no earlier correspondences; the search seeds itself from the nearest super-tile (bt_seed_kernel, inside the timed scope) — kernel time (the target's operands exist: any earlier search built them)"}}
             ms_f32 = time_search(ct, 5, nn1_bf16=2)
             ms_bf16 = time_search(ct, 5, nn1_f16=2)
             one_shot["indexed_target_bf16_filter"] = {"ms": ms_bf16, "M_corr_per_s": n_q / ms_bf16 / 1e3,

@@ -786,7 +786,7 @@ struct StWaveLds {
     uint32_t list[ST_CAP];                                    // (chunk relative to the slice << 7) | query slot
 };
 
-// the listed chunks against their queries: four per step, 16 lanes each
+// the listed chunks against their queries: 16 lanes per chunk, four chunks per wave-instruction
 template <int QG>
 __device__ __forceinline__ void st_flush(StWaveLds<QG>& L, uint32_t cnt, uint32_t chunk0, const float4* __restrict__ records, uint32_t lane)
 {
@@ -794,20 +794,30 @@ __device__ __forceinline__ void st_flush(StWaveLds<QG>& L, uint32_t cnt, uint32_
     return;
 #endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (uint32_t e0 = 0; e0 < cnt; e0 += 4) {
-        const uint32_t e = e0 + (lane >> 4);
-        const bool valid = e < cnt;
-        const uint32_t ent = L.list[valid ? e : 0], slot = ent & 127u;
-        const float4 q = L.q[slot];
-        const float4 rec = records[(size_t)(chunk0 + (ent >> 7)) * 16 + (lane & 15)];          // (padding records: x = +inf, never accepted)
-        const uint32_t d = d2_exact_bits(q.x, q.y, q.z, rec.x, rec.y, rec.z);
-        unsigned long long key = (valid && d < 0x7F7FFFFFu) ? (((unsigned long long)d << 32) | __float_as_uint(rec.w)) : ~0ull;   // FLT_MAX gate
+    for (uint32_t e0 = 0; e0 < cnt; e0 += 8) {                 // eight chunks per round: both record loads of a lane are in flight together
+        bool valid[2];
+        uint32_t slot[2];
+        float4 q[2], rec[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t e = e0 + 4u * u + (lane >> 4);
+            valid[u] = e < cnt;
+            const uint32_t ent = L.list[valid[u] ? e : 0];
+            slot[u] = ent & 127u;
+            q[u] = L.q[slot[u]];
+            rec[u] = records[(size_t)(chunk0 + (ent >> 7)) * 16 + (lane & 15)];          // (padding records: x = +inf, never accepted)
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t d = d2_exact_bits(q[u].x, q[u].y, q[u].z, rec[u].x, rec[u].y, rec[u].z);
+            unsigned long long key = (valid[u] && d < 0x7F7FFFFFu) ? (((unsigned long long)d << 32) | __float_as_uint(rec[u].w)) : ~0ull;   // FLT_MAX gate
 #define PCR_ST_MIN(CTRL) { const unsigned long long w = ((unsigned long long)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(key >> 32), CTRL, 0xF, 0xF, false) << 32) | \
                                                       (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)key, CTRL, 0xF, 0xF, false);                              \
                            key = w < key ? w : key; }
-        PCR_ST_MIN(0xB1) PCR_ST_MIN(0x4E) PCR_ST_MIN(0x141) PCR_ST_MIN(0x140)                 // quad xor 1, xor 2, half-row mirror, row mirror
+            PCR_ST_MIN(0xB1) PCR_ST_MIN(0x4E) PCR_ST_MIN(0x141) PCR_ST_MIN(0x140)             // quad xor 1, xor 2, half-row mirror, row mirror
 #undef PCR_ST_MIN
-        if ((lane & 15) == 0 && key != ~0ull) atomicMin(&L.best[slot], key);
+            if ((lane & 15) == 0 && key != ~0ull) atomicMin(&L.best[slot[u]], key);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
@@ -817,7 +827,7 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
     const float4* __restrict__ centres, const uint4* __restrict__ ops, const float4* __restrict__ records, uint32_t n_rec, uint32_t n_super,
     uint32_t supers_per_slice, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
     unsigned long long* __restrict__ keys, const int* __restrict__ stop, unsigned long long* __restrict__ stats,
-    uint32_t xq, uint32_t qblocks, uint32_t slices, uint32_t flush_at)
+    uint32_t xq, uint32_t qblocks, uint32_t slices, uint32_t flush_at, uint32_t dense_at)
 {
     const int stopv = stop ? (stop[0] | stop[1]) : 0;
     constexpr int TPS = BT_SUPER / 32;
@@ -870,6 +880,8 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
     }
     __syncthreads();
     uint32_t cnt = 0;                                         // entries in the wave's list (wave-uniform)
+    bool refresh = false;                                     // LDS holds better candidates than the thresholds in registers (wave-uniform)
+    uint32_t st_dense = 0;
     uint4 bq[QG];
     for (uint32_t S = sb; S < se; S++) {
         const uint32_t buf = (S - sb) & 1u;
@@ -918,7 +930,29 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
                     const unsigned long long m = __builtin_amdgcn_ballot_w64((int)o[g] < 0);
                     if (!m) continue;
                     const uint32_t k = (uint32_t)__popcll(m);
-                    if (cnt + k > (uint32_t)ST_CAP) { st_flush<QG>(L, cnt, sb * TPS * 2, records, lane); st_flushes++; st_eval += cnt; cnt = 0; }
+                    if (k >= dense_at) {
+                        // Many columns of this group flag the SAME tile (a sorted working cloud behind coarse seeds: the first search of a
+                        // loop): the flagged half-lanes evaluate their chunk in place — the 32 lanes of a half read the same 16 records
+                        // (uniform addresses, four loads in flight), every lane for its own query — instead of filling the list with up to
+                        // 64 entries per group and tile (lists that overflowed several times per tile: 1.17 ms for such a search, 0.5x now)
+                        if ((int)o[g] < 0) {
+                            const float4 q = L.q[g * 32 + n];
+                            const float4* rp = records + (size_t)(sb * TPS * 2 + (crel >> 7)) * 16;
+                            unsigned long long kb = ~0ull;
+#pragma unroll 4
+                            for (int j = 0; j < 16; j++) {
+                                const float4 rec = rp[j];                                   // (padding records: x = +inf, never accepted)
+                                const uint32_t d = d2_exact_bits(q.x, q.y, q.z, rec.x, rec.y, rec.z);
+                                const unsigned long long key = ((unsigned long long)d << 32) | __float_as_uint(rec.w);
+                                if (d < 0x7F7FFFFFu && key < kb) kb = key;                   // FLT_MAX gate
+                            }
+                            if (kb != ~0ull) atomicMin(&L.best[g * 32 + n], kb);
+                        }
+                        st_eval += k; st_dense++;
+                        refresh = true;
+                        continue;
+                    }
+                    if (cnt + k > (uint32_t)ST_CAP) { st_flush<QG>(L, cnt, sb * TPS * 2, records, lane); st_flushes++; st_eval += cnt; cnt = 0; refresh = true; }
                     if ((int)o[g] < 0) L.list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = crel | (uint32_t)(g * 32) | n;
                     cnt += k;
                 }
@@ -926,15 +960,19 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
             A = An;
         }
         if (cnt >= flush_at || (cnt && S + 1 == se)) {
-            // the chunks flagged so far, evaluated together; the thresholds of their queries fall before the next operands are built.
-            // (Not after every super-tile: a flush is a dependent global round trip, longer than a super-tile's 32 MFMAs, and the other
-            // three waves of the workgroup wait for it at the barrier below — 0.54 against 0.50 ms per search.)
-            st_flush<QG>(L, cnt, sb * TPS * 2, records, lane); st_flushes++; st_eval += cnt; cnt = 0;
+            // the chunks flagged so far, evaluated together.  (Not after every super-tile: a flush is a dependent global round trip,
+            // longer than a super-tile's 32 MFMAs, and the other three waves of the workgroup wait for it at the barrier below.)
+            st_flush<QG>(L, cnt, sb * TPS * 2, records, lane); st_flushes++; st_eval += cnt; cnt = 0; refresh = true;
+        }
+        if (refresh) {
+            // the thresholds fall to what was found before the next operands are built
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
             for (int p = 0; p < QG / 2; p++) {
                 const uint32_t fb = (uint32_t)(L.best[(2 * p + (h ? 1 : 0)) * 32 + n] >> 32);   // (~0 >> 32 is a NaN pattern: fminf keeps thr)
                 thr[p] = ok[p] ? fminf(thr[p], __uint_as_float(fb)) : thr[p];
             }
+            refresh = false;
         }
         if (S + 1 < se) { sA[buf ^ 1u][threadIdx.x] = pre0; sA[buf ^ 1u][NN_BLOCK + threadIdx.x] = pre1; }
         __syncthreads();
@@ -965,6 +1003,7 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
     if (stats) {
         if (lane == 0) {
             if (st_flushes) atomicAdd(&stats[2], (unsigned long long)st_flushes);                 // joint evaluations (wave level)
+            if (st_dense) atomicAdd(&stats[7], (unsigned long long)st_dense);                     // (group, tile) pairs evaluated in place
             if (st_eval) atomicAdd(&stats[6], (unsigned long long)st_eval);                       // (query, chunk) pairs evaluated exactly
         }
         if (threadIdx.x == 0) {
@@ -1132,6 +1171,8 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
         // XCD-aware launch (tune nn1_xcd: 1 / 2 / 4 = query-block groups per 8 XCDs, -1 = the plain 2-D launch): see the kernel
         // STRACK: entries in a wave's list from which the end of a super-tile evaluates them (tune nn1_sign_flush; the end of the slice always does)
         const uint32_t st_flush_at = (uint32_t)std::min<int64_t>(std::max<int64_t>(tune_get(ctx, "nn1_sign_flush", 64), 1), 1 << 20);
+        // ... and flagged half-lanes of one (group, tile) from which they evaluate their chunk in place instead of listing it (tune nn1_sign_dense)
+        const uint32_t st_dense_at = (uint32_t)std::min<int64_t>(std::max<int64_t>(tune_get(ctx, "nn1_sign_dense", 12), 1), 65);
         int64_t xq = tune_get(ctx, "nn1_xcd", NN_XCD_DEFAULT);
         if ((xq != 1 && xq != 2 && xq != 4) || slices < 8 || (uint64_t)qblocks * slices >= (1ull << 27)) xq = 0;
         const dim3 grid = xq ? dim3(8u * ((qblocks + (uint32_t)xq - 1) / (uint32_t)xq) * ((slices + 8u / (uint32_t)xq - 1) / (8u / (uint32_t)xq)), 1) : dim3(qblocks, slices);
@@ -1140,7 +1181,7 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
                        src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, merge_atomic, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices)
 #define PCR_STRACK(Q)                                                                                                                      \
     hipLaunchKernelGGL((nn1_strack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records, n_super * BT_SUPER, n_super, sps,  \
-                       src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices, st_flush_at)
+                       src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices, st_flush_at, st_dense_at)
         if (sign) { if (qg == 2) PCR_STRACK(2); else PCR_STRACK(4); }
         else if (f16) { if (qg == 2) PCR_BTRACK(2, true, g->ops16); else PCR_BTRACK(4, true, g->ops16); }
         else { if (qg == 2) PCR_BTRACK(2, false, g->ops); else PCR_BTRACK(4, false, g->ops); }

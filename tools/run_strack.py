@@ -38,6 +38,22 @@ for rep in range(2):
                 ctx.tune(k_, 0)
 if len(runs) > 1:
     print("pose bits equal:", len(set(poses.values())) == 1)
+# the first search of a loop whose stale seeds belong to ANOTHER query order (a 3-iteration run keeps the caller's order, a 20-iteration run
+# sorts its working cloud): seeds of cold quality in front of spatially sorted queries — every column of a wave flags the same tiles
+for label, tunes in runs:
+    for k_, v_ in tunes.items():
+        ctx.tune(k_, v_)
+    firsts = []
+    for _ in range(3):
+        ctx.tune("prof", 0)
+        ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=3, eps=0.0)
+        ctx.tune("prof", 1); ctx.prof_reset()
+        ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=iters, eps=0.0)
+        firsts.append(ctx.prof_get_each("nn1_brute")[0])
+    print(f"first search of a sorted loop behind a short unsorted run, {label}: " + " ".join(f"{v:.3f}" for v in firsts) + " ms (seed kernels included)")
+    for k_ in tunes:
+        if k_ != "nn1_sign":
+            ctx.tune(k_, 0)
 ctx.tune("prof", 0)
 
 
