@@ -2,7 +2,7 @@
 """STRACK (sign form of the f16 filter: the default, nn1_sign = 0) against HTRACK (minimum tracking, nn1_sign = 2) on the BASELINE pair: duration of every search of a
 20-iteration ICP loop (HIP events), and the exact-branch statistics of a cold, a perturbed-warm and a converged-warm search.
 usage: run_strack.py [n] [iters]        env PCR_TUNE="key=value,..." applies to both arms"""
-import importlib, os, sys
+import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 pcr = importlib.import_module("hands-on-point-cloud-processing_amd")
@@ -32,7 +32,11 @@ for rep in range(2):
         each = ctx.prof_get_each("nn1_brute")
         poses[label] = T.tobytes()
         fam = ctx.mfma_check()["last_nn1_kernel"]
-        print(f"rep {rep} {label} ({fam}): avg {each.mean():.4f} ms, last5 {each[-5:].mean():.4f}; each: " + " ".join(f"{v:.3f}" for v in each))
+        ctx.tune("prof", 0)
+        walls = []
+        for _ in range(5):                                   # wall time of the whole call, no event pairs
+            t0 = time.perf_counter(); ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=iters, eps=0.0); walls.append((time.perf_counter() - t0) * 1e3 / iters)
+        print(f"rep {rep} {label} ({fam}): avg {each.mean():.4f} ms, last5 {each[-5:].mean():.4f}; wall per iteration of a {iters}-iteration call {sorted(walls)[2]:.4f} ms; each: " + " ".join(f"{v:.3f}" for v in each))
         for k_ in tunes:
             if k_ != "nn1_sign":
                 ctx.tune(k_, 0)
