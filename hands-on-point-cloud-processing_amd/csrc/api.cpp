@@ -474,6 +474,15 @@ int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[4])
     return pcr::ht_mfma_selftest(ctx, trials, worst);
 }
 
+int pcr_selftest_sign_f16(pcr_ctx* ctx, int trials, uint64_t out[4])
+{
+    if (!ctx || !out || trials < 0 || trials > 4096) return PCR_ERR_ARG;
+    unsigned long long r[4];
+    const int rc = pcr::st_sign_selftest(ctx, trials, r);
+    for (int k = 0; k < 4; k++) out[k] = r[k];
+    return rc;
+}
+
 int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out)
 {
     if (!ctx || !out) return PCR_ERR_ARG;

@@ -1642,6 +1642,82 @@ int ht_mfma_selftest(pcr_ctx* ctx, int trials, double worst[4])
     return PCR_OK;
 }
 
+// ---- self-test of STRACK's DECISION (pcr_selftest_sign_f16; a short form is part of the f16 verdict below).  The sign form adds to the
+// f16 filter's assumptions nothing but st_theta's rounding — this checks the property the search relies on directly, on the device: for
+// random queries / targets of a super-tile (the regimes of kernel_tile, a power-of-two scale per tile) and thresholds placed ON the exact
+// distance of one pair, one ulp below and above it, and a factor away, EVERY pair whose A1 distance (f32, unfused, as the exact
+// evaluation computes it) lies at or below its query's threshold must come out of the kernel's own operand code + MFMA with its sign set.
+// out = { pairs at or below their threshold, of those WITHOUT the sign (must be 0), pairs with the sign set, pairs in all }.
+__global__ __launch_bounds__(64) void st_selftest_kernel(const float* __restrict__ rt, const float* __restrict__ thr, const float* __restrict__ scale, float* __restrict__ out)
+{
+    const uint32_t lane = threadIdx.x, T = blockIdx.x, n = lane & 31;
+    const bool h = lane >= 32;
+    const float sc = scale[T];
+    const float* q = rt + ((size_t)T * 64 + n) * 3;                        // query n (cloud units)
+    const float* t = rt + ((size_t)T * 64 + 32 + n) * 3;                   // target row n (cloud units)
+    uint32_t P[4], Q[4];
+    st_setup(q[0], q[1], q[2], make_float4(0.0f, 0.0f, 0.0f, sc), thr[(size_t)T * 32 + n], sc * sc, P, Q);
+    const uint4 B = h ? make_uint4(Q[0], Q[1], Q[2], Q[3]) : make_uint4(P[0], P[1], P[2], P[3]);
+    const uint4 A = ht_target_operand(t[0] * sc, t[1] * sc, t[2] * sc, true, h);          // (exact scaling)
+    f32x16 zero;
+#pragma unroll
+    for (int j = 0; j < 16; j++) zero[j] = 0.0f;
+    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), zero, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; j++) out[((size_t)T * 64 + lane) * 16 + j] = acc[j];
+}
+
+int st_sign_selftest(pcr_ctx* ctx, int trials, unsigned long long res[4])
+{
+    res[0] = res[1] = res[2] = res[3] = 0;
+    if (trials <= 0) return PCR_OK;
+    const size_t n_tiles = (size_t)trials + SELF_EDGE;
+    // one upload: [n_tiles][64 rows (32 queries, 32 targets)] x 3 floats, [n_tiles][32] thresholds, [n_tiles] scales
+    const size_t rt_floats = n_tiles * 192, thr_off = rt_floats, sc_off = thr_off + n_tiles * 32, in_floats = sc_off + n_tiles;
+    std::vector<float> in(in_floats, 0.0f);
+    SelfRng rng{ 0x5160F16Full };
+    auto a1 = [](const float* a, const float* b) { const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2]; return (dx * dx + dy * dy) + dz * dz; };
+    for (size_t T = 0; T < n_tiles; T++) {
+        const int regime = T < (size_t)trials ? 0 : 1 + (int)((T - trials) % 4);
+        float* q = &in[T * 192]; float* t = &in[T * 192 + 96];
+        kernel_tile(rng, regime, true, q, t);                              // scaled units ...
+        const float sc = std::ldexp(1.0f, rng.range(-8, 8)), inv = 1.0f / sc;
+        for (int i = 0; i < 192; i++) in[T * 192 + i] *= inv;              // ... -> cloud units (exact)
+        in[sc_off + T] = sc;
+        for (int n = 0; n < 32; n++) {
+            const float d = a1(&q[n * 3], &t[((n * 7 + (int)T) % 32) * 3]);
+            float th = d;
+            switch (n % 4) {
+            case 1: th = std::nextafter(d, 0.0f); break;
+            case 2: th = std::nextafter(d, 3.0e38f); break;
+            case 3: th = d * std::ldexp(1.0f, rng.range(-2, 2)) * (1.0f + (float)rng.uni()); break;
+            default: break;
+            }
+            in[thr_off + T * 32 + n] = th;
+        }
+    }
+    float* out = nullptr; void* d_in = nullptr; float* d_out = nullptr;
+    const size_t out_bytes = n_tiles * 64 * 16 * sizeof(float);
+    int rc = selftest_run(ctx, in.data(), in.size() * sizeof(float), out_bytes, &out, &d_in, &d_out);
+    if (rc) return rc;
+    const float* df = (const float*)d_in;
+    hipLaunchKernelGGL(st_selftest_kernel, dim3((unsigned)n_tiles), dim3(64), 0, ctx->stream, df, df + thr_off, df + sc_off, d_out);
+    PCR_HIP(ctx, hipGetLastError());
+    PCR_HIP(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t T = 0; T < n_tiles; T++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int reg = 0; reg < 16; reg++) {
+                const int n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                uint32_t bits; std::memcpy(&bits, &out[(T * 64 + lane) * 16 + reg], 4);
+                const bool flagged = (bits >> 31) != 0;
+                const float d = a1(&in[(T * 64 + n) * 3], &in[(T * 64 + 32 + m) * 3]);
+                const bool must = d <= in[thr_off + T * 32 + n];
+                res[0] += must; res[1] += must && !flagged; res[2] += flagged; res[3] += 1;
+            }
+    return PCR_OK;
+}
+
 // The verdict the dispatcher acts on (launch_nn1_brute): the short form of the self-test above, once per context and form, with HALF of
 // every assumed bound as the pass mark — accumulation (random and structured) <= 8 u sum|a b| of the 16 assumed; the whole filter value
 // <= 41 u (Q + W) of 82 (f16) / <= 17.1 of 34.2 (bf16); the underflow regime <= 2 u of the 4 u ht_setup subtracts.  A form that fails is
@@ -1656,7 +1732,12 @@ bool mfma_verdict(pcr_ctx* ctx, bool f16)
     const auto t0 = std::chrono::steady_clock::now();
     double* w = f16 ? ctx->mfma_worst16 : ctx->mfma_worstbf;
     const int rc = f16 ? ht_mfma_selftest(ctx, 2, w) : bt_mfma_selftest(ctx, 2, w);
-    const bool ok = rc == PCR_OK && w[0] > 0.0 && w[0] <= 8.0 && w[3] <= 8.0 && w[1] <= (f16 ? 41.0 : 17.1) && w[2] <= 2.0;
+    bool ok = rc == PCR_OK && w[0] > 0.0 && w[0] <= 8.0 && w[3] <= 8.0 && w[1] <= (f16 ? 41.0 : 17.1) && w[2] <= 2.0;
+    if (ok && f16) {
+        // ... and the decision of the sign form (STRACK, the default search on this form): no pair at or below its threshold without the sign
+        unsigned long long sg[4];
+        ok = st_sign_selftest(ctx, 2, sg) == PCR_OK && sg[0] > 0 && sg[1] == 0;
+    }
     v = ok ? 1 : 0;
     ctx->mfma_check_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return ok;

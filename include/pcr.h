@@ -319,6 +319,13 @@ int pcr_nn1_stats(pcr_ctx* ctx, uint64_t out[16]);
  *   worst[3] = as worst[0] on the structured tiles                                                    (<= 16) */
 int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[4]);
 int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[4]);
+/* The DECISION of the sign form of the f16 filter (STRACK, csrc/nn1_brute.hip — the default exhaustive search on targets that fit f16:
+ * the query's threshold rides in two K-slots, an accumulator is bound - threshold, its sign bit says whether the record can matter),
+ * checked on THIS device: `trials` random super-tile tiles + 8 in the f16 underflow regimes, a power-of-two scale per tile, thresholds
+ * ON the exact distance of one pair, one ulp below / above it and a factor away, through the kernel's own operand code and MFMA.
+ * out = { pairs whose exact f32 distance lies at or below their query's threshold, of those WITHOUT the sign — must be 0 —,
+ * pairs with the sign set, pairs in all }.  A short form is part of the once-per-context check below. */
+int pcr_selftest_sign_f16(pcr_ctx* ctx, int trials, uint64_t out[4]);
 /* The library runs a short form of the two self-tests ITSELF, once per context, before it first picks a matrix-core kernel, and only
  * uses a form whose four figures stay within HALF of what its bound assumes (f16 -> bf16 -> the f32 filters, whose bounds need IEEE
  * arithmetic only).  This reports the verdicts (-1 = not run yet; run_now != 0 runs them), the figures, the host time the checks

@@ -57,6 +57,18 @@ def test_bf16_matrix_core_arithmetic_is_within_the_bound_the_filter_assumes(ctx)
     assert 0.0 < small16 <= 2.0, small16
 
 
+def test_sign_form_never_misses_a_pair_at_or_below_its_threshold(ctx):
+    """STRACK's decision, checked on the device under test (pcr_selftest_sign_f16): through the kernel's own operand code and MFMA, every
+    pair whose exact f32 distance lies at or below its query's threshold — thresholds ON a pair's distance, one ulp below / above it and
+    a factor away; search magnitudes and the f16 underflow regimes; a power-of-two scale per tile — comes out with its sign set.  How
+    many signs are set needlessly is the price of the bound's slack (reported, bounded loosely)."""
+    le, missed, flagged, total = ctx.selftest_sign_f16(1024)
+    assert total == (1024 + 8) * 1024 and le >= 1024 * 32 * 0.7           # (one ulp below: the pair itself need not be flagged)
+    assert missed == 0, (le, missed, flagged, total)
+    assert flagged >= le and flagged <= le + 0.02 * total, (le, flagged, total)
+    assert ctx.selftest_sign_f16(2)[1] == 0                                # the short form the verdict runs
+
+
 def test_library_checks_the_matrix_core_arithmetic_itself_and_falls_back(ctx, orc, synth):
     """The dispatcher consults a once-per-context verdict before it first uses a matrix-core kernel; a failing verdict (forced here
     with the tune key) moves the search to the next form — f16 -> bf16 -> the f32 filters — with the same bits out."""
