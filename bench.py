@@ -178,9 +178,11 @@ def main():
 
     # PCR_BENCH_WATCHDOG_S=<seconds>: a rank that is still running after that long dumps the Python stack of every thread to stderr and
     # exits (a deadlocked multi-rank run then says WHERE each rank waits instead of hanging until the caller's timeout)
-    if os.environ.get("PCR_BENCH_WATCHDOG_S"):
+    # Default 1 200 s (the whole default line takes one to two minutes); 0 = off.
+    watchdog_s = int(os.environ.get("PCR_BENCH_WATCHDOG_S", "1200"))
+    if watchdog_s > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["PCR_BENCH_WATCHDOG_S"]), exit=True)
+        faulthandler.dump_traceback_later(watchdog_s, exit=True)
 
     import numpy as np
     import torch   # device sync + torch.distributed (RCCL) plumbing; loaded BEFORE libpcr_hip.so so that the

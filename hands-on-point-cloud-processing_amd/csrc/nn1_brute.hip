@@ -764,14 +764,18 @@ __global__ __launch_bounds__(NN_BLOCK, (F16 && QG == 4) ? PCR_BT_WAVES : 1) void
 // re-evaluated by the move / nn1_seed_kernel, or bt_seed_kernel's for a cold search), so the question per pair is not "what is the
 // minimum" but "can this record matter": with the query's threshold folded into the two free K-slots the accumulator is
 // bound - threshold and its sign bit answers (st_setup / st_theta, grid_common.hpp: error analysis there).  Per (query group, tile)
-// the vector ALU ORs 16 accumulators (8 full-rate v_or3_b32) and the wave tests ONE word per tile; no minimum, no chunk tracking, no
-// second pass.  A set sign = "the 16 records of this half-lane's chunk may hold one at or below the query's threshold": the lane notes
-// (chunk, query) in a wave-private LDS list and the scan goes on; at the end of a super-tile (and when the list is full) the wave
-// evaluates the listed chunks TOGETHER — 16 lanes per chunk, one record each, one coalesced 256-byte load, A1 arithmetic, canonical
-// (d2, index) minimum by DPP and a 64-bit LDS minimum per query — and the queries' thresholds fall to what was found before the next
-// super-tile's operands are built.  (First form: the flagged lane evaluated its 16 records itself, one dependent load after the
-// other, the other 63 lanes waiting — one such visit per query and slice-with-a-candidate: 0.59 ms against HTRACK's 0.50.)
-// Same keys bit for bit: a record at or below a query's final answer always raises its flag, the exact evaluation decides.
+// the vector ALU ORs 16 accumulators (8 v_or3_b32 — half-rate like v_min3, it turned out: what is saved is the tracking) and the wave
+// tests ONE word per tile; no minimum, no chunk tracking, no second pass.  A set sign = "the 16 records of this half-lane's chunk may
+// hold one at or below the query's threshold": the lane notes (chunk, query) in a wave-private LDS list and the scan goes on; when the
+// list holds nn1_sign_flush entries at the end of a super-tile, when it is full, and at the end of the slice the wave evaluates the
+// listed chunks TOGETHER — 16 lanes per chunk, one record each, one coalesced 256-byte load, A1 arithmetic, canonical (d2, index)
+// minimum by DPP and a 64-bit LDS minimum per query — and the queries' thresholds fall to what was found before the next super-tile's
+// operands are built.  Where nn1_sign_dense or more columns of a group flag the SAME tile (sorted queries behind coarse seeds) the
+// flagged half-lanes evaluate their chunk in place instead (uniform addresses per half: broadcast loads).  (First form: every flagged
+// lane evaluated its 16 records itself at once, one dependent load after the other, the other 63 lanes waiting — one such visit per
+// query and slice-with-a-candidate: 0.59 ms against HTRACK's 0.50.)
+// Same keys bit for bit: a record at or below a query's final answer always raises its flag, the exact evaluation decides
+// (pcr_selftest_sign_f16 checks the first half of that sentence on the device, the parity suite the whole).
 #ifndef PCR_ST_WAVES
 #define PCR_ST_WAVES 4
 #endif
@@ -1115,7 +1119,7 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
 // sends them to the exact grid.)  Tune keys read here — every one 0 = default:
 //   nn1_variant (above) · nn1_bf16 (1 force / 2 forbid the matrix-core forms) · nn1_f16 (1 / 2 the same for the f16 form) ·
 //   nn1_sign (STRACK: 2 = never) · nn1_sign_flush (list entries from which the end
-//   of a super-tile evaluates them, default 64) ·
+//   of a super-tile evaluates them, default 64) · nn1_sign_dense (flagged half-lanes of one (group, tile) from which they evaluate in place, 12) ·
 //   nn1_btrack_qg (query groups of 32 per wave: 2 or 4; default 2 up to 49 152 queries) · nn1_supers_per_slice / nn1_btrack_blocks
 //   (slice length of the matrix-core launch directly / via the workgroup count, default 14 336) · nn1_xcd (XCD-aware launch: 1 / 2 / 4
 //   query-block groups per 8 XCDs, -1 plain 2-D launch; default 4) · nn1_cold_seed (2 = off) · nn1_warm_start (2 = off) ·

@@ -349,6 +349,7 @@ int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
  *              caller-side loop seed each other as the searches inside pcr_icp_p2p_f32 do
  *  exhaustive  nn1_btrack_qg [2 up to 49 152 queries, else 4] · nn1_supers_per_slice [from nn1_btrack_blocks = 14 336] ·
  *              nn1_sign_flush [64: entries of a wave's list of flagged chunks from which the end of a super-tile evaluates them] ·
+ *              nn1_sign_dense [12: flagged half-lanes of one (group, tile) from which they evaluate their chunk in place] ·
  *              nn1_xcd [4] 1 / 2 / 4, -1 plain launch · nn1_cold_seed, nn1_warm_start [on] 2 = off · nn1_chunks_per_slice [from
  *              nn1_etrack_blocks = 32 768] · nn1_tiles_per_slice [from nn1_target_blocks = 16 384] · bt_sort_work [on] 2 = off
  *  exact grid  grid_order [0: Morton from 500 000 points] 1 x-sorted / 2 Morton · grid_mode [by index] 1 plain / 2 x-window / 3 spheres ·
