@@ -1597,13 +1597,16 @@ static int sort_queries_any(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
     return (fine == 1 || (fine == 0 && !g->x_sorted && src->n >= 65536)) ? sort_queries_fine(ctx, g, src) : sort_queries(ctx, g, src);
 }
 
-// the 1-NN index of a target cloud, cached on the cloud.  Large targets get the Morton-ordered records the sphere walk wants
-// (tune grid_order: 0 auto = Morton from 500 000 points, 1 = x-sorted, 2 = Morton).
+// the 1-NN index of a target cloud, cached on the cloud: Morton-ordered records + bounding spheres (the sphere walk) from 256 points on
+// (tune grid_order: 0 auto, 1 = x-sorted, 2 = Morton).  Until the second session of round 3 only targets of 500 000 points and more
+// got it; measured then on 20-iteration loops and one-shot searches from 1 000 to 250 000 points (tools/run_grid_order.py,
+// profiles/r03_grid_order.txt): the sphere walk is ahead at every size — 120 k: 78.0 -> 64.5 us per iteration, 250 k: 143.9 -> 116.5,
+// 4 000: 30.0 -> 28.1, the first search of a fresh 120 k target 855 -> 707 us.
 int build_target_grid(pcr_ctx* ctx, const pcr_cloud* tgt)
 {
     if (tgt->grid) return PCR_OK;
     const int64_t ord = tune_get(ctx, "grid_order", 0);
-    const int order = (ord == 2 || (ord == 0 && tgt->n >= 500000)) ? GRID_ORDER_MORTON : GRID_ORDER_X;
+    const int order = (ord == 2 || (ord == 0 && tgt->n >= 256)) ? GRID_ORDER_MORTON : GRID_ORDER_X;
     Grid* g = nullptr;
     ProfScope p(ctx, "grid_build");
     int rc = grid_build(ctx, tgt, &g, 0.0, order);
@@ -1806,7 +1809,10 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         launch_blocks = (nblocks + unit - 1) / unit * unit;
     }
     ctx->last_nn1_kernel = "grid";
-    // TILE SEARCH (grid_tile.hpp; tune grid_tile: 0 auto = targets of 500 000 points and more, 1 on, 2 off): the seeded searches of a loop
+    // TILE SEARCH (grid_tile.hpp; tune grid_tile: 0 auto = targets of 4 000 000 points and more, 1 on, 2 off — the tile search is ahead of the
+    // sphere walk once the pose has settled, behind it while many queries are deferred; over a 20-iteration loop from the start pose the
+    // walk wins below ~4 M points: 500 k 195 against 310 us per iteration, 1 M 368 / 490, 2 M 753 / 858, 4 M 1 527 / 1 510, 10 M 4.7 / 3.7 ms;
+    // profiles/r03_grid_order.txt): the seeded searches of a loop
     // whose working cloud is in the order of a Morton-ordered index — one wave per 32 consecutive queries shares rows, sphere tests and
     // record loads, and passes of more than four runs are filtered on the f16 matrix pipe; queries whose ball exceeds
     // grid_tile_bmax_pct % of a cell edge (default 400) and passes with more than grid_tile_keep surviving runs (default 512) go to a
@@ -1824,7 +1830,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     // the target's grid against targets per occupied cell; a spatially compact shard keeps its local density and the tile search.
     const bool dense = ctx->work_cells > 0 && g->occupied > 0 &&
                        (double)ns / (double)ctx->work_cells >= 0.4 * (double)tgt->n / (double)g->occupied;
-    if (mode == 2 && warm == 3 && sorted && !perm && wpos && cap2 < __builtin_inff() && tile_tune != 2 && (tile_tune == 1 || (tgt->n >= 500000 && dense))) {
+    if (mode == 2 && warm == 3 && sorted && !perm && wpos && cap2 < __builtin_inff() && tile_tune != 2 && (tile_tune == 1 || (tgt->n >= 4000000 && dense))) {
         // the segmented list of deferred queries: 32 slots per group of 32 queries + one count per group (far_list is free here: the
         // hand-off of far queries to the exhaustive kernel only exists for unbounded searches)
         const size_t n_groups_sz = (ns + 31) / 32, need = n_groups_sz * 32 + n_groups_sz;

@@ -352,11 +352,11 @@ int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
  *              nn1_sign_dense [12: flagged half-lanes of one (group, tile) from which they evaluate their chunk in place] ·
  *              nn1_xcd [4] 1 / 2 / 4, -1 plain launch · nn1_cold_seed, nn1_warm_start [on] 2 = off · nn1_chunks_per_slice [from
  *              nn1_etrack_blocks = 32 768] · nn1_tiles_per_slice [from nn1_target_blocks = 16 384] · bt_sort_work [on] 2 = off
- *  exact grid  grid_order [0: Morton from 500 000 points] 1 x-sorted / 2 Morton · grid_mode [by index] 1 plain / 2 x-window / 3 spheres ·
+ *  exact grid  grid_order [0: Morton + bounding spheres from 256 points] 1 x-sorted / 2 Morton · grid_mode [by index] 1 plain / 2 x-window / 3 spheres ·
  *              grid_lanes [16] · grid_cell_um, grid_cell_scale_x100 [150 for Morton], grid_occupancy_x10 [20], grid_max_cells ·
  *              grid_sort_queries, grid_sort_work, grid_warm_start, grid_wpos, grid_seed_run, grid_far_brute [on] 2 = off ·
  *              grid_sort_fine [auto] 1 / 2 · grid_query_bins_log2 [22], grid_query_bin_min [2] · grid_xcd_run [32 from 4 096 blocks]
- *              -1 = identity · grid_tile [0: targets from 500 000 points, working cloud about as dense as the target] 1 on / 2 off, grid_tile_bmax_pct [400], grid_tile_keep [512],
+ *              -1 = identity · grid_tile [0: targets from 4 000 000 points, working cloud about as dense as the target] 1 on / 2 off, grid_tile_bmax_pct [400], grid_tile_keep [512],
  *              grid_tile_lim_pct [1000], grid_tile_reach_pct [200], grid_tile_total_mult [16], grid_tile_min_members [8],
  *              grid_tile_list_segs [1], grid_tile_filter [on] 2 = off (csrc/grid.hip launch_nn1_grid) · knn_cell_scale_x100, knn_slices
  *  ICP loop    icp_pipeline [0 = 1 device-resident] -1 synchronous · icp_chunk [4] · icp_bounded_search [on] 2 = off ·
