@@ -11,6 +11,8 @@ a = sys.argv[1:]
 n = int(a[0]) if len(a) > 0 else 120000
 iters = int(a[1]) if len(a) > 1 else 20
 src, tgt = synth.kitti_like_pair(n)
+if os.environ.get("NSRC"):                                   # a source shard of a strong-scaling run: the first NSRC sources against the whole target
+    src = np.ascontiguousarray(src[:, : int(os.environ["NSRC"])])
 ctx = pcr.Context(0)
 ctx.tune("nn_method", 1)
 for kv in os.environ.get("PCR_TUNE", "").split(","):
@@ -70,8 +72,9 @@ def stats_of(label, c_src, warm_calls):
         ctx.tune("grid_stats", 1); ctx.nn1_async(ct, c_src); ctx.sync(); w = ctx.nn1_stats(); ctx.tune("grid_stats", 0)
         ctx.tune("nn1_async_in_loop", 0)
         clk = w[4] / w[5] * 100.0 if w[5] else 0.0
-        print(f"{label} nn1_sign={sign} ({ctx.mfma_check()['last_nn1_kernel']}): exact-branch visits {w[2]} ({w[2] / max(n / 128, 1):.1f} per wave-of-128-queries), "
-              f"chunk evaluations {w[6]} ({w[6] / n:.2f} per query), clock {clk:.0f} MHz")
+        nq = src.shape[1]
+        print(f"{label} nn1_sign={sign} ({ctx.mfma_check()['last_nn1_kernel']}): exact-branch visits {w[2]} ({w[2] / max(nq / 128, 1):.1f} per wave-of-128-queries), "
+              f"chunk evaluations {w[6]} ({w[6] / nq:.2f} per query), clock {clk:.0f} MHz")
 
 
 stats_of("cold, identity pose     ", cs, 0)
