@@ -916,22 +916,37 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
 #pragma unroll PCR_ST_UNROLL
         for (int tt = 0; tt < TPS; tt++) {
             const uint4 An = sA[buf][min(tt + 1, TPS - 1) * 64 + lane];       // the next tile's operand, one tile ahead
-            uint32_t o[QG], any = 0;
+            // ONE chain of ORs over the 64 accumulators of the tile's four groups (8 v_or3_b32 per group and nothing to combine afterwards:
+            // 32 vector instructions per tile instead of 36); which group raised a sign is found out in the rare branch, by running the
+            // tile's MFMAs again
+            uint32_t any;
+            {
+                const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, bq[0]), zero, 0, 0, 0);
+                any = __float_as_uint(acc[0]) | __float_as_uint(acc[1]) | __float_as_uint(acc[2]);
 #pragma unroll
-            for (int g = 0; g < QG; g++) {
+                for (int j = 3; j + 1 < 16; j += 2) any = any | __float_as_uint(acc[j]) | __float_as_uint(acc[j + 1]);
+                any |= __float_as_uint(acc[15]);
+            }
+#pragma unroll
+            for (int g = 1; g < QG; g++) {
                 const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
-                uint32_t v = __float_as_uint(acc[0]) | __float_as_uint(acc[1]) | __float_as_uint(acc[2]);
 #pragma unroll
-                for (int j = 3; j + 1 < 16; j += 2) v = v | __float_as_uint(acc[j]) | __float_as_uint(acc[j + 1]);
-                o[g] = v | __float_as_uint(acc[15]);
-                any |= o[g];
+                for (int j = 0; j < 16; j += 2) any = any | __float_as_uint(acc[j]) | __float_as_uint(acc[j + 1]);
             }
             if (__builtin_amdgcn_ballot_w64((int)any < 0)) {
                 // rare: some half-lane's chunk (records 32 T + 16 h ...) may hold a record at or below its query's threshold
                 const uint32_t crel = (((S - sb) * TPS + (uint32_t)tt) * 2 + (h ? 1u : 0u)) << 7;
 #pragma unroll
                 for (int g = 0; g < QG; g++) {
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64((int)o[g] < 0);
+                    uint32_t og;
+                    {
+                        const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, bq[g]), zero, 0, 0, 0);
+                        og = __float_as_uint(acc[0]) | __float_as_uint(acc[1]) | __float_as_uint(acc[2]);
+#pragma unroll
+                        for (int j = 3; j + 1 < 16; j += 2) og = og | __float_as_uint(acc[j]) | __float_as_uint(acc[j + 1]);
+                        og |= __float_as_uint(acc[15]);
+                    }
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64((int)og < 0);
                     if (!m) continue;
                     const uint32_t k = (uint32_t)__popcll(m);
                     if (k >= dense_at) {
@@ -939,7 +954,7 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
                         // loop): the flagged half-lanes evaluate their chunk in place — the 32 lanes of a half read the same 16 records
                         // (uniform addresses, four loads in flight), every lane for its own query — instead of filling the list with up to
                         // 64 entries per group and tile (lists that overflowed several times per tile: 1.17 ms for such a search, 0.5x now)
-                        if ((int)o[g] < 0) {
+                        if ((int)og < 0) {
                             const float4 q = L.q[g * 32 + n];
                             const float4* rp = records + (size_t)(sb * TPS * 2 + (crel >> 7)) * 16;
                             unsigned long long kb = ~0ull;
@@ -957,7 +972,7 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
                         continue;
                     }
                     if (cnt + k > (uint32_t)ST_CAP) { st_flush<QG>(L, cnt, sb * TPS * 2, records, lane); st_flushes++; st_eval += cnt; cnt = 0; refresh = true; }
-                    if ((int)o[g] < 0) L.list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = crel | (uint32_t)(g * 32) | n;
+                    if ((int)og < 0) L.list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = crel | (uint32_t)(g * 32) | n;
                     cnt += k;
                 }
             }
