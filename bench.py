@@ -505,9 +505,11 @@ def main():
                                 "x 32 targets — operands scaled per 256-target super-tile and cut into two f16 pieces, every piece product exact in f32 — "
                                 "with the query's threshold (the exact distance of its best candidate so far: the previous correspondence re-evaluated, "
                                 "then whatever the scan finds) folded into the two remaining K-slots, so that an accumulator is bound - threshold and "
-                                "its SIGN says whether the record can matter; the vector ALU ORs the 16 accumulators of a lane (8 full-rate v_or3_b32) "
-                                "and the wave tests one word per tile; a lane whose sign is set evaluates its chunk of 16 records with the exact unfused "
-                                "arithmetic and lowers the threshold in its operand at once)") if sign else
+                                "its SIGN says whether the record can matter; the vector ALU ORs the 64 accumulators a lane holds for a tile's four query groups in "
+                                "one chain (32 v_or3_b32 — a half-rate instruction like v_min3: what the sign form saves is the minimum tracking) and the "
+                                "wave tests one word per tile; flagged (query, 16-record chunk) pairs go to a wave-private LDS list and are evaluated "
+                                "together with the exact unfused arithmetic, 16 lanes per chunk, the thresholds fall before the next super-tile's operands "
+                                "are built; one operand setup per query and super-tile, the halves exchanged by v_permlane32_swap)") if sign else
                                ("pcr::nn1_btrack_kernel<4, true> = HTRACK, operands staged through LDS per workgroup (exhaustive scan of every (query, 16-target chunk): the expanded-form lower "
                                 "bound of ALL pairs on the f16 matrix pipe — operands scaled per 256-target super-tile and cut into two f16 pieces each, "
                                 "every piece product exact in f32, ONE v_mfma_f32_32x32x16_f16 per 32 queries x 32 targets; the vector ALU takes the "
@@ -527,7 +529,9 @@ def main():
                     "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
                     "algorithmic": ((f"{flops_pp} f16 flop per (query, target) pair (all 16 K-slots of the one MFMA carry data: 14 piece products + the two "
                                      f"pieces of the threshold) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16.  Per 1024 pairs: one MFMA "
-                                     "(32 cycles of the SIMD's matrix pipe) and 9 vector instructions (8 v_or3_b32 + the share of one compare per tile)")
+                                     "(32 cycles of the SIMD's matrix pipe) and 13 vector instructions all told (PMC SQ_INSTS_VALU / SQ_INSTS_MFMA: 8 v_or3_b32 in the tile "
+                                     "loop, 3 of the operand setup per super-tile, the rest prologue / lists); the two pipes share the SIMD's issue port, so the "
+                                     "launch is issue-bound, not matrix-bound (DESIGN.md 5, profiles/r03_ubench_sign_filter.txt)")
                                     if sign else
                                     f"{flops_pp} {'f16' if f16 else 'bf16'} flop per (query, target) pair ({flops_pp // 2} piece products that carry data, of "
                                     f"the {16 if f16 else 32} K-slots executed) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16 / bf16.  On this chip "
