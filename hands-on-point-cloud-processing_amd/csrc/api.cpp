@@ -145,10 +145,37 @@ static int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out)
     if (!c) return fail(ctx, PCR_ERR_NOMEM, "cloud alloc");
     c->n = n;
     c->cap = padded(n);
+    for (int k = 0; k < 2; k++)
+        if (ctx->spare_base[k] && ctx->spare_cap[k] == c->cap) {          // a buffer an earlier working copy gave back (cloud_release)
+            c->base = ctx->spare_base[k];
+            ctx->spare_base[k] = nullptr; ctx->spare_cap[k] = 0;
+            *out = c;
+            return PCR_OK;
+        }
     hipError_t e = hipMalloc((void**)&c->base, 3 * c->cap * sizeof(float));
     if (e != hipSuccess) { delete c; return fail(ctx, PCR_ERR_HIP, "hipMalloc(cloud)", e); }
     *out = c;
     return PCR_OK;
+}
+
+void cloud_release(pcr_ctx* ctx, pcr_cloud* c)
+{
+    if (!c) return;
+    if (ctx && ctx->qperm_src == c) ctx->qperm_src = nullptr;
+    if (ctx && ctx->keys_src == c) ctx->keys_src = nullptr;
+    if (ctx && ctx->keys_tgt == c) { ctx->keys_tgt = nullptr; ctx->keys_warm = false; ctx->wpos_valid = false; }
+    if (ctx && ctx->work_orig_src == c) ctx->work_orig_src = nullptr;
+    if (ctx && (ctx->keys_seed_src == c || ctx->keys_seed_tgt == c)) { ctx->keys_seeded = false; ctx->keys_seed_src = ctx->keys_seed_tgt = nullptr; }
+    cloud_modified(c);
+    if (c->base) {
+        // (buffers beyond 2 GB are not kept: a spare slot is a convenience, not a cache of the caller's memory)
+        int slot = -1;
+        if (ctx && 3 * c->cap * sizeof(float) <= ((size_t)2 << 30))
+            for (int k = 0; k < 2 && slot < 0; k++) if (!ctx->spare_base[k]) slot = k;
+        if (slot >= 0) { ctx->spare_base[slot] = c->base; ctx->spare_cap[slot] = c->cap; }
+        else hipFree(c->base);                                             // (synchronises the device: nothing in flight can still read it)
+    }
+    delete c;
 }
 
 }  // namespace pcr
@@ -206,6 +233,7 @@ int pcr_ctx_destroy(pcr_ctx* ctx)
     hipStreamSynchronize(ctx->stream);
     prof_flush(ctx);
     pcr_comm_destroy(ctx);
+    for (int k = 0; k < 2; k++) if (ctx->spare_base[k]) hipFree(ctx->spare_base[k]);
     if (ctx->keys) hipFree(ctx->keys);
     if (ctx->far_list) hipFree(ctx->far_list);
     if (ctx->icp_state_dev) hipFree(ctx->icp_state_dev);
@@ -337,14 +365,7 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
 {
     if (!c) return PCR_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
-    if (ctx && ctx->qperm_src == c) ctx->qperm_src = nullptr;
-    if (ctx && ctx->keys_src == c) ctx->keys_src = nullptr;
-    if (ctx && ctx->keys_tgt == c) { ctx->keys_tgt = nullptr; ctx->keys_warm = false; ctx->wpos_valid = false; }
-    if (ctx && ctx->work_orig_src == c) ctx->work_orig_src = nullptr;
-    if (ctx && (ctx->keys_seed_src == c || ctx->keys_seed_tgt == c)) { ctx->keys_seeded = false; ctx->keys_seed_src = ctx->keys_seed_tgt = nullptr; }
-    cloud_modified(c);
-    if (c->base) hipFree(c->base);
-    delete c;
+    cloud_release(ctx, c);
     return PCR_OK;
 }
 

@@ -121,6 +121,10 @@ struct pcr_ctx {
     size_t work_orig_cap = 0;
     size_t work_orig_n = 0;
     const pcr_cloud* work_orig_src = nullptr;
+    // two spare cloud buffers (base, cap): the working copies an ICP call clones and gives back (cloud_release) are re-used by the next
+    // clone of the same size instead of two hipMalloc + two hipFree (each free a device synchronisation) per call
+    float* spare_base[2] = { nullptr, nullptr };
+    size_t spare_cap[2] = { 0, 0 };
     uint32_t work_cells = 0;              // distinct target-grid cells the sorted working cloud occupies (0: unknown); valid after the sort's synchronisation
     double* partials = nullptr;           // block rows of the Kabsch pass (8192 x 58 doubles)
     size_t partials_cap = 0;
@@ -220,6 +224,10 @@ struct LoopHint {
 };
 int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2 = __builtin_inff());
 void cloud_modified(pcr_cloud* c);
+// gives a cloud back WITHOUT synchronising the stream: its buffer goes to the context's spare slots (or is freed when both are taken).
+// Safe for work enqueued on ctx->stream that still reads the cloud: the buffer stays allocated, and whoever gets it next writes it on
+// the same stream.  (pcr_cloud_destroy = the same behind a stream synchronisation: the public contract.)
+void cloud_release(pcr_ctx* ctx, pcr_cloud* c);
 int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
 int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
 int nn1_unpack(pcr_ctx* ctx, size_t n, uint32_t* idx_dev, float* d2_dev);

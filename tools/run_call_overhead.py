@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Wall time of whole pcr_icp_p2p_f32 calls with few iterations (what a registration pipeline that calls ICP often pays per call):
+the per-call overhead = wall(k iterations) - k x (steady per-iteration time).  usage: run_call_overhead.py [n]"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+pcr = importlib.import_module("hands-on-point-cloud-processing_amd")
+synth = importlib.import_module("hands-on-point-cloud-processing_amd.synth")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
+src, tgt = synth.kitti_like_pair(n)
+ctx = pcr.Context(0)
+cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+for method, name in ((2, "exact grid"), (1, "brute force")):
+    ctx.tune("nn_method", method)
+    ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=20, eps=0.0)
+    res = {}
+    for k in (0, 1, 2, 3, 5, 10, 20, 40):
+        w = []
+        for _ in range(7):
+            t0 = time.perf_counter(); ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=k, eps=0.0); w.append((time.perf_counter() - t0) * 1e3)
+        res[k] = sorted(w)[3]
+    slope = (res[40] - res[20]) / 20.0
+    print(f"n {n} {name}: wall ms by max_iter " + ", ".join(f"{k}: {v:.3f}" for k, v in res.items()) + f"; steady {slope * 1e3:.1f} us/iteration; per-call overhead ~ {res[20] - 20 * slope:.3f} ms (at 20), {res[0]:.3f} ms (max_iter 0)")
