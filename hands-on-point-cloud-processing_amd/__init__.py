@@ -61,6 +61,7 @@ ABI_SYMBOLS = [
     "pcr_prof_reset", "pcr_prof_get", "pcr_prof_get_each", "pcr_tune_set",
     "pcr_grid_stats", "pcr_nn1_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_selftest_sign_f16", "pcr_ctx_mfma_check", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_match_inter_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
+    "pcr_ctx_trim", "pcr_ctx_parked_bytes", "pcr_cloud_sort_for_target", "pcr_nn1_f32_loop",
     "pcr_db64_radius_rows", "pcr_rows_destroy", "pcr_rows_info", "pcr_rows_row_ptr", "pcr_rows_fetch", "pcr_rows_reduce", "pcr_rows_moments",
 ]
 
@@ -93,6 +94,10 @@ def lib():
     L.pcr_nn1_f32.argtypes = [vp, vp, vp, vp, vp]
     L.pcr_nn1_f32_async.argtypes = [vp, vp, vp]
     L.pcr_nn1_fetch.argtypes = [vp, sz, vp, vp]
+    L.pcr_ctx_trim.argtypes = [vp]
+    L.pcr_ctx_parked_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.pcr_cloud_sort_for_target.argtypes = [vp, vp, vp, vp]
+    L.pcr_nn1_f32_loop.argtypes = [vp, vp, vp, C.c_float]
     L.pcr_transform_f32.argtypes = [vp, vp, vp]
     L.pcr_kabsch_sums.argtypes = [vp, vp, vp, C.c_float, vp, C.POINTER(C.c_int64), C.POINTER(C.c_float)]
     L.pcr_kabsch_solve.argtypes = [vp, vp, vp]
@@ -477,6 +482,24 @@ class Context:
 
     def nn1_async(self, tgt: Cloud, src: Cloud):
         self._ck(lib().pcr_nn1_f32_async(self.h, tgt.h, src.h))
+
+    def nn1_loop(self, tgt: Cloud, src: Cloud, max_corr: float):
+        """one search of a caller's own ICP-style loop: seeded by the previous call, bounded by the gate (registration.cpp:936)"""
+        self._ck(lib().pcr_nn1_f32_loop(self.h, tgt.h, src.h, C.c_float(max_corr)))
+
+    def sort_for_target(self, tgt: Cloud, cloud: Cloud) -> np.ndarray:
+        """re-orders `cloud` in place into the order of the target's index; returns the original index of every position"""
+        orig = np.empty(len(cloud), np.uint32)
+        self._ck(lib().pcr_cloud_sort_for_target(self.h, tgt.h, cloud.h, orig.ctypes.data if len(cloud) else None))
+        return orig
+
+    def trim(self):
+        self._ck(lib().pcr_ctx_trim(self.h))
+
+    def parked_bytes(self) -> int:
+        b = C.c_uint64()
+        self._ck(lib().pcr_ctx_parked_bytes(self.h, C.byref(b)))
+        return int(b.value)
 
     def nn1_fetch(self, n: int):
         idx = np.empty(n, np.uint32)

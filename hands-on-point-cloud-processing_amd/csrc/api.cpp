@@ -139,6 +139,12 @@ int launch_nn1(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool re
     return nn1_auto_grid(ctx, tgt, reuse_perm, src->n) ? launch_nn1_grid(ctx, tgt, src, reuse_perm, cap2) : launch_nn1_brute(ctx, tgt, src, reuse_perm);
 }
 
+static void spare_trim(pcr_ctx* ctx)
+{
+    for (int k = 0; k < 2; k++)
+        if (ctx->spare_base[k]) { hipFree(ctx->spare_base[k]); ctx->spare_base[k] = nullptr; ctx->spare_cap[k] = 0; }
+}
+
 static int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out)
 {
     pcr_cloud* c = new (std::nothrow) pcr_cloud();
@@ -146,27 +152,38 @@ static int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out)
     c->n = n;
     c->cap = padded(n);
     for (int k = 0; k < 2; k++)
-        if (ctx->spare_base[k] && ctx->spare_cap[k] == c->cap) {          // a buffer an earlier working copy gave back (cloud_release)
+        if (ctx->spare_base[k] && ctx->spare_cap[k] == c->cap) {          // a buffer an ICP loop's working copy gave back (cloud_release)
             c->base = ctx->spare_base[k];
             ctx->spare_base[k] = nullptr; ctx->spare_cap[k] = 0;
             *out = c;
             return PCR_OK;
         }
+    // a miss: what the slots hold belongs to a working size that is no longer the caller's — freed here, so that parked buffers never
+    // outlive the loops that use them by more than one allocation (hipFree waits for the device: the hipMalloc below does too)
+    spare_trim(ctx);
     hipError_t e = hipMalloc((void**)&c->base, 3 * c->cap * sizeof(float));
     if (e != hipSuccess) { delete c; return fail(ctx, PCR_ERR_HIP, "hipMalloc(cloud)", e); }
     *out = c;
     return PCR_OK;
 }
 
-void cloud_release(pcr_ctx* ctx, pcr_cloud* c)
+static void cloud_forget(pcr_ctx* ctx, pcr_cloud* c)
 {
-    if (!c) return;
     if (ctx && ctx->qperm_src == c) ctx->qperm_src = nullptr;
     if (ctx && ctx->keys_src == c) ctx->keys_src = nullptr;
     if (ctx && ctx->keys_tgt == c) { ctx->keys_tgt = nullptr; ctx->keys_warm = false; ctx->wpos_valid = false; }
     if (ctx && ctx->work_orig_src == c) ctx->work_orig_src = nullptr;
     if (ctx && (ctx->keys_seed_src == c || ctx->keys_seed_tgt == c)) { ctx->keys_seeded = false; ctx->keys_seed_src = ctx->keys_seed_tgt = nullptr; }
     cloud_modified(c);
+}
+
+// INTERNAL working copies only (the clone an ICP loop moves, the sorted copy that replaces it): the buffer is parked in one of two
+// per-context slots for the next clone of the same size — no synchronisation, work in flight may still read it; whoever gets it next
+// writes it on the same stream.  Clouds the CALLER owns never come here: pcr_cloud_destroy frees (below).
+void cloud_release(pcr_ctx* ctx, pcr_cloud* c)
+{
+    if (!c) return;
+    cloud_forget(ctx, c);
     if (c->base) {
         // (buffers beyond 2 GB are not kept: a spare slot is a convenience, not a cache of the caller's memory)
         int slot = -1;
@@ -233,7 +250,7 @@ int pcr_ctx_destroy(pcr_ctx* ctx)
     hipStreamSynchronize(ctx->stream);
     prof_flush(ctx);
     pcr_comm_destroy(ctx);
-    for (int k = 0; k < 2; k++) if (ctx->spare_base[k]) hipFree(ctx->spare_base[k]);
+    spare_trim(ctx);
     if (ctx->keys) hipFree(ctx->keys);
     if (ctx->far_list) hipFree(ctx->far_list);
     if (ctx->icp_state_dev) hipFree(ctx->icp_state_dev);
@@ -365,7 +382,26 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
 {
     if (!c) return PCR_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
-    cloud_release(ctx, c);
+    cloud_forget(ctx, c);
+    if (c->base) hipFree(c->base);        // the caller's memory goes back to the device at once, whatever context the handle is destroyed through
+    delete c;
+    return PCR_OK;
+}
+
+int pcr_ctx_parked_bytes(const pcr_ctx* ctx, uint64_t* bytes)
+{
+    if (!ctx || !bytes) return PCR_ERR_ARG;
+    *bytes = 0;
+    for (int k = 0; k < 2; k++) if (ctx->spare_base[k]) *bytes += 3 * (uint64_t)ctx->spare_cap[k] * sizeof(float);
+    return PCR_OK;
+}
+
+int pcr_ctx_trim(pcr_ctx* ctx)
+{
+    if (!ctx) return PCR_ERR_ARG;
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    spare_trim(ctx);
     return PCR_OK;
 }
 
@@ -376,6 +412,35 @@ int pcr_nn1_f32_async(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src)
     // tune "nn1_async_in_loop" = 1: the caller iterates (its own ICP-style loop on the same pair) — the search may then be seeded by the
     // correspondences of its previous call exactly as the searches inside pcr_icp_p2p_f32 are (same results, bit for bit)
     return launch_nn1(ctx, tgt, src, tune_get(ctx, "nn1_async_in_loop", 0) > 0);
+}
+
+int pcr_nn1_f32_loop(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr)
+{
+    if (!ctx || !tgt || !src || !(max_corr > 0.0f)) return fail(ctx, PCR_ERR_ARG, "pcr_nn1_f32_loop");
+    const float gate = tune_get(ctx, "icp_bounded_search", 1) == 1 ? max_corr : __builtin_inff();
+    const LoopHint hint(ctx, 1000);       // (the dispatcher's rule for loops, as in pcr_cloud_sort_for_target)
+    return launch_nn1(ctx, tgt, src, true, gate);
+}
+
+int pcr_cloud_sort_for_target(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud* cloud, uint32_t* orig_index)
+{
+    if (!ctx || !tgt || !cloud || cloud == tgt) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_sort_for_target");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = cloud->n;
+    pcr_cloud* w = cloud;
+    const LoopHint hint(ctx, 1000);       // (a caller that sorts its cloud iterates: the dispatcher's rule for loops)
+    int rc = nn1_auto_grid(ctx, tgt, true, n) ? grid_sort_working_cloud(ctx, tgt, &w, true) : bt_sort_working_cloud(ctx, tgt, &w, true);
+    if (rc) return rc;
+    const bool sorted = ctx->work_orig_src == cloud && ctx->work_orig_n == n;
+    if (orig_index && n) {
+        if (sorted) {
+            PCR_HIP(ctx, hipMemcpyAsync(orig_index, ctx->work_orig, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            for (size_t i = 0; i < n; i++) orig_index[i] = (uint32_t)i;      // (the library left the order alone: small clouds, switched off)
+        }
+    }
+    return PCR_OK;
 }
 
 int pcr_nn1_fetch(pcr_ctx* ctx, size_t n, uint32_t* idx, float* d2)

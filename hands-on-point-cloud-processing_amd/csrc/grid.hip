@@ -1646,7 +1646,7 @@ __global__ __launch_bounds__(GR_BLOCK) void permute_cloud_kernel(const float* __
 // its queries with coalesced loads (no perm indirection), writes keys / winner positions coalesced, and the Kabsch pass walks
 // pairs whose targets are neighbours in the record array.  ctx->work_orig[t] = index the point had in the caller's cloud (the
 // "last kept pair" of registration.cpp:939 is defined in that order).  The sums are exact, so the order changes no result.
-int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work)
+int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, bool in_place)
 {
     pcr_cloud* w = *work;
     const size_t n = w->n;
@@ -1668,6 +1668,7 @@ int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->work_orig, ctx->qperm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
     if (e != hipSuccess) { pcr_cloud_destroy(ctx, sorted); return fail(ctx, PCR_ERR_HIP, "grid_sort_working_cloud", e); }
+    if (in_place) { std::swap(w->base, sorted->base); std::swap(w, sorted); cloud_modified(sorted); }   // the caller's handle keeps its identity and gets the sorted buffer
     cloud_release(ctx, w);                                         // (no synchronisation: the permute above still reads it — the buffer stays allocated)
     *work = sorted;
     ctx->work_orig_src = sorted;
@@ -1682,7 +1683,7 @@ int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work
 // of one here, one there (a source cloud in random order is the worst case: measured 0.620 -> 0.600 ms per 120 k x 120 k search).
 // ctx->work_orig[t] = the index the point had in the caller's cloud, as in grid_sort_working_cloud; the sums are exact, so the
 // order changes no result.  Costs one key kernel, one 30-bit radix sort and one gather.
-int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work)
+int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, bool in_place)
 {
     pcr_cloud* w = *work;
     const size_t n = w->n;
@@ -1723,6 +1724,7 @@ int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work)
     }
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->work_orig, v_out, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
     if (e != hipSuccess) { pcr_cloud_destroy(ctx, sorted); return fail(ctx, PCR_ERR_HIP, "bt_sort_working_cloud", e); }
+    if (in_place) { std::swap(w->base, sorted->base); std::swap(w, sorted); cloud_modified(sorted); }
     cloud_release(ctx, w);                                         // (no synchronisation: the permute above still reads it — the buffer stays allocated)
     *work = sorted;
     ctx->work_orig_src = sorted;

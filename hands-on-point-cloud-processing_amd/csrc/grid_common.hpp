@@ -214,8 +214,8 @@ int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt);
 // builds (and caches on tgt) the 1-NN grid if needed, then groups the queries `src` by coarse cell -> ctx->qperm
 int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
 // replaces *work by its cell-sorted copy (ctx->work_orig = original indices); no-op for empty clouds / tune grid_sort_work = 2
-int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
+int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, bool in_place);
 // the same for a brute-force loop over the matrix-core index: *work in the Morton order of the target's super-tiles (no-op without that index)
-int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
+int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, bool in_place);
 
 }  // namespace pcr

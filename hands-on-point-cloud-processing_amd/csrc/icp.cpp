@@ -120,7 +120,7 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
         st.iters_run++;
     }
     hipStreamSynchronize(ctx->stream);
-    pcr_cloud_destroy(ctx, work);
+    cloud_release(ctx, work);             // (the loop's own working copy: parked for the next call's clone)
     if (rc) return rc;
     memcpy(out_T, T_total, sizeof T_total);                                      // :1008-1009
     prof_flush(ctx);
@@ -237,7 +237,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     } else {
         hipStreamSynchronize(ctx->stream);
     }
-    pcr_cloud_destroy(ctx, work);
+    cloud_release(ctx, work);             // (synchronised above; the loop's own working copy: parked for the next call's clone)
     if (rc) return rc;
     const IcpState& f = host[RING];
     if (f.overflow) return fail(ctx, PCR_ERR_STATE, "ICP: a kept source point lies more than 2^20 target extents away from the target");

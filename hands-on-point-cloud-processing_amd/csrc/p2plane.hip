@@ -191,7 +191,7 @@ extern "C" int pcr_icp_p2plane_f32(pcr_ctx* ctx, const pcr_cloud* src, const pcr
     }
     hipStreamSynchronize(ctx->stream);
     if (partials_dev) hipFree(partials_dev);
-    pcr_cloud_destroy(ctx, work);
+    cloud_release(ctx, work);             // (synchronised above; the loop's own working copy)
     if (rc) return rc;
     memcpy(out_T, T_total, sizeof T_total);
     prof_flush(ctx);

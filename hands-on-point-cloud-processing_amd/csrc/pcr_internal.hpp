@@ -228,8 +228,8 @@ void cloud_modified(pcr_cloud* c);
 // Safe for work enqueued on ctx->stream that still reads the cloud: the buffer stays allocated, and whoever gets it next writes it on
 // the same stream.  (pcr_cloud_destroy = the same behind a stream synchronisation: the public contract.)
 void cloud_release(pcr_ctx* ctx, pcr_cloud* c);
-int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
-int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work);
+int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, bool in_place = false);
+int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, bool in_place = false);
 int nn1_unpack(pcr_ctx* ctx, size_t n, uint32_t* idx_dev, float* d2_dev);
 int launch_transform(pcr_ctx* ctx, pcr_cloud* c, const float R[9], const float t[3]);
 int cloud_absmax(pcr_ctx* ctx, const pcr_cloud* c, float* out);       // largest finite |coordinate|, cached on the cloud (grid.hip)

@@ -60,7 +60,12 @@ int pcr_cloud_clone(pcr_ctx* ctx, const pcr_cloud* src, pcr_cloud** out);
 int pcr_cloud_assign(pcr_ctx* ctx, pcr_cloud* dst, const pcr_cloud* src);   /* dst <- src, same size, on device */
 int pcr_cloud_read(pcr_ctx* ctx, const pcr_cloud* c, float* host_xyz, int layout);
 size_t pcr_cloud_size(const pcr_cloud* c);
+/* synchronises the context's stream, then frees the cloud's HBM (hipFree) — whatever context it is destroyed through */
 int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c);
+/* The ICP loops clone the source into a working copy; that copy's buffer is parked on the context (at most two, each <= 2 GB, replaced
+ * as soon as a call needs another size) so that the next call's clone costs no hipMalloc / hipFree.  pcr_ctx_trim frees what is parked. */
+int pcr_ctx_trim(pcr_ctx* ctx);
+int pcr_ctx_parked_bytes(const pcr_ctx* ctx, uint64_t* bytes);   /* HBM held by those parked buffers right now */
 
 /* ---- A6 (search): 1-NN correspondence, brute force over LDS-tiled targets ----------------------------
  * replaces the loop `for i: tar_mat_index.index->findNeighbors(result_set, query, ...)`,
@@ -72,6 +77,17 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c);
 int pcr_nn1_f32(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, uint32_t* idx, float* d2);
 /* same, results stay in HBM (context workspace) for the Kabsch step; asynchronous on the ctx stream */
 int pcr_nn1_f32_async(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
+/* ---- a caller's OWN loop over the same pair (what the searches inside pcr_icp_p2p_f32 do, one call at a time) --------------------
+ * pcr_cloud_sort_for_target: re-orders `cloud` IN PLACE into the order of the target's index (built if needed), once, before the loop:
+ *   the queries of a wave are then neighbours in space (coalesced loads, shared candidates; at >= 4 M target points the tile search
+ *   needs it).  orig_index (host, n entries, may be NULL) receives, per position of the re-ordered cloud, the index the point had
+ *   before; pcr_kabsch_sums reports `last_kept` in the ORIGINAL numbering for such a cloud (registration.cpp:939's "last pair").
+ *   Moving the cloud with pcr_transform_f32 keeps the order valid; results of pcr_nn1_fetch are in the re-ordered numbering.
+ * pcr_nn1_f32_loop: one search of such a loop — seeded by the previous call's correspondences, and bounded by the gate of
+ *   registration.cpp:936: a pair is only ever kept if d2 < max_corr, so a query with no target inside the gate comes back as
+ *   "none" (idx UINT32_MAX, d2 +inf) instead of with a neighbour the caller would discard.  Same kept pairs, same sums, bit for bit. */
+int pcr_cloud_sort_for_target(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud* cloud, uint32_t* orig_index);
+int pcr_nn1_f32_loop(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr);
 /* fetch the results of the last pcr_nn1_f32_async for n queries */
 int pcr_nn1_fetch(pcr_ctx* ctx, size_t n, uint32_t* idx, float* d2);
 

@@ -54,6 +54,7 @@ def lib():
         L.orc_nn1_tiecount_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p, f32p, sz, u32p]
         L.orc_knn_f64.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_int, i32p, f64p]
         L.orc_radius_f64.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_double, i64p, C.c_void_p, C.c_void_p]
+        L.orc_radius_count_f64_mt.argtypes = [f64p, sz, C.c_int, f64p, sz, C.c_double, i64p, C.c_int]
         L.orc_radius_f32.argtypes = [f32p, sz, C.c_int, f32p, sz, C.c_float, i64p, C.c_void_p, C.c_void_p]
         L.orc_transform_f32.argtypes = [f32p, f32p, f32p, sz, f32p, f32p]
         L.orc_kabsch_accumulate.restype = C.c_int64
@@ -188,6 +189,16 @@ def radius_f64(db, q, r):
     dist = np.empty(max(1, int(row[-1])), np.float64)
     lib().orc_radius_f64(db, db.shape[0], dim, q, m, r, row, idx.ctypes.data, dist.ctypes.data)
     return row, idx[: row[-1]], dist[: row[-1]]
+
+
+def radius_count_f64_mt(db, q, r, threads=8):
+    """row counts only, on host threads (the same comparison pair by pair as radius_f64)"""
+    db = np.ascontiguousarray(db, np.float64)
+    q = np.ascontiguousarray(q, np.float64)
+    m, dim = q.shape
+    cnt = np.empty(m, np.int64)
+    lib().orc_radius_count_f64_mt(db, db.shape[0], dim, q, m, r, cnt, threads)
+    return cnt
 
 
 def radius_f32(db, q, r):

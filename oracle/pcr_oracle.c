@@ -166,6 +166,40 @@ void orc_radius_f64(const double* db, size_t n, int dim, const double* q, size_t
     row_ptr[m] = w;
 }
 
+/* counts only, on host threads: counts[qi] = |{ j : dist(db_j, q_qi) <= r }| — the same comparison, pair by pair, as orc_radius_f64
+ * (the full-size test compares EVERY row count of the 120 000-point scan: 1.44e10 pairs) */
+typedef struct { const double* db; size_t n; int dim; const double* q; size_t b, e; double r; int64_t* counts; } orc_rcount_job;
+static void* orc_rcount_worker(void* p)
+{
+    const orc_rcount_job* jb = (const orc_rcount_job*)p;
+    for (size_t qi = jb->b; qi < jb->e; qi++) {
+        int64_t c = 0;
+        for (size_t j = 0; j < jb->n; j++)
+            c += orc_dist_f64(jb->db + j * (size_t)jb->dim, jb->q + qi * (size_t)jb->dim, jb->dim) <= jb->r;   /* resultSet.hpp:133 */
+        jb->counts[qi] = c;
+    }
+    return NULL;
+}
+
+void orc_radius_count_f64_mt(const double* db, size_t n, int dim, const double* q, size_t m, double r, int64_t* counts, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if ((size_t)threads > m) threads = m ? (int)m : 1;
+    pthread_t th[256];
+    orc_rcount_job job[256];
+    int live[256];
+    for (int t = 0; t < threads; t++) {
+        orc_rcount_job jb = { db, n, dim, q, m * (size_t)t / (size_t)threads, m * (size_t)(t + 1) / (size_t)threads, r, counts };
+        job[t] = jb;
+        live[t] = 0;
+        if (t + 1 < threads) live[t] = pthread_create(&th[t], NULL, orc_rcount_worker, &job[t]) == 0;
+        if (!live[t]) orc_rcount_worker(&job[t]);
+    }
+    for (int t = 0; t < threads; t++)
+        if (live[t]) pthread_join(th[t], NULL);
+}
+
 void orc_radius_f32(const float* db, size_t n, int dim, const float* q, size_t m, float r,
                     int64_t* row_ptr, int32_t* idx, float* dist)
 {

@@ -66,6 +66,8 @@ void orc_knn_f64(const double* db, size_t n, int dim, const double* q, size_t m,
 void orc_radius_f64(const double* db, size_t n, int dim, const double* q, size_t m, double r,
                     int64_t* row_ptr, int32_t* idx, double* dist);
 /* float variant used by Homework7/hw7/src/kdtree.cpp (ElemType float): d = sqrtf(sum) in f32 */
+/* row counts only, on `threads` host threads (same comparison pair by pair) */
+void orc_radius_count_f64_mt(const double* db, size_t n, int dim, const double* q, size_t m, double r, int64_t* counts, int threads);
 void orc_radius_f32(const float* db, size_t n, int dim, const float* q, size_t m, float r,
                     int64_t* row_ptr, int32_t* idx, float* dist);
 

@@ -63,5 +63,42 @@ def test_c5_10M_pair_exact_search_shard_linearity_and_pose(pcr, orc, synth):
             assert np.array_equal(Tw.view(np.uint32), Tt.view(np.uint32)), it
             assert sw["last_pairs"] == stt["last_pairs"] and np.float32(sw["last_loss"]).view(np.uint32) == np.float32(stt["last_loss"]).view(np.uint32)
         ctx.tune("grid_tile", 0)
+        # (7) searches INSIDE a tile-search loop against the reference's own nanoflann (f32, leaf 2: registration.cpp:903-905, compiled from
+        # /root/reference into oracle/_ref; a tree over the full 10 M target): a caller-stepped loop over the sorted working cloud — the
+        # kernels pcr_icp_p2p_f32 launches — and 131 072 sampled queries of its 3rd search (most queries still deferred to the list walk)
+        # and of its 6th (the tile search serves nearly all), index and d2 bits (tie-set rule of SURVEY 7.2)
+        work = cs.clone()
+        orig = ctx.sort_for_target(ct, work)
+        assert np.array_equal(np.sort(orig), np.arange(N, dtype=np.uint32))
+        rng = np.random.default_rng(7)
+        for it in range(6):
+            ctx.nn1_loop(ct, work, 1.0)
+            kern = ctx.mfma_check()["last_nn1_kernel"]
+            assert it < 2 or kern == "grid-tile", (it, kern)
+            if it in (2, 5):
+                idx, d2 = ctx.nn1_fetch(N)
+                cur = work.numpy()
+                sel = np.sort(rng.choice(N, 131072 if orc.have_ref() else 64, replace=False))
+                q = np.ascontiguousarray(cur[:, sel])
+                if orc.have_ref():
+                    ridx, rd2, _, _ = orc.ref_nano_nn1_f32(tgt, q, leaf=2, threads=16)
+                else:
+                    ridx, rd2 = orc.nn1_f32_mt(tgt, q, threads=16)
+                inside = rd2 < np.float32(1.0)                               # the loop's searches are bounded by the gate (:936)
+                assert inside.mean() > 0.99
+                gi, gd = idx[sel], d2[sel]
+                assert (gi[~inside] == 0xFFFFFFFF).all() and np.isinf(gd[~inside]).all()
+                assert np.array_equal(gd[inside].view(np.uint32), rd2[inside].view(np.uint32)), it
+                diff = np.flatnonzero(inside & (gi != ridx))
+                assert (gi[diff] < ridx[diff]).all()                         # a genuine tie: the product returns the lowest index
+                for j in (gi[diff], ridx[diff]):
+                    ex, ey, ez = (q[c, diff] - tgt[c, j] for c in range(3))
+                    assert np.array_equal(((ex * ex + ey * ey) + ez * ez).astype(np.float32).view(np.uint32), gd[diff].view(np.uint32))
+            sums, last, _ = ctx.kabsch_sums(ct, work, 1.0)
+            rc, R, t = pcr.kabsch_solve(sums)
+            assert rc == 0
+            Td = np.eye(4, dtype=np.float32); Td[:3, :3], Td[:3, 3] = R, t
+            ctx.transform(work, Td)
+        work.free()
     finally:
         ctx.close()

@@ -938,6 +938,68 @@ def test_context_owns_its_handles(pcr, synth):
     c.free()
 
 
+def test_working_copies_are_parked_callers_clouds_are_freed(pcr, synth):
+    """only the ICP loops' own working copies are parked on the context (for the next call's clone); a cloud the CALLER
+    destroys goes back to the device at once, parked buffers of another size are dropped by the next allocation, pcr_ctx_trim frees them."""
+    with pcr.Context(0) as ctx:
+        assert ctx.parked_bytes() == 0
+        a, b = ctx.cloud(synth.kitti_like_pair(3001)[0]), ctx.cloud(synth.kitti_like_pair(7777)[0])
+        a.free(); b.free()
+        assert ctx.parked_bytes() == 0                               # odd-sized caller clouds: nothing stays behind
+        src, tgt = synth.kitti_like_pair(5000)
+        cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+        T1, _ = ctx.icp_point2point(cs, ct, max_iter=3)
+        p1 = ctx.parked_bytes()
+        assert 0 < p1 <= 2 * 3 * 4 * (5000 + 2048)                   # the loop's clone and its sorted copy, nothing else
+        T2, _ = ctx.icp_point2point(cs, ct, max_iter=3)              # the reuse path: same buffers, same result
+        assert ctx.parked_bytes() == p1 and np.array_equal(T1.view(np.uint32), T2.view(np.uint32))
+        s2, t2 = synth.kitti_like_pair(9000)
+        c2, d2 = ctx.cloud(s2), ctx.cloud(t2)                        # another size: the stale spares are dropped on the miss
+        assert ctx.parked_bytes() == 0
+        ctx.icp_point2point(c2, d2, max_iter=2)
+        assert 0 < ctx.parked_bytes() <= 2 * 3 * 4 * (9000 + 2048)
+        ctx.trim()
+        assert ctx.parked_bytes() == 0
+
+
+def test_caller_stepped_loop_equals_icp_call(pcr, synth):
+    """pcr_cloud_sort_for_target + pcr_nn1_f32_loop + pcr_kabsch_sums + pcr_kabsch_solve + pcr_transform_f32 stepped by the caller
+    = pcr_icp_p2p_f32, pose bits and kept pairs, with the exact grid and with the exhaustive search (registration.cpp:917-1006)."""
+    for n, method in ((30000, 2), (30000, 1), (3000, 0)):
+        src, tgt = synth.kitti_like_pair(n)
+        with pcr.Context(0) as ctx:
+            ctx.tune("nn_method", method)
+            cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+            T_ref, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=6, eps=0.0)
+            work = cs.clone()
+            orig = ctx.sort_for_target(ct, work)
+            assert np.array_equal(np.sort(orig), np.arange(n, dtype=np.uint32))
+            assert np.array_equal(work.numpy(), src[:, orig])
+            T = np.eye(4, dtype=np.float32)
+            for it in range(6):
+                ctx.nn1_loop(ct, work, 1.0)
+                sums, last, _ = ctx.kabsch_sums(ct, work, 1.0)
+                rc, R, t = pcr.kabsch_solve(sums)
+                assert rc == 0
+                Td = np.eye(4, dtype=np.float32); Td[:3, :3], Td[:3, 3] = R, t
+                T = pcr_mat4(Td, T)
+                ctx.transform(work, Td)
+            assert int(sums[15]) == st["last_pairs"]
+            assert np.array_equal(T.view(np.uint32), T_ref.view(np.uint32)), (n, method)
+
+
+def pcr_mat4(A, B):
+    """T_delta . T_total in f32, row by row as mat4_mul_f32 composes it (registration.cpp:1000-1002)"""
+    out = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            acc = np.float32(0.0)
+            for k in range(4):
+                acc = np.float32(acc + np.float32(A[i, k] * B[k, j]))
+            out[i, j] = acc
+    return out
+
+
 def test_icp_bounded_search_with_outliers(pcr, synth):
     """Partial overlap: 10 % of the source has no target within the max_corres_dist gate.  The grid search bounded by that gate
     (default inside ICP loops), the unbounded exact search and brute force give the same pose bits and statistics."""
