@@ -675,7 +675,7 @@ def grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha):
     ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=3, eps=0.0)
     w = ctx.nn1_stats()
     ctx.tune("grid_stats", 0); ctx.tune("prof", 0)
-    tile = family == "grid-tile"
+    tile = family in ("grid-tile", "grid-stile")
     gpmc = load_pmc("latest_pmc_grid.json", sha)
     if gpmc and (gpmc.get("n") != n_t or n_q != n_t):
         gpmc = None

@@ -716,7 +716,7 @@ __global__ __launch_bounds__(GR_BLOCK, (LIST && !STATS) ? PCR_LIST_WAVES : 1) vo
     unsigned long long* __restrict__ stats, const float* __restrict__ tx, const float* __restrict__ ty,
     const float* __restrict__ tz, uint32_t nt, int warm_start, float cap2,
     uint32_t* __restrict__ far_list, uint32_t* __restrict__ far_count, uint32_t far_cap,
-    uint32_t* __restrict__ wpos, uint32_t xcd_run, const uint32_t* __restrict__ list_count, uint32_t list_segs)
+    uint32_t* __restrict__ wpos, uint32_t xcd_run, const uint32_t* __restrict__ list_count, uint32_t list_segs, uint32_t* __restrict__ list_queue = nullptr)
 {
     // pipelined ICP: once the loop has ended the enqueued tail is a no-op.  The flags are REQUESTED here and tested below, after the
     // query's own loads have been issued: one memory round trip of every launch's serial chain less.
@@ -738,7 +738,21 @@ __global__ __launch_bounds__(GR_BLOCK, (LIST && !STATS) ? PCR_LIST_WAVES : 1) vo
     const uint32_t n_seg = LIST ? (ns + 31u) / 32u : 0u;
     const uint32_t lb = LIST ? ((gridDim.x % 256u == 0u) ? xcd_block(blockIdx.x, 32u) : blockIdx.x) : 0u;
     const uint32_t wv = LIST ? lb * (GR_BLOCK / 64) + (threadIdx.x >> 6) : 0u;
-    const uint32_t seg0 = wv * list_segs, seg1 = min(n_seg, seg0 + list_segs);
+    uint32_t seg0 = wv * list_segs, seg1 = min(n_seg, seg0 + list_segs);
+    // QUEUE form of the list mode (list_queue != nullptr; the sign tile search, grid_stile.hpp): the non-empty segments were appended to
+    // list_queue[2 ...] (their number in [0]) by the waves that deferred them, and a FIXED number of resident waves draw them one by one
+    // through the ticket counter [1] — no workgroup is launched for the empty segments (at the converged pose 0.4 % of the queries are
+    // deferred, yet one workgroup per four segments cost 0.18 ms of a 1.5 ms search), and the load balances itself.  Every wave leaves as
+    // soon as the ticket it draws lies beyond the list: the grid drains.
+    const bool queue = LIST && list_queue != nullptr;
+    for (;;) {
+    if (queue) {
+        uint32_t it = 0;
+        if ((threadIdx.x & 63u) == 0u) it = atomicAdd(&list_queue[1], 1u);
+        it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+        if (it >= min(list_queue[0], n_seg)) break;
+        seg0 = min(list_queue[2 + it], n_seg - 1u); seg1 = seg0 + 1u;
+    }
     for (uint32_t cs = seg0; LIST ? cs < seg1 : true; cs += 64) {
     uint32_t total = 0;
     if (LIST) {
@@ -1022,6 +1036,8 @@ __global__ __launch_bounds__(GR_BLOCK, (LIST && !STATS) ? PCR_LIST_WAVES : 1) vo
         if (!LIST) break;
     }
     if (!LIST) break;
+    }
+    if (!queue) break;
     }
 }
 
@@ -1391,18 +1407,29 @@ static int sort_queries_fine(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
 // Morton key of a point on a lattice of cubic cells over the bounding box (lo, inv = 1024 / longest extent); non-finite points last
 __global__ __launch_bounds__(GR_BLOCK) void bt_keys_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
                                                            float lox, float loy, float loz, float ivx, float ivy, float ivz,
-                                                           unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+                                                           unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, int fine_bits)
 {
     const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float px = x[i], py = y[i], pz = z[i];
-    unsigned long long key = 1ull << 30;
+    unsigned long long key = 1ull << (30 + 3 * fine_bits);
     if (finite3(px, py, pz)) {
-        const uint32_t c[3] = { (uint32_t)fminf(fmaxf((px - lox) * ivx, 0.0f), 1023.0f), (uint32_t)fminf(fmaxf((py - loy) * ivy, 0.0f), 1023.0f),
-                                (uint32_t)fminf(fmaxf((pz - loz) * ivz, 0.0f), 1023.0f) };
+        const float f[3] = { fminf(fmaxf((px - lox) * ivx, 0.0f), 1023.0f), fminf(fmaxf((py - loy) * ivy, 0.0f), 1023.0f), fminf(fmaxf((pz - loz) * ivz, 0.0f), 1023.0f) };
+        const uint32_t c[3] = { (uint32_t)f[0], (uint32_t)f[1], (uint32_t)f[2] };
         key = 0;
         for (int b = 0; b < 10; b++)
             for (int k = 0; k < 3; k++) key |= (unsigned long long)((c[k] >> b) & 1u) << (3 * b + k);
+        if (fine_bits > 0) {
+            // large targets: the position INSIDE the lattice cell refines the order (fine_bits per axis) — a cell of a 10 M-point scan holds
+            // hundreds of points, and runs of 16 records in arrival order are as wide as the cell (their bounding spheres prune nothing)
+            const float sc = (float)(1u << fine_bits);
+            unsigned long long sub = 0;
+            for (int k = 0; k < 3; k++) {
+                const uint32_t s = min((uint32_t)((f[k] - (float)c[k]) * sc), (1u << fine_bits) - 1u);
+                for (int b = 0; b < fine_bits; b++) sub |= (unsigned long long)((s >> b) & 1u) << (3 * b + k);
+            }
+            key = (key << (3 * fine_bits)) | sub;
+        }
     }
     keys[i] = key;
     vals[i] = i;
@@ -1515,7 +1542,145 @@ void bt_free(BtIndex* b)
 {
     if (!b) return;
     if (b->block) hipFree(b->block);
+    if (b->tile_block) hipFree(b->tile_block);
     delete b;
+}
+
+// ---- extras of the sign tile search (grid_stile.hpp)
+// the fine lattice cell of a coordinate exactly as bt_keys_kernel bins it (monotone non-decreasing in v: the box of a pass maps to a cell range)
+__device__ __forceinline__ uint32_t bt_fine_cell(float v, float lo, float inv) { return (uint32_t)fminf(fmaxf((v - lo) * inv, 0.0f), 1023.0f); }
+// 10 bits -> every third bit (bt_keys_kernel's key: bit 3 b + k = bit b of c[k])
+__device__ __forceinline__ uint32_t spread3_10(uint32_t x)
+{
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+__device__ __forceinline__ uint32_t bt_morton(uint32_t cx, uint32_t cy, uint32_t cz) { return spread3_10(cx) | (spread3_10(cy) << 1) | (spread3_10(cz) << 2); }
+// the Morton key a record was sorted by (non-finite records and padding: beyond every cell)
+__device__ __forceinline__ uint32_t bt_record_key(const float4 r, float lox, float loy, float loz, float inv)
+{
+    if (!finite3(r.x, r.y, r.z)) return 1u << 30;
+    return bt_morton(bt_fine_cell(r.x, lox, inv), bt_fine_cell(r.y, loy, inv), bt_fine_cell(r.z, loz, inv));
+}
+
+// counts of the coarse cells from the boundaries of the sorted records: the first record of a cell subtracts its position, the last one adds
+// its position + 1 (two atomics per occupied cell, modulo 2^32); an exclusive scan of the counts is cell_start.  Non-finite records and
+// padding (key 2^30) count into the entry behind the last cell.
+__global__ __launch_bounds__(GR_BLOCK) void bt_cell_count_kernel(const float4* __restrict__ rec, uint32_t n_rec, float lox, float loy, float loz, float inv,
+                                                                 int shift, uint32_t* __restrict__ count)
+{
+    const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (i >= n_rec) return;
+    const uint32_t c = bt_record_key(rec[i], lox, loy, loz, inv) >> shift;
+    const bool first = i == 0 || (bt_record_key(rec[i - 1], lox, loy, loz, inv) >> shift) != c;
+    const bool last = i + 1 == n_rec || (bt_record_key(rec[i + 1], lox, loy, loz, inv) >> shift) != c;
+    if (first) atomicSub(&count[c], i);
+    if (last) atomicAdd(&count[c], i + 1u);
+}
+
+// bounding sphere of every tile of 32 records (centre = middle of the box of its finite members, radius rounded up; no finite member: radius < 0)
+__global__ __launch_bounds__(GR_BLOCK) void bt_tile_spheres_kernel(const float4* __restrict__ records, uint32_t n_tiles, float4* __restrict__ spheres)
+{
+    const uint32_t t = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (t >= n_tiles) return;
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int j = 0; j < 32; j++) {
+        const float4 r = records[(size_t)t * 32 + j];
+        if (finite3(r.x, r.y, r.z)) {
+            mn[0] = fminf(mn[0], r.x); mn[1] = fminf(mn[1], r.y); mn[2] = fminf(mn[2], r.z);
+            mx[0] = fmaxf(mx[0], r.x); mx[1] = fmaxf(mx[1], r.y); mx[2] = fmaxf(mx[2], r.z);
+        }
+    }
+    if (mn[0] > mx[0]) { spheres[t] = make_float4(0.f, 0.f, 0.f, -1.0f); return; }
+    const float cx = 0.5f * mn[0] + 0.5f * mx[0], cy = 0.5f * mn[1] + 0.5f * mx[1], cz = 0.5f * mn[2] + 0.5f * mx[2];
+    float r2 = 0.f;
+    for (int j = 0; j < 32; j++) {
+        const float4 r = records[(size_t)t * 32 + j];
+        if (finite3(r.x, r.y, r.z)) {
+            const float dx = r.x - cx, dy = r.y - cy, dz = r.z - cz;
+            r2 = fmaxf(r2, (dx * dx + dy * dy) + dz * dz);
+        }
+    }
+    spheres[t] = make_float4(cx, cy, cz, sqrtf(r2) * 1.00001f + 1e-30f);    // rounded up (build_spheres_kernel)
+}
+
+__global__ __launch_bounds__(GR_BLOCK) void bt_scatter_gpos_kernel(const float4* __restrict__ grid_rec, uint32_t n_grid, uint32_t n_orig, uint32_t* __restrict__ gpos_of_orig)
+{
+    const uint32_t p = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (p >= n_grid) return;
+    const uint32_t o = __float_as_uint(grid_rec[p].w);
+    if (o < n_orig) gpos_of_orig[o] = p;
+}
+
+__global__ __launch_bounds__(GR_BLOCK) void bt_gather_gpos_kernel(const float4* __restrict__ bt_rec, uint32_t n_bt, uint32_t n_orig, const uint32_t* __restrict__ gpos_of_orig,
+                                                                  uint32_t* __restrict__ g_of_b)
+{
+    const uint32_t p = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (p >= n_bt) return;
+    const uint32_t o = __float_as_uint(bt_rec[p].w);
+    g_of_b[p] = o < n_orig ? gpos_of_orig[o] : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(GR_BLOCK) void bt_invert_gpos_kernel(const uint32_t* __restrict__ g_of_b, uint32_t n_bt, uint32_t n_grid, uint32_t* __restrict__ b_of_g)
+{
+    const uint32_t p = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (p >= n_bt) return;
+    const uint32_t gp = g_of_b[p];
+    if (gp < n_grid) b_of_g[gp] = p;
+}
+
+#include "grid_stile.hpp"
+
+int bt_ensure_tile(pcr_ctx* ctx, const pcr_cloud* tgt)
+{
+    BtIndex* bt = tgt->bt;
+    const Grid* g = tgt->grid;
+    if (!bt || !g || !bt->safe || !bt->n_tiles) return fail(ctx, PCR_ERR_STATE, "bt_ensure_tile: no index");
+    if (bt->tile_block && bt->g_of == g) return PCR_OK;
+    if (bt->tile_block) { PCR_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipFree(bt->tile_block); bt->tile_block = nullptr; bt->g_of = nullptr; }
+    const size_t n = tgt->n, n_pad = bt->n_tiles * 32, n_tiles = bt->n_tiles;
+    // coarse cells: 9 bits per axis (the longest extent / 512: 31 cm on a 160 m scene; 2^27 + 2 table entries, sparsely touched) — tune
+    // grid_stile_cbits 6 .. 9 (measured at 10 M points: 8 bits 2.05 ms per converged search, 9 bits 1.90: a pass tests a third of the tiles)
+    const int cbits = (int)std::min<int64_t>(9, std::max<int64_t>(6, tune_get(ctx, "grid_stile_cbits", 9)));
+    const size_t n_cells = (size_t)1 << (3 * cbits);
+    const size_t off_sph = ((n_cells + 2) * sizeof(uint32_t) + 255) & ~(size_t)255, off_gob = off_sph + ((n_tiles * sizeof(float4) + 255) & ~(size_t)255),
+                 off_bog = off_gob + ((n_pad * sizeof(uint32_t) + 255) & ~(size_t)255),
+                 total = off_bog + ((g->n_chunks * GRID_CHUNK * sizeof(uint32_t) + 255) & ~(size_t)255);
+    const size_t scan_blocks = (n_cells + 2 + SC_TILE - 1) / SC_TILE;
+    int rc = ensure_scratch(ctx, std::max(n * sizeof(uint32_t), (scan_blocks + 1) * sizeof(uint32_t)) + 256);
+    if (rc) return rc;
+    char* blk = nullptr;
+    hipError_t e = hipMalloc((void**)&blk, total);
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "hipMalloc(tile extras)", e);
+    bt->tile_block = blk;
+    bt->cell_start = (uint32_t*)blk; bt->tile_spheres = (float4*)(blk + off_sph); bt->g_of_b = (uint32_t*)(blk + off_gob); bt->b_of_g = (uint32_t*)(blk + off_bog);
+    bt->cbits = cbits;
+    e = hipMemsetAsync(bt->cell_start, 0, (n_cells + 2) * sizeof(uint32_t), ctx->stream);
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "tile extras", e);
+    hipLaunchKernelGGL(bt_cell_count_kernel, dim3((unsigned)((n_pad + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_pad,
+                       bt->key_lo[0], bt->key_lo[1], bt->key_lo[2], bt->key_inv, 3 * (10 - cbits), bt->cell_start);
+    uint32_t* totals = (uint32_t*)ctx->scratch;
+    rc = exclusive_scan_u32(ctx, bt->cell_start, bt->cell_start, n_cells + 2, totals, totals + scan_blocks);
+    if (rc) return rc;
+    uint32_t* gpos = (uint32_t*)ctx->scratch;                 // (stream order: the scan is done with the scratch before the scatter writes it)
+    hipLaunchKernelGGL(bt_tile_spheres_kernel, dim3((unsigned)((n_tiles + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_tiles,
+                       bt->tile_spheres);
+    const size_t n_grid = g->n_chunks * GRID_CHUNK;           // (the grid's records are padded to whole runs)
+    hipLaunchKernelGGL(bt_scatter_gpos_kernel, dim3((unsigned)((n_grid + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, g->records, (uint32_t)n_grid,
+                       (uint32_t)n, gpos);
+    hipLaunchKernelGGL(bt_gather_gpos_kernel, dim3((unsigned)((n_pad + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_pad,
+                       (uint32_t)n, gpos, bt->g_of_b);
+    e = hipMemsetAsync(bt->b_of_g, 0xFF, n_grid * sizeof(uint32_t), ctx->stream);
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "tile extras", e);
+    hipLaunchKernelGGL(bt_invert_gpos_kernel, dim3((unsigned)((n_pad + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->g_of_b, (uint32_t)n_pad,
+                       (uint32_t)n_grid, bt->b_of_g);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "tile extras", e);
+    bt->g_of = g;
+    return PCR_OK;
 }
 
 int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt)
@@ -1530,8 +1695,13 @@ int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt)
     const size_t off_cen = n_pad * sizeof(float4), off_ops = off_cen + ((n_super * sizeof(float4) + 255) & ~(size_t)255),
                  off_o16 = off_ops + n_tiles * 128 * sizeof(uint4), off_bb = off_o16 + n_tiles * 64 * sizeof(uint4),
                  off_flag = off_bb + ((bb_blocks * 6 * sizeof(float) + 255) & ~(size_t)255), total = off_flag + 256;
+    // order inside a lattice cell: arrival order below 1 M points (a cell holds a few points at most), a 6-bit-per-axis Morton code of
+    // the position inside the cell from there on (tune bt_fine_bits: 0 auto, 1 .. 7 bits, -1 none)
+    int64_t fb_tune = tune_get(ctx, "bt_fine_bits", 0);
+    const int fine_bits = fb_tune < 0 ? 0 : fb_tune > 0 ? (int)std::min<int64_t>(fb_tune, 7) : (n >= ((size_t)1 << 20) ? 6 : 0);
+    const int key_bits = 31 + 3 * fine_bits;
     size_t temp_bytes = 0;
-    sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, 31, ctx->stream);
+    sort_pairs_u64_u32(nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, key_bits, ctx->stream);
     const size_t a4 = (n * 4 + 255) & ~(size_t)255, a8 = (n * 8 + 255) & ~(size_t)255;
     int rc = ensure_scratch(ctx, 2 * a8 + 2 * a4 + temp_bytes + 256);
     if (rc) { delete bt; return rc; }
@@ -1575,8 +1745,8 @@ int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt)
         uint32_t* v_out = (uint32_t*)(sc + 2 * a8 + a4);
         char* temp = sc + 2 * a8 + 2 * a4;
         hipLaunchKernelGGL(bt_keys_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(), (uint32_t)n,
-                           lo[0], lo[1], lo[2], iv[0], iv[1], iv[2], k_in, v_in);
-        e = sort_pairs_u64_u32(temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, 31, ctx->stream);
+                           lo[0], lo[1], lo[2], iv[0], iv[1], iv[2], k_in, v_in, fine_bits);
+        e = sort_pairs_u64_u32(temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, key_bits, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)((n_pad + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, tgt->x(), tgt->y(), tgt->z(),
                                (uint32_t)n, (uint32_t)n_pad, v_out, bt->records);
@@ -1715,7 +1885,7 @@ int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, 
     if (rc) return rc;
     const unsigned blocks = (unsigned)((n + GR_BLOCK - 1) / GR_BLOCK);
     hipLaunchKernelGGL(bt_keys_kernel, dim3(blocks), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), (uint32_t)n, bt->key_lo[0], bt->key_lo[1],
-                       bt->key_lo[2], bt->key_inv, bt->key_inv, bt->key_inv, k_in, v_in);
+                       bt->key_lo[2], bt->key_inv, bt->key_inv, bt->key_inv, k_in, v_in, 0);
     hipError_t e = sort_pairs_u64_u32(temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, 31, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(permute_cloud_kernel, dim3(blocks), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), v_out, (uint32_t)n, sorted->x(), sorted->y(),
@@ -1842,7 +2012,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     if (mode == 2 && warm == 3 && sorted && !perm && wpos && cap2 < __builtin_inff() && tile_tune != 2 && (tile_tune == 1 || (tgt->n >= 4000000 && dense))) {
         // the segmented list of deferred queries: 32 slots per group of 32 queries + one count per group (far_list is free here: the
         // hand-off of far queries to the exhaustive kernel only exists for unbounded searches)
-        const size_t n_groups_sz = (ns + 31) / 32, need = n_groups_sz * 32 + n_groups_sz;
+        const size_t n_groups_sz = (ns + 31) / 32, need = n_groups_sz * 32 + n_groups_sz + (n_groups_sz + 2);     // (+ the queue of non-empty segments)
         if (ctx->far_cap < need) {
             if (ctx->far_list) { PCR_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->far_list); ctx->far_list = nullptr; ctx->far_cap = 0; }
             PCR_HIP(ctx, hipMalloc((void**)&ctx->far_list, (need + 1) * sizeof(uint32_t)));
@@ -1850,21 +2020,77 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         }
         uint32_t* dlist = ctx->far_list;
         uint32_t* dcount = ctx->far_list + n_groups_sz * 32;
-        const float bmax = (float)tune_get(ctx, "grid_tile_bmax_pct", 400) * 0.01f * g->p.h;
         const float lim_k = (float)tune_get(ctx, "grid_tile_lim_pct", 1000) * 0.01f, reach_k = (float)tune_get(ctx, "grid_tile_reach_pct", 200) * 0.01f;
+        const uint32_t min_members = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, tune_get(ctx, "grid_tile_min_members", 8)));
+        const uint32_t n_groups = (uint32_t)((ns + 31) / 32);
+        const uint32_t list_segs = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, tune_get(ctx, "grid_tile_list_segs", 1)));
+        const unsigned lblocks = (unsigned)(((n_groups_sz + (size_t)list_segs * 4 - 1) / ((size_t)list_segs * 4) + 255) / 256 * 256);      // (whole XCD runs)
+        // SIGN TILE SEARCH (grid_stile.hpp, round 4; tune grid_stile: 0 auto = on where the f16 matrix pipe passed the device check and the
+        // target's Morton-ordered index fits f16, 2 = the round-3 tile kernel): one wave per 64 consecutive queries, the candidate tiles
+        // of the target's matrix-core index found through coarse Morton cells and run spheres, one MFMA per tile and 32 queries whose
+        // SIGN says whether a record can matter.  Knobs: grid_stile_bmax_cm (largest ball of a served query, default 60), grid_stile_keep (candidate
+        // tiles a pass may keep, 768), grid_stile_cells (coarse cells a pass may open, 512), grid_stile_flush / grid_stile_dense (STRACK's list rules, 64 / 12).
+        bool stile = tune_get(ctx, "grid_stile", 0) != 2 && mfma_verdict(ctx, true);
+        if (stile) {
+            rc = bt_ensure(ctx, tgt);
+            if (rc) return rc;
+            BtIndex* bt = tgt->bt;
+            stile = bt && bt->safe && bt->n_tiles;
+            if (stile && bt->bad16_host < 0) {
+                int flag = 1;
+                PCR_HIP(ctx, hipMemcpyAsync(&flag, bt->bad16, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                bt->bad16_host = flag;
+            }
+            stile = stile && bt->bad16_host == 0;
+            if (stile && (rc = bt_ensure_tile(ctx, tgt))) return rc;
+        }
+        if (stile) {
+            const BtIndex* bt = tgt->bt;
+            const float sbmax = (float)tune_get(ctx, "grid_stile_bmax_cm", 60) * 0.01f;
+            const uint32_t skeep = (uint32_t)std::min<int64_t>(SL_KEEP, std::max<int64_t>(2, tune_get(ctx, "grid_stile_keep", SL_KEEP)));
+            const uint32_t scells = (uint32_t)std::min<int64_t>(1 << 15, std::max<int64_t>(1, tune_get(ctx, "grid_stile_cells", 512)));
+            const uint32_t sflush = (uint32_t)std::min<int64_t>(SL_CAP, std::max<int64_t>(1, tune_get(ctx, "grid_stile_flush", 64)));
+            const uint32_t sdense = (uint32_t)std::min<int64_t>(65, std::max<int64_t>(1, tune_get(ctx, "grid_stile_dense", 12)));
+            const float ssplit = (float)tune_get(ctx, "grid_stile_split_mm", 40) * 0.001f;     // largest ball of a pass from which its near tiles go first
+            const uint32_t n_waves = (uint32_t)((ns + 63) / 64);
+            size_t sblocks = (n_waves + (GR_BLOCK / 64) - 1) / (GR_BLOCK / 64);
+            int64_t srun = tune_get(ctx, "grid_xcd_run", 0);
+            if (srun == 0) srun = sblocks >= 4096 ? 32 : -1;
+            uint32_t sxcd = 0;
+            if (srun > 0) { sxcd = (uint32_t)srun; const size_t unit = 8 * (size_t)sxcd; sblocks = (sblocks + unit - 1) / unit * unit; }
+            ctx->last_nn1_kernel = "grid-stile";
+            // the list walk draws the non-empty segments from a queue (tune grid_stile_queue: 2 = one workgroup per four segments as before);
+            // grid_stile_list_wgs resident workgroups serve it (default 8 per CU)
+            uint32_t* lqueue = tune_get(ctx, "grid_stile_queue", 1) == 1 ? dcount + n_groups_sz : nullptr;
+            const unsigned qblocks = (unsigned)std::min<int64_t>(65535, std::max<int64_t>(1, tune_get(ctx, "grid_stile_list_wgs", 8 * (int64_t)ctx->prop.multiProcessorCount)));
+            const unsigned lblocks_s = lqueue ? qblocks : lblocks;
+            const uint32_t list_segs_s = lqueue ? 1u : list_segs;
+            if (lqueue) PCR_HIP(ctx, hipMemsetAsync(lqueue, 0, 2 * sizeof(uint32_t), ctx->stream));
+            ProfScope p(ctx, "nn1_grid", 1);
+#define PCR_STILE(ST)                                                                                                                       \
+    hipLaunchKernelGGL((nn1_stile_kernel<ST>), dim3((unsigned)sblocks), dim3(GR_BLOCK), 0, ctx->stream, bt->records, bt->ops16, bt->centres,           \
+                       bt->tile_spheres, bt->cell_start, bt->g_of_b, bt->b_of_g, g->records, (uint32_t)(g->n_chunks * GRID_CHUNK), bt->key_lo[0], bt->key_lo[1], \
+                       bt->key_lo[2], bt->key_inv, 3 * (10 - bt->cbits), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev,    \
+                       stats_dev, cap2, wpos, dlist, dcount, lqueue, sxcd, sbmax, n_waves, n_groups, lim_k, reach_k, skeep, scells, min_members, sflush, sdense, ssplit, (uint32_t)(bt->n_tiles / 8)); \
+    hipLaunchKernelGGL((nn1_grid_kernel<16, ST, 2, true>), dim3(lblocks_s), dim3(GR_BLOCK), 0, ctx->stream, g->records, g->spheres, g->cell_start, g->p,   \
+                       src->x(), src->y(), src->z(), (const uint32_t*)dlist, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(),     \
+                       tgt->y(), tgt->z(), (uint32_t)tgt->n, 3, cap2, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, wpos, 0u, (const uint32_t*)dcount, list_segs_s, lqueue)
+            if (stats_dev) { PCR_STILE(true); } else { PCR_STILE(false); }
+#undef PCR_STILE
+            PCR_HIP(ctx, hipGetLastError());
+            return PCR_OK;
+        }
+        const float bmax = (float)tune_get(ctx, "grid_tile_bmax_pct", 400) * 0.01f * g->p.h;
         const uint32_t keep_max = (uint32_t)std::min<int64_t>(TL_KEEP, std::max<int64_t>(2, tune_get(ctx, "grid_tile_keep", 512)));
         // (the filter of large passes runs on the f16 matrix pipe: only where this device's arithmetic passed the library's own check)
         const int use_filter = (tune_get(ctx, "grid_tile_filter", 1) == 1 && mfma_verdict(ctx, true)) ? 1 : 0;
-        const uint32_t min_members = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, tune_get(ctx, "grid_tile_min_members", 8)));
         const uint32_t total_mult = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, tune_get(ctx, "grid_tile_total_mult", 16)));
-        const uint32_t n_groups = (uint32_t)((ns + 31) / 32);
         size_t tblocks = (n_groups + (GR_BLOCK / 64) - 1) / (GR_BLOCK / 64);
         int64_t trun = tune_get(ctx, "grid_xcd_run", 0);
         if (trun == 0) trun = tblocks >= 4096 ? 32 : -1;
         uint32_t txcd = 0;
         if (trun > 0) { txcd = (uint32_t)trun; const size_t unit = 8 * (size_t)txcd; tblocks = (tblocks + unit - 1) / unit * unit; }
-        const uint32_t list_segs = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, tune_get(ctx, "grid_tile_list_segs", 1)));
-        const unsigned lblocks = (unsigned)(((n_groups_sz + (size_t)list_segs * 4 - 1) / ((size_t)list_segs * 4) + 255) / 256 * 256);      // (whole XCD runs)
         ctx->last_nn1_kernel = "grid-tile";
         {
             ProfScope p(ctx, "nn1_grid", 1);

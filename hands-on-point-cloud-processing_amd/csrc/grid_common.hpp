@@ -95,6 +95,18 @@ struct BtIndex {
     size_t n_tiles = 0;
     float key_lo[3] = { 0.f, 0.f, 0.f }, key_inv = 0.f;   // the lattice of the Morton keys the records are ordered by (bt_sort_working_cloud)
     bool safe = false;                // every finite coordinate below 5e17 in magnitude (and at least one finite point)
+    // ---- extras of the SIGN TILE SEARCH of large-target loops (grid_stile.hpp; built on first use by bt_ensure_tile, one more allocation):
+    // cell_start[c] = first record whose Morton key, cut to cbits bits per axis, is >= c (2^(3 cbits) + 1 entries: the records of coarse
+    // cell c are [cell_start[c], cell_start[c + 1]), non-finite records and padding lie behind the last entry); tile_spheres = bounding
+    // sphere of every tile of 32 records (radius < 0 = no finite member); g_of_b[p] = position of record p in the
+    // records of the cell grid `g_of` (the winner positions of a loop — ctx->wpos — stay in that numbering for the walk and the Kabsch pass)
+    void* tile_block = nullptr;
+    uint32_t* cell_start = nullptr;
+    int cbits = 0;
+    float4* tile_spheres = nullptr;
+    uint32_t* g_of_b = nullptr;
+    uint32_t* b_of_g = nullptr;       // ... and the inverse (0xFFFFFFFF: a padding record of the grid)
+    const Grid* g_of = nullptr;
 };
 // HTRACK operand helpers (device): v ~ p1 + p2 in f16 (round toward zero, then the remainder), and the 16 bytes a lane holds for
 // target row t'' (already scaled): lanes < 32  [x: t1 t2 t1 t2 | y: t1 t2 t1 t2],  lanes >= 32  [z: t1 t2 t1 t2 | w1 w2 0 0]
@@ -211,6 +223,8 @@ __device__ __forceinline__ void st_setup(float qx, float qy, float qz, const flo
 void bt_free(BtIndex* b);
 // builds (and caches on tgt) the index if it is not there yet
 int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt);
+// ... and the extras of the sign tile search (needs tgt->grid and a safe tgt->bt; rebuilt when the grid changed)
+int bt_ensure_tile(pcr_ctx* ctx, const pcr_cloud* tgt);
 // builds (and caches on tgt) the 1-NN grid if needed, then groups the queries `src` by coarse cell -> ctx->qperm
 int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
 // replaces *work by its cell-sorted copy (ctx->work_orig = original indices); no-op for empty clouds / tune grid_sort_work = 2

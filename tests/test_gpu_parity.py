@@ -488,9 +488,12 @@ def test_icp_sphere_walk_gate_as_bound_and_any_working_order(ctx, synth, n):
     cs.free(); ct.free(); cm.free()
 
 
+@pytest.mark.parametrize("flavour", ["stile", "tile"])
 @pytest.mark.parametrize("n", [30000, 200000])
-def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n):
-    """The tile search of the large-target loops (csrc/grid_tile.hpp: one wave per 32 consecutive queries of the sorted working cloud,
+def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n, flavour):
+    """flavour "stile": the SIGN tile search (csrc/grid_stile.hpp, round 4: 64 queries per wave over the target's Morton-ordered matrix-core
+    index, the sign form of the f16 filter); "tile": round 3's tile kernel (tune grid_stile = 2).
+    The tile search of the large-target loops (csrc/grid_tile.hpp: one wave per 32 consecutive queries of the sorted working cloud,
     far queries deferred to the cell walk in list mode), forced onto small pairs: pose bits, pair count and loss of every iteration
     count, gate and ball limit equal the exhaustive search's — with non-finite, far-away, gated-out and duplicated points in the
     clouds, and with the limits so tight that whole groups overflow a wave and take the deferral path."""
@@ -508,10 +511,21 @@ def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n):
         for it in its:
             ref[gate, it] = ctx.icp_point2point(cs, ct, max_corr=gate, max_iter=it, eps=0.0)
     ctx.tune("nn_method", 2); ctx.tune("grid_order", 2); ctx.tune("grid_mode", 3); ctx.tune("grid_tile", 1)
+    ctx.tune("grid_stile", 2 if flavour == "tile" else 0)
     cm = ctx.cloud(tgt)                                    # a fresh cloud: its index is built Morton-ordered
     used = set()
-    for bmax, pipe in ((0, 0), (5, 0), (150, 0), (400, -1), (50, 1)):
-        ctx.tune("grid_tile_bmax_pct", bmax); ctx.tune("icp_pipeline", pipe)
+    # (ball limit, loop, extra knobs): for the sign tile search also lists flushed after every entry / chunks always evaluated in place /
+    # never in place, passes limited to 2 tiles or 1 coarse cell (whole waves overflow and take the deferral path), coarser / finer cells
+    arms = ((0, 0, {}), (5, 0, {}), (150, 0, {}), (400, -1, {}), (50, 1, {}))
+    if flavour == "stile":
+        arms = ((0, 0, {}), (1, 0, {}), (30, 0, {"grid_stile_flush": 1}), (200, -1, {"grid_stile_dense": 1}), (10, 1, {"grid_stile_dense": 65}),
+                (100, 0, {"grid_stile_keep": 2}), (100, 0, {"grid_stile_cells": 1}), (300, 0, {"grid_stile_cells": 4096, "grid_tile_min_members": 1}),
+                (20, 0, {"grid_stile_queue": 2}), (20, 0, {"grid_stile_list_wgs": 1}), (60, 0, {"grid_stile_split_mm": 1}))
+    for bmax, pipe, extra in arms:
+        ctx.tune("grid_stile_bmax_cm" if flavour == "stile" else "grid_tile_bmax_pct", bmax); ctx.tune("icp_pipeline", pipe)
+        for k in ("grid_stile_flush", "grid_stile_dense", "grid_stile_keep", "grid_stile_cells", "grid_tile_min_members", "grid_stile_queue", "grid_stile_list_wgs",
+                  "grid_stile_split_mm"):
+            ctx.tune(k, extra.get(k, 0))
         for gate in gates:
             for it in its:
                 T, st = ctx.icp_point2point(cs, cm, max_corr=gate, max_iter=it, eps=0.0)
@@ -522,10 +536,12 @@ def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n):
                 for k in ("iters_run", "last_pairs", "empty_pairs"):
                     assert st[k] == r[1][k], (k, bmax, pipe, gate, it)
                 assert np.float32(st["last_loss"]).view(np.uint32) == np.float32(r[1]["last_loss"]).view(np.uint32)
-    assert used == {"grid-tile"}, used
+    assert used == {"grid-stile" if flavour == "stile" else "grid-tile"}, used
     # the exits of the state machine with the tile search's two launches in the enqueued tail: convergence at the 16th iteration
     # (registration.cpp:948-958 with eps large), no pair at all (the loop stops at once), max_iter 0
-    ctx.tune("grid_tile_bmax_pct", 0)
+    for k in ("grid_tile_bmax_pct", "grid_stile_bmax_cm", "grid_stile_flush", "grid_stile_dense", "grid_stile_keep", "grid_stile_cells", "grid_tile_min_members",
+              "grid_stile_queue", "grid_stile_list_wgs", "grid_stile_split_mm"):
+        ctx.tune(k, 0)
     for pipe in (0, -1):
         ctx.tune("icp_pipeline", pipe)
         for kw in (dict(max_corr=1.0, max_iter=40, eps=1e30), dict(max_corr=1e-12, max_iter=9, eps=0.0), dict(max_corr=1.0, max_iter=0, eps=0.0)):
@@ -546,7 +562,7 @@ def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n):
     w = ctx.nn1_stats()
     ctx.tune("grid_stats", 0)
     assert w[0] > 0 and w[6] < n, w                       # (sparse clouds: balls of the size of a cell — most queries take the walk at 30 000 points)
-    for k in ("nn_method", "grid_order", "grid_mode", "grid_tile", "grid_tile_bmax_pct", "icp_pipeline"):
+    for k in ("nn_method", "grid_order", "grid_mode", "grid_tile", "grid_tile_bmax_pct", "icp_pipeline", "grid_stile"):
         ctx.tune(k, 0)
     cs.free(); ct.free(); cm.free(); ca.free()
 

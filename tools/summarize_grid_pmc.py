@@ -15,7 +15,7 @@ SKIP = 2          # the index-building one-shot search and the cold first search
 
 
 def kind(name):
-    if "nn1_tile_kernel" in name:
+    if "nn1_tile_kernel" in name or "nn1_stile_kernel" in name:
         return "tile"
     if "nn1_grid_kernel" in name:
         return "list" if ", true>" in name.split("(")[0] else "walk"
