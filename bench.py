@@ -47,7 +47,8 @@ VALU_PEAK_TOPS_NOFMA = 78.6     # the same issue rate counted one op per lane-sl
 HBM_PEAK_GBS = 8000.0
 OPS_PER_PAIR = 9                # 3 sub + 3 mul + 2 add + 1 compare per (query, target) pair — the exact kernel's work
 ETRACK_FLOPS_PER_PAIR = 6       # the f32 filter's algorithm: 3 FMAs per (query, target) pair (csrc/nn1_brute.hip, ETRACK)
-STRACK_FLOPS_PER_PAIR = 32      # the sign form of the f16 filter: all 16 K-slots carry data (HTRACK's 14 + the two pieces of the query's threshold)
+STRACK_FLOPS_PER_PAIR = 28      # the sign form of the f16 filter: the same 14 data products as HTRACK (the two K-slots that carry the query's threshold are
+                                # bookkeeping, not data: they count under executed_slots — ADVICE r3: keeps roofline.frac comparable with round 2's)
 HTRACK_FLOPS_PER_PAIR = 28      # the f16 filter's algorithm: 14 f16 multiply-adds per pair that carry data (3 coordinates x 4 piece products + 2 pieces of
                                 # |t''|^2) of the 16 K-slots ONE v_mfma_f32_32x32x16_f16 provides (csrc/nn1_brute.hip, HTRACK)
 BTRACK_FLOPS_PER_PAIR = 54      # the bf16 filter's algorithm: 27 bf16 multiply-adds per pair that carry data (3 coordinates x 8 piece products + 3 pieces
@@ -162,6 +163,11 @@ def main():
                          "GPUs (strong scaling), brute force; c5 (configs[4]): ONE 10M x 10M pair, sources sharded, exact grid; "
                          "c4 (configs[3]): 80-hypothesis plane count + radius-NN r = 1 on the 120k scan (one GPU)")
     ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl")
+    ap.add_argument("--shard", choices=["spatial", "contiguous"], default="spatial",
+                    help="N > 1: how the sources of the ONE pair are dealt to the ranks.  spatial (default): pcr_cloud_shard_spatial — the cloud in the "
+                         "order of the target's index cut into 64 runs per rank, dealt round-robin (every rank keeps the scene's local density); "
+                         "contiguous: blocks of the caller's (shuffled) order, pcr_shard_range.  Same pose bits either way (exact sums)")
+    ap.add_argument("--no-predict", action="store_true", help="skip the one-GPU shard timings behind predicted_scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the configs[3] block of the default line")
     ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] block of the default line")
@@ -288,6 +294,55 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def shard_of(full_np, ct):
+        """this rank's sources of the ONE pair: (device cloud, host copy of it)"""
+        if world == 1:
+            return ctx.cloud(full_np), full_np
+        if args.shard == "contiguous":
+            b, e = pcr.shard_range(full_np.shape[1], world, rank)
+            part = np.ascontiguousarray(full_np[:, b:e])
+            return ctx.cloud(part), part
+        full = ctx.cloud(full_np)
+        sh = ctx.shard_spatial(ct, full, world, rank)
+        full.free()
+        return sh, sh.numpy()
+
+    def predicted_scaling(full_np, ct, method, iters, T_final, counts=(2, 4, 8)):
+        """What ONE rank of an N-rank strong-scaling run has to do, timed on THIS GPU for every rank's shard (no collective: the message is
+        <= 832 B, latency-bound): ms per iteration of an `iters`-iteration ICP from the start pose (wall, no event pairs), and the steady
+        search at the final pose (HIP events).  predicted efficiency = T_1 / (N x the slowest rank's T) — the figure the driver's 8-GPU run
+        is to be held against; the all-reduce (~25 us per iteration) is NOT in it."""
+        def measure(cloud):
+            ctx.tune("nn_method", method); ctx.tune("prof", 0)
+            ctx.icp_point2point(cloud, ct, max_corr=1.0, max_iter=2, eps=0.0)
+            best = None
+            for _ in range(3):
+                ctx.sync(); t0 = time.perf_counter()
+                ctx.icp_point2point(cloud, ct, max_corr=1.0, max_iter=iters, eps=0.0)
+                dt = (time.perf_counter() - t0) * 1e3 / iters
+                best = dt if best is None else min(best, dt)
+            ctx.tune("prof", 1); ctx.prof_reset()
+            ctx.icp_point2point(cloud, ct, init_T=T_final, max_corr=1.0, max_iter=8, eps=0.0)
+            each = np.concatenate([ctx.prof_get_each("nn1_brute"), ctx.prof_get_each("nn1_grid")])
+            ctx.tune("prof", 0)
+            return best, float(each[2:].mean()) if each.size > 2 else float("nan")
+        full = ctx.cloud(full_np)
+        t1, s1 = measure(full)
+        out = {"iterations": iters, "one_rank": {"ms_per_iteration": t1, "steady_search_ms": s1}, "sharding": "spatial (pcr_cloud_shard_spatial, 64 runs per rank)",
+               "note": "every rank's shard of the ONE pair run on this one GPU, one after the other; efficiency = T_1 / (N x slowest rank); the "
+                       "per-iteration all-reduce (56 + 2N f64, latency-bound) is not included; no multi-GPU hardware was involved"}
+        for N in counts:
+            per, srch, sizes = [], [], []
+            for r in range(N):
+                sh = ctx.shard_spatial(ct, full, N, r)
+                a, b = measure(sh)
+                per.append(a); srch.append(b); sizes.append(len(sh))
+                sh.free()
+            out[str(N)] = {"ms_per_iteration_slowest_rank": max(per), "ms_per_iteration_by_rank": per, "efficiency": t1 / (N * max(per)),
+                           "steady_search_ms_slowest_rank": max(srch), "steady_search_efficiency": s1 / (N * max(srch)), "points_by_rank": sizes}
+        full.free()
+        return out
+
     def prepare(cs, ct, method, src_np):
         """one-time preparation, whatever --warmup says: the index over the (replicated) target and the code objects of every kernel
         of the loop — a 2-iteration ICP of a small slice of this rank's sources; initialisation, not a step"""
@@ -353,9 +408,10 @@ def main():
     if args.workload == "c2":
         n = args.points or 120000
         full_src, tgt = synth.kitti_like_pair(n)
-        b, e = pcr.shard_range(n, world, rank)
-        src = np.ascontiguousarray(full_src[:, b:e])
-        cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+        ct = ctx.cloud(tgt)
+        ctx.tune("nn_method", 2)                                  # (the shard plan orders the sources by the target's cell index, whatever search follows)
+        cs, src = shard_of(full_src, ct)
+        ctx.tune("nn_method", 0)
         main_method = 1 if args.nn == "brute" else 2
         T, st, dt = timed_icp(cs, ct, main_method, src)
         nn_name = "nn1_brute" if args.nn == "brute" else "nn1_grid"
@@ -479,6 +535,8 @@ def main():
                     "scaling": "weak", "n_src_per_rank": n, "note": "every rank owns a different 120k-point shard of the source scan, target replicated"}
             cw.free()
 
+        # what the 1 / 2 / 4 / 8 reading of the metric should show: every rank's shard timed on this one GPU (world == 1 only: no collective inside)
+        pred_c2 = predicted_scaling(full_src, ct, main_method, args.steps, T) if (extras and world == 1 and not args.no_predict) else None
         # (grid_roofline runs ICP loops — collectives under world > 1 — so EVERY rank calls it, not only the one that prints)
         groof_c2 = grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha) if args.nn == "grid" else None
         if rank == 0:
@@ -527,8 +585,8 @@ def main():
                                 "branch-free; only the winning chunk is evaluated with the exact unfused arithmetic; the previous correspondence of "
                                 "each query, re-evaluated exactly, seeds the bound)")) if default_kernels else f"nn1 variant={args.variant}",
                     "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
-                    "algorithmic": ((f"{flops_pp} f16 flop per (query, target) pair (all 16 K-slots of the one MFMA carry data: 14 piece products + the two "
-                                     f"pieces of the threshold) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16.  Per 1024 pairs: one MFMA "
+                    "algorithmic": ((f"{flops_pp} f16 flop per (query, target) pair (the 14 piece products that carry data; the two K-slots with the "
+                                     f"pieces of the query's threshold count under executed_slots) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16.  Per 1024 pairs: one MFMA "
                                      "(32 cycles of the SIMD's matrix pipe) and 13 vector instructions all told (PMC SQ_INSTS_VALU / SQ_INSTS_MFMA: 8 v_or3_b32 in the tile "
                                      "loop, 3 of the operand setup per super-tile, the rest prologue / lists); the two pipes share the SIMD's issue port, so the "
                                      "launch is issue-bound, not matrix-bound (DESIGN.md 5, profiles/r03_ubench_sign_filter.txt)")
@@ -587,7 +645,8 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": workload, "nn": args.nn, "n_src_this_rank": n_q, "n_src_total": n, "n_tgt": n_t, "max_corr": 1.0,
-                           "sharding": f"sources x{world} (contiguous blocks of the ONE pair), target replicated", "collective": collective,
+                           "sharding": f"sources x{world} ({'spatial: pcr_cloud_shard_spatial, 64 runs of the index-ordered cloud per rank dealt round-robin' if args.shard == 'spatial' else 'contiguous blocks of the ONE pair: pcr_shard_range'}), target replicated",
+                           "collective": collective,
                            "pose_err_vs_gt_fro": gt_err, "kept_pairs_last_iter": int(st["last_pairs"]), "lib_sha16": sha,
                            "first_timed_iteration": "seeded by the warm-up run's correspondences (as every iteration after the first of an ICP is)",
                            "M_corr_per_s_three_readings": ({"warm_icp_iteration (= value)": n * args.steps / dt / 1e6,
@@ -598,6 +657,10 @@ def main():
                 "roofline": roofline,
                 "kernels": dict(({"nn1_exact_track": exact_line} if exact_line else {}), **stream_kernels(bd, n_q, int(st["last_pairs"]) * n_q // max(n, 1))),
             }
+            # the fixed tail of an iteration (sums + solve + move + the bench's own event pairs): what caps strong scaling on a small pair
+            out["tail_us_per_iteration"] = (dt * 1e3 / args.steps - kern_s * 1e3) * 1e3
+            if pred_c2 is not None:
+                out["predicted_scaling"] = pred_c2
             if one_shot:
                 out["one_shot"] = one_shot
             if grid_extra is not None:
@@ -621,10 +684,9 @@ def main():
     if args.workload == "c5" or (args.workload == "c2" and not args.no_c5 and not args.no_extras):
         n5 = (args.points or 10_000_000) if args.workload == "c5" else args.c5_points
         full_src, tgt = synth.kitti_like_pair(n5)
-        b, e = pcr.shard_range(n5, world, rank)
-        src = np.ascontiguousarray(full_src[:, b:e])
-        del full_src
-        cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+        ct = ctx.cloud(tgt)
+        ctx.tune("nn_method", 2)
+        cs, src = shard_of(full_src, ct)
         steps5 = args.steps if args.workload == "c5" else min(args.steps, 10)
         warm5 = args.warmup if args.workload == "c5" else min(args.warmup, 2)
         T, st, dt = timed_icp(cs, ct, 2, src, prof=1, steps=steps5, warmup=warm5)
@@ -633,6 +695,8 @@ def main():
         bd = kernel_breakdown(cs, ct, 2, min(steps5, 5))
         n_q, n_t = src.shape[1], tgt.shape[1]
         groof = grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha)      # (every rank: its ICP loops are collective)
+        pred_c5 = predicted_scaling(full_src, ct, 2, 20, T) if (world == 1 and not args.no_predict) else None
+        del full_src
         if rank == 0:
             c5 = {"metric": METRIC, "value": n5 * steps5 / dt / 1e6, "unit": "M corr/s", "icp_iter_per_s": steps5 / dt, "n_gpus": world, "steps": steps5,
                   "warmup": warm5, "ms_per_step": dt * 1e3 / steps5, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
@@ -640,12 +704,14 @@ def main():
                   "config": {"workload": f"point-to-point ICP iteration on ONE {n_t} x {n5} pair = exact grid 1-NN + Kabsch + transform; BASELINE.json "
                                          "configs[4] (sources sharded over the GPUs, one all-reduce of 56 + 2N f64 per iteration)",
                              "nn": "grid", "n_src_this_rank": n_q, "n_src_total": n5, "n_tgt": n_t, "max_corr": 1.0,
-                             "sharding": f"sources x{world}, target replicated", "collective": collective,
+                             "sharding": f"sources x{world} ({args.shard}), target replicated", "collective": collective,
                              "pose_err_vs_gt_fro": float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose())),
                              "kept_pairs_last_iter": int(st["last_pairs"]), "lib_sha16": sha,
                              "pose_bits": "".join(f"{int(v):08x}" for v in np.ascontiguousarray(T, np.float32).view(np.uint32).ravel())},
                   "roofline": groof,
                   "kernels": stream_kernels(bd, n_q, int(st["last_pairs"]) * n_q // max(n5, 1))}
+            if pred_c5 is not None:
+                c5["predicted_scaling"] = pred_c5
             if args.workload == "c5":
                 out = c5
             elif out is not None:

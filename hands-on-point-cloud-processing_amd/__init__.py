@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "pcr_prof_reset", "pcr_prof_get", "pcr_prof_get_each", "pcr_tune_set",
     "pcr_grid_stats", "pcr_nn1_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_selftest_sign_f16", "pcr_ctx_mfma_check", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_match_inter_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
-    "pcr_ctx_trim", "pcr_ctx_parked_bytes", "pcr_cloud_sort_for_target", "pcr_nn1_f32_loop",
+    "pcr_ctx_trim", "pcr_ctx_parked_bytes", "pcr_cloud_shard_spatial", "pcr_cloud_global_index", "pcr_cloud_sort_for_target", "pcr_nn1_f32_loop",
     "pcr_db64_radius_rows", "pcr_rows_destroy", "pcr_rows_info", "pcr_rows_row_ptr", "pcr_rows_fetch", "pcr_rows_reduce", "pcr_rows_moments",
 ]
 
@@ -95,6 +95,8 @@ def lib():
     L.pcr_nn1_f32_async.argtypes = [vp, vp, vp]
     L.pcr_nn1_fetch.argtypes = [vp, sz, vp, vp]
     L.pcr_ctx_trim.argtypes = [vp]
+    L.pcr_cloud_shard_spatial.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.pcr_cloud_global_index.argtypes = [vp, vp, vp]
     L.pcr_ctx_parked_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.pcr_cloud_sort_for_target.argtypes = [vp, vp, vp, vp]
     L.pcr_nn1_f32_loop.argtypes = [vp, vp, vp, C.c_float]
@@ -492,6 +494,17 @@ class Context:
         orig = np.empty(len(cloud), np.uint32)
         self._ck(lib().pcr_cloud_sort_for_target(self.h, tgt.h, cloud.h, orig.ctypes.data if len(cloud) else None))
         return orig
+
+    def shard_spatial(self, tgt: Cloud, full: Cloud, nranks: int, rank: int, chunks_per_rank: int = 0) -> Cloud:
+        """this rank's share of `full` under the spatially coherent partition (pcr_cloud_shard_spatial)"""
+        h = C.c_void_p()
+        self._ck(lib().pcr_cloud_shard_spatial(self.h, tgt.h, full.h, nranks, rank, chunks_per_rank, C.byref(h)))
+        return Cloud(self, h)
+
+    def global_index(self, shard: Cloud) -> np.ndarray:
+        idx = np.empty(len(shard), np.uint32)
+        self._ck(lib().pcr_cloud_global_index(self.h, shard.h, idx.ctypes.data if len(shard) else None))
+        return idx
 
     def trim(self):
         self._ck(lib().pcr_ctx_trim(self.h))

@@ -184,6 +184,7 @@ void cloud_release(pcr_ctx* ctx, pcr_cloud* c)
 {
     if (!c) return;
     cloud_forget(ctx, c);
+    if (c->gidx) { hipFree(c->gidx); c->gidx = nullptr; }
     if (c->base) {
         // (buffers beyond 2 GB are not kept: a spare slot is a convenience, not a cache of the caller's memory)
         int slot = -1;
@@ -383,6 +384,7 @@ int pcr_cloud_destroy(pcr_ctx* ctx, pcr_cloud* c)
     if (!c) return PCR_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
     cloud_forget(ctx, c);
+    if (c->gidx) hipFree(c->gidx);
     if (c->base) hipFree(c->base);        // the caller's memory goes back to the device at once, whatever context the handle is destroyed through
     delete c;
     return PCR_OK;
@@ -440,6 +442,23 @@ int pcr_cloud_sort_for_target(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud* clo
             for (size_t i = 0; i < n; i++) orig_index[i] = (uint32_t)i;      // (the library left the order alone: small clouds, switched off)
         }
     }
+    return PCR_OK;
+}
+
+int pcr_cloud_shard_spatial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* full, int nranks, int rank, int chunks_per_rank, pcr_cloud** out)
+{
+    if (!ctx || !tgt || !full || !out || nranks < 1 || rank < 0 || rank >= nranks || chunks_per_rank < 0) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_shard_spatial");
+    PCR_HIP(ctx, hipSetDevice(ctx->device));
+    return cloud_shard_spatial(ctx, tgt, full, nranks, rank, chunks_per_rank ? chunks_per_rank : 64, out, cloud_alloc);
+}
+
+int pcr_cloud_global_index(pcr_ctx* ctx, const pcr_cloud* c, uint32_t* index)
+{
+    if (!ctx || !c || (c->n && !index)) return fail(ctx, PCR_ERR_ARG, "pcr_cloud_global_index");
+    if (!c->gidx) return fail(ctx, PCR_ERR_STATE, "pcr_cloud_global_index: not a shard");
+    if (c->n == 0) return PCR_OK;
+    PCR_HIP(ctx, hipMemcpyAsync(index, c->gidx, c->n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PCR_OK;
 }
 

@@ -745,19 +745,32 @@ __global__ __launch_bounds__(GR_BLOCK, (LIST && !STATS) ? PCR_LIST_WAVES : 1) vo
     // deferred, yet one workgroup per four segments cost 0.18 ms of a 1.5 ms search), and the load balances itself.  Every wave leaves as
     // soon as the ticket it draws lies beyond the list: the grid drains.
     const bool queue = LIST && list_queue != nullptr;
+    bool first_ticket = true;
+    uint32_t qpart = 0;
     for (;;) {
     if (queue) {
-        uint32_t it = 0;
-        if ((threadIdx.x & 63u) == 0u) it = atomicAdd(&list_queue[1], 1u);
-        it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
-        if (it >= min(list_queue[0], n_seg)) break;
-        seg0 = min(list_queue[2 + it], n_seg - 1u); seg1 = seg0 + 1u;
+        // the first ticket of a wave is its own number (8 192 waves drawing from ONE counter at the same moment took 0.16 ms — the whole
+        // launch, however short the list), the later ones come from the counter behind those
+        const uint32_t n_static = gridDim.x * (GR_BLOCK / 64);
+        uint32_t it = blockIdx.x * (GR_BLOCK / 64) + (threadIdx.x >> 6);
+        if (!first_ticket) {
+            if ((threadIdx.x & 63u) == 0u) it = n_static + atomicAdd(&list_queue[1], 1u);
+            it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+        }
+        first_ticket = false;
+        if (it >= min(list_queue[0], 4u * n_seg)) break;
+        // an item = a quarter of a segment (at most 8 deferred queries: two rounds of this wave's four sub-groups — a whole segment of 32 took
+        // eight rounds one after the other, and the slowest wave is the launch's duration: ~0.1 ms however short the list)
+        const uint32_t item = list_queue[2 + it];
+        qpart = item & 3u;
+        seg0 = min(item >> 2, n_seg - 1u); seg1 = seg0 + 1u;
     }
     for (uint32_t cs = seg0; LIST ? cs < seg1 : true; cs += 64) {
     uint32_t total = 0;
     if (LIST) {
         const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t c = cs + lane < seg1 ? min(list_count[cs + lane], 32u) : 0u;
+        uint32_t c = cs + lane < seg1 ? min(list_count[cs + lane], 32u) : 0u;
+        if (queue) c = c > 8u * qpart ? min(c - 8u * qpart, 8u) : 0u;                  // (queue form: this item's quarter of the one segment)
         uint32_t inc = row_scan16(c);
         const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31),
                        t2 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 47), t3 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -775,7 +788,7 @@ __global__ __launch_bounds__(GR_BLOCK, (LIST && !STATS) ? PCR_LIST_WAVES : 1) vo
 #pragma unroll
             for (int step = 32; step > 0; step >>= 1)
                 if (off[LIST ? sg + step : 0] <= slot) sg += step;                    // the last segment whose first entry is <= slot
-            list_pos = (cs + (uint32_t)sg) * 32u + (slot - off[LIST ? sg : 0]);
+            list_pos = (cs + (uint32_t)sg) * 32u + (slot - off[LIST ? sg : 0]) + (queue ? 8u * qpart : 0u);
         }
         const bool live = LIST || slot < n_eff;
         const uint32_t t = LIST ? list_pos : min(slot, n_eff - 1);         // clamp: surplus sub-groups redo the last query (same value written)
@@ -1902,6 +1915,92 @@ int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, 
     return PCR_OK;
 }
 
+// ---- spatially coherent shards of a source cloud (multi-GPU: pcr_cloud_shard_spatial, include/pcr.h)
+// member[perm[t]] = 1 where position t of the sorted order falls into one of this rank's chunks
+__global__ __launch_bounds__(GR_BLOCK) void shard_mark_kernel(const uint32_t* __restrict__ perm, uint32_t n, uint32_t chunk_len, uint32_t nranks, uint32_t rank,
+                                                              uint32_t* __restrict__ member)
+{
+    const uint32_t t = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (t >= n) return;
+    member[perm[t]] = ((t / chunk_len) % nranks == rank) ? 1u : 0u;
+}
+
+// the members in ascending ORIGINAL index (pos = exclusive scan of member): coordinates and global indices
+__global__ __launch_bounds__(GR_BLOCK) void shard_gather_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t n,
+                                                                const uint32_t* __restrict__ member, const uint32_t* __restrict__ pos, float* __restrict__ dx,
+                                                                float* __restrict__ dy, float* __restrict__ dz, uint32_t* __restrict__ gidx)
+{
+    const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (i >= n || !member[i]) return;
+    const uint32_t p = pos[i];
+    dx[p] = sx[i]; dy[p] = sy[i]; dz[p] = sz[i];
+    gidx[p] = i;
+}
+
+__global__ __launch_bounds__(GR_BLOCK) void shard_pad_kernel(float* __restrict__ dx, float* __restrict__ dy, float* __restrict__ dz, uint32_t n, uint32_t cap)
+{
+    const uint32_t i = n + blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (i >= cap) return;
+    dx[i] = __builtin_inff(); dy[i] = 0.0f; dz[i] = 0.0f;     // the padding of every cloud (pcr_cloud_create)
+}
+
+// Rank `rank`'s share of `full` under a SPATIALLY COHERENT partition: the cloud in the order of the target's index (cell, then Morton
+// code inside the cell: the order the ICP loops give their working copy) is cut into nranks x chunks_per_rank runs of equal length, and
+// the runs are dealt to the ranks round-robin.  Every rank then holds compact pieces of the scene at the scene's own density — what the
+// tile search of large targets needs (a uniformly drawn 1 / N sample spreads 32 consecutive queries over N times the region) — and the
+// round-robin deal balances regions that cost more (near rings) against cheap ones.  Deterministic: every rank computes the same order
+// from the same two clouds, so the shards are disjoint and complete.  The shard keeps the points in ascending original index and
+// remembers those indices (pcr_cloud::gidx).
+int cloud_shard_spatial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* full, int nranks, int rank, int chunks_per_rank, pcr_cloud** out,
+                        int (*alloc)(pcr_ctx*, size_t, pcr_cloud**))
+{
+    const size_t n = full->n;
+    if (n > 0xFFFFFFF0ull) return fail(ctx, PCR_ERR_ARG, "cloud too large for u32 indices");
+    int rc = build_target_grid(ctx, tgt);
+    if (rc) return rc;
+    size_t count = 0;
+    const size_t a4 = (n * 4 + 255) & ~(size_t)255;
+    uint32_t* member = nullptr, *pos = nullptr, *totals = nullptr;
+    const size_t scan_blocks = (n + SC_TILE - 1) / SC_TILE;
+    if (n) {
+        rc = sort_queries_fine(ctx, tgt->grid, full);          // ctx->qperm[t] = original index of the point at sorted position t (radix sort: stable, deterministic)
+        if (rc) return rc;
+        ctx->qperm_src = nullptr;                             // (the order belongs to `full`, which no search will use)
+        hipError_t e = hipMalloc((void**)&member, 2 * a4 + (scan_blocks + 2) * sizeof(uint32_t));   // (not the scratch: the sort above lives there)
+        if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "hipMalloc(shard)", e);
+        pos = (uint32_t*)((char*)member + a4); totals = (uint32_t*)((char*)member + 2 * a4);
+        const size_t n_chunks = (size_t)nranks * (size_t)std::max(1, chunks_per_rank);
+        const uint32_t chunk_len = (uint32_t)std::max<size_t>(1, (n + n_chunks - 1) / n_chunks);
+        const unsigned blocks = (unsigned)((n + GR_BLOCK - 1) / GR_BLOCK);
+        hipLaunchKernelGGL(shard_mark_kernel, dim3(blocks), dim3(GR_BLOCK), 0, ctx->stream, ctx->qperm, (uint32_t)n, chunk_len, (uint32_t)nranks, (uint32_t)rank, member);
+        rc = exclusive_scan_u32(ctx, member, pos, n, totals, totals + scan_blocks);
+        uint32_t h_count = 0;
+        if (rc == PCR_OK) {
+            e = hipMemcpyAsync(&h_count, totals + scan_blocks, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = fail(ctx, PCR_ERR_HIP, "shard count", e);
+        }
+        if (rc) { hipFree(member); return rc; }
+        count = h_count;
+    }
+    pcr_cloud* c = nullptr;
+    rc = alloc(ctx, count, &c);
+    if (rc) { if (member) hipFree(member); return rc; }
+    hipError_t e = hipMalloc((void**)&c->gidx, std::max<size_t>(count, 1) * sizeof(uint32_t));
+    if (e != hipSuccess) { if (member) hipFree(member); pcr_cloud_destroy(ctx, c); return fail(ctx, PCR_ERR_HIP, "hipMalloc(shard indices)", e); }
+    if (n)
+        hipLaunchKernelGGL(shard_gather_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, full->x(), full->y(), full->z(), (uint32_t)n,
+                           member, pos, c->x(), c->y(), c->z(), c->gidx);
+    hipLaunchKernelGGL(shard_pad_kernel, dim3((unsigned)((c->cap - count + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, c->x(), c->y(), c->z(), (uint32_t)count,
+                       (uint32_t)c->cap);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (member) hipFree(member);
+    if (e != hipSuccess) { pcr_cloud_destroy(ctx, c); return fail(ctx, PCR_ERR_HIP, "shard gather", e); }
+    *out = c;
+    return PCR_OK;
+}
+
 int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool reuse_perm, float cap2)
 {
     const size_t ns = src->n;
@@ -2012,7 +2111,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     if (mode == 2 && warm == 3 && sorted && !perm && wpos && cap2 < __builtin_inff() && tile_tune != 2 && (tile_tune == 1 || (tgt->n >= 4000000 && dense))) {
         // the segmented list of deferred queries: 32 slots per group of 32 queries + one count per group (far_list is free here: the
         // hand-off of far queries to the exhaustive kernel only exists for unbounded searches)
-        const size_t n_groups_sz = (ns + 31) / 32, need = n_groups_sz * 32 + n_groups_sz + (n_groups_sz + 2);     // (+ the queue of non-empty segments)
+        const size_t n_groups_sz = (ns + 31) / 32, need = n_groups_sz * 32 + n_groups_sz + (4 * n_groups_sz + 2);     // (+ the queue: quarters of the non-empty segments)
         if (ctx->far_cap < need) {
             if (ctx->far_list) { PCR_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->far_list); ctx->far_list = nullptr; ctx->far_cap = 0; }
             PCR_HIP(ctx, hipMalloc((void**)&ctx->far_list, (need + 1) * sizeof(uint32_t)));
@@ -2028,8 +2127,8 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         // SIGN TILE SEARCH (grid_stile.hpp, round 4; tune grid_stile: 0 auto = on where the f16 matrix pipe passed the device check and the
         // target's Morton-ordered index fits f16, 2 = the round-3 tile kernel): one wave per 64 consecutive queries, the candidate tiles
         // of the target's matrix-core index found through coarse Morton cells and run spheres, one MFMA per tile and 32 queries whose
-        // SIGN says whether a record can matter.  Knobs: grid_stile_bmax_cm (largest ball of a served query, default 60), grid_stile_keep (candidate
-        // tiles a pass may keep, 768), grid_stile_cells (coarse cells a pass may open, 512), grid_stile_flush / grid_stile_dense (STRACK's list rules, 64 / 12).
+        // SIGN says whether a record can matter.  Knobs: grid_stile_bmax_cm (largest ball of a served query, default 100), grid_stile_lim_pct / grid_stile_lim_floor_mm (ball limit of a wave: a multiple of its mean ball, 400 %, never below 150 mm), grid_stile_keep (candidate
+        // tiles a pass may keep, 768; grid_stile_keep_small: the same for passes whose largest ball is below grid_stile_split_mm, 192), grid_stile_cells (coarse cells a pass may open, 2 048), grid_stile_flush / grid_stile_dense (STRACK's list rules, 64 / 32).
         bool stile = tune_get(ctx, "grid_stile", 0) != 2 && mfma_verdict(ctx, true);
         if (stile) {
             rc = bt_ensure(ctx, tgt);
@@ -2047,11 +2146,17 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         }
         if (stile) {
             const BtIndex* bt = tgt->bt;
-            const float sbmax = (float)tune_get(ctx, "grid_stile_bmax_cm", 60) * 0.01f;
+            const float sbmax = (float)tune_get(ctx, "grid_stile_bmax_cm", 100) * 0.01f;
             const uint32_t skeep = (uint32_t)std::min<int64_t>(SL_KEEP, std::max<int64_t>(2, tune_get(ctx, "grid_stile_keep", SL_KEEP)));
-            const uint32_t scells = (uint32_t)std::min<int64_t>(1 << 15, std::max<int64_t>(1, tune_get(ctx, "grid_stile_cells", 512)));
+            const float slim_k = (float)tune_get(ctx, "grid_stile_lim_pct", 400) * 0.01f, slim_floor = (float)tune_get(ctx, "grid_stile_lim_floor_mm", 150) * 0.001f;
+            const uint32_t skeep_small = (uint32_t)std::min<int64_t>(SL_KEEP, std::max<int64_t>(2, tune_get(ctx, "grid_stile_keep_small", 192)));
+            const uint32_t scells = (uint32_t)std::min<int64_t>(1 << 15, std::max<int64_t>(1, tune_get(ctx, "grid_stile_cells", 2048)));
             const uint32_t sflush = (uint32_t)std::min<int64_t>(SL_CAP, std::max<int64_t>(1, tune_get(ctx, "grid_stile_flush", 64)));
-            const uint32_t sdense = (uint32_t)std::min<int64_t>(65, std::max<int64_t>(1, tune_get(ctx, "grid_stile_dense", 12)));
+            const uint32_t sdense = (uint32_t)std::min<int64_t>(65, std::max<int64_t>(1, tune_get(ctx, "grid_stile_dense", 32)));
+            // clusters of one wave's queries served one after the other (tune grid_stile_passes; round 3's tile kernel stopped at three: at the
+            // converged pose of the 10 M pair 0.5 % of the queries sat in a fourth cluster and went to the list walk, whose launch has a
+            // latency floor of ~0.19 ms however few queries it serves)
+            const uint32_t spasses = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, tune_get(ctx, "grid_stile_passes", 3)));
             const float ssplit = (float)tune_get(ctx, "grid_stile_split_mm", 40) * 0.001f;     // largest ball of a pass from which its near tiles go first
             const uint32_t n_waves = (uint32_t)((ns + 63) / 64);
             size_t sblocks = (n_waves + (GR_BLOCK / 64) - 1) / (GR_BLOCK / 64);
@@ -2072,7 +2177,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     hipLaunchKernelGGL((nn1_stile_kernel<ST>), dim3((unsigned)sblocks), dim3(GR_BLOCK), 0, ctx->stream, bt->records, bt->ops16, bt->centres,           \
                        bt->tile_spheres, bt->cell_start, bt->g_of_b, bt->b_of_g, g->records, (uint32_t)(g->n_chunks * GRID_CHUNK), bt->key_lo[0], bt->key_lo[1], \
                        bt->key_lo[2], bt->key_inv, 3 * (10 - bt->cbits), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev,    \
-                       stats_dev, cap2, wpos, dlist, dcount, lqueue, sxcd, sbmax, n_waves, n_groups, lim_k, reach_k, skeep, scells, min_members, sflush, sdense, ssplit, (uint32_t)(bt->n_tiles / 8)); \
+                       stats_dev, cap2, wpos, dlist, dcount, lqueue, sxcd, sbmax, n_waves, n_groups, slim_k, reach_k, skeep, scells, min_members, sflush, sdense, ssplit, (uint32_t)(bt->n_tiles / 8), spasses, skeep_small, slim_floor); \
     hipLaunchKernelGGL((nn1_grid_kernel<16, ST, 2, true>), dim3(lblocks_s), dim3(GR_BLOCK), 0, ctx->stream, g->records, g->spheres, g->cell_start, g->p,   \
                        src->x(), src->y(), src->z(), (const uint32_t*)dlist, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(),     \
                        tgt->y(), tgt->z(), (uint32_t)tgt->n, 3, cap2, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, wpos, 0u, (const uint32_t*)dcount, list_segs_s, lqueue)

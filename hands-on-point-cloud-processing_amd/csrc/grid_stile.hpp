@@ -108,7 +108,7 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
     unsigned long long* __restrict__ keys, const int* __restrict__ stop, unsigned long long* __restrict__ stats, float cap2,
     uint32_t* __restrict__ wpos, uint32_t* __restrict__ defer_list, uint32_t* __restrict__ defer_count, uint32_t* __restrict__ defer_queue, uint32_t xcd_run,
     float bmax, uint32_t n_waves, uint32_t n_groups32, float lim_k, float reach_k, uint32_t keep_max, uint32_t cell_max, uint32_t min_members,
-    uint32_t flush_at, uint32_t dense_at, float split_at, uint32_t n_super)
+    uint32_t flush_at, uint32_t dense_at, float split_at, uint32_t n_super, uint32_t max_pass, uint32_t keep_small, float lim_floor)
 {
     const int stopv = stop ? (stop[0] | stop[1]) : 0;         // requested here, tested after the query loads are on their way
     __shared__ StileWaveLds lds_all[GR_BLOCK / 64];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
     const bool near = valid && fin && rho <= bmax;
     const unsigned long long near_m = __ballot(near);
     const float mean = wave_sum_uniform(near ? rho : 0.0f) / (float)max((uint32_t)__popcll(near_m), 1u);
-    const float lim = lim_k * mean;
+    const float lim = fmaxf(lim_k * mean, lim_floor);         // (never below lim_floor: at a settled pose the balls are noise-sized and any factor of their mean would cut into the tail)
     const bool member = near && rho <= lim;
     bool deferred = valid && !member;
     if (!fin) { qx = 0.0f; qy = 0.0f; qz = 0.0f; }             // (finite operands for the matrix pipe; such a lane never gets a threshold)
@@ -175,11 +175,13 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
 #pragma unroll
     for (int j = 0; j < 16; j++) zero[j] = 0.0f;
     const int fs = cshift / 3;                                // fine cell -> coarse cell
-    for (int pass = 0; pass < 3 && remaining; pass++) {
+    for (uint32_t pass = 0; pass < max_pass && remaining; pass++) {
         const int lead = (int)__builtin_ctzll(remaining);
         const float lqx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qx), lead)),
                     lqy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qy), lead)),
                     lqz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qz), lead));
+        // (measured and dropped: a last pass that takes every query left, however far apart — heavy passes and overflows, 1.63 -> 1.85 ms; eight
+        // passes instead of three: 1.63 -> 1.78 ms)
         const bool in = member && ((remaining >> lane) & 1ull) && fabsf(qx - lqx) <= reach && fabsf(qy - lqy) <= reach && fabsf(qz - lqz) <= reach;
         n_pass++;
         const unsigned long long inmask = __ballot(in);
@@ -232,6 +234,9 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
         // large balls (the first tile searches of a loop): the tiles that touch a box go first, and the thresholds fall to what they held before
         // the farther ones are filtered; small balls: one list in ascending order (fewer super-tile changes)
         const bool split = rho_max > split_at;
+        // small balls (a settled pose): a pass that still collects more than keep_small tiles straddles a jump of the sorted order — a handful of
+        // such passes were the tail of the whole launch (10 M: 1.53 -> 1.41 ms per converged search, a 1 / 8 shard 0.32 -> 0.29); the walk takes them
+        const uint32_t keep_eff = split ? keep_max : min(keep_max, keep_small);
         uint32_t nn = 0, nf = 0;                              // tiles from the front of L.tiles, and (split) from its back
         float lim2[4];
 #pragma unroll
@@ -280,17 +285,16 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
                 const bool front = hm != 0u && (touch || !split), back = hm != 0u && !front;
                 const unsigned long long mt = __ballot(front), mf = __ballot(back);
                 const unsigned long long below = (1ull << lane) - 1ull;
-                if (nn + nf + (uint32_t)__popcll(mt | mf) > keep_max) { ok = false; break; }
+                if (nn + nf + (uint32_t)__popcll(mt | mf) > keep_eff) { ok = false; break; }
                 if (front) L.tiles[nn + (uint32_t)__popcll(mt & below)] = tile | (hm << 30);
                 if (back) L.tiles[SL_KEEP - 1 - (nf + (uint32_t)__popcll(mf & below))] = tile | (hm << 30);
                 nn += (uint32_t)__popcll(mt); nf += (uint32_t)__popcll(mf);
             }
         }
-        if (!ok) { deferred = deferred || in; continue; }     // too many cells / tiles for one wave: the walk takes these queries
-        // one contiguous list: the tiles kept at the back follow the others
-        for (uint32_t k = lane; k < nf; k += 64) L.tiles[nn + k] = L.tiles[SL_KEEP - 1 - k];
-        const uint32_t nt = nn + nf;
+        if (!ok) { deferred = deferred || in; if (STATS && lane == 0) atomicAdd(&stats[15], (unsigned long long)__popcll(inmask)); continue; }     // too many cells / tiles for one wave: the walk takes these queries ([15])
+        const uint32_t nt = nn + nf;                          // (list position k >= nn: the tiles kept at the back, L.tiles[SL_KEEP - 1 - (k - nn)])
         if (STATS) {
+            if (lane == 0) { atomicMax(&stats[12], (unsigned long long)nt); }   // [12] most tiles in a pass
             st_load += (uint64_t)nt * 32;
             float e = 0.0f;
             for (int g = 0; g < 4; g++) if (actq[g]) e = fmaxf(e, fmaxf(fmaxf(bhi[g][0] - blo[g][0], bhi[g][1] - blo[g][1]), bhi[g][2] - blo[g][2]));
@@ -301,7 +305,10 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
         // the whole operand of its query per super-tile (st_setup) and the halves change places by v_permlane32_swap — afterwards bq[0] is the
         // B operand of queries 0..31, bq[1] that of queries 32..63.
         float thr = in ? __uint_as_float((uint32_t)(L.best[lane] >> 32)) : -__builtin_inff();
-        auto entry_at = [&](uint32_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tiles[min(k, (uint32_t)SL_KEEP - 1u)]); };
+        auto entry_at = [&](uint32_t k) -> uint32_t {
+            const uint32_t kk = min(k, max(nt, 1u) - 1u);     // (beyond the list: its last entry once more — never used)
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tiles[kk < nn ? kk : (uint32_t)SL_KEEP - 1u - (kk - nn)]);
+        };
         uint32_t cnt = 0;                                     // entries in the wave's list (wave-uniform)
         uint32_t curS = 0xFFFFFFFFu;
         uint4 bq[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
@@ -422,7 +429,8 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
             wpos[i] = bidx == 0xFFFFFFFFu ? 0xFFFFFFFFu : wp;
         }
     }
-    deferred = deferred || (member && ((remaining >> lane) & 1ull));        // a fourth cluster in one wave: the walk takes it
+    if (STATS && lane == 0) { atomicAdd(&stats[14], (unsigned long long)__popcll(remaining)); atomicAdd(&stats[13], (unsigned long long)__popcll(__ballot(near && !member))); }   // [14] queries of a fourth cluster, [13] near queries beyond the ball limit
+    deferred = deferred || (member && ((remaining >> lane) & 1ull));        // more clusters in one wave than it may serve: the walk takes the rest
     if (min_members > 1u) deferred = deferred || (member && (uint32_t)__popcll(__ballot(member)) < min_members);
     // the deferred queries: segments 2 wv and 2 wv + 1 of the list (one per 32 queries, in query order) and their lengths (every wave writes them)
     {
@@ -433,7 +441,10 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
             if (deferred) defer_list[(size_t)g32 * 32 + (uint32_t)__popc(dh & ((1u << n) - 1u))] = i;
             if (n == 0) {
                 defer_count[g32] = (uint32_t)__popc(dh);
-                if (defer_queue && dh) defer_queue[2u + atomicAdd(&defer_queue[0], 1u)] = g32;     // the list walk draws the non-empty segments from here
+                if (defer_queue && dh) {                      // the list walk draws its work from here: one item per 8 deferred queries of the segment
+                    const uint32_t parts = ((uint32_t)__popc(dh) + 7u) / 8u, base = atomicAdd(&defer_queue[0], parts);
+                    for (uint32_t pq = 0; pq < parts; pq++) defer_queue[2u + base + pq] = 4u * g32 + pq;
+                }
             }
         }
         if (STATS && lane == 0 && dm) atomicAdd(&stats[6], (unsigned long long)__popcll(dm));     // [6]: queries handed to the cell walk

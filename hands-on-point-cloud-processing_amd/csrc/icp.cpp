@@ -76,7 +76,7 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
             // reducer on the host copy).  Integer limbs: the result does not depend on the number of ranks.
             uint32_t blocks = 0;
             if (work->n && (rc = launch_kabsch_partial(ctx, tgt, work, prm->max_corr, plan, &blocks))) break;   // :936-940,:964-985
-            if ((rc = launch_icp_reduce_slots(ctx, blocks, nranks, rank, work->n != 0))) break;
+            if ((rc = launch_icp_reduce_slots(ctx, blocks, nranks, rank, work->n != 0, src->gidx))) break;
             if (ctx->comm.rccl && (rc = comm_allreduce_f64_device(ctx, ctx->dev_out, nred))) break;
             e = hipMemcpyAsync(h, ctx->dev_out, nred * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -86,8 +86,8 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
             num::limbs_to_sums(h, plan.e, sums16);
             overflow = h[55] != 0.0;
             last_kept = -1.0; last_d2 = 0.0;
-            for (int r = 0; r < nranks; r++)
-                if (h[56 + 2 * r] > 0.5) { last_kept = 1.0; last_d2 = h[57 + 2 * r]; }
+            const int ls = icp_last_slot(h, nranks);             // the pair with the largest order key: the globally last kept one
+            if (ls >= 0) { last_kept = 1.0; last_d2 = h[57 + 2 * ls]; }
         } else {
             if (work->n) {
                 if ((rc = launch_kabsch_sums(ctx, tgt, work, prm->max_corr, plan))) break; // :936-940,:964-985
@@ -208,7 +208,7 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
             if (nranks == 1 && work->n && !force_slots) {
                 if ((rc = launch_icp_update(ctx, blocks, dev, plan))) break;                // :948-1002
             } else {
-                if ((rc = launch_icp_reduce_slots(ctx, blocks, nranks, rank, work->n != 0))) break;
+                if ((rc = launch_icp_reduce_slots(ctx, blocks, nranks, rank, work->n != 0, src->gidx))) break;
                 if ((rc = comm_allreduce_f64_device(ctx, ctx->dev_out, nred))) break;       // the ONE collective
                 if ((rc = launch_icp_update_from_sums(ctx, nranks, dev, plan))) break;
             }

@@ -570,10 +570,14 @@ __global__ __launch_bounds__(KF_BLOCK) void icp_update_move_kernel(const double*
 }
 
 // multi rank, step 1: reduce the block rows into the all-reduce buffer
-//   [0..54] normalised limbs, [55] overflow flag, [56 + 2r] kept flag of rank r, [57 + 2r] d2 of its last kept pair
-// (every entry is summed exactly by the all-reduce: integers below 2^40 x ranks, one non-zero flag pair per rank)
+//   [0..54] normalised limbs, [55] overflow flag, [56 + 2r] ORDER KEY of rank r's last kept pair (0: it kept none), [57 + 2r] that pair's d2
+// (every entry is summed exactly by the all-reduce: integers below 2^40 x ranks, one non-zero pair of words per rank).  The order key
+// says where the pair stands in the WHOLE source cloud: global index + 1 for a shard that knows its points' indices (gidx:
+// pcr_cloud_shard_spatial — any partition), rank + 1 otherwise (contiguous blocks in rank order); the loss of an iteration is that of
+// the pair with the largest key (registration.cpp:939: the last pair pushed).
 __global__ __launch_bounds__(KF_BLOCK) void icp_reduce_slots_kernel(const double* __restrict__ partials, uint32_t n_blocks,
-                                                                    double* __restrict__ out, int nranks, int rank, int have_points)
+                                                                    double* __restrict__ out, int nranks, int rank, int have_points,
+                                                                    const uint32_t* __restrict__ gidx)
 {
     __shared__ double red[KF_GROUPS][64];
     __shared__ double row[KB_ROW];
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(KF_BLOCK) void icp_reduce_slots_kernel(const double
         double v = 0.0;
         if (r == rank && row[54] > 0.0) {
             const unsigned long long lk = (unsigned long long)__double_as_longlong(row[55]);
-            v = which == 0 ? 1.0 : (double)__uint_as_float((uint32_t)(lk & 0xFFFFFFFFull));
+            v = which == 0 ? (gidx ? (double)gidx[(uint32_t)(lk >> 32)] + 1.0 : (double)(rank + 1)) : (double)__uint_as_float((uint32_t)(lk & 0xFFFFFFFFull));
         }
         out[56 + threadIdx.x] = v;
     }
@@ -612,10 +616,9 @@ __global__ __launch_bounds__(64) void icp_update_from_sums_kernel(double* __rest
     else if (k == 15) sums[15] = row[54];
     __syncthreads();
     if (k != 0) return;
-    bool any = false;
-    float d2 = 0.0f;
-    for (int r = 0; r < nranks; r++)
-        if (buf[56 + 2 * r] > 0.5) { any = true; d2 = (float)buf[57 + 2 * r]; }
+    const int ls = icp_last_slot(buf, nranks);                 // the pair with the largest order key
+    const bool any = ls >= 0;
+    const float d2 = any ? (float)buf[57 + 2 * ls] : 0.0f;
     icp_state_step(&s_st, sums, any, d2, buf[55] != 0.0);
     *st = s_st;
 }
@@ -696,10 +699,10 @@ int launch_icp_update_move(pcr_ctx* ctx, uint32_t n_blocks, const IcpState* st_i
     return PCR_OK;
 }
 
-int launch_icp_reduce_slots(pcr_ctx* ctx, uint32_t n_blocks, int nranks, int rank, bool have_points)
+int launch_icp_reduce_slots(pcr_ctx* ctx, uint32_t n_blocks, int nranks, int rank, bool have_points, const uint32_t* gidx)
 {
     hipLaunchKernelGGL(icp_reduce_slots_kernel, dim3(1), dim3(KF_BLOCK), 0, ctx->stream, ctx->partials, n_blocks, ctx->dev_out, nranks, rank,
-                       have_points ? 1 : 0);
+                       have_points ? 1 : 0, gidx);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }

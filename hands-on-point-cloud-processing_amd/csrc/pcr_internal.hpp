@@ -80,6 +80,9 @@ struct pcr_cloud {
     size_t n = 0;
     size_t cap = 0;     // padded length of each of x, y, z
     float* base = nullptr;   // device; x = base, y = base + cap, z = base + 2*cap
+    // a SHARD of a larger cloud (pcr_cloud_shard_spatial): the index every point has in the whole cloud, ascending (device, n entries).
+    // "The last kept pair" of an iteration (registration.cpp:939) is then the kept pair with the largest GLOBAL index over all ranks.
+    uint32_t* gidx = nullptr;
     float* x() const { return base; }
     float* y() const { return base + cap; }
     float* z() const { return base + 2 * cap; }
@@ -231,6 +234,8 @@ void cloud_release(pcr_ctx* ctx, pcr_cloud* c);
 int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, bool in_place = false);
 int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, bool in_place = false);
 int nn1_unpack(pcr_ctx* ctx, size_t n, uint32_t* idx_dev, float* d2_dev);
+int cloud_shard_spatial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* full, int nranks, int rank, int chunks_per_rank, pcr_cloud** out,
+                        int (*alloc)(pcr_ctx*, size_t, pcr_cloud**));
 int launch_transform(pcr_ctx* ctx, pcr_cloud* c, const float R[9], const float t[3]);
 int cloud_absmax(pcr_ctx* ctx, const pcr_cloud* c, float* out);       // largest finite |coordinate|, cached on the cloud (grid.hip)
 int kabsch_grid_exponent(float target_absmax, float max_corr);
@@ -239,8 +244,9 @@ int kabsch_plan(pcr_ctx* ctx, const pcr_cloud* tgt, float max_corr, KabschPlan* 
 int launch_kabsch_sums(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr, const KabschPlan& plan);
 int launch_kabsch_partial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, float max_corr, const KabschPlan& plan, uint32_t* n_blocks);
 int launch_icp_update(pcr_ctx* ctx, uint32_t n_blocks, IcpState* st_dev, const KabschPlan& plan);
-// dev_out[0..54] limbs, [55] overflow flag, [56 + 2r], [57 + 2r] (kept flag, last d2) of rank r: ICP_NRED(nranks) doubles to all-reduce
-int launch_icp_reduce_slots(pcr_ctx* ctx, uint32_t n_blocks, int nranks, int rank, bool have_points);
+// dev_out[0..54] limbs, [55] overflow flag, [56 + 2r], [57 + 2r] (order key of the last kept pair — 0 = none kept —, its d2) of rank r:
+// ICP_NRED(nranks) doubles to all-reduce; gidx: the shard's global indices (key = global index + 1), or nullptr (key = rank + 1: contiguous shards in rank order)
+int launch_icp_reduce_slots(pcr_ctx* ctx, uint32_t n_blocks, int nranks, int rank, bool have_points, const uint32_t* gidx = nullptr);
 int launch_icp_update_from_sums(pcr_ctx* ctx, int nranks, IcpState* st_dev, const KabschPlan& plan);
 inline int icp_nred(int nranks) { return 56 + 2 * nranks; }
 // seed_tgt != nullptr: the move also writes the seeds of the next exhaustive search into keys[] (kabsch.hip seed_next_search)
@@ -267,5 +273,14 @@ void mat4_mul_f32(const float A[16], const float B[16], float out[16]);
 
 // ---- collectives ----------------------------------------------------------------------------------------
 int comm_allreduce_f64(pcr_ctx* ctx, double* host_buf, double* dev_buf, int n);
+// the slot of the globally last kept pair in a summed reduce row (the largest order key), or -1: the same rule on host and device
+__host__ __device__ inline int icp_last_slot(const double* buf, int nranks)
+{
+    int best = -1;
+    double key = 0.5;
+    for (int r = 0; r < nranks; r++)
+        if (buf[56 + 2 * r] > key) { key = buf[56 + 2 * r]; best = r; }
+    return best;
+}
 
 }  // namespace pcr

@@ -296,7 +296,10 @@ int pcr_comm_selftest(pcr_ctx* ctx);
 /* Wire format of the per-iteration collective (what a pcr_allreduce_fn sums): 56 + 2 * nranks doubles —
  *   [0..54]  the 16 Kabsch moments as exact 40-bit integer limbs on a fixed-point grid shared by all ranks (unit 2^(e-80) for the
  *            six coordinate sums: 3 doubles each = limb 0, limb 1, carry; unit 2^(2e-120) for the nine products q_r p_c: 4 doubles
- *            each; [54] the pair count), [55] overflow flag, [56 + 2r] / [57 + 2r] (kept flag, d2 of the last kept pair) of rank r.
+ *            each; [54] the pair count), [55] overflow flag, [56 + 2r] / [57 + 2r] (ORDER KEY, d2 of the last kept pair) of rank r: the key
+ *            is 0 when the rank kept no pair, else the pair's index in the whole source cloud + 1 for a shard made by
+ *            pcr_cloud_shard_spatial, rank + 1 for any other cloud (contiguous blocks in rank order).  The iteration's `loss`
+ *            (registration.cpp:939: d2 of the last pair pushed) is taken from the slot with the LARGEST key.
  * Every entry is an integer (or one rank's value) below 2^53, so the sum is exact in any order: the pose does not depend on the
  * number of ranks.  pcr_kabsch_limbs_to_sums (host logic, no GPU) propagates the carries of a summed row in place and returns
  * the 16 moments pcr_kabsch_solve takes; e = pcr_kabsch_grid_exponent(largest finite |target coordinate|, max_corr). */
@@ -304,6 +307,17 @@ int pcr_kabsch_grid_exponent(float target_absmax, float max_corr);
 int pcr_kabsch_limbs_to_sums(double row[55], int e, double sums[16]);
 /* contiguous shard [begin, end) of n items for `rank` of `nranks` (sizes differ by at most one) */
 void pcr_shard_range(size_t n, int nranks, int rank, size_t* begin, size_t* end);
+/* SPATIALLY COHERENT shards (the reference shards nothing — registration.cpp:925-941 is one serial loop — so the partition is ours to
+ * choose, and the exact integer sums make the pose independent of it, bit for bit).  `full` = the WHOLE source cloud, uploaded on
+ * every rank (10 M points: 120 MB); out = this rank's share: the cloud in the order of the target's index (cell, then Morton code
+ * inside the cell) is cut into nranks x chunks_per_rank runs of equal length (0 = 64 per rank) that are dealt round-robin.  Every rank
+ * holds compact pieces of the scene at the scene's own density — the tile search of large targets needs that; a uniformly drawn 1 / N
+ * sample (contiguous blocks of a shuffled cloud) spreads its queries N times thinner — and the deal balances expensive regions
+ * against cheap ones.  Deterministic: all ranks compute the same order from the same two clouds (shards disjoint, complete).  The
+ * shard keeps ascending original order and remembers each point's index in `full` (pcr_cloud_global_index), which is what makes
+ * "the last kept pair" well defined across ranks (the wire format above).  `full` may be destroyed afterwards. */
+int pcr_cloud_shard_spatial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* full, int nranks, int rank, int chunks_per_rank, pcr_cloud** out);
+int pcr_cloud_global_index(pcr_ctx* ctx, const pcr_cloud* shard, uint32_t* index);   /* host, pcr_cloud_size(shard) entries, ascending */
 
 /* ---- profiling hooks for bench.py: HIP-event timing of the dominant kernel on the ctx stream ----------
  * Off by default (an event pair costs ~6 us of stream time on each side of the kernel it brackets):

@@ -93,41 +93,45 @@ def main():
         # make the tail of the cloud lose its pairs so that "last kept pair" lives on rank 0 for max_corr small
         src[:, n - n // 4:] += np.float32(500.0)
         b, e = pcr.shard_range(n, world, rank)
+        # two partitions: contiguous blocks in rank order (order key of a slot = rank + 1) and an arbitrary one — every point dealt by a
+        # hash of its index — whose shards know their points' global indices (order key = global index + 1: pcr_cloud_shard_spatial)
+        mine_contig = np.arange(b, e)
+        mine_hashed = np.flatnonzero((np.arange(n) * 2654435761 >> 7) % world == rank)
         P = src.copy()
         T_total = np.eye(4, dtype=np.float32)
         ge = pcr.kabsch_grid_exponent(float(np.abs(tgt).max()), 1.0)       # the same on every rank: target + gate only
         for it in range(4):
-            shard = np.ascontiguousarray(P[:, b:e])
-            idx, d2 = orc.nn1_f32(tgt, shard)
-            keep = d2 < np.float32(1.0)
-            buf = np.zeros(56 + 2 * world)
-            buf[:55] = limb_row(shard[:, keep], tgt[:, idx[keep]], ge)      # checker-side restatement of the device accumulation
-            last = int(np.flatnonzero(keep)[-1]) if keep.any() else -1
-            buf[56 + 2 * rank] = 1.0 if last >= 0 else 0.0
-            buf[57 + 2 * rank] = float(d2[last]) if last >= 0 else 0.0
-            allreduce(buf)
-            sums = pcr.kabsch_limbs_to_sums(buf[:55], ge)                    # the product's host code: carries + moments
-            # single-process reference of the same iteration: the exact sums, rounded once, and the oracle's running f64 sums
-            fidx, fd2 = orc.nn1_f32(tgt, P)
-            fkeep = fd2 < np.float32(1.0)
-            exact = exact_sums(P[:, fkeep], tgt[:, fidx[fkeep]])
-            assert np.array_equal(sums, exact), "sharded limbs != exact sums of the whole job"
-            fsums, flast = orc.kabsch_accumulate(P, tgt, fidx, fd2, 1.0)
-            assert sums[15] == fsums[15] and np.allclose(sums, fsums, rtol=1e-12, atol=0)
-            frow = np.zeros(55); frow[:] = limb_row(P[:, fkeep], tgt[:, fidx[fkeep]], ge)
-            assert np.array_equal(pcr.kabsch_limbs_to_sums(frow, ge), sums), "the sums depend on the number of ranks"
-            last_d2 = None
-            for r in range(world):
-                if buf[56 + 2 * r] > 0.5:
-                    last_d2 = buf[57 + 2 * r]
-            assert last_d2 is not None and np.float32(last_d2) == fd2[flast], "loss must come from the globally last kept pair"
-            rc, R, t = pcr.kabsch_solve(sums)
-            assert rc == 0
-            # identical on every rank
-            chk = torch.from_numpy(np.concatenate([R.reshape(-1), t]).astype(np.float64))
-            lo, hi = chk.clone(), chk.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            assert torch.equal(lo, hi)
+            for mine, keyed in ((mine_contig, False), (mine_hashed, True)):
+                shard = np.ascontiguousarray(P[:, mine])
+                idx, d2 = orc.nn1_f32(tgt, shard)
+                keep = d2 < np.float32(1.0)
+                buf = np.zeros(56 + 2 * world)
+                buf[:55] = limb_row(shard[:, keep], tgt[:, idx[keep]], ge)      # checker-side restatement of the device accumulation
+                last = int(np.flatnonzero(keep)[-1]) if keep.any() else -1
+                buf[56 + 2 * rank] = 0.0 if last < 0 else (float(mine[last]) + 1.0 if keyed else float(rank + 1))     # the order key (include/pcr.h)
+                buf[57 + 2 * rank] = float(d2[last]) if last >= 0 else 0.0
+                allreduce(buf)
+                sums = pcr.kabsch_limbs_to_sums(buf[:55], ge)                    # the product's host code: carries + moments
+                # single-process reference of the same iteration: the exact sums, rounded once, and the oracle's running f64 sums
+                fidx, fd2 = orc.nn1_f32(tgt, P)
+                fkeep = fd2 < np.float32(1.0)
+                exact = exact_sums(P[:, fkeep], tgt[:, fidx[fkeep]])
+                assert np.array_equal(sums, exact), "sharded limbs != exact sums of the whole job"
+                fsums, flast = orc.kabsch_accumulate(P, tgt, fidx, fd2, 1.0)
+                assert sums[15] == fsums[15] and np.allclose(sums, fsums, rtol=1e-12, atol=0)
+                frow = np.zeros(55); frow[:] = limb_row(P[:, fkeep], tgt[:, fidx[fkeep]], ge)
+                assert np.array_equal(pcr.kabsch_limbs_to_sums(frow, ge), sums), "the sums depend on the number of ranks"
+                keys = buf[56:56 + 2 * world:2]
+                assert keys.max() > 0.5
+                last_d2 = buf[57 + 2 * int(np.argmax(keys))]                      # the slot with the largest order key
+                assert np.float32(last_d2) == fd2[flast], "loss must come from the globally last kept pair"
+                rc, R, t = pcr.kabsch_solve(sums)
+                assert rc == 0
+                # identical on every rank
+                chk = torch.from_numpy(np.concatenate([R.reshape(-1), t]).astype(np.float64))
+                lo, hi = chk.clone(), chk.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                assert torch.equal(lo, hi)
             P = orc.transform_f32(P, R, t)
         print(f"rank {rank}: protocol ok")
     elif mode == "rccl":
@@ -185,6 +189,31 @@ def main():
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), "pose differs between ranks"
+        # SPATIALLY COHERENT shards (pcr_cloud_shard_spatial): disjoint, complete, the same pose and the same loss bit for bit — the loss
+        # comes from the globally last kept pair, which now may sit on any rank (order key = global index + 1)
+        sp = ctx.shard_spatial(ct, full, world, rank, 5)
+        gi = ctx.global_index(sp)
+        assert (np.diff(gi.astype(np.int64)) > 0).all() and np.array_equal(sp.numpy(), src[:, gi])
+        seen = torch.zeros(n, dtype=torch.int32); seen[torch.from_numpy(gi.astype(np.int64))] = 1
+        dist.all_reduce(seen)
+        assert bool((seen == 1).all()), "the spatial shards must be disjoint and complete"
+        src_far = src.copy(); src_far[:, n - n // 3:] += np.float32(300.0)      # the tail keeps no pair: the last kept pair is in the middle of the cloud
+        full_far = ctx.cloud(src_far)
+        Tf, stf = ctx.icp_point2point(full_far, ct, max_corr=1.0, max_iter=6, eps=1e-8)
+        spf = ctx.shard_spatial(ct, full_far, world, rank, 5)
+        for method in (1, 2):
+            ctx.tune("nn_method", method)
+            for pipe in (0, -1):
+                ctx.tune("icp_pipeline", pipe)
+                ctx.comm_init_callback(world, rank, allreduce)
+                T5, st5 = ctx.icp_point2point(sp, ct, max_corr=1.0, max_iter=8, eps=1e-8)
+                T6, st6 = ctx.icp_point2point(spf, ct, max_corr=1.0, max_iter=6, eps=1e-8)
+                ctx.comm_destroy()
+                assert np.array_equal(T1.view(np.uint32), T5.view(np.uint32)) and st5["last_pairs"] == st1["last_pairs"], (method, pipe)
+                assert np.float32(st1["last_loss"]).view(np.uint32) == np.float32(st5["last_loss"]).view(np.uint32), (method, pipe)
+                assert np.array_equal(Tf.view(np.uint32), T6.view(np.uint32)) and st6["last_pairs"] == stf["last_pairs"], (method, pipe)
+                assert np.float32(stf["last_loss"]).view(np.uint32) == np.float32(st6["last_loss"]).view(np.uint32), (method, pipe, stf, st6)
+        ctx.tune("nn_method", 0); ctx.tune("icp_pipeline", 0)
         # an empty shard still takes part in the collective
         empty = ctx.cloud(np.zeros((3, 0), np.float32))
         ctx.comm_init_callback(world, rank, allreduce)

@@ -52,7 +52,8 @@ def check_line(line, n):
     assert line["scaling"] == "strong" and line["higher_is_better"] is True
     cfg = line["config"]
     assert cfg["sharding"].startswith(f"sources x{n} ")
-    assert cfg["n_src_total"] == 120000 and abs(cfg["n_src_this_rank"] - 120000 / n) <= 1
+    # (spatial shards, the default: whole runs of the index-ordered cloud, 64 per rank — the sizes differ by at most one run)
+    assert cfg["n_src_total"] == 120000 and abs(cfg["n_src_this_rank"] - 120000 / n) <= 120000 / (64 * n) + 1
     assert cfg["collective"] == ("none" if n == 1 else "torch")
     assert cfg["pose_err_vs_gt_fro"] < 0.5          # three iterations in: moving towards the known pose (identity start: 0.54)
     assert line["roofline"]["frac"] > 0 and line["roofline"]["avg_launch_ms"] > 0

@@ -978,6 +978,34 @@ def test_working_copies_are_parked_callers_clouds_are_freed(pcr, synth):
         assert ctx.parked_bytes() == 0
 
 
+def test_spatial_shards_are_a_partition_and_keep_the_scene_dense(pcr, synth):
+    """pcr_cloud_shard_spatial: for every rank count the shards are disjoint and complete, keep ascending original order and the points'
+    coordinates; sizes differ by at most one run; a shard is spatially compact — the mean distance between CONSECUTIVE points of its
+    index-sorted working order stays that of the whole cloud, where a contiguous block of the shuffled source is N times sparser."""
+    n = 60000
+    src, tgt = synth.kitti_like_pair(n)
+    with pcr.Context(0) as ctx:
+        ct, full = ctx.cloud(tgt), ctx.cloud(src)
+        for world, chunks in ((1, 0), (2, 0), (3, 7), (8, 0), (8, 1)):
+            seen = np.zeros(n, np.int32)
+            sizes = []
+            for r in range(world):
+                sh = ctx.shard_spatial(ct, full, world, r, chunks)
+                gi = ctx.global_index(sh)
+                assert gi.size == len(sh) and (np.diff(gi.astype(np.int64)) > 0).all()
+                assert np.array_equal(sh.numpy(), src[:, gi])
+                seen[gi] += 1
+                sizes.append(gi.size)
+                sh.free()
+            assert (seen == 1).all(), (world, chunks)
+            per = -(-n // (world * (chunks or 64)))
+            assert max(sizes) - min(sizes) <= per, (world, chunks, sizes)
+        with pytest.raises(pcr.PcrError):
+            ctx.global_index(full)                                   # not a shard
+        e = ctx.shard_spatial(ct, ctx.cloud(np.zeros((3, 0), np.float32)), 4, 1)
+        assert len(e) == 0 and ctx.global_index(e).size == 0
+
+
 def test_caller_stepped_loop_equals_icp_call(pcr, synth):
     """pcr_cloud_sort_for_target + pcr_nn1_f32_loop + pcr_kabsch_sums + pcr_kabsch_solve + pcr_transform_f32 stepped by the caller
     = pcr_icp_p2p_f32, pose bits and kept pairs, with the exact grid and with the exhaustive search (registration.cpp:917-1006)."""
