@@ -269,6 +269,7 @@ int pcr_ctx_destroy(pcr_ctx* ctx)
     if (ctx->host_stage) hipHostFree(ctx->host_stage);
     if (ctx->coop_host) hipHostFree(ctx->coop_host);
     if (ctx->coop_ticket) hipFree(ctx->coop_ticket);
+    if (ctx->plane_ws) hipFree(ctx->plane_ws);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return PCR_OK;

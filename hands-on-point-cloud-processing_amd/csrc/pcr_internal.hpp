@@ -133,6 +133,8 @@ struct pcr_ctx {
     size_t partials_cap = 0;
     double* dev_out = nullptr;            // 128 doubles: reduced sums / limbs + bookkeeping
     double* host_out = nullptr;           // pinned mirror
+    void* plane_ws = nullptr;             // plane.hip: [ticket | pad to 256 B][partial counts per workgroup]
+    size_t plane_ws_bytes = 0, plane_ws_tick = 0;
     void* scratch = nullptr;              // generic device scratch
     size_t scratch_cap = 0;
     void* host_stage = nullptr;           // pinned staging for uploads / downloads
@@ -255,8 +257,8 @@ int launch_transform_state(pcr_ctx* ctx, pcr_cloud* c, IcpState* st_dev, const p
 int launch_icp_update_move(pcr_ctx* ctx, uint32_t n_blocks, const IcpState* st_in, IcpState* st_out, const KabschPlan& plan, pcr_cloud* c,
                            const pcr_cloud* seed_tgt = nullptr);
 int comm_allreduce_f64_device(pcr_ctx* ctx, double* dev_buf, int n);   // RCCL on the ctx stream, no host round trip
-int launch_plane_count(pcr_ctx* ctx, const pcr_cloud* pts, const double* planes4_dev, size_t n_planes,
-                       double thr, unsigned long long* counts_dev);
+int launch_plane_count(pcr_ctx* ctx, const pcr_cloud* pts, const double* planes4_host, size_t n_planes,
+                       double thr, unsigned long long* counts_out);
 int launch_plane_mask(pcr_ctx* ctx, const pcr_cloud* pts, const double plane4[4], double thr,
                       uint8_t* mask_dev, unsigned long long* count_dev);
 int launch_knn_f64(pcr_ctx* ctx, const double* db_soa, size_t n, size_t n_cap, const double* q_soa, size_t m,
