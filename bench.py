@@ -846,6 +846,7 @@ def bench_c4(ctx, pcr, synth, np, args):
     d.free(); c.free()
     step_ms = plane_ms + radius_kernel_ms
     out_bytes = 12.0 * total + 8.0 * n
+    c4pmc = load_pmc("latest_pmc_c4.json", lib_sha16(pcr)) if n == 120000 else None
     res = {
         "metric": "M radius queries/sec + M point-hypothesis evaluations/sec, 120k-pt KITTI scan, 1 MI355X (BASELINE configs[3])",
         "value": n / step_ms / 1e3, "unit": "M scan points/s through (80-plane inlier count + radius-NN r = 1)", "n_gpus": 1, "steps": reps,
@@ -869,7 +870,10 @@ def bench_c4(ctx, pcr, synth, np, args):
                    "note": "results are 12 B per reported neighbour (i32 index + f64 distance): the call is D2H-bound at this boundary; kernels: grid build, "
                            "count, fill, per-row ascending-index sort, distances"},
         "roofline": {"bound": "hbm", "achieved": out_bytes / radius_kernel_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": out_bytes / radius_kernel_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": out_bytes / radius_kernel_ms / 1e6 / HBM_PEAK_GBS,
+                     "traffic": ((c4pmc["fetch_bytes_per_launch_corrected_x2"] + c4pmc["write_bytes_per_launch"]) if c4pmc else None),
+                     "traffic_note": (f"HBM-side bytes of one filled call (FETCH_SIZE x 2 + WRITE_SIZE over its radius kernels), {c4pmc['source']}" if c4pmc else
+                                      "null: no PMC pass of the radius kernels with the library loaded now (tools/gpu_pmc_c4.sh)"),
                      "kernel": "radius pipeline (count + fill + sort + dist)",
                      "algorithmic": "compulsory output bytes: 12 B per reported neighbour + 8 B row pointer per query"},
     }

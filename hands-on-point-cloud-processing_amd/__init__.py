@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_prof_get_each", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_nn1_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_selftest_sign_f16", "pcr_ctx_mfma_check", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
+    "pcr_grid_stats", "pcr_nn1_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_selftest_mfma_bf16_v2", "pcr_selftest_mfma_f16_v2", "pcr_selftest_sign_f16", "pcr_ctx_mfma_check", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_match_inter_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
     "pcr_ctx_trim", "pcr_ctx_parked_bytes", "pcr_cloud_shard_spatial", "pcr_cloud_global_index", "pcr_cloud_sort_for_target", "pcr_nn1_f32_loop",
     "pcr_db64_radius_rows", "pcr_rows_destroy", "pcr_rows_info", "pcr_rows_row_ptr", "pcr_rows_fetch", "pcr_rows_reduce", "pcr_rows_moments",
@@ -138,6 +138,8 @@ def lib():
     L.pcr_nn1_stats.argtypes = [vp, vp]
     L.pcr_selftest_mfma_bf16.argtypes = [vp, C.c_int, vp]
     L.pcr_selftest_mfma_f16.argtypes = [vp, C.c_int, vp]
+    L.pcr_selftest_mfma_bf16_v2.argtypes = [vp, C.c_int, vp]
+    L.pcr_selftest_mfma_f16_v2.argtypes = [vp, C.c_int, vp]
     L.pcr_selftest_sign_f16.argtypes = [vp, C.c_int, vp]
     L.pcr_ctx_mfma_check.argtypes = [vp, C.c_int, C.POINTER(MfmaCheck)]
     L.pcr_voxel_filter_f32.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
@@ -424,13 +426,13 @@ class Context:
         """(accumulation error on random operands in 2^-24 sum|a b|, filter-value error in 2^-24 (|r|^2 + |t|^2), absolute error in 2^-24
         in the small-magnitude regime, accumulation error on the structured tiles) measured on this device — include/pcr.h"""
         out = (C.c_double * 4)()
-        self._ck(lib().pcr_selftest_mfma_bf16(self.h, int(trials), out))
+        self._ck(lib().pcr_selftest_mfma_bf16_v2(self.h, int(trials), out))
         return tuple(float(v) for v in out)
 
     def selftest_mfma_f16(self, trials: int = 64):
         """the same for the f16 form (one MFMA per tile, two-piece scaled operands)"""
         out = (C.c_double * 4)()
-        self._ck(lib().pcr_selftest_mfma_f16(self.h, int(trials), out))
+        self._ck(lib().pcr_selftest_mfma_f16_v2(self.h, int(trials), out))
         return tuple(float(v) for v in out)
 
     def selftest_sign_f16(self, trials: int = 64):

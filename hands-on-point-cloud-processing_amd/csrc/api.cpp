@@ -568,16 +568,36 @@ int pcr_prof_get_each(pcr_ctx* ctx, const char* kernel, double* ms, size_t cap, 
     return PCR_OK;
 }
 
-int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[4])
+// (the two-value entry points keep the contract round 2 shipped — a caller built against that header passes a 2-double array;
+// the four-value forms are the _v2 symbols)
+int pcr_selftest_mfma_bf16_v2(pcr_ctx* ctx, int trials, double worst[4])
 {
     if (!ctx || !worst || trials < 0 || trials > 4096) return PCR_ERR_ARG;
     return pcr::bt_mfma_selftest(ctx, trials, worst);
 }
 
-int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[4])
+int pcr_selftest_mfma_f16_v2(pcr_ctx* ctx, int trials, double worst[4])
 {
     if (!ctx || !worst || trials < 0 || trials > 4096) return PCR_ERR_ARG;
     return pcr::ht_mfma_selftest(ctx, trials, worst);
+}
+
+int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[2])
+{
+    double w4[4];
+    if (!worst) return PCR_ERR_ARG;
+    const int rc = pcr_selftest_mfma_bf16_v2(ctx, trials, w4);
+    if (rc == PCR_OK) { worst[0] = w4[0]; worst[1] = w4[1]; }
+    return rc;
+}
+
+int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[2])
+{
+    double w4[4];
+    if (!worst) return PCR_ERR_ARG;
+    const int rc = pcr_selftest_mfma_f16_v2(ctx, trials, w4);
+    if (rc == PCR_OK) { worst[0] = w4[0]; worst[1] = w4[1]; }
+    return rc;
 }
 
 int pcr_selftest_sign_f16(pcr_ctx* ctx, int trials, uint64_t out[4])

@@ -442,11 +442,18 @@ static int cloud_knn_coop(pcr_ctx* ctx, const Grid* g, const float* q_rows, size
 {
     // a small coherent (fine-grained) host buffer of its own: [done word | values | indices], and a ticket word in device memory
     constexpr size_t OFF_V = 256, OFF_I = OFF_V + KNN_COOP_MAX * 32 * 8, TOTAL = OFF_I + KNN_COOP_MAX * 32 * 4;
-    if (!ctx->coop_host) {
-        PCR_HIP(ctx, hipHostMalloc(&ctx->coop_host, TOTAL, hipHostMallocCoherent | hipHostMallocMapped));
-        memset(ctx->coop_host, 0, TOTAL);
-        PCR_HIP(ctx, hipMalloc((void**)&ctx->coop_ticket, 256));
-        PCR_HIP(ctx, hipMemset(ctx->coop_ticket, 0, 256));
+    if (!ctx->coop_host || !ctx->coop_ticket) {
+        // (both or neither: a failure between the two allocations must not leave a host buffer behind that makes the next call skip the
+        // ticket's allocation and launch with a null pointer — ADVICE r3)
+        if (ctx->coop_host) { hipHostFree(ctx->coop_host); ctx->coop_host = nullptr; }
+        if (ctx->coop_ticket) { hipFree(ctx->coop_ticket); ctx->coop_ticket = nullptr; }
+        void* host = nullptr; uint32_t* ticket = nullptr;
+        hipError_t e = hipHostMalloc(&host, TOTAL, hipHostMallocCoherent | hipHostMallocMapped);
+        if (e == hipSuccess) e = hipMalloc((void**)&ticket, 256);
+        if (e == hipSuccess) e = hipMemset(ticket, 0, 256);
+        if (e != hipSuccess) { if (host) hipHostFree(host); if (ticket) hipFree(ticket); return fail(ctx, PCR_ERR_HIP, "knn coop buffers", e); }
+        memset(host, 0, TOTAL);
+        ctx->coop_host = host; ctx->coop_ticket = ticket;
     }
     char* st = (char*)ctx->coop_host;
     volatile uint32_t* done = (volatile uint32_t*)st;

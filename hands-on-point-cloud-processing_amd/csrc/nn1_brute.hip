@@ -1122,8 +1122,11 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
 //
 //   target                          search                                   kernel
 //   ------------------------------  ---------------------------------------  -----------------------------------------------------------
-//   >= 8 192 points, fits f16       any seeded one (cold ones seed themselves) STRACK  nn1_strack_kernel<4 | 2>       (variant 8: one-slice launches too)
-//   >= 8 192 points, fits f16       cold one-slice launches; nn1_sign = 2    HTRACK  nn1_btrack_kernel<4 | 2, true>   (variant 7)
+//   >= 8 192 points, fits f16       any (a cold search seeds itself first)   STRACK  nn1_strack_kernel<4 | 2>       (variant 8: small targets too)
+//   —                               only on request (nn1_sign = 2)           HTRACK  nn1_btrack_kernel<4 | 2, true>   (variant 7: the minimum-tracking form of
+//                                                                            the f16 filter — round 4: no default path reaches it any more; measured cold,
+//                                                                            8 192 ... 60 000 points: STRACK 0.020 / 0.044 / 0.090 / 0.235 ms against 0.029 /
+//                                                                            0.052 / 0.105 / 0.253; it stays as the parity sweeps' second f16 kernel)
 //   >= 8 192 points, beyond f16     any                                      BTRACK  nn1_btrack_kernel<4 | 2, false>  (variant 6)
 //   either form failing the device check (mfma_verdict), or nn1_bf16 = 2     the two rows below
 //   >= 2 048 points                 inside a loop / index exists / 2nd search ETRACK  nn1_etrack_kernel<4>             (variant 4)
@@ -1189,8 +1192,10 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     // (120 k: 8 super-tiles per slice, the measured optimum of both forms since their unsettled queries are filtered again)
     uint32_t slices = 1;
     const uint32_t sps = slice_plan(n_super, qblocks, tune_get(ctx, "nn1_supers_per_slice", 0), tune_get(ctx, "nn1_btrack_blocks", 14336), &slices);
-    // a cold, sliced search seeds itself from the nearest super-tile (tune nn1_cold_seed: 2 = off)
-    const bool cold_seed = !warm && (slices > 1 || force_sign) && tune_get(ctx, "nn1_cold_seed", 1) == 1;
+    // a cold search seeds itself from the nearest super-tile (tune nn1_cold_seed: 2 = off, 3 = only sliced launches — round 3's rule, under which
+    // the one-slice launches of small targets were HTRACK's last default use)
+    const int64_t cs_tune = tune_get(ctx, "nn1_cold_seed", 1);
+    const bool cold_seed = !warm && (cs_tune == 1 || (cs_tune == 3 && (slices > 1 || force_sign)));
     const int merge_atomic = (slices > 1 || warm || cold_seed) ? 1 : 0;
     // STRACK, the sign form of the f16 filter, serves every search that starts from a candidate per query in keys[]: the searches seeded by
     // the move of the previous iteration (kabsch.hip seed_next_search), the cold ones that seed themselves (bt_seed_kernel: 0.55 ms against

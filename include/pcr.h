@@ -347,8 +347,11 @@ int pcr_nn1_stats(pcr_ctx* ctx, uint64_t out[16]);
  *   worst[1] = max (|G - (w - 2 r.t)| - 2 u) / (u (|r|^2 + |t|^2)), the kernel's operand layout       (assume <= 34.2 bf16 / <= 82 f16)
  *   worst[2] = max |G - (w - 2 r.t)| / u over pairs with |r|^2 + |t|^2 <= 2^-6 (f16 underflow regime)  (HTRACK subtracts 4 u)
  *   worst[3] = as worst[0] on the structured tiles                                                    (<= 16) */
-int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[4]);
-int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[4]);
+int pcr_selftest_mfma_bf16_v2(pcr_ctx* ctx, int trials, double worst[4]);
+int pcr_selftest_mfma_f16_v2(pcr_ctx* ctx, int trials, double worst[4]);
+/* the round-2 forms of the same self-tests: worst[0] and worst[1] only (a caller built against the older header passes two doubles) */
+int pcr_selftest_mfma_bf16(pcr_ctx* ctx, int trials, double worst[2]);
+int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[2]);
 /* The DECISION of the sign form of the f16 filter (STRACK, csrc/nn1_brute.hip — the default exhaustive search on targets that fit f16:
  * the query's threshold rides in two K-slots, an accumulator is bound - threshold, its sign bit says whether the record can matter),
  * checked on THIS device: `trials` random super-tile tiles + 8 in the f16 underflow regimes, a power-of-two scale per tile, thresholds

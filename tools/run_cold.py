@@ -15,7 +15,7 @@ ctx.tune("nn_method", 1)
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
 ctx.tune("nn1_variant", 2); ri, rd = ctx.nn1(ct, cs); ctx.tune("nn1_variant", 0)
 ctx.nn1(ct, cs)                                              # index, code objects
-for label, tunes in (("HTRACK", {"nn1_sign": 2}),
+for label, tunes in (("HTRACK", {"nn1_sign": 2}), ("HTRACK r3 rule", {"nn1_cold_seed": 3}),
                      ("STRACK", {}),
                      ("HTRACK", {"nn1_sign": 2}), ("STRACK", {})):
     for k_, v_ in tunes.items():
