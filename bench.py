@@ -427,7 +427,7 @@ def main():
         # ---- the shader clock the chip holds under the headline kernel's own load: s_memtime / s_memrealtime stamps of a diagnostics
         # launch (tune grid_stats) that follows 40 back-to-back launches of the same seeded search; median of 3
         clock_mhz = None
-        if extras and args.nn == "brute" and family in ("strack", "htrack", "btrack"):
+        if extras and args.nn == "brute" and family in ("strack2", "strack", "htrack", "btrack"):
             ca = cs.clone(); ctx.transform(ca, T)
             ctx.tune("nn_method", 1); ctx.tune("prof", 0); ctx.tune("nn1_async_in_loop", 1)
             clocks = []
@@ -441,6 +441,18 @@ def main():
             ctx.tune("nn1_async_in_loop", 0)
             ca.free()
             clock_mhz = sorted(clocks)[len(clocks) // 2] if clocks else None
+
+        # ---- STRACK2 (two levels of the sign filter): how many matrix instructions a search at the final pose executes (diagnostics launch)
+        s2_counts = None
+        if args.nn == "brute" and family == "strack2":
+            ca = cs.clone(); ctx.transform(ca, T)
+            ctx.tune("nn_method", 1); ctx.tune("prof", 0); ctx.tune("nn1_async_in_loop", 1)
+            ctx.nn1_async(ct, ca); ctx.nn1_async(ct, ca)
+            ctx.tune("grid_stats", 1); ctx.nn1_async(ct, ca); ctx.tune("grid_stats", 0)
+            w = ctx.nn1_stats()
+            ctx.tune("nn1_async_in_loop", 0)
+            ca.free()
+            s2_counts = {"level1_mfma": int(w[8]), "level2_mfma": int(w[10]), "level2_tiles_flagged": int(w[9]), "chunks_evaluated_exactly": int(w[6])}
 
         # ---- the exact-only kernel (the 9-op convention's own kernel), the cold searches: a few launches each, HIP-event timed
         exact_line, one_shot = None, None
@@ -542,13 +554,18 @@ def main():
         if rank == 0:
             gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
             if args.nn == "brute":
-                sign = family == "strack"
-                f16 = family in ("strack", "htrack")
-                bf16 = family in ("strack", "htrack", "btrack")
+                two = family == "strack2"
+                sign = family in ("strack", "strack2")
+                f16 = family in ("strack2", "strack", "htrack")
+                bf16 = family in ("strack2", "strack", "htrack", "btrack")
                 slots_pp = 32 if f16 else 64                 # flop per pair of ALL K-slots the matrix instruction(s) execute (16 / 2 x 16 multiply-adds)
                 flops_pp = STRACK_FLOPS_PER_PAIR if sign else HTRACK_FLOPS_PER_PAIR if f16 else BTRACK_FLOPS_PER_PAIR if bf16 else ETRACK_FLOPS_PER_PAIR
                 peak_tf = MFMA_BF16_PEAK_TFLOPS if bf16 else VALU_PEAK_TFLOPS
                 achieved_tflops = flops_pp * pairs / kern_s / 1e12
+                if two and s2_counts:
+                    # the two-level form does NOT run every (query, record) pair through the matrix pipe: its algorithmic work is what it executes —
+                    # 14 data-carrying K-slots x 32 x 32 x 2 flop per MFMA of either level (counted by a diagnostics launch at the final pose)
+                    achieved_tflops = (s2_counts["level1_mfma"] + s2_counts["level2_mfma"]) * 32 * 32 * 14 * 2 / kern_s / 1e12
                 compulsory_bytes = 12.0 * n_t + 12.0 * n_q + 8.0 * n_q        # targets + sources + (idx, d2) key
                 pmc = load_pmc("latest_pmc.json", sha) if (default_kernels and n_q == 120000 == n_t) else None
                 roofline = {
@@ -558,7 +575,12 @@ def main():
                     "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
                                      f"kernel with this very libpcr_hip.so (sha {sha}), {pmc['source']}") if pmc else
                                     "null: PMC counters need a rocprofv3 wrapper (tools/gpu_check.sh); none was collected with the library loaded now",
-                    "kernel": (("pcr::nn1_strack_kernel<4> = STRACK, the SIGN form of the f16 matrix-core filter, operands staged through LDS per workgroup "
+                    "kernel": (("pcr::nn1_strack2_kernel<4> = STRACK2, the SIGN form of the f16 matrix-core filter at TWO LEVELS (csrc/nn1_sphere.hpp): level 1 — one MFMA row "
+                               "per CHUNK of 16 records (its bounding sphere: |r - c| <= sqrt(thr) + rho as a sum of 16 K-slot products whose sign answers), over every "
+                               "chunk of the target: a sixteenth of the per-record filter's matrix and vector work; level 2 — the tiles of 32 records that hold a "
+                               "flagged chunk through the per-record sign filter (STRACK's operands), flagged (query, 16-record chunk) pairs evaluated with the exact "
+                               "unfused arithmetic, four lanes per chunk; thresholds = the exact distance of the best candidate so far (the previous correspondence "
+                               "re-evaluated by the move, then whatever the scan finds)") if two else (("pcr::nn1_strack_kernel<4> = STRACK, the SIGN form of the f16 matrix-core filter, operands staged through LDS per workgroup "
                                 "(exhaustive: the expanded-form lower bound of ALL (query, target) pairs from ONE v_mfma_f32_32x32x16_f16 per 32 queries "
                                 "x 32 targets — operands scaled per 256-target super-tile and cut into two f16 pieces, every piece product exact in f32 — "
                                 "with the query's threshold (the exact distance of its best candidate so far: the previous correspondence re-evaluated, "
@@ -583,13 +605,18 @@ def main():
                                ("pcr::nn1_etrack_kernel<4> (exhaustive scan of every (query, 16-target chunk); chunk-centred targets broadcast through the "
                                 "scalar cache; expanded-form lower bound = 3 FMAs per pair (v_pk_fma_f32), min-tree + first/second minimum tracked "
                                 "branch-free; only the winning chunk is evaluated with the exact unfused arithmetic; the previous correspondence of "
-                                "each query, re-evaluated exactly, seeds the bound)")) if default_kernels else f"nn1 variant={args.variant}",
+                                "each query, re-evaluated exactly, seeds the bound)"))) if default_kernels else f"nn1 variant={args.variant}",
                     "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
-                    "algorithmic": ((f"{flops_pp} f16 flop per (query, target) pair (the 14 piece products that carry data; the two K-slots with the "
+                    "algorithmic": (((f"the matrix work the two-level filter EXECUTES at the final pose: {s2_counts['level1_mfma']} level-1 + {s2_counts['level2_mfma']} level-2 "
+                                     f"v_mfma_f32_32x32x16_f16 per launch x 32 x 32 x 14 data-carrying K-slots x 2 flop (a diagnostics launch counts them; every chunk of the "
+                                     f"target gets its level-1 row for every query: {pairs / 16:.3e} (query, chunk) pairs) — NOT {pairs:.3e} pairs x 28 flop: the per-record "
+                                     "filter runs only where a chunk's sphere reaches the query's ball.  The launch is bound by vector issue (operand setups, OR chains, "
+                                     "lists), not by the matrix pipe; pairs_per_s prices the same launch in (query, target) pairs settled per second") if (two and s2_counts) else
+                                    (f"{flops_pp} f16 flop per (query, target) pair (the 14 piece products that carry data; the two K-slots with the "
                                      f"pieces of the query's threshold count under executed_slots) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16.  Per 1024 pairs: one MFMA "
                                      "(32 cycles of the SIMD's matrix pipe) and 13 vector instructions all told (PMC SQ_INSTS_VALU / SQ_INSTS_MFMA: 8 v_or3_b32 in the tile "
                                      "loop, 3 of the operand setup per super-tile, the rest prologue / lists); the two pipes share the SIMD's issue port, so the "
-                                     "launch is issue-bound, not matrix-bound (DESIGN.md 5, profiles/r03_ubench_sign_filter.txt)")
+                                     "launch is issue-bound, not matrix-bound (DESIGN.md 5, profiles/r03_ubench_sign_filter.txt)"))
                                     if sign else
                                     f"{flops_pp} {'f16' if f16 else 'bf16'} flop per (query, target) pair ({flops_pp // 2} piece products that carry data, of "
                                     f"the {16 if f16 else 32} K-slots executed) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16 / bf16.  On this chip "
@@ -604,6 +631,11 @@ def main():
                                     "re-evaluation of the winning chunk are overhead, not numerator.  peak = 157.3 TF/s vector f32 (FMA = 2).  "
                                     "SURVEY.md 8d's 9-op-per-pair convention describes the EXACT kernel: kernels.nn1_exact_track"),
                     "kernel_family": family,
+                    "two_level": ({"counts_at_the_final_pose": s2_counts, "pairs_per_s": pairs / kern_s,
+                                   "equivalent_strack_frac": STRACK_FLOPS_PER_PAIR * pairs / kern_s / 1e12 / peak_tf,
+                                   "note": "equivalent_strack_frac = what roofline.frac would read if every (query, target) pair had gone through the per-record "
+                                           "filter (28 flop) in this launch's time — an equivalent for comparison with earlier rounds (0.33-0.38), not a bound"}
+                                  if (two and s2_counts) else None),
                     "survey_8d_convention": {"achieved": OPS_PER_PAIR * pairs / kern_s / 1e12, "peak": VALU_PEAK_TOPS_NOFMA, "unit": "T lane-ops/s",
                                              "ratio": OPS_PER_PAIR * pairs / kern_s / 1e12 / VALU_PEAK_TOPS_NOFMA,
                                              "note": "SURVEY.md 8d's own figure: 9 f32 lane-ops per (query, target) pair / 78.6 T lane-ops/s.  It "

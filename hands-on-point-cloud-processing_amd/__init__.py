@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "pcr_icp_p2p_f32", "pcr_plane_count_f64", "pcr_plane_mask_f64", "pcr_knn_f64", "pcr_radius_f64",
     "pcr_comm_unique_id", "pcr_comm_init_rccl", "pcr_comm_init_callback", "pcr_comm_destroy", "pcr_comm_selftest", "pcr_shard_range",
     "pcr_prof_reset", "pcr_prof_get", "pcr_prof_get_each", "pcr_tune_set",
-    "pcr_grid_stats", "pcr_nn1_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_selftest_mfma_bf16_v2", "pcr_selftest_mfma_f16_v2", "pcr_selftest_sign_f16", "pcr_ctx_mfma_check", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
+    "pcr_grid_stats", "pcr_nn1_stats", "pcr_selftest_mfma_bf16", "pcr_selftest_mfma_f16", "pcr_selftest_mfma_bf16_v2", "pcr_selftest_mfma_f16_v2", "pcr_selftest_sign_f16", "pcr_selftest_sphere_f16", "pcr_ctx_mfma_check", "pcr_voxel_filter_f32", "pcr_iss_keypoints_f32", "pcr_icp_p2plane_f32", "pcr_cloud_knn_f64", "pcr_normals_knn_f64", "pcr_cloud_pca_f64", "pcr_fast_eigen3x3", "pcr_ground_seeds_f64", "pcr_ground_detection_f64",
     "pcr_nn1_desc_f32", "pcr_match_union_f32", "pcr_match_inter_f32", "pcr_ransac_sample_quads", "pcr_consensus_count_f32", "pcr_ransac_global_f32", "pcr_db64_create", "pcr_db64_destroy", "pcr_db64_size", "pcr_db64_knn", "pcr_db64_radius",
     "pcr_ctx_trim", "pcr_ctx_parked_bytes", "pcr_cloud_shard_spatial", "pcr_cloud_global_index", "pcr_cloud_sort_for_target", "pcr_nn1_f32_loop",
     "pcr_db64_radius_rows", "pcr_rows_destroy", "pcr_rows_info", "pcr_rows_row_ptr", "pcr_rows_fetch", "pcr_rows_reduce", "pcr_rows_moments",
@@ -141,6 +141,7 @@ def lib():
     L.pcr_selftest_mfma_bf16_v2.argtypes = [vp, C.c_int, vp]
     L.pcr_selftest_mfma_f16_v2.argtypes = [vp, C.c_int, vp]
     L.pcr_selftest_sign_f16.argtypes = [vp, C.c_int, vp]
+    L.pcr_selftest_sphere_f16.argtypes = [vp, C.c_int, vp]
     L.pcr_ctx_mfma_check.argtypes = [vp, C.c_int, C.POINTER(MfmaCheck)]
     L.pcr_voxel_filter_f32.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
     L.pcr_iss_keypoints_f32.argtypes = [vp, vp, C.POINTER(IssParams), vp, vp, vp, C.POINTER(C.c_uint64)]
@@ -440,6 +441,12 @@ class Context:
         sign set — must be 0 —, pairs with the sign set, pairs in all)"""
         out = (C.c_uint64 * 4)()
         self._ck(lib().pcr_selftest_sign_f16(self.h, int(trials), out))
+        return tuple(int(v) for v in out)
+
+    def selftest_sphere_f16(self, trials: int = 64):
+        """(pairs that must be flagged, of those missed, pairs flagged, pairs) of the level-1 chunk-sphere form of the sign filter (STRACK2)"""
+        out = (C.c_uint64 * 4)()
+        self._ck(lib().pcr_selftest_sphere_f16(self.h, int(trials), out))
         return tuple(int(v) for v in out)
 
     def mfma_check(self, run_now: bool = False):

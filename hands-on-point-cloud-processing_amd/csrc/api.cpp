@@ -609,6 +609,15 @@ int pcr_selftest_sign_f16(pcr_ctx* ctx, int trials, uint64_t out[4])
     return rc;
 }
 
+int pcr_selftest_sphere_f16(pcr_ctx* ctx, int trials, uint64_t out[4])
+{
+    if (!ctx || !out || trials < 0 || trials > 4096) return PCR_ERR_ARG;
+    unsigned long long r[4];
+    const int rc = pcr::st_sphere_selftest(ctx, trials, r);
+    for (int k = 0; k < 4; k++) out[k] = r[k];
+    return rc;
+}
+
 int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out)
 {
     if (!ctx || !out) return PCR_ERR_ARG;

@@ -1556,7 +1556,99 @@ void bt_free(BtIndex* b)
     if (!b) return;
     if (b->block) hipFree(b->block);
     if (b->tile_block) hipFree(b->tile_block);
+    if (b->l1_block) hipFree(b->l1_block);
     delete b;
+}
+
+// ---- level 1 of the two-level sign filter (grid_common.hpp: the statement; nn1_sphere.hpp: the search)
+// one workgroup per level-1 super-tile: centre = mean of its finite records, scale = the power of two with |t - C|_inf scale <= 2^7
+__global__ __launch_bounds__(GR_BLOCK) void bt_l1_centres_kernel(const float4* __restrict__ rec, uint32_t n_rec, uint32_t n_l1, float4* __restrict__ centres, int* __restrict__ bad)
+{
+    __shared__ float red[4][GR_BLOCK / 64];
+    const uint32_t s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (s >= n_l1) return;
+    constexpr int PER = BT_L1_SUPER / GR_BLOCK;
+    float cx = 0.f, cy = 0.f, cz = 0.f, cnt = 0.f;
+    float4 r[PER];
+    bool fin[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const size_t p = (size_t)s * BT_L1_SUPER + (size_t)u * GR_BLOCK + threadIdx.x;
+        r[u] = p < n_rec ? rec[p] : make_float4(__builtin_inff(), 0.f, 0.f, 0.f);
+        fin[u] = finite3(r[u].x, r[u].y, r[u].z);
+        if (fin[u]) { cx += r[u].x; cy += r[u].y; cz += r[u].z; cnt += 1.0f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cx += __shfl_xor(cx, o, 64); cy += __shfl_xor(cy, o, 64); cz += __shfl_xor(cz, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+    if (lane == 0) { red[0][wave] = cx; red[1][wave] = cy; red[2][wave] = cz; red[3][wave] = cnt; }
+    __syncthreads();
+    cx = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]); cy = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    cz = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]); cnt = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+    if (cnt > 0.f) { cx /= cnt; cy /= cnt; cz /= cnt; }
+    float rho = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; u++)
+        if (fin[u]) rho = fmaxf(rho, fmaxf(fmaxf(fabsf(r[u].x - cx), fabsf(r[u].y - cy)), fabsf(r[u].z - cz)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rho = fmaxf(rho, __shfl_xor(rho, o, 64));
+    __syncthreads();
+    if (lane == 0) red[0][wave] = rho;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    rho = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    int k = 0;
+    if (rho > 0.f) {
+        int e2;
+        (void)frexpf(rho, &e2);                            // rho <= 2^e2
+        k = 7 - e2;
+        if (k < -60 || k > 60) { atomicOr(bad, 1); k = k < 0 ? -60 : 60; }
+    }
+    centres[s] = make_float4(cx, cy, cz, ldexpf(1.0f, k));
+}
+
+// one thread per chunk of 16 records: its row of its level-1 tile (MFMA row m <-> chunk 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3), so that
+// the 16 accumulators of lane-half h are the chunks 16 h + i of the tile, in order)
+__global__ __launch_bounds__(GR_BLOCK) void bt_l1_ops_kernel(const float4* __restrict__ rec, uint32_t n_rec, uint32_t n_l1_tiles, const float4* __restrict__ centres,
+                                                             uint4* __restrict__ ops)
+{
+    const uint32_t gid = blockIdx.x * GR_BLOCK + threadIdx.x;
+    const uint32_t T = gid >> 5, m = gid & 31;
+    if (T >= n_l1_tiles) return;
+    const uint32_t chunk = T * 32 + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+    const float4 C = centres[T / (BT_L1_SUPER / 512)];
+    float tx[16], ty[16], tz[16];
+    bool fin[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const size_t p = (size_t)chunk * 16 + j;
+        const float4 r = p < n_rec ? rec[p] : make_float4(__builtin_inff(), 0.f, 0.f, 0.f);
+        tx[j] = (r.x - C.x) * C.w; ty[j] = (r.y - C.y) * C.w; tz[j] = (r.z - C.z) * C.w;       // exact scaling, |.| <= 2^7 (unless the super-tile is flagged bad)
+        fin[j] = finite3(r.x, r.y, r.z) && fabsf(tx[j]) <= 128.0f && fabsf(ty[j]) <= 128.0f && fabsf(tz[j]) <= 128.0f;
+    }
+    uint4 lo, hi;
+    l1_chunk_operand(tx, ty, tz, fin, lo, hi);
+    ops[(size_t)T * 64 + m] = lo;
+    ops[(size_t)T * 64 + 32 + m] = hi;
+}
+
+int bt_ensure_l1(pcr_ctx* ctx, const pcr_cloud* tgt)
+{
+    BtIndex* bt = tgt->bt;
+    if (!bt || !bt->safe || !bt->n_tiles) return fail(ctx, PCR_ERR_STATE, "bt_ensure_l1: no index");
+    if (bt->l1_block) return PCR_OK;
+    const size_t n_pad = bt->n_tiles * 32, n_l1 = (n_pad + BT_L1_SUPER - 1) / BT_L1_SUPER, n_l1_tiles = n_l1 * (BT_L1_SUPER / 512);
+    const size_t off_ops = (n_l1 * sizeof(float4) + 255) & ~(size_t)255, off_flag = off_ops + n_l1_tiles * 64 * sizeof(uint4), total = off_flag + 256;
+    char* blk = nullptr;
+    hipError_t e = hipMalloc((void**)&blk, total);
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "hipMalloc(level-1 operands)", e);
+    bt->l1_block = blk; bt->l1_centres = (float4*)blk; bt->l1_ops = (uint4*)(blk + off_ops); bt->l1_bad = (int*)(blk + off_flag); bt->n_l1_super = n_l1;
+    e = hipMemsetAsync(bt->l1_bad, 0, sizeof(int), ctx->stream);
+    if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "level-1 operands", e);
+    hipLaunchKernelGGL(bt_l1_centres_kernel, dim3((unsigned)n_l1), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_pad, (uint32_t)n_l1, bt->l1_centres, bt->l1_bad);
+    hipLaunchKernelGGL(bt_l1_ops_kernel, dim3((unsigned)((n_l1_tiles * 32 + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_pad,
+                       (uint32_t)n_l1_tiles, bt->l1_centres, bt->l1_ops);
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
 }
 
 // ---- extras of the sign tile search (grid_stile.hpp)

@@ -100,6 +100,14 @@ struct BtIndex {
     // cell c are [cell_start[c], cell_start[c + 1]), non-finite records and padding lie behind the last entry); tile_spheres = bounding
     // sphere of every tile of 32 records (radius < 0 = no finite member); g_of_b[p] = position of record p in the
     // records of the cell grid `g_of` (the winner positions of a loop — ctx->wpos — stay in that numbering for the walk and the Kabsch pass)
+    // ---- level 1 of the two-level sign filter (STRACK2, nn1_sphere.hpp; bt_ensure_l1): per level-1 super-tile of BT_L1_SUPER records a centre
+    // + power-of-two scale, per chunk of 16 records ONE operand row (its bounding sphere): [level-1 tile of 32 chunks][64 lanes] x 16 bytes
+    void* l1_block = nullptr;
+    float4* l1_centres = nullptr;
+    uint4* l1_ops = nullptr;
+    size_t n_l1_super = 0;
+    int l1_bad_host = -1;             // a level-1 super-tile whose scale left the f16 range (device flag behind l1_ops, read lazily)
+    int* l1_bad = nullptr;
     void* tile_block = nullptr;
     uint32_t* cell_start = nullptr;
     int cbits = 0;
@@ -220,11 +228,135 @@ __device__ __forceinline__ void st_setup(float qx, float qy, float qz, const flo
     Q[3] = st_theta(thr, sc2, Rs);
 }
 
+// ---- LEVEL 1 of the two-level sign filter (STRACK2, nn1_sphere.hpp): one MFMA row per CHUNK of 16 records instead of one per record.  A chunk
+// with bounding sphere (c, rho) cannot hold a record at or below a query's threshold thr unless |r - c| <= s + rho (s = sqrt(thr), scaled
+// units of the LEVEL-1 super-tile of 4 096 records: centre C1, power-of-two scale with |t - C1| scale <= 2^7), i.e. unless
+//     F = (|c|^2 - rho^2) - 2 r.c - 2 s rho - (s^2 - |r|^2) <= 0 :
+// the same bilinear form as the record filter with w -> W = |c|^2 - rho^2, ONE more product (-2 rho)(s) — it takes the K-slot of the z
+// coordinate's (t2, r2) piece product, which is dropped (<= 2^-22 |2 c_z r_z| <= 4 u (Q + W): inside the 24 u the budget of the f16 form
+// leaves unused) — and the threshold pieces in the last two slots as before.  What makes it a theorem (header of st_setup_l1):
+//   * the centre is the value its two f16 pieces REPRESENT (c~ = p1 + p2, chosen by the index build), so it carries no rounding at all,
+//     and rho >= the largest distance of the chunk's records from THAT point (f32 arithmetic, rounded up by 2^-18 + 2^-12, then up to
+//     an f16: the slot holds -2 rho exactly and W uses the same value);
+//   * W is stored below its value by 2^-16 (|c~|^2 + rho^2) (the pieces' rounding toward zero, the accumulation of its slots and of the
+//     cross term's target share), s above its value by 2^-11 (f16, rounded up: covers the A1-versus-true mismatch of the distance that
+//     defines the threshold and the accumulation of the 2 rho s slot), the threshold by 2^-18 |theta| (st_theta_l1: 64 u, of which 16.2 u
+//     pay for its own slots' accumulation and 20 u for s'^2 - s^2);
+//   * a chunk whose records spread over more than 2^7 scaled units (16 Morton-consecutive records across half the super-tile: padding,
+//     pathological clouds) gets the sphere (C1, 222 >= 2^7 sqrt 3) that holds every record of the super-tile; a chunk without a finite
+//     record gets W = +inf (never flagged).
+// The assumption is the f16 form's own (accumulation error <= 16 u sum |a b|: mfma_verdict); the device self-test of this form
+// (pcr_selftest_sphere_f16) checks the statement itself: no (query, chunk) pair with a record at or below the threshold without its sign.
+constexpr int BT_L1_SUPER = 4096;      // records per level-1 super-tile: 256 chunks = 8 level-1 tiles of 32 chunks = 16 super-tiles
+
+// f16 value >= v (v >= 0): rounded toward zero after adding 2^-9 of itself + 2^-23 (an f16 conversion toward zero loses < 2^-10 of a
+// normal value, < 2^-24 of a subnormal one); returned as the 16-bit pattern and as the float it represents
+__device__ __forceinline__ uint32_t f16_up(float v, float& rep)
+{
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(v, 0.001953125f, v) + 1.1920928955078125e-07f, 0.0f);
+    rep = (float)a.x;
+    return __builtin_bit_cast(uint32_t, a) & 0xFFFFu;
+}
+
+// the two lanes' words of MFMA row `m` of a level-1 tile for one chunk: t[16][3] = the chunk's records in the scaled units of its level-1
+// super-tile (exact scaling), fin[16] = finite and inside the super-tile's range
+__device__ __forceinline__ void l1_chunk_operand(const float (&tx)[16], const float (&ty)[16], const float (&tz)[16], const bool (&fin)[16], uint4& lo, uint4& hi)
+{
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (fin[j]) {
+            any = true;
+            mn[0] = fminf(mn[0], tx[j]); mx[0] = fmaxf(mx[0], tx[j]);
+            mn[1] = fminf(mn[1], ty[j]); mx[1] = fmaxf(mx[1], ty[j]);
+            mn[2] = fminf(mn[2], tz[j]); mx[2] = fmaxf(mx[2], tz[j]);
+        }
+    if (!any) {                                               // no finite record: W = +inf, never flagged
+        lo = make_uint4(0u, 0u, 0u, 0u);
+        hi = make_uint4(0u, 0u, 0x7C00u, HT_THETA_CONSTS);
+        return;
+    }
+    // the centre = what the two f16 pieces of -2 c represent
+    uint32_t p[3][2];
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float mid = 0.5f * mn[k] + 0.5f * mx[k];
+        ht_split(-2.0f * mid, p[k][0], p[k][1]);
+        typedef __fp16 h1 __attribute__((ext_vector_type(2)));
+        const float a1 = (float)__builtin_bit_cast(h1, p[k][0]).x, a2 = (float)__builtin_bit_cast(h1, p[k][1]).x;
+        c[k] = -0.5f * (a1 + a2);                             // exact: two f16 values of at most 22 significant bits in all
+    }
+    float r2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (fin[j]) {
+            const float dx = tx[j] - c[0], dy = ty[j] - c[1], dz = tz[j] - c[2];
+            r2 = fmaxf(r2, (dx * dx + dy * dy) + dz * dz);
+        }
+    float rho = __builtin_fmaf(sqrtf(r2), 3.814697265625e-06f, sqrtf(r2)) + 2.44140625e-04f;      // up: 2^-18 of itself + 2^-12
+    if (!(rho <= 128.0f)) {                                   // spread over more than half the super-tile: the sphere of the whole super-tile
+        c[0] = c[1] = c[2] = 0.0f;
+        p[0][0] = p[0][1] = p[1][0] = p[1][1] = p[2][0] = p[2][1] = 0u;
+        rho = 222.0f;
+    }
+    float rho16;
+    (void)f16_up(rho, rho16);
+    uint32_t m2, m2lo;
+    ht_split(-2.0f * rho16, m2, m2lo);                        // (-2 rho16 is an f16 value: the second piece is zero)
+    const float wc = (c[0] * c[0] + c[1] * c[1]) + c[2] * c[2], wr = rho16 * rho16;
+    const float W = __builtin_fmaf(-wr, 1.0000152587890625f, wc * 0.9999847412109375f) - 9.5367431640625e-07f;   // wc (1 - 2^-16) - wr (1 + 2^-16) - 2^-20
+    uint32_t w1, w2;
+    ht_split(W, w1, w2);
+    lo = make_uint4(p[0][0] | (p[0][1] << 16), p[0][0] | (p[0][1] << 16), p[1][0] | (p[1][1] << 16), p[1][0] | (p[1][1] << 16));
+    hi = make_uint4(p[2][0] | (p[2][1] << 16), p[2][0] | (m2 << 16), w1 | (w2 << 16), HT_THETA_CONSTS);
+}
+
+// the threshold slots of the level-1 form: as st_theta, rounded up by 2^-18 |theta| (see above)
+__device__ __forceinline__ uint32_t st_theta_l1(float thr, float sc2, float Rs)
+{
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    constexpr float LIM = 2129920000.0f;                      // 65 000 x 2^15
+    float th = __builtin_amdgcn_fmed3f(__builtin_fmaf(thr, sc2, -Rs), -LIM, LIM);
+    th = __builtin_fmaf(fabsf(th), 3.814697265625e-06f, th);                                  // + 2^-18 |theta|
+    const h2 a = __builtin_amdgcn_cvt_pkrtz(th * 3.0517578125e-05f, 0.0f);                    // hi = rtz(theta / 2^15)
+    const float rem = __builtin_fmaf(-(float)a.x, 32768.0f, th);                              // exact
+    float lo = rem * 0.015625f;
+    lo = __builtin_fmaf(fabsf(lo), 0.001953125f, lo) + 1.1920928955078125e-07f;              // up: 2^-9 of itself + 2^-23
+    const h2 b = __builtin_amdgcn_cvt_pkrtz(lo, 0.0f);
+    return ((__builtin_bit_cast(uint32_t, a) ^ 0x8000u) & 0xFFFFu) | ((__builtin_bit_cast(uint32_t, b) ^ 0x8000u) << 16);
+}
+
+// query side of the level-1 form for one (query, level-1 super-tile): P = the lower half-lane's words (x pieces, y pieces), Q = the upper
+// half-lane's (z: r1 r1 | r2, s | 1 1 | threshold pieces).  s = sqrt(thr) scale, rounded UP into an f16 (0 for "never": thr = -inf)
+__device__ __forceinline__ void st_setup_l1(float qx, float qy, float qz, const float4 C, float thr, float sc2, uint32_t P[4], uint32_t Q[4])
+{
+    constexpr float KAPPA = 0.99999237060546875f;             // 1 - 2^-17
+    const float sc = C.w;
+    const float rx = __builtin_amdgcn_fmed3f((qx - C.x) * sc, -32000.0f, 32000.0f), ry = __builtin_amdgcn_fmed3f((qy - C.y) * sc, -32000.0f, 32000.0f),
+                rz = __builtin_amdgcn_fmed3f((qz - C.z) * sc, -32000.0f, 32000.0f);
+    const float Rs = __builtin_fmaf(__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)), KAPPA, -PCR_HT_ABS_SLACK);
+    ht_pair(rx, P[0], P[1]);
+    ht_pair(ry, P[2], P[3]);
+    uint32_t z2;
+    ht_pair(rz, Q[0], z2);
+    const float s2 = __builtin_amdgcn_fmed3f(thr * sc2, 0.0f, 2129920000.0f);                // (thr = -inf: 0)
+    float srep;
+    const uint32_t s16 = f16_up(sqrtf(s2), srep);
+    Q[1] = (z2 & 0xFFFFu) | (s16 << 16);
+    Q[2] = 0x3C003C00u;
+    Q[3] = st_theta_l1(thr, sc2, Rs);
+}
+
 void bt_free(BtIndex* b);
 // builds (and caches on tgt) the index if it is not there yet
 int bt_ensure(pcr_ctx* ctx, const pcr_cloud* tgt);
 // ... and the extras of the sign tile search (needs tgt->grid and a safe tgt->bt; rebuilt when the grid changed)
 int bt_ensure_tile(pcr_ctx* ctx, const pcr_cloud* tgt);
+// ... and level 1 of the two-level sign filter (needs a safe tgt->bt)
+int bt_ensure_l1(pcr_ctx* ctx, const pcr_cloud* tgt);
 // builds (and caches on tgt) the 1-NN grid if needed, then groups the queries `src` by coarse cell -> ctx->qperm
 int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src);
 // replaces *work by its cell-sorted copy (ctx->work_orig = original indices); no-op for empty clouds / tune grid_sort_work = 2

@@ -1032,6 +1032,8 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_ST_WAVES) void nn1_strack_kernel(
     }
 }
 
+#include "nn1_sphere.hpp"
+
 // ICP iterations after the first: the previous correspondence, re-evaluated exactly against the moved query, is a genuine
 // candidate and therefore an upper bound of the new answer from the first instruction on (ETRACK settles every far slice with it).
 __global__ __launch_bounds__(NN_BLOCK) void nn1_seed_kernel(const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, uint32_t nt,
@@ -1185,7 +1187,9 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     // query groups (of 32) per wave: four amortise the per-tile operand loads best on a full batch; a source shard of a strong-scaling run
     // (15-30 k queries against the whole target) fills the chip better with two — measured, per ICP iteration: 15 k queries 0.158 -> 0.137
     // ms, 30 k 0.241 -> 0.218, 60 k 0.378 / 0.375, 120 k 0.664 -> 0.723
-    const int qg = tune_get(ctx, "nn1_btrack_qg", ns <= 49152 ? 2 : 4) == 2 ? 2 : 4;
+    int qg = tune_get(ctx, "nn1_btrack_qg", ns <= 49152 ? 2 : 4) == 2 ? 2 : 4;
+    if (tune_get(ctx, "nn1_variant", 0) == 9 || tune_get(ctx, "nn1_sphere", 0) == 1 || (tune_get(ctx, "nn1_sphere", 0) == 0 && tune_get(ctx, "nn1_variant", 0) == 0 && f16 &&
+        tgt->n >= 32768 && tune_get(ctx, "nn1_btrack_qg", 0) == 0)) qg = 4;                     // (STRACK2 holds four groups per wave)
     const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                          // queries per workgroup
     const uint32_t qblocks = (uint32_t)((ns + qpb - 1) / qpb);
     const uint32_t n_super = (uint32_t)(g->n_tiles / (BT_SUPER / 32));
@@ -1206,7 +1210,23 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     const int64_t sign_tune = tune_get(ctx, "nn1_sign", 0);
     const bool sign = force_sign ? (warm || cold_seed) : f16 && sign_tune != 2 && (warm || cold_seed);
     const bool reseed = sign && warm && !pre_seeded && tune_get(ctx, "nn1_cold_seed", 1) == 1;
-    ctx->last_nn1_kernel = sign ? "strack" : f16 ? "htrack" : "btrack";
+    // STRACK2 (nn1_sphere.hpp): the sign filter at two levels — one MFMA row per chunk of 16 records first.  Tune nn1_sphere: 0 auto (targets from
+    // 32 768 points on, where a level-1 super-tile of 4 096 records is a small part of the cloud), 1 = always, 2 = never; nn1_variant 9 forces it.
+    const int64_t sph_tune = tune_get(ctx, "nn1_sphere", 0), variant_now = tune_get(ctx, "nn1_variant", 0);
+    bool sphere = sign && f16 && qg == 4 && sph_tune != 2 && (variant_now == 9 || sph_tune == 1 || (variant_now == 0 && tgt->n >= 32768));
+    if (sphere) {
+        int rc1 = bt_ensure_l1(ctx, tgt);
+        if (rc1) return rc1;
+        BtIndex* bt = tgt->bt;
+        if (bt->l1_bad_host < 0) {
+            int flag = 1;
+            PCR_HIP(ctx, hipMemcpyAsync(&flag, bt->l1_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            bt->l1_bad_host = flag;
+        }
+        sphere = bt->l1_bad_host == 0;
+    }
+    ctx->last_nn1_kernel = sphere ? "strack2" : sign ? "strack" : f16 ? "htrack" : "btrack";
     if (warm) seed_warm(ctx, tgt, src, pre_seeded);
     else if (merge_atomic && !cold_seed) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
     unsigned long long* stats_dev = nullptr;
@@ -1231,7 +1251,17 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
 #define PCR_STRACK(Q)                                                                                                                      \
     hipLaunchKernelGGL((nn1_strack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records, n_super * BT_SUPER, n_super, sps,  \
                        src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices, st_flush_at, st_dense_at)
-        if (sign) { if (qg == 2) PCR_STRACK(2); else PCR_STRACK(4); }
+        if (sphere) {
+            const uint32_t n_l1 = (uint32_t)g->n_l1_super;
+            uint32_t s2_slices = 1;
+            const uint32_t l1ps = slice_plan(n_l1, qblocks, tune_get(ctx, "nn1_sphere_l1_per_slice", 0), tune_get(ctx, "nn1_sphere_blocks", 1024), &s2_slices);
+            int64_t xq2 = tune_get(ctx, "nn1_xcd", NN_XCD_DEFAULT);
+            if ((xq2 != 1 && xq2 != 2 && xq2 != 4) || s2_slices < 8 || (uint64_t)qblocks * s2_slices >= (1ull << 27)) xq2 = 0;
+            const dim3 grid2 = xq2 ? dim3(8u * ((qblocks + (uint32_t)xq2 - 1) / (uint32_t)xq2) * ((s2_slices + 8u / (uint32_t)xq2 - 1) / (8u / (uint32_t)xq2)), 1) : dim3(qblocks, s2_slices);
+            hipLaunchKernelGGL((nn1_strack2_kernel<4>), grid2, dim3(NN_BLOCK), 0, ctx->stream, g->l1_centres, g->l1_ops, g->centres, g->ops16, g->records, n_super * BT_SUPER,
+                               n_l1, l1ps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)xq2, qblocks, s2_slices, st_flush_at);
+        }
+        else if (sign) { if (qg == 2) PCR_STRACK(2); else PCR_STRACK(4); }
         else if (f16) { if (qg == 2) PCR_BTRACK(2, true, g->ops16); else PCR_BTRACK(4, true, g->ops16); }
         else { if (qg == 2) PCR_BTRACK(2, false, g->ops); else PCR_BTRACK(4, false, g->ops); }
 #undef PCR_STRACK
@@ -1316,12 +1346,12 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     // The matrix-core forms, from a target's FIRST search on: the index (operands in Morton order, bt_ensure) costs one bounding-box
     // round trip and ~0.2 ms at 120 k points, less than the kernel saves (small targets stay on the f32 filters: 44 against 53 us per
     // ICP iteration at 4 000 points, 114 against 72 at 20 000 — profiles/r02_mfma_filter_experiments.txt)
-    if (variant == 6 || variant == 7 || variant == 8 || (variant == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)))) {
+    if (variant == 6 || variant == 7 || variant == 8 || variant == 9 || (variant == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)))) {
         rc = bt_ensure(ctx, tgt);
         if (rc) return rc;
         if (tgt->bt->safe && tgt->bt->n_tiles) {
             // HTRACK: one f16 MFMA per tile instead of two bf16 ones, when the cloud fits f16's range (the flag of the operand build, read once)
-            bool f16 = variant == 7 || variant == 8 || (variant == 0 && f16_tune != 2 && (f16_tune == 1 || NN_F16_DEFAULT));
+            bool f16 = variant == 7 || variant == 8 || variant == 9 || (variant == 0 && f16_tune != 2 && (f16_tune == 1 || NN_F16_DEFAULT));
             if (f16 && tgt->bt->bad16_host < 0) {
                 int flag = 1;
                 PCR_HIP(ctx, hipMemcpyAsync(&flag, tgt->bt->bad16, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1333,7 +1363,7 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
             // either is first chosen (mfma_verdict: once per context, cached): a form whose measured error exceeds half of what its bound
             // budgets is not used here; the f32 filters below (bounds from IEEE arithmetic alone) answer instead.
             if (f16 && !mfma_verdict(ctx, true)) f16 = false;
-            if (f16 || mfma_verdict(ctx, false)) return launch_matrix(ctx, tgt, src, f16, warm, pre_seeded, f16 && variant == 8);
+            if (f16 || mfma_verdict(ctx, false)) return launch_matrix(ctx, tgt, src, f16, warm, pre_seeded, f16 && (variant == 8 || variant == 9));
         }
     }
     // ETRACK needs the cell index (chunked, centred copy of the target): cold searches take it when that index exists or will be needed
@@ -1742,6 +1772,133 @@ int st_sign_selftest(pcr_ctx* ctx, int trials, unsigned long long res[4])
     return PCR_OK;
 }
 
+// ---- self-test of the LEVEL-1 statement of STRACK2 (pcr_selftest_sphere_f16; a short form is part of the f16 verdict below): random level-1
+// tiles — 32 chunks of 16 records in the scaled range of a level-1 super-tile: tight clusters, wide ones, chunks spread beyond 2^7 (the
+// whole-super-tile sphere), chunks without a finite record, records on the edge of the range — through the index build's own operand code
+// (l1_chunk_operand), the kernel's query code (st_setup_l1) and the MFMA, a power-of-two scale per tile; queries near a chunk, inside one, far
+// away, at the clamp; thresholds ON the exact A1 distance to some record, one ulp below / above it, a factor away, zero.  EVERY (query,
+// chunk) pair with a record whose A1 distance is at or below the query's threshold must come out with its sign set.
+// out = { such pairs, of those WITHOUT the sign (must be 0), pairs with the sign set, pairs in all }.
+__global__ __launch_bounds__(64) void sp_selftest_kernel(const float* __restrict__ rec, const float* __restrict__ qs, const float* __restrict__ thr, const float* __restrict__ scale,
+                                                         float* __restrict__ out)
+{
+    const uint32_t lane = threadIdx.x, T = blockIdx.x, n = lane & 31;
+    const bool h = lane >= 32;
+    const float sc = scale[T];
+    // row n of the tile <-> chunk 16 ((n >> 2) & 1) + 4 (n >> 3) + (n & 3) (bt_l1_ops_kernel)
+    const uint32_t chunk = 16 * ((n >> 2) & 1) + 4 * (n >> 3) + (n & 3);
+    float tx[16], ty[16], tz[16];
+    bool fin[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float* r = rec + (((size_t)T * 32 + chunk) * 16 + j) * 3;    // cloud units; the level-1 centre is the origin
+        tx[j] = r[0] * sc; ty[j] = r[1] * sc; tz[j] = r[2] * sc;
+        fin[j] = fabsf(r[0]) <= 3.0e38f && fabsf(r[1]) <= 3.0e38f && fabsf(r[2]) <= 3.0e38f && fabsf(tx[j]) <= 128.0f && fabsf(ty[j]) <= 128.0f && fabsf(tz[j]) <= 128.0f;
+    }
+    uint4 lo, hi;
+    l1_chunk_operand(tx, ty, tz, fin, lo, hi);
+    const uint4 A = h ? hi : lo;
+    const float* q = qs + ((size_t)T * 32 + n) * 3;
+    uint32_t P[4], Q[4];
+    st_setup_l1(q[0], q[1], q[2], make_float4(0.0f, 0.0f, 0.0f, sc), thr[(size_t)T * 32 + n], sc * sc, P, Q);
+    const uint4 B = h ? make_uint4(Q[0], Q[1], Q[2], Q[3]) : make_uint4(P[0], P[1], P[2], P[3]);
+    f32x16 zero;
+#pragma unroll
+    for (int j = 0; j < 16; j++) zero[j] = 0.0f;
+    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), zero, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; j++) out[((size_t)T * 64 + lane) * 16 + j] = acc[j];
+}
+
+int st_sphere_selftest(pcr_ctx* ctx, int trials, unsigned long long res[4])
+{
+    res[0] = res[1] = res[2] = res[3] = 0;
+    if (trials <= 0) return PCR_OK;
+    const size_t n_tiles = (size_t)trials;
+    // one upload: [n_tiles][32 chunks][16 records] x 3 floats | [n_tiles][32 queries] x 3 | [n_tiles][32] thresholds | [n_tiles] scales
+    const size_t rec_floats = n_tiles * 32 * 16 * 3, q_off = rec_floats, thr_off = q_off + n_tiles * 96, sc_off = thr_off + n_tiles * 32, in_floats = sc_off + n_tiles;
+    std::vector<float> in(in_floats, 0.0f);
+    SelfRng rng{ 0x5B4E2E16Full };
+    auto a1 = [](const float* a, const float* b) { const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2]; return (dx * dx + dy * dy) + dz * dz; };
+    for (size_t T = 0; T < n_tiles; T++) {
+        const float sc = std::ldexp(1.0f, rng.range(-8, 8)), inv = 1.0f / sc;
+        in[sc_off + T] = sc;
+        float* rec = &in[T * 32 * 16 * 3];
+        for (int c = 0; c < 32; c++) {
+            // scaled units, |.| <= 128: a cluster of radius 2^-12 .. 2^6 around a centre in the box (clipped to it), now and then spread over
+            // the whole box, on its faces, or empty
+            const int kind = (int)(rng.uni() * 16.0);
+            const float rad = kind == 0 ? 250.0f : std::ldexp(1.0f, rng.range(-12, 6));
+            float cen[3];
+            for (int k = 0; k < 3; k++) cen[k] = rng.sym(120.0f);
+            for (int j = 0; j < 16; j++)
+                for (int k = 0; k < 3; k++) {
+                    float v = cen[k] + rng.sym(1.0f) * rad;
+                    v = std::min(std::max(v, -128.0f), 128.0f);
+                    if (kind == 1 && j < 4) v = (rng.uni() < 0.5 ? -128.0f : 128.0f);
+                    if (kind == 2) v = std::numeric_limits<float>::quiet_NaN();                     // an empty chunk
+                    if (kind == 3 && j == 5) v = std::numeric_limits<float>::infinity();            // one non-finite record among finite ones
+                    rec[(c * 16 + j) * 3 + k] = v * inv;                                              // -> cloud units (exact)
+                }
+        }
+        float* q = &in[q_off + T * 96];
+        for (int n = 0; n < 32; n++) {
+            const int kind = (int)(rng.uni() * 8.0);
+            const int c = (int)(rng.uni() * 32.0) % 32, j = (int)(rng.uni() * 16.0) % 16;
+            const float* near = &rec[(c * 16 + j) * 3];
+            for (int k = 0; k < 3; k++) {
+                float v;
+                if (kind <= 3) v = (std::isfinite(near[k]) ? near[k] * sc : 0.0f) + rng.sym(1.0f) * std::ldexp(1.0f, rng.range(-10, 5));     // near a record
+                else if (kind == 4) v = rng.sym(128.0f);                                                                             // somewhere in the box
+                else if (kind == 5) v = rng.sym(1.0f) * std::ldexp(1.0f, rng.range(7, 14));                                           // outside, up to the clamp
+                else if (kind == 6) v = rng.sym(40000.0f);                                                                            // beyond the clamp
+                else v = std::isfinite(near[k]) ? near[k] * sc : 0.0f;                                                                  // ON a record
+                q[n * 3 + k] = v * inv;
+            }
+            // threshold: the exact A1 distance to a record of some chunk (finite ones only), displaced
+            const int c2 = (n * 5 + (int)T) % 32, j2 = (n * 3) % 16;
+            const float* tr = &rec[(c2 * 16 + j2) * 3];
+            float d = (std::isfinite(tr[0]) && std::isfinite(tr[1]) && std::isfinite(tr[2])) ? a1(&q[n * 3], tr) : 1.0f * inv * inv;
+            if (!(d < 3.0e38f)) d = 3.0e38f;
+            float th = d;
+            switch (n % 6) {
+            case 1: th = std::nextafter(d, 0.0f); break;
+            case 2: th = std::nextafter(d, 3.0e38f); break;
+            case 3: th = d * std::ldexp(1.0f, rng.range(-3, 3)) * (1.0f + (float)rng.uni()); break;
+            case 4: th = 0.0f; break;
+            default: break;
+            }
+            in[thr_off + T * 32 + n] = th;
+        }
+    }
+    float* out = nullptr; void* d_in = nullptr; float* d_out = nullptr;
+    const size_t out_bytes = n_tiles * 64 * 16 * sizeof(float);
+    int rc = selftest_run(ctx, in.data(), in.size() * sizeof(float), out_bytes, &out, &d_in, &d_out);
+    if (rc) return rc;
+    const float* df = (const float*)d_in;
+    hipLaunchKernelGGL(sp_selftest_kernel, dim3((unsigned)n_tiles), dim3(64), 0, ctx->stream, df, df + q_off, df + thr_off, df + sc_off, d_out);
+    PCR_HIP(ctx, hipGetLastError());
+    PCR_HIP(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t T = 0; T < n_tiles; T++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int reg = 0; reg < 16; reg++) {
+                const int n = lane & 31, chunk = 16 * (lane >> 5) + reg;       // accumulator `reg` of lane-half h <-> chunk 16 h + reg of the tile
+                uint32_t bits; std::memcpy(&bits, &out[(T * 64 + lane) * 16 + reg], 4);
+                const bool flagged = (bits >> 31) != 0;
+                const float* q = &in[q_off + (T * 32 + n) * 3];
+                const float th = in[thr_off + T * 32 + n];
+                bool must = false;
+                for (int j = 0; j < 16 && !must; j++) {
+                    const float* t = &in[((T * 32 + chunk) * 16 + j) * 3];
+                    if (!(std::isfinite(t[0]) && std::isfinite(t[1]) && std::isfinite(t[2]))) continue;
+                    must = a1(q, t) <= th;
+                }
+                res[0] += must; res[1] += must && !flagged; res[2] += flagged; res[3] += 1;
+            }
+    return PCR_OK;
+}
+
 // The verdict the dispatcher acts on (launch_nn1_brute): the short form of the self-test above, once per context and form, with HALF of
 // every assumed bound as the pass mark — accumulation (random and structured) <= 8 u sum|a b| of the 16 assumed; the whole filter value
 // <= 41 u (Q + W) of 82 (f16) / <= 17.1 of 34.2 (bf16); the underflow regime <= 2 u of the 4 u ht_setup subtracts.  A form that fails is
@@ -1761,6 +1918,8 @@ bool mfma_verdict(pcr_ctx* ctx, bool f16)
         // ... and the decision of the sign form (STRACK, the default search on this form): no pair at or below its threshold without the sign
         unsigned long long sg[4];
         ok = st_sign_selftest(ctx, 2, sg) == PCR_OK && sg[0] > 0 && sg[1] == 0;
+        // ... and the level-1 statement of the two-level form (STRACK2): no (query, chunk) pair with a record at or below the threshold without it
+        if (ok) ok = st_sphere_selftest(ctx, 4, sg) == PCR_OK && sg[0] > 0 && sg[1] == 0;
     }
     v = ok ? 1 : 0;
     ctx->mfma_check_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

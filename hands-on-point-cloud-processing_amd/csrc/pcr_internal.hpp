@@ -195,6 +195,7 @@ void prof_flush(pcr_ctx* ctx);
 // ---- kernel launchers (defined in the .hip files) --------------------------------------------------
 int bt_mfma_selftest(pcr_ctx* ctx, int trials, double worst[4]);
 int ht_mfma_selftest(pcr_ctx* ctx, int trials, double worst[4]);
+int st_sphere_selftest(pcr_ctx* ctx, int trials, unsigned long long res[4]);   // nn1_brute.hip: the level-1 (chunk sphere) statement of STRACK2
 int st_sign_selftest(pcr_ctx* ctx, int trials, unsigned long long res[4]);   // nn1_brute.hip: the sign form's decision, checked on the device
 bool mfma_verdict(pcr_ctx* ctx, bool f16);     // cached per context; runs the short self-test on first use
 int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bool in_loop);

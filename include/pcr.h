@@ -359,6 +359,12 @@ int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[2]);
  * out = { pairs whose exact f32 distance lies at or below their query's threshold, of those WITHOUT the sign — must be 0 —,
  * pairs with the sign set, pairs in all }.  A short form is part of the once-per-context check below. */
 int pcr_selftest_sign_f16(pcr_ctx* ctx, int trials, uint64_t out[4]);
+/* The LEVEL-1 statement of the two-level form of that filter (STRACK2, csrc/nn1_sphere.hpp: one MFMA row per CHUNK of 16 records — its bounding
+ * sphere — before any per-record row): `trials` random level-1 tiles of 32 chunks (tight and wide clusters, chunks spread beyond the scaled
+ * range, empty chunks, non-finite records) against 32 queries each (near, inside, far, beyond the clamp) with thresholds on / one ulp off / a
+ * factor off exact distances and zero, through the index build's operand code, the kernel's query code and the MFMA.
+ * out = { (query, chunk) pairs with a record at or below the threshold, of those WITHOUT the sign (must be 0), pairs flagged, pairs }. */
+int pcr_selftest_sphere_f16(pcr_ctx* ctx, int trials, uint64_t out[4]);
 /* The library runs a short form of the two self-tests ITSELF, once per context, before it first picks a matrix-core kernel, and only
  * uses a form whose four figures stay within HALF of what its bound assumes (f16 -> bf16 -> the f32 filters, whose bounds need IEEE
  * arithmetic only).  This reports the verdicts (-1 = not run yet; run_now != 0 runs them), the figures, the host time the checks

@@ -69,6 +69,16 @@ def test_sign_form_never_misses_a_pair_at_or_below_its_threshold(ctx):
     assert ctx.selftest_sign_f16(2)[1] == 0                                # the short form the verdict runs
 
 
+def test_sphere_form_never_misses_a_chunk_with_a_record_at_or_below_the_threshold(ctx):
+    """STRACK2's level 1 (csrc/nn1_sphere.hpp, grid_common.hpp l1_chunk_operand / st_setup_l1): the chunk-sphere form of the sign filter through
+    the index build's operand code, the kernel's query code and the MFMA, on the device under test — no (query, chunk) pair with a record at or
+    below the query's threshold comes out without its sign; the form prunes (most pairs are not flagged)."""
+    must, missed, flagged, pairs = ctx.selftest_sphere_f16(512)
+    assert pairs == 512 * 32 * 32 and must > 20000, (must, pairs)
+    assert missed == 0, (must, missed)
+    assert flagged < 0.6 * pairs, (flagged, pairs)
+
+
 def test_library_checks_the_matrix_core_arithmetic_itself_and_falls_back(ctx, orc, synth):
     """The dispatcher consults a once-per-context verdict before it first uses a matrix-core kernel; a failing verdict (forced here
     with the tune key) moves the search to the next form — f16 -> bf16 -> the f32 filters — with the same bits out."""
@@ -175,20 +185,23 @@ def test_sign_filter_bad_seeds_nonfinite_queries_and_full_lists(ctx, orc, synth)
     ref = [ctx.nn1(ct, c_) for c_ in clouds]
     oi, od = orc.nn1_f32(tgt, poses[0])
     assert np.array_equal(ref[0][0], oi) and np.array_equal(bits32(ref[0][1]), bits32(od))
-    for qg, flush, sps in ((4, 0, 0), (2, 1, 0), (4, 100000, 1), (2, 0, 3), (4, 1, 200), (4, 3, 0)):
-        ctx.tune("nn1_btrack_qg", qg); ctx.tune("nn1_sign_flush", flush); ctx.tune("nn1_supers_per_slice", sps)
-        ctx.tune("nn1_variant", 8)
+    # (variant 8: STRACK; 9: STRACK2, the two-level form — sps then is its slice length in level-1 super-tiles)
+    for qg, flush, sps, variant in ((4, 0, 0, 8), (2, 1, 0, 8), (4, 100000, 1, 8), (2, 0, 3, 8), (4, 1, 200, 8), (4, 3, 0, 8),
+                                    (4, 0, 0, 9), (4, 1, 1, 9), (4, 100000, 2, 9), (4, 3, 200, 9)):
+        ctx.tune("nn1_btrack_qg", qg); ctx.tune("nn1_sign_flush", flush); ctx.tune("nn1_supers_per_slice", sps if variant == 8 else 0)
+        ctx.tune("nn1_sphere_l1_per_slice", sps if variant == 9 else 0)
+        ctx.tune("nn1_variant", variant)
         ctx.tune("nn1_async_in_loop", 1)
         fresh = ctx.cloud(tgt)                                       # the first search is cold: it seeds itself
         for k, c_ in enumerate(clouds + clouds[:2]):
             ctx.nn1_async(fresh, c_)
-            assert ctx.mfma_check()["last_nn1_kernel"] == "strack", (qg, flush, sps, k)
+            assert ctx.mfma_check()["last_nn1_kernel"] == ("strack" if variant == 8 else "strack2"), (qg, flush, sps, variant, k)
             idx, d2 = ctx.nn1_fetch(n)
             ri, rd = ref[k % len(clouds)]
             assert np.array_equal(idx, ri) and np.array_equal(bits32(d2), bits32(rd)), (qg, flush, sps, k, int((idx != ri).sum()))
         ctx.tune("nn1_async_in_loop", 0)
         fresh.free()
-    for k_ in ("nn1_btrack_qg", "nn1_sign_flush", "nn1_supers_per_slice", "nn1_variant", "nn_method"):
+    for k_ in ("nn1_btrack_qg", "nn1_sign_flush", "nn1_supers_per_slice", "nn1_sphere_l1_per_slice", "nn1_variant", "nn_method"):
         ctx.tune(k_, 0)
     for c_ in clouds:
         c_.free()
@@ -249,7 +262,7 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
 # reference), 4 ETRACK (expanded-form f32 filter on the grid's chunked target copy), 6 BTRACK (the filter on the bf16 matrix cores,
 # three-piece operands), 7 HTRACK (one f16 MFMA per tile, two-piece scaled operands), 8 STRACK (the sign form of the f16 filter for every
 # search that has or can make itself a seed; HTRACK where none exists) — csrc/nn1_brute.hip, table above launch_nn1_brute
-VARIANTS = [1, 2, 4, 6, 7, 8]
+VARIANTS = [1, 2, 4, 6, 7, 8, 9]
 
 
 def set_variant(ctx, v):
