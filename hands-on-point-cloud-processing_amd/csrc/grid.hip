@@ -2200,7 +2200,10 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     // the target's grid against targets per occupied cell; a spatially compact shard keeps its local density and the tile search.
     const bool dense = ctx->work_cells > 0 && g->occupied > 0 &&
                        (double)ns / (double)ctx->work_cells >= 0.4 * (double)tgt->n / (double)g->occupied;
-    if (mode == 2 && warm == 3 && sorted && !perm && wpos && cap2 < __builtin_inff() && tile_tune != 2 && (tile_tune == 1 || (tgt->n >= 4000000 && dense))) {
+    // (round 4: the FIRST search of a loop too — warm == 0: no correspondences yet — where the sign tile search can make itself a seed per query:
+    // stile_seed_kernel, tune grid_stile_cold: 2 = the plain walk as before)
+    const bool cold_tile = warm == 0 && reuse_perm && tune_get(ctx, "grid_stile_cold", 1) == 1 && tune_get(ctx, "grid_stile", 0) != 2;
+    if (mode == 2 && (warm == 3 || cold_tile) && sorted && !perm && wpos && cap2 < __builtin_inff() && tile_tune != 2 && (tile_tune == 1 || (tgt->n >= 4000000 && dense))) do {
         // the segmented list of deferred queries: 32 slots per group of 32 queries + one count per group (far_list is free here: the
         // hand-off of far queries to the exhaustive kernel only exists for unbounded searches)
         const size_t n_groups_sz = (ns + 31) / 32, need = n_groups_sz * 32 + n_groups_sz + (4 * n_groups_sz + 2);     // (+ the queue: quarters of the non-empty segments)
@@ -2236,6 +2239,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
             stile = stile && bt->bad16_host == 0;
             if (stile && (rc = bt_ensure_tile(ctx, tgt))) return rc;
         }
+        if (!stile && warm != 3) break;                       // (a cold search without the sign tile search: the plain walk below)
         if (stile) {
             const BtIndex* bt = tgt->bt;
             const float sbmax = (float)tune_get(ctx, "grid_stile_bmax_cm", 100) * 0.01f;
@@ -2265,6 +2269,16 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
             const uint32_t list_segs_s = lqueue ? 1u : list_segs;
             if (lqueue) PCR_HIP(ctx, hipMemsetAsync(lqueue, 0, 2 * sizeof(uint32_t), ctx->stream));
             ProfScope p(ctx, "nn1_grid", 1);
+            if (warm == 0) {
+                // COLD: a seed per query from its own coarse cell of the target's Morton-ordered index — the best of up to 32 records spread
+                // evenly over the cell's range (a genuine candidate decimetres from the true neighbour, where the plain walk's first search had
+                // to open its cube blindly: 13.3 ms at 10 M points) — written as the winner position the tile search seeds itself from
+                hipLaunchKernelGGL(stile_seed_kernel, dim3((unsigned)((ns + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, bt->cell_start, bt->g_of_b,
+                                   bt->key_lo[0], bt->key_lo[1], bt->key_lo[2], bt->key_inv, 3 * (10 - bt->cbits), src->x(), src->y(), src->z(), (uint32_t)ns, wpos,
+                                   ctx->stop_flag_dev, (uint32_t)std::min<int64_t>(256, std::max<int64_t>(1, tune_get(ctx, "grid_stile_cold_own", 32))),
+                                   (uint32_t)std::min<int64_t>(64, std::max<int64_t>(0, tune_get(ctx, "grid_stile_cold_per", 4))));
+            }
+
 #define PCR_STILE(ST)                                                                                                                       \
     hipLaunchKernelGGL((nn1_stile_kernel<ST>), dim3((unsigned)sblocks), dim3(GR_BLOCK), 0, ctx->stream, bt->records, bt->ops16, bt->centres,           \
                        bt->tile_spheres, bt->cell_start, bt->g_of_b, bt->b_of_g, g->records, (uint32_t)(g->n_chunks * GRID_CHUNK), bt->key_lo[0], bt->key_lo[1], \
@@ -2303,7 +2317,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         }
         PCR_HIP(ctx, hipGetLastError());
         return PCR_OK;
-    }
+    } while (0);
     {
         ProfScope p(ctx, "nn1_grid", 1);
 #define PCR_GRID2(GG, ST, MD)                                                                                          \

@@ -96,6 +96,61 @@ __device__ __forceinline__ uint32_t sl_or16(const f32x16 acc)
     return a | __float_as_uint(acc[15]);
 }
 
+// the seed of a COLD tile search: the best of up to 32 records, evenly spread over the records of the query's own coarse cell (Morton order inside
+// it: spread in space too), as a winner position in the cell grid's numbering; 0xFFFFFFFF when the cell is empty (the query is deferred to the walk)
+__global__ __launch_bounds__(GR_BLOCK) void stile_seed_kernel(const float4* __restrict__ records, const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ g_of_b,
+                                                              float klx, float kly, float klz, float kinv, int cshift,
+                                                              const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
+                                                              uint32_t* __restrict__ wpos, const int* __restrict__ stop, uint32_t own, uint32_t per)
+{
+    const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
+    if (i >= ns || (stop && (stop[0] | stop[1]))) return;
+    const float qx = sx[i], qy = sy[i], qz = sz[i];
+    uint32_t out = 0xFFFFFFFFu;
+    if (finite3(qx, qy, qz)) {
+        const int fs = cshift / 3;
+        unsigned long long best = ~0ull;
+        uint32_t bp = 0;
+        // the own cell with up to `own` samples, the 26 around it with up to `per` each (a query half a metre off its surface sits in an empty
+        // cell of 31 cm; its neighbours are not); nothing there: the same one and two levels up (cells of 2 and 4 edges — an aligned block of
+        // 8 / 64 cells is one contiguous range of the Morton-ordered records too)
+        for (int lvl = 0; lvl < 3 && best == ~0ull; lvl++) {
+            const int sh = fs + lvl;
+            const uint32_t side = 1024u >> sh;                // cells per axis at this level
+            const uint32_t cx = bt_fine_cell(qx, klx, kinv) >> sh, cy = bt_fine_cell(qy, kly, kinv) >> sh, cz = bt_fine_cell(qz, klz, kinv) >> sh;
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const uint32_t x = cx + (uint32_t)dx, y = cy + (uint32_t)dy, z = cz + (uint32_t)dz;
+                        if (x >= side || y >= side || z >= side) continue;             // (also: wrapped below zero)
+                        const uint32_t code = bt_morton(x, y, z);
+                        const uint32_t b = cell_start[code << (3 * lvl)], e = cell_start[(code + 1u) << (3 * lvl)];
+                        if (b >= e) continue;
+                        const uint32_t cnt = e - b, take = min(cnt, (dx | dy | dz) == 0 ? own : per);
+                        for (uint32_t k0 = 0; k0 < take; k0 += 4) {
+                            float4 rec[4];
+                            uint32_t p[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const uint32_t k = min(k0 + (uint32_t)u, take - 1u);
+                                p[u] = b + (uint32_t)(((unsigned long long)k * cnt) / take);
+                                rec[u] = records[p[u]];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const float ex = qx - rec[u].x, ey = qy - rec[u].y, ez = qz - rec[u].z;
+                                const uint32_t d = __float_as_uint((ex * ex + ey * ey) + ez * ez);   // A1, unfused
+                                const unsigned long long key = ((unsigned long long)d << 32) | p[u];
+                                if (d < 0x7F7FFFFFu && key < best) { best = key; bp = p[u]; }
+                            }
+                        }
+                    }
+        }
+        if (best != ~0ull) out = g_of_b[bp];
+    }
+    wpos[i] = out;
+}
+
 #ifndef PCR_STILE_WAVES
 #define PCR_STILE_WAVES 5
 #endif

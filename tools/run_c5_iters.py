@@ -48,7 +48,7 @@ if os.environ.get("STATS_AT"):
     for k in [int(v) for v in os.environ["STATS_AT"].split(",")]:
         ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=k, eps=0.0)
         w = ctx.nn1_stats()
-        print(f"search {k}: cand/q {w[0] / nq:.1f} spheres/q {w[2] / nq:.1f} deferred {100.0 * w[6] / nq:.1f} % passes/group {w[7] / (nq / 32):.2f} filter passes {w[8]} unsettled {w[9]} far stages {w[3]}")
+        print(f"search {k}: cand/q {w[0] / nq:.1f} spheres/q {w[2] / nq:.1f} deferred {100.0 * w[6] / nq:.1f} % passes/group {w[7] / (nq / 32):.2f} filter passes {w[8]} unsettled {w[9]} setups {w[3]}; deferred because: beyond the ball limit {w[13]}, more clusters than passes {w[14]}, pass overflow {w[15]}; most tiles in a pass {w[12]}")
     ctx.tune("grid_stats", 0)
 if os.environ.get("STATS"):
     ca = cs.clone(); ctx.transform(ca, T)
