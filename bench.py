@@ -427,7 +427,7 @@ def main():
         # ---- the shader clock the chip holds under the headline kernel's own load: s_memtime / s_memrealtime stamps of a diagnostics
         # launch (tune grid_stats) that follows 40 back-to-back launches of the same seeded search; median of 3
         clock_mhz = None
-        if extras and args.nn == "brute" and family in ("strack2", "strack", "htrack", "btrack"):
+        if extras and args.nn == "brute" and family in ("strack3", "strack2", "strack", "htrack", "btrack"):
             ca = cs.clone(); ctx.transform(ca, T)
             ctx.tune("nn_method", 1); ctx.tune("prof", 0); ctx.tune("nn1_async_in_loop", 1)
             clocks = []
@@ -442,17 +442,17 @@ def main():
             ca.free()
             clock_mhz = sorted(clocks)[len(clocks) // 2] if clocks else None
 
-        # ---- STRACK2 (two levels of the sign filter): how many matrix instructions a search at the final pose executes (diagnostics launch)
+        # ---- STRACK3 / STRACK2 (the sign filter at three / two levels): how many matrix instructions a search at the final pose executes — the last
+        # search of a 9-iteration loop from that pose (the loop sorts its working cloud along the target's order, as the timed loop does), diagnostics launch
         s2_counts = None
-        if args.nn == "brute" and family == "strack2":
-            ca = cs.clone(); ctx.transform(ca, T)
-            ctx.tune("nn_method", 1); ctx.tune("prof", 0); ctx.tune("nn1_async_in_loop", 1)
-            ctx.nn1_async(ct, ca); ctx.nn1_async(ct, ca)
-            ctx.tune("grid_stats", 1); ctx.nn1_async(ct, ca); ctx.tune("grid_stats", 0)
+        if args.nn == "brute" and family in ("strack3", "strack2"):
+            ctx.tune("nn_method", 1); ctx.tune("prof", 0)
+            ctx.tune("grid_stats", 1)
+            ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=9, eps=0.0)
+            ctx.tune("grid_stats", 0)
             w = ctx.nn1_stats()
-            ctx.tune("nn1_async_in_loop", 0)
-            ca.free()
-            s2_counts = {"level1_mfma": int(w[8]), "level2_mfma": int(w[10]), "level2_tiles_flagged": int(w[9]), "chunks_evaluated_exactly": int(w[6])}
+            s2_counts = {"level0_mfma": int(w[7]) if family == "strack3" else 0, "level1_tiles_flagged": int(w[3]) if family == "strack3" else None,
+                         "level1_mfma": int(w[8]), "level2_mfma": int(w[10]), "level2_tiles_flagged": int(w[9]), "chunks_evaluated_exactly": int(w[6])}
 
         # ---- the exact-only kernel (the 9-op convention's own kernel), the cold searches: a few launches each, HIP-event timed
         exact_line, one_shot = None, None
@@ -554,10 +554,11 @@ def main():
         if rank == 0:
             gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
             if args.nn == "brute":
-                two = family == "strack2"
-                sign = family in ("strack", "strack2")
-                f16 = family in ("strack2", "strack", "htrack")
-                bf16 = family in ("strack2", "strack", "htrack", "btrack")
+                two = family in ("strack2", "strack3")
+                three = family == "strack3"
+                sign = family in ("strack", "strack2", "strack3")
+                f16 = family in ("strack3", "strack2", "strack", "htrack")
+                bf16 = family in ("strack3", "strack2", "strack", "htrack", "btrack")
                 slots_pp = 32 if f16 else 64                 # flop per pair of ALL K-slots the matrix instruction(s) execute (16 / 2 x 16 multiply-adds)
                 flops_pp = STRACK_FLOPS_PER_PAIR if sign else HTRACK_FLOPS_PER_PAIR if f16 else BTRACK_FLOPS_PER_PAIR if bf16 else ETRACK_FLOPS_PER_PAIR
                 peak_tf = MFMA_BF16_PEAK_TFLOPS if bf16 else VALU_PEAK_TFLOPS
@@ -565,7 +566,7 @@ def main():
                 if two and s2_counts:
                     # the two-level form does NOT run every (query, record) pair through the matrix pipe: its algorithmic work is what it executes —
                     # 14 data-carrying K-slots x 32 x 32 x 2 flop per MFMA of either level (counted by a diagnostics launch at the final pose)
-                    achieved_tflops = (s2_counts["level1_mfma"] + s2_counts["level2_mfma"]) * 32 * 32 * 14 * 2 / kern_s / 1e12
+                    achieved_tflops = (s2_counts["level0_mfma"] + s2_counts["level1_mfma"] + s2_counts["level2_mfma"]) * 32 * 32 * 14 * 2 / kern_s / 1e12
                 compulsory_bytes = 12.0 * n_t + 12.0 * n_q + 8.0 * n_q        # targets + sources + (idx, d2) key
                 pmc = load_pmc("latest_pmc.json", sha) if (default_kernels and n_q == 120000 == n_t) else None
                 roofline = {
@@ -575,12 +576,19 @@ def main():
                     "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
                                      f"kernel with this very libpcr_hip.so (sha {sha}), {pmc['source']}") if pmc else
                                     "null: PMC counters need a rocprofv3 wrapper (tools/gpu_check.sh); none was collected with the library loaded now",
-                    "kernel": (("pcr::nn1_strack2_kernel<4> = STRACK2, the SIGN form of the f16 matrix-core filter at TWO LEVELS (csrc/nn1_sphere.hpp): level 1 — one MFMA row "
+                    "kernel": ((("pcr::nn1_strack3_kernel<1> = STRACK3, the SIGN form of the f16 matrix-core filter at THREE LEVELS (csrc/nn1_sphere.hpp), one wave per 32 "
+                               "queries: level 0 — one MFMA row per level-1 TILE of 512 records (its bounding sphere, in the scale of a level-0 super-tile of 131 072 "
+                               "records: |r - c| <= sqrt(thr) + rho as a sum of 16 K-slot products whose sign answers), over EVERY row of the target; level 1 — the chunk "
+                               "rows (16 records each) of the level-1 tiles level 0 flagged; level 2 — the per-record rows of the tiles of 32 records that hold a flagged "
+                               "chunk; flagged (query, 16-record chunk) pairs evaluated with the exact unfused arithmetic, four lanes per chunk; thresholds = the exact "
+                               "distance of the best candidate so far (the previous correspondence re-evaluated by the move, then whatever the scan finds).  Exhaustive "
+                               "in the brute-force contract's sense: no record is skipped without a computed sign that says it cannot matter") if three else
+                               ("pcr::nn1_strack2_kernel<4> = STRACK2, the SIGN form of the f16 matrix-core filter at TWO LEVELS (csrc/nn1_sphere.hpp): level 1 — one MFMA row "
                                "per CHUNK of 16 records (its bounding sphere: |r - c| <= sqrt(thr) + rho as a sum of 16 K-slot products whose sign answers), over every "
                                "chunk of the target: a sixteenth of the per-record filter's matrix and vector work; level 2 — the tiles of 32 records that hold a "
                                "flagged chunk through the per-record sign filter (STRACK's operands), flagged (query, 16-record chunk) pairs evaluated with the exact "
                                "unfused arithmetic, four lanes per chunk; thresholds = the exact distance of the best candidate so far (the previous correspondence "
-                               "re-evaluated by the move, then whatever the scan finds)") if two else (("pcr::nn1_strack_kernel<4> = STRACK, the SIGN form of the f16 matrix-core filter, operands staged through LDS per workgroup "
+                               "re-evaluated by the move, then whatever the scan finds)")) if two else (("pcr::nn1_strack_kernel<4> = STRACK, the SIGN form of the f16 matrix-core filter, operands staged through LDS per workgroup "
                                 "(exhaustive: the expanded-form lower bound of ALL (query, target) pairs from ONE v_mfma_f32_32x32x16_f16 per 32 queries "
                                 "x 32 targets — operands scaled per 256-target super-tile and cut into two f16 pieces, every piece product exact in f32 — "
                                 "with the query's threshold (the exact distance of its best candidate so far: the previous correspondence re-evaluated, "
@@ -607,11 +615,13 @@ def main():
                                 "branch-free; only the winning chunk is evaluated with the exact unfused arithmetic; the previous correspondence of "
                                 "each query, re-evaluated exactly, seeds the bound)"))) if default_kernels else f"nn1 variant={args.variant}",
                     "launches": int(nn_launches), "avg_launch_ms": kern_s * 1e3, "kernel_M_corr_per_s": n_q / kern_s / 1e6,
-                    "algorithmic": (((f"the matrix work the two-level filter EXECUTES at the final pose: {s2_counts['level1_mfma']} level-1 + {s2_counts['level2_mfma']} level-2 "
-                                     f"v_mfma_f32_32x32x16_f16 per launch x 32 x 32 x 14 data-carrying K-slots x 2 flop (a diagnostics launch counts them; every chunk of the "
-                                     f"target gets its level-1 row for every query: {pairs / 16:.3e} (query, chunk) pairs) — NOT {pairs:.3e} pairs x 28 flop: the per-record "
-                                     "filter runs only where a chunk's sphere reaches the query's ball.  The launch is bound by vector issue (operand setups, OR chains, "
-                                     "lists), not by the matrix pipe; pairs_per_s prices the same launch in (query, target) pairs settled per second") if (two and s2_counts) else
+                    "algorithmic": (((f"the matrix work the hierarchical filter EXECUTES at the final pose: {s2_counts['level0_mfma']} level-0 + {s2_counts['level1_mfma']} level-1 + "
+                                     f"{s2_counts['level2_mfma']} level-2 v_mfma_f32_32x32x16_f16 per launch x 32 x 32 x 14 data-carrying K-slots x 2 flop (a diagnostics launch "
+                                     f"counts them; every {'level-1 tile' if three else 'chunk'} of the target gets its row for every query: {pairs / (512 if three else 16):.3e} "
+                                     f"(query, row) pairs) — NOT {pairs:.3e} pairs x 28 flop: the finer rows run only where a sphere reaches the query's ball.  The launch has "
+                                     "left both roofs: it executes a few GFLOP and moves a few MB (hbm_view), and its time is the chain of dependent steps of ONE wave — "
+                                     "operands -> level 0 -> listed level-1 tiles -> listed level-2 tiles -> exact evaluation -> thresholds, each a trip to memory (DESIGN.md 5: "
+                                     "wave lives 10-35 us, all 3 750 waves resident at once).  pairs_per_s prices the same launch in (query, target) pairs settled per second") if (two and s2_counts) else
                                     (f"{flops_pp} f16 flop per (query, target) pair (the 14 piece products that carry data; the two K-slots with the "
                                      f"pieces of the query's threshold count under executed_slots) x {pairs:.3e} pairs per launch; peak = 2 500 TF/s dense f16.  Per 1024 pairs: one MFMA "
                                      "(32 cycles of the SIMD's matrix pipe) and 13 vector instructions all told (PMC SQ_INSTS_VALU / SQ_INSTS_MFMA: 8 v_or3_b32 in the tile "
@@ -636,6 +646,9 @@ def main():
                                    "note": "equivalent_strack_frac = what roofline.frac would read if every (query, target) pair had gone through the per-record "
                                            "filter (28 flop) in this launch's time — an equivalent for comparison with earlier rounds (0.33-0.38), not a bound"}
                                   if (two and s2_counts) else None),
+                    "hbm_view": {"algorithmic_bytes": compulsory_bytes, "achieved": compulsory_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
+                                 "note": "targets + sources + keys once per launch against the 8 TB/s roof: the search is nowhere near it either"},
                     "survey_8d_convention": {"achieved": OPS_PER_PAIR * pairs / kern_s / 1e12, "peak": VALU_PEAK_TOPS_NOFMA, "unit": "T lane-ops/s",
                                              "ratio": OPS_PER_PAIR * pairs / kern_s / 1e12 / VALU_PEAK_TOPS_NOFMA,
                                              "note": "SURVEY.md 8d's own figure: 9 f32 lane-ops per (query, target) pair / 78.6 T lane-ops/s.  It "

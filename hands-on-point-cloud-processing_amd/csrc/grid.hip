@@ -1631,22 +1631,143 @@ __global__ __launch_bounds__(GR_BLOCK) void bt_l1_ops_kernel(const float4* __res
     ops[(size_t)T * 64 + 32 + m] = hi;
 }
 
+// the per-record operands in the scale of the record's LEVEL-1 super-tile (bt_ops16_kernel with the level-1 centres: 128 tiles per super-tile)
+__global__ __launch_bounds__(GR_BLOCK) void bt_l1_rec_ops_kernel(const float4* __restrict__ rec, uint32_t n_tiles, const float4* __restrict__ centres, uint4* __restrict__ ops)
+{
+    const uint32_t gid = blockIdx.x * GR_BLOCK + threadIdx.x;
+    const uint32_t T = gid >> 5, m = gid & 31;
+    if (T >= n_tiles) return;
+    const uint32_t p = T * 32 + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+    const float4 r = rec[p];
+    const float4 C = centres[T / (BT_L1_SUPER / 32)];
+    const float tx = (r.x - C.x) * C.w, ty = (r.y - C.y) * C.w, tz = (r.z - C.z) * C.w;         // exact scaling, |.| <= 2^7 (unless the super-tile is flagged bad)
+    const bool fin = finite3(r.x, r.y, r.z) && fabsf(tx) <= 128.0f && fabsf(ty) <= 128.0f && fabsf(tz) <= 128.0f;
+    ops[(size_t)T * 64 + m] = ht_target_operand(tx, ty, tz, fin, false);
+    ops[(size_t)T * 64 + 32 + m] = ht_target_operand(tx, ty, tz, fin, true);
+}
+
+// ---- level 0 (STRACK3): one row per level-1 tile = the bounding sphere of its 512 records, in the scale of a level-0 super-tile of
+// BT_L0_SUPER records.  Centres: one workgroup per level-0 super-tile, two passes over its records (mean of the finite ones, then the
+// largest |.|_inf distance from it -> the power-of-two scale with every record inside 2^7 units)
+__global__ __launch_bounds__(GR_BLOCK) void bt_l0_centres_kernel(const float4* __restrict__ rec, uint32_t n_rec, uint32_t n_l0, float4* __restrict__ centres, int* __restrict__ bad)
+{
+    __shared__ float red[4][GR_BLOCK / 64];
+    const uint32_t s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (s >= n_l0) return;
+    const size_t base = (size_t)s * BT_L0_SUPER, end = min(base + (size_t)BT_L0_SUPER, (size_t)n_rec);
+    float cx = 0.f, cy = 0.f, cz = 0.f, cnt = 0.f;
+    for (size_t p = base + threadIdx.x; p < end; p += GR_BLOCK) {
+        const float4 r = rec[p];
+        if (finite3(r.x, r.y, r.z)) { cx += r.x; cy += r.y; cz += r.z; cnt += 1.0f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cx += __shfl_xor(cx, o, 64); cy += __shfl_xor(cy, o, 64); cz += __shfl_xor(cz, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+    if (lane == 0) { red[0][wave] = cx; red[1][wave] = cy; red[2][wave] = cz; red[3][wave] = cnt; }
+    __syncthreads();
+    cx = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]); cy = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    cz = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]); cnt = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+    if (cnt > 0.f) { cx /= cnt; cy /= cnt; cz /= cnt; }
+    if (!finite3(cx, cy, cz)) { cx = 0.f; cy = 0.f; cz = 0.f; if (threadIdx.x == 0) atomicOr(bad, 1); }      // (sums beyond f32: no level 0 for this cloud)
+    float rho = 0.f;
+    for (size_t p = base + threadIdx.x; p < end; p += GR_BLOCK) {
+        const float4 r = rec[p];
+        if (finite3(r.x, r.y, r.z)) rho = fmaxf(rho, fmaxf(fmaxf(fabsf(r.x - cx), fabsf(r.y - cy)), fabsf(r.z - cz)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rho = fmaxf(rho, __shfl_xor(rho, o, 64));
+    __syncthreads();
+    if (lane == 0) red[0][wave] = rho;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    rho = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    int k = 0;
+    if (rho > 0.f) {
+        int e2;
+        (void)frexpf(rho, &e2);                            // rho <= 2^e2
+        k = 7 - e2;
+        if (k < -60 || k > 60) { atomicOr(bad, 1); k = k < 0 ? -60 : 60; }
+    }
+    centres[s] = make_float4(cx, cy, cz, ldexpf(1.0f, k));
+}
+
+// one wave per level-1 tile: its row of its level-0 tile (row m <-> level-1 tile 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3) of the 32, as the chunks
+// of a level-1 tile: the 16 accumulators of lane-half h are the tiles 16 h + i, in order)
+__global__ __launch_bounds__(GR_BLOCK) void bt_l0_ops_kernel(const float4* __restrict__ rec, uint32_t n_rec, uint32_t n_rows, const float4* __restrict__ centres,
+                                                             uint4* __restrict__ ops)
+{
+    const uint32_t lane = threadIdx.x & 63, T1 = blockIdx.x * (GR_BLOCK / 64) + (threadIdx.x >> 6);
+    if (T1 >= n_rows) return;
+    const float4 C = centres[T1 / (BT_L0_SUPER / 512)];
+    float tx[8], ty[8], tz[8];
+    bool fin[8];
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const size_t p = (size_t)T1 * 512 + (size_t)j * 64 + lane;
+        const float4 r = p < n_rec ? rec[p] : make_float4(__builtin_inff(), 0.f, 0.f, 0.f);
+        tx[j] = (r.x - C.x) * C.w; ty[j] = (r.y - C.y) * C.w; tz[j] = (r.z - C.z) * C.w;       // exact scaling, |.| <= 2^7 (unless the super-tile is flagged bad)
+        fin[j] = finite3(r.x, r.y, r.z) && fabsf(tx[j]) <= 128.0f && fabsf(ty[j]) <= 128.0f && fabsf(tz[j]) <= 128.0f;
+        if (fin[j]) {
+            any = true;
+            mn[0] = fminf(mn[0], tx[j]); mx[0] = fmaxf(mx[0], tx[j]);
+            mn[1] = fminf(mn[1], ty[j]); mx[1] = fmaxf(mx[1], ty[j]);
+            mn[2] = fminf(mn[2], tz[j]); mx[2] = fmaxf(mx[2], tz[j]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o, 64)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o, 64)); }
+    any = __builtin_amdgcn_ballot_w64(any) != 0ull;
+    uint32_t pp[3][2] = { { 0u, 0u }, { 0u, 0u }, { 0u, 0u } };
+    float c[3] = { 0.0f, 0.0f, 0.0f };
+    float r2 = 0.0f;
+    if (any) {
+        sph_centre(mn, mx, pp, c);                                         // (the same on every lane)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (fin[j]) {
+                const float dx = tx[j] - c[0], dy = ty[j] - c[1], dz = tz[j] - c[2];
+                r2 = fmaxf(r2, (dx * dx + dy * dy) + dz * dz);
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, o, 64));
+    }
+    if (lane != 0) return;
+    uint4 lo, hi;
+    sph_finish(any, pp, c, r2, lo, hi);
+    const uint32_t T0 = T1 >> 5, j = T1 & 31u, m = (((j >> 2) & 3u) << 3) | ((j >> 4) << 2) | (j & 3u);
+    ops[(size_t)T0 * 64 + m] = lo;
+    ops[(size_t)T0 * 64 + 32 + m] = hi;
+}
+
 int bt_ensure_l1(pcr_ctx* ctx, const pcr_cloud* tgt)
 {
     BtIndex* bt = tgt->bt;
     if (!bt || !bt->safe || !bt->n_tiles) return fail(ctx, PCR_ERR_STATE, "bt_ensure_l1: no index");
     if (bt->l1_block) return PCR_OK;
     const size_t n_pad = bt->n_tiles * 32, n_l1 = (n_pad + BT_L1_SUPER - 1) / BT_L1_SUPER, n_l1_tiles = n_l1 * (BT_L1_SUPER / 512);
-    const size_t off_ops = (n_l1 * sizeof(float4) + 255) & ~(size_t)255, off_flag = off_ops + n_l1_tiles * 64 * sizeof(uint4), total = off_flag + 256;
+    const size_t n_l0 = (n_pad + BT_L0_SUPER - 1) / BT_L0_SUPER, n_l0_tiles = n_l0 * (BT_L0_SUPER / 512 / 32);
+    const size_t off_ops = (n_l1 * sizeof(float4) + 255) & ~(size_t)255, off_rec = off_ops + n_l1_tiles * 64 * sizeof(uint4),
+                 off_c0 = off_rec + bt->n_tiles * 64 * sizeof(uint4), off_ops0 = (off_c0 + n_l0 * sizeof(float4) + 255) & ~(size_t)255,
+                 off_flag = off_ops0 + n_l0_tiles * 64 * sizeof(uint4), total = off_flag + 256;
     char* blk = nullptr;
     hipError_t e = hipMalloc((void**)&blk, total);
     if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "hipMalloc(level-1 operands)", e);
-    bt->l1_block = blk; bt->l1_centres = (float4*)blk; bt->l1_ops = (uint4*)(blk + off_ops); bt->l1_bad = (int*)(blk + off_flag); bt->n_l1_super = n_l1;
+    bt->l1_block = blk; bt->l1_centres = (float4*)blk; bt->l1_ops = (uint4*)(blk + off_ops); bt->l1_rec_ops = (uint4*)(blk + off_rec);
+    bt->l0_centres = (float4*)(blk + off_c0); bt->l0_ops = (uint4*)(blk + off_ops0); bt->n_l0_super = n_l0;
+    bt->l1_bad = (int*)(blk + off_flag); bt->n_l1_super = n_l1;
     e = hipMemsetAsync(bt->l1_bad, 0, sizeof(int), ctx->stream);
     if (e != hipSuccess) return fail(ctx, PCR_ERR_HIP, "level-1 operands", e);
     hipLaunchKernelGGL(bt_l1_centres_kernel, dim3((unsigned)n_l1), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_pad, (uint32_t)n_l1, bt->l1_centres, bt->l1_bad);
     hipLaunchKernelGGL(bt_l1_ops_kernel, dim3((unsigned)((n_l1_tiles * 32 + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_pad,
                        (uint32_t)n_l1_tiles, bt->l1_centres, bt->l1_ops);
+    hipLaunchKernelGGL(bt_l1_rec_ops_kernel, dim3((unsigned)((bt->n_tiles * 32 + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)bt->n_tiles,
+                       bt->l1_centres, bt->l1_rec_ops);
+    hipLaunchKernelGGL(bt_l0_centres_kernel, dim3((unsigned)n_l0), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_pad, (uint32_t)n_l0, bt->l0_centres, bt->l1_bad);
+    hipLaunchKernelGGL(bt_l0_ops_kernel, dim3((unsigned)((n_l0_tiles * 32 + GR_BLOCK / 64 - 1) / (GR_BLOCK / 64))), dim3(GR_BLOCK), 0, ctx->stream, bt->records, (uint32_t)n_pad,
+                       (uint32_t)(n_l0_tiles * 32), bt->l0_centres, bt->l0_ops);
     PCR_HIP(ctx, hipGetLastError());
     return PCR_OK;
 }

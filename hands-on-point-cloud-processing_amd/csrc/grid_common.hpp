@@ -105,6 +105,11 @@ struct BtIndex {
     void* l1_block = nullptr;
     float4* l1_centres = nullptr;
     uint4* l1_ops = nullptr;
+    uint4* l1_rec_ops = nullptr;      // the per-RECORD operands once more, in the scale of the record's level-1 super-tile ([tile][64 lanes] x 16 bytes): level 2 of
+                                      // STRACK2 then needs no operand setup of its own (one per query and 4 096 records instead of one per 256)
+    float4* l0_centres = nullptr;     // level 0 of STRACK3: one row per LEVEL-1 TILE (the bounding sphere of its 512 records), level-0 super-tiles of
+    uint4* l0_ops = nullptr;          // BT_L0_SUPER records share a centre and a scale ([level-0 tile][64 lanes] x 16 bytes, 32 rows per tile)
+    size_t n_l0_super = 0;
     size_t n_l1_super = 0;
     int l1_bad_host = -1;             // a level-1 super-tile whose scale left the f16 range (device flag behind l1_ops, read lazily)
     int* l1_bad = nullptr;
@@ -248,6 +253,7 @@ __device__ __forceinline__ void st_setup(float qx, float qy, float qz, const flo
 // The assumption is the f16 form's own (accumulation error <= 16 u sum |a b|: mfma_verdict); the device self-test of this form
 // (pcr_selftest_sphere_f16) checks the statement itself: no (query, chunk) pair with a record at or below the threshold without its sign.
 constexpr int BT_L1_SUPER = 4096;      // records per level-1 super-tile: 256 chunks = 8 level-1 tiles of 32 chunks = 16 super-tiles
+constexpr int BT_L0_SUPER = 131072;    // records per level-0 super-tile: 256 level-1 tiles = 8 level-0 tiles of 32 rows (one row per level-1 tile)
 
 // f16 value >= v (v >= 0): rounded toward zero after adding 2^-9 of itself + 2^-23 (an f16 conversion toward zero loses < 2^-10 of a
 // normal value, < 2^-24 of a subnormal one); returned as the 16-bit pattern and as the float it represents
@@ -259,28 +265,11 @@ __device__ __forceinline__ uint32_t f16_up(float v, float& rep)
     return __builtin_bit_cast(uint32_t, a) & 0xFFFFu;
 }
 
-// the two lanes' words of MFMA row `m` of a level-1 tile for one chunk: t[16][3] = the chunk's records in the scaled units of its level-1
-// super-tile (exact scaling), fin[16] = finite and inside the super-tile's range
-__device__ __forceinline__ void l1_chunk_operand(const float (&tx)[16], const float (&ty)[16], const float (&tz)[16], const bool (&fin)[16], uint4& lo, uint4& hi)
+// the sphere rows of the level-1 form in two steps, so that a row can stand for any set of records (a chunk of 16: one thread; a level-1 tile of
+// 512: one wave, nn1 level 0):  sph_centre — the centre = what the two f16 pieces of -2 (middle of the set's box) represent;  sph_finish — the
+// row's two 16-byte words from that centre and r2 = the largest squared distance of a member from it (any = the set has a finite member)
+__device__ __forceinline__ void sph_centre(const float (&mn)[3], const float (&mx)[3], uint32_t (&p)[3][2], float (&c)[3])
 {
-    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < 16; j++)
-        if (fin[j]) {
-            any = true;
-            mn[0] = fminf(mn[0], tx[j]); mx[0] = fmaxf(mx[0], tx[j]);
-            mn[1] = fminf(mn[1], ty[j]); mx[1] = fmaxf(mx[1], ty[j]);
-            mn[2] = fminf(mn[2], tz[j]); mx[2] = fmaxf(mx[2], tz[j]);
-        }
-    if (!any) {                                               // no finite record: W = +inf, never flagged
-        lo = make_uint4(0u, 0u, 0u, 0u);
-        hi = make_uint4(0u, 0u, 0x7C00u, HT_THETA_CONSTS);
-        return;
-    }
-    // the centre = what the two f16 pieces of -2 c represent
-    uint32_t p[3][2];
-    float c[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float mid = 0.5f * mn[k] + 0.5f * mx[k];
@@ -289,13 +278,14 @@ __device__ __forceinline__ void l1_chunk_operand(const float (&tx)[16], const fl
         const float a1 = (float)__builtin_bit_cast(h1, p[k][0]).x, a2 = (float)__builtin_bit_cast(h1, p[k][1]).x;
         c[k] = -0.5f * (a1 + a2);                             // exact: two f16 values of at most 22 significant bits in all
     }
-    float r2 = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 16; j++)
-        if (fin[j]) {
-            const float dx = tx[j] - c[0], dy = ty[j] - c[1], dz = tz[j] - c[2];
-            r2 = fmaxf(r2, (dx * dx + dy * dy) + dz * dz);
-        }
+}
+__device__ __forceinline__ void sph_finish(bool any, uint32_t (&p)[3][2], float (&c)[3], float r2, uint4& lo, uint4& hi)
+{
+    if (!any) {                                               // no finite record: W = +inf, never flagged
+        lo = make_uint4(0u, 0u, 0u, 0u);
+        hi = make_uint4(0u, 0u, 0x7C00u, HT_THETA_CONSTS);
+        return;
+    }
     float rho = __builtin_fmaf(sqrtf(r2), 3.814697265625e-06f, sqrtf(r2)) + 2.44140625e-04f;      // up: 2^-18 of itself + 2^-12
     if (!(rho <= 128.0f)) {                                   // spread over more than half the super-tile: the sphere of the whole super-tile
         c[0] = c[1] = c[2] = 0.0f;
@@ -314,6 +304,35 @@ __device__ __forceinline__ void l1_chunk_operand(const float (&tx)[16], const fl
     hi = make_uint4(p[2][0] | (p[2][1] << 16), p[2][0] | (m2 << 16), w1 | (w2 << 16), HT_THETA_CONSTS);
 }
 
+// the two lanes' words of MFMA row `m` of a level-1 tile for one chunk: t[16][3] = the chunk's records in the scaled units of its level-1
+// super-tile (exact scaling), fin[16] = finite and inside the super-tile's range
+__device__ __forceinline__ void l1_chunk_operand(const float (&tx)[16], const float (&ty)[16], const float (&tz)[16], const bool (&fin)[16], uint4& lo, uint4& hi)
+{
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (fin[j]) {
+            any = true;
+            mn[0] = fminf(mn[0], tx[j]); mx[0] = fmaxf(mx[0], tx[j]);
+            mn[1] = fminf(mn[1], ty[j]); mx[1] = fmaxf(mx[1], ty[j]);
+            mn[2] = fminf(mn[2], tz[j]); mx[2] = fmaxf(mx[2], tz[j]);
+        }
+    uint32_t p[3][2] = { { 0u, 0u }, { 0u, 0u }, { 0u, 0u } };
+    float c[3] = { 0.0f, 0.0f, 0.0f };
+    float r2 = 0.0f;
+    if (any) {
+        sph_centre(mn, mx, p, c);
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (fin[j]) {
+                const float dx = tx[j] - c[0], dy = ty[j] - c[1], dz = tz[j] - c[2];
+                r2 = fmaxf(r2, (dx * dx + dy * dy) + dz * dz);
+            }
+    }
+    sph_finish(any, p, c, r2, lo, hi);
+}
+
 // the threshold slots of the level-1 form: as st_theta, rounded up by 2^-18 |theta| (see above)
 __device__ __forceinline__ uint32_t st_theta_l1(float thr, float sc2, float Rs)
 {
@@ -330,8 +349,10 @@ __device__ __forceinline__ uint32_t st_theta_l1(float thr, float sc2, float Rs)
 }
 
 // query side of the level-1 form for one (query, level-1 super-tile): P = the lower half-lane's words (x pieces, y pieces), Q = the upper
-// half-lane's (z: r1 r1 | r2, s | 1 1 | threshold pieces).  s = sqrt(thr) scale, rounded UP into an f16 (0 for "never": thr = -inf)
-__device__ __forceinline__ void st_setup_l1(float qx, float qy, float qz, const float4 C, float thr, float sc2, uint32_t P[4], uint32_t Q[4])
+// half-lane's (z: r1 r1 | r2, s | 1 1 | threshold pieces).  s = sqrt(thr) scale, rounded UP into an f16 (0 for "never": thr = -inf).
+// Q2 (optional): the upper half-lane's words of the RECORD form in the same scale (st_setup's: z: r1 r1 | r2 r2 | 1 1 | st_theta) — level 2 of
+// STRACK2 filters the records of a level-1 super-tile with operands in that super-tile's scale, so both forms come out of one setup.
+__device__ __forceinline__ void st_setup_l1(float qx, float qy, float qz, const float4 C, float thr, float sc2, uint32_t P[4], uint32_t Q[4], uint32_t* Q2 = nullptr)
 {
     constexpr float KAPPA = 0.99999237060546875f;             // 1 - 2^-17
     const float sc = C.w;
@@ -348,6 +369,7 @@ __device__ __forceinline__ void st_setup_l1(float qx, float qy, float qz, const 
     Q[1] = (z2 & 0xFFFFu) | (s16 << 16);
     Q[2] = 0x3C003C00u;
     Q[3] = st_theta_l1(thr, sc2, Rs);
+    if (Q2) { Q2[0] = Q[0]; Q2[1] = z2; Q2[2] = 0x3C003C00u; Q2[3] = st_theta(thr, sc2, Rs); }
 }
 
 void bt_free(BtIndex* b);

@@ -20,7 +20,9 @@ static bool icp_uses_grid(const pcr_ctx* ctx, const pcr_cloud* tgt) { return nn1
 static int icp_sort_for_brute(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, uint64_t max_iter)
 {
     ctx->work_orig_src = nullptr;
-    if (max_iter < 8 || tgt->n < 8192 || tune_get(ctx, "nn1_bf16", 0) == 2) return PCR_OK;      // (the sort costs ~0.1 ms at 120 k, an iteration gains ~0.02 ms)
+    // (the sort costs ~0.1 ms at 120 k; an iteration of STRACK gains ~0.02 ms from it, one of the sphere forms — targets from 32 768 points — ~0.05 ms:
+    // their level-0 / level-1 rows are shared by the 32 queries of a group only when those are neighbours)
+    if (max_iter < (tgt->n >= 32768 ? 3u : 8u) || tgt->n < 8192 || tune_get(ctx, "nn1_bf16", 0) == 2) return PCR_OK;
     const int64_t v = tune_get(ctx, "nn1_variant", 0);
     if (v != 0 && v != 6 && v != 7) return PCR_OK;
     return bt_sort_working_cloud(ctx, tgt, work);

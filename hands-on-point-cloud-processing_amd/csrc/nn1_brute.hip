@@ -1188,7 +1188,7 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     // (15-30 k queries against the whole target) fills the chip better with two — measured, per ICP iteration: 15 k queries 0.158 -> 0.137
     // ms, 30 k 0.241 -> 0.218, 60 k 0.378 / 0.375, 120 k 0.664 -> 0.723
     int qg = tune_get(ctx, "nn1_btrack_qg", ns <= 49152 ? 2 : 4) == 2 ? 2 : 4;
-    if (tune_get(ctx, "nn1_variant", 0) == 9 || tune_get(ctx, "nn1_sphere", 0) == 1 || (tune_get(ctx, "nn1_sphere", 0) == 0 && tune_get(ctx, "nn1_variant", 0) == 0 && f16 &&
+    if (tune_get(ctx, "nn1_variant", 0) == 9 || tune_get(ctx, "nn1_variant", 0) == 10 || tune_get(ctx, "nn1_sphere", 0) == 1 || (tune_get(ctx, "nn1_sphere", 0) == 0 && tune_get(ctx, "nn1_variant", 0) == 0 && f16 &&
         tgt->n >= 32768 && tune_get(ctx, "nn1_btrack_qg", 0) == 0)) qg = 4;                     // (STRACK2 holds four groups per wave)
     const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                          // queries per workgroup
     const uint32_t qblocks = (uint32_t)((ns + qpb - 1) / qpb);
@@ -1213,7 +1213,10 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     // STRACK2 (nn1_sphere.hpp): the sign filter at two levels — one MFMA row per chunk of 16 records first.  Tune nn1_sphere: 0 auto (targets from
     // 32 768 points on, where a level-1 super-tile of 4 096 records is a small part of the cloud), 1 = always, 2 = never; nn1_variant 9 forces it.
     const int64_t sph_tune = tune_get(ctx, "nn1_sphere", 0), variant_now = tune_get(ctx, "nn1_variant", 0);
-    bool sphere = sign && f16 && qg == 4 && sph_tune != 2 && (variant_now == 9 || sph_tune == 1 || (variant_now == 0 && tgt->n >= 32768));
+    bool sphere = sign && f16 && qg == 4 && sph_tune != 2 && (variant_now == 9 || variant_now == 10 || sph_tune == 1 || (variant_now == 0 && tgt->n >= 32768));
+    // ... and STRACK3, the same with a level 0 in front (one row per level-1 tile of 512 records): the default wherever the sphere form runs
+    // (tune nn1_sphere_levels: 2 = STRACK2; nn1_variant 9 forces STRACK2, 10 STRACK3)
+    const bool three = variant_now == 10 || (variant_now != 9 && tune_get(ctx, "nn1_sphere_levels", 0) != 2);
     if (sphere) {
         int rc1 = bt_ensure_l1(ctx, tgt);
         if (rc1) return rc1;
@@ -1226,7 +1229,7 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
         }
         sphere = bt->l1_bad_host == 0;
     }
-    ctx->last_nn1_kernel = sphere ? "strack2" : sign ? "strack" : f16 ? "htrack" : "btrack";
+    ctx->last_nn1_kernel = sphere ? (three ? "strack3" : "strack2") : sign ? "strack" : f16 ? "htrack" : "btrack";
     if (warm) seed_warm(ctx, tgt, src, pre_seeded);
     else if (merge_atomic && !cold_seed) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
     unsigned long long* stats_dev = nullptr;
@@ -1251,15 +1254,43 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
 #define PCR_STRACK(Q)                                                                                                                      \
     hipLaunchKernelGGL((nn1_strack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records, n_super * BT_SUPER, n_super, sps,  \
                        src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices, st_flush_at, st_dense_at)
-        if (sphere) {
+        if (sphere && three) {
+            // one wave per 128 (64: tune nn1_sphere_qg = 2) queries and slice of level-0 super-tiles (131 072 records each: one slice up to there)
+            const uint32_t n_l0 = (uint32_t)g->n_l0_super;
+            const int64_t qg3_t = tune_get(ctx, "nn1_sphere_qg", 0);
+            const uint32_t qg3 = qg3_t == 4 ? 4u : qg3_t == 2 ? 2u : 1u;      // (one group of 32 queries per wave: 120 000 queries are 3 750 waves for 1 024 SIMDs — the search is a chain of
+                                                                           // dependent trips to memory per wave, and waves are what hides them)
+            const uint32_t qblocks3 = (uint32_t)((ns + (size_t)(NN_BLOCK / 64) * 32 * qg3 - 1) / ((size_t)(NN_BLOCK / 64) * 32 * qg3));
+            uint32_t s3_slices = 1;
+            const uint32_t l0ps = slice_plan(n_l0, qblocks3, tune_get(ctx, "nn1_sphere_l0_per_slice", 0), tune_get(ctx, "nn1_sphere_blocks", 1024), &s3_slices);
+            const dim3 grid3(qblocks3, s3_slices);
+            const uint32_t s3_flush_end = (uint32_t)std::min<int64_t>(std::max<int64_t>(tune_get(ctx, "nn1_sphere_flush_end", 1), 1), S2_CAP);   // entries from which the end of a level-1 super-tile evaluates them
+#define PCR_STRACK3(Q)                                                                                                                     \
+    hipLaunchKernelGGL((nn1_strack3_kernel<Q>), grid3, dim3(NN_BLOCK), 0, ctx->stream, g->l0_centres, g->l0_ops, g->l1_centres, g->l1_ops, g->l1_rec_ops, g->records,  \
+                       n_super * BT_SUPER, n_l0, l0ps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, std::min<uint32_t>(st_flush_at, (uint32_t)S2_CAP), s3_flush_end)
+            if (qg3 == 1) PCR_STRACK3(1); else if (qg3 == 2) PCR_STRACK3(2); else PCR_STRACK3(4);
+#undef PCR_STRACK3
+        }
+        else if (sphere) {
+            // slices = ranges of level-1 super-tiles x phases of their eight level-1 tiles (tune nn1_sphere_phases: 1 / 2 / 4 / 8); groups of 32
+            // queries per wave: tune nn1_sphere_qg (2 / 4)
             const uint32_t n_l1 = (uint32_t)g->n_l1_super;
-            uint32_t s2_slices = 1;
-            const uint32_t l1ps = slice_plan(n_l1, qblocks, tune_get(ctx, "nn1_sphere_l1_per_slice", 0), tune_get(ctx, "nn1_sphere_blocks", 1024), &s2_slices);
+            const int64_t ph_t = tune_get(ctx, "nn1_sphere_phases", 0), qg_t = tune_get(ctx, "nn1_sphere_qg", 0);
+            const uint32_t phases = (ph_t == 1 || ph_t == 2 || ph_t == 4 || ph_t == 8) ? (uint32_t)ph_t : 4u;
+            const uint32_t qg2 = qg_t == 2 ? 2u : 4u;
+            const uint32_t qblocks2 = (uint32_t)((ns + (size_t)(NN_BLOCK / 64) * 32 * qg2 - 1) / ((size_t)(NN_BLOCK / 64) * 32 * qg2));
+            uint32_t ranges = 1;
+            const uint32_t l1ps = slice_plan(n_l1, qblocks2, tune_get(ctx, "nn1_sphere_l1_per_slice", 0), tune_get(ctx, "nn1_sphere_blocks", 1024), &ranges);
+            const uint32_t s2_slices = ranges * phases;
             int64_t xq2 = tune_get(ctx, "nn1_xcd", NN_XCD_DEFAULT);
-            if ((xq2 != 1 && xq2 != 2 && xq2 != 4) || s2_slices < 8 || (uint64_t)qblocks * s2_slices >= (1ull << 27)) xq2 = 0;
-            const dim3 grid2 = xq2 ? dim3(8u * ((qblocks + (uint32_t)xq2 - 1) / (uint32_t)xq2) * ((s2_slices + 8u / (uint32_t)xq2 - 1) / (8u / (uint32_t)xq2)), 1) : dim3(qblocks, s2_slices);
-            hipLaunchKernelGGL((nn1_strack2_kernel<4>), grid2, dim3(NN_BLOCK), 0, ctx->stream, g->l1_centres, g->l1_ops, g->centres, g->ops16, g->records, n_super * BT_SUPER,
-                               n_l1, l1ps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)xq2, qblocks, s2_slices, st_flush_at);
+            if ((xq2 != 1 && xq2 != 2 && xq2 != 4) || s2_slices < 8 || (uint64_t)qblocks2 * s2_slices >= (1ull << 27)) xq2 = 0;
+            if (!xq2 && s2_slices > 65535u) return fail(ctx, PCR_ERR_ARG, "STRACK2: more slices than a launch has rows");
+            const dim3 grid2 = xq2 ? dim3(8u * ((qblocks2 + (uint32_t)xq2 - 1) / (uint32_t)xq2) * ((s2_slices + 8u / (uint32_t)xq2 - 1) / (8u / (uint32_t)xq2)), 1) : dim3(qblocks2, s2_slices);
+#define PCR_STRACK2(Q)                                                                                                                     \
+    hipLaunchKernelGGL((nn1_strack2_kernel<Q>), grid2, dim3(NN_BLOCK), 0, ctx->stream, g->l1_centres, g->l1_ops, g->l1_rec_ops, g->records, n_super * BT_SUPER,  \
+                       n_l1, l1ps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)xq2, qblocks2, s2_slices, st_flush_at, phases)
+            if (qg2 == 2) PCR_STRACK2(2); else PCR_STRACK2(4);
+#undef PCR_STRACK2
         }
         else if (sign) { if (qg == 2) PCR_STRACK(2); else PCR_STRACK(4); }
         else if (f16) { if (qg == 2) PCR_BTRACK(2, true, g->ops16); else PCR_BTRACK(4, true, g->ops16); }
@@ -1346,12 +1377,12 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
     // The matrix-core forms, from a target's FIRST search on: the index (operands in Morton order, bt_ensure) costs one bounding-box
     // round trip and ~0.2 ms at 120 k points, less than the kernel saves (small targets stay on the f32 filters: 44 against 53 us per
     // ICP iteration at 4 000 points, 114 against 72 at 20 000 — profiles/r02_mfma_filter_experiments.txt)
-    if (variant == 6 || variant == 7 || variant == 8 || variant == 9 || (variant == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)))) {
+    if (variant == 6 || variant == 7 || variant == 8 || variant == 9 || variant == 10 || (variant == 0 && bf16_tune != 2 && (bf16_tune == 1 || (NN_BF16_DEFAULT && tgt->n >= 8192)))) {
         rc = bt_ensure(ctx, tgt);
         if (rc) return rc;
         if (tgt->bt->safe && tgt->bt->n_tiles) {
             // HTRACK: one f16 MFMA per tile instead of two bf16 ones, when the cloud fits f16's range (the flag of the operand build, read once)
-            bool f16 = variant == 7 || variant == 8 || variant == 9 || (variant == 0 && f16_tune != 2 && (f16_tune == 1 || NN_F16_DEFAULT));
+            bool f16 = variant == 7 || variant == 8 || variant == 9 || variant == 10 || (variant == 0 && f16_tune != 2 && (f16_tune == 1 || NN_F16_DEFAULT));
             if (f16 && tgt->bt->bad16_host < 0) {
                 int flag = 1;
                 PCR_HIP(ctx, hipMemcpyAsync(&flag, tgt->bt->bad16, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1363,7 +1394,7 @@ int launch_nn1_brute(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, b
             // either is first chosen (mfma_verdict: once per context, cached): a form whose measured error exceeds half of what its bound
             // budgets is not used here; the f32 filters below (bounds from IEEE arithmetic alone) answer instead.
             if (f16 && !mfma_verdict(ctx, true)) f16 = false;
-            if (f16 || mfma_verdict(ctx, false)) return launch_matrix(ctx, tgt, src, f16, warm, pre_seeded, f16 && (variant == 8 || variant == 9));
+            if (f16 || mfma_verdict(ctx, false)) return launch_matrix(ctx, tgt, src, f16, warm, pre_seeded, f16 && (variant == 8 || variant == 9 || variant == 10));
         }
     }
     // ETRACK needs the cell index (chunked, centred copy of the target): cold searches take it when that index exists or will be needed

@@ -62,7 +62,7 @@ def check_line(line, n):
 def test_bench_one_rank_line(one_rank):
     check_line(one_rank, 1)
     assert "weak" not in one_rank
-    assert one_rank["roofline"]["kernel_family"] == "strack2"
+    assert one_rank["roofline"]["kernel_family"] == "strack3"
     assert one_rank["roofline"]["survey_8d_convention"]["ratio"] > 0
     assert one_rank["roofline"]["shader_clock"]["mhz"] > 500
     assert one_rank["c5"]["config"]["n_src_total"] == 200000

@@ -185,23 +185,26 @@ def test_sign_filter_bad_seeds_nonfinite_queries_and_full_lists(ctx, orc, synth)
     ref = [ctx.nn1(ct, c_) for c_ in clouds]
     oi, od = orc.nn1_f32(tgt, poses[0])
     assert np.array_equal(ref[0][0], oi) and np.array_equal(bits32(ref[0][1]), bits32(od))
-    # (variant 8: STRACK; 9: STRACK2, the two-level form — sps then is its slice length in level-1 super-tiles)
+    # (variant 8: STRACK; 9: STRACK2, the two-level form — sps then is its slice length in level-1 super-tiles; 10: STRACK3, the three-level form —
+    # qg then is its number of query groups per wave, sps the entries from which the end of a level-1 super-tile evaluates them)
     for qg, flush, sps, variant in ((4, 0, 0, 8), (2, 1, 0, 8), (4, 100000, 1, 8), (2, 0, 3, 8), (4, 1, 200, 8), (4, 3, 0, 8),
-                                    (4, 0, 0, 9), (4, 1, 1, 9), (4, 100000, 2, 9), (4, 3, 200, 9)):
-        ctx.tune("nn1_btrack_qg", qg); ctx.tune("nn1_sign_flush", flush); ctx.tune("nn1_supers_per_slice", sps if variant == 8 else 0)
+                                    (4, 0, 0, 9), (4, 1, 1, 9), (4, 100000, 2, 9), (4, 3, 200, 9),
+                                    (1, 0, 0, 10), (1, 1, 0, 10), (1, 100000, 64, 10), (2, 0, 0, 10), (2, 3, 16, 10), (4, 0, 0, 10), (4, 100000, 128, 10), (4, 1, 1, 10)):
+        ctx.tune("nn1_btrack_qg", qg if variant != 10 else 0); ctx.tune("nn1_sign_flush", flush); ctx.tune("nn1_supers_per_slice", sps if variant == 8 else 0)
         ctx.tune("nn1_sphere_l1_per_slice", sps if variant == 9 else 0)
+        ctx.tune("nn1_sphere_qg", qg if variant == 10 else 0); ctx.tune("nn1_sphere_flush_end", sps if variant == 10 else 0)
         ctx.tune("nn1_variant", variant)
         ctx.tune("nn1_async_in_loop", 1)
         fresh = ctx.cloud(tgt)                                       # the first search is cold: it seeds itself
         for k, c_ in enumerate(clouds + clouds[:2]):
             ctx.nn1_async(fresh, c_)
-            assert ctx.mfma_check()["last_nn1_kernel"] == ("strack" if variant == 8 else "strack2"), (qg, flush, sps, variant, k)
+            assert ctx.mfma_check()["last_nn1_kernel"] == {8: "strack", 9: "strack2", 10: "strack3"}[variant], (qg, flush, sps, variant, k)
             idx, d2 = ctx.nn1_fetch(n)
             ri, rd = ref[k % len(clouds)]
             assert np.array_equal(idx, ri) and np.array_equal(bits32(d2), bits32(rd)), (qg, flush, sps, k, int((idx != ri).sum()))
         ctx.tune("nn1_async_in_loop", 0)
         fresh.free()
-    for k_ in ("nn1_btrack_qg", "nn1_sign_flush", "nn1_supers_per_slice", "nn1_sphere_l1_per_slice", "nn1_variant", "nn_method"):
+    for k_ in ("nn1_btrack_qg", "nn1_sign_flush", "nn1_supers_per_slice", "nn1_sphere_l1_per_slice", "nn1_sphere_qg", "nn1_sphere_flush_end", "nn1_variant", "nn_method"):
         ctx.tune(k_, 0)
     for c_ in clouds:
         c_.free()
@@ -261,8 +264,10 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
 # nn1_variant: 1 FTRACK (fused-filter tracking, exact decision; no index), 2 TRACK (the exact arithmetic for every pair: the on-device
 # reference), 4 ETRACK (expanded-form f32 filter on the grid's chunked target copy), 6 BTRACK (the filter on the bf16 matrix cores,
 # three-piece operands), 7 HTRACK (one f16 MFMA per tile, two-piece scaled operands), 8 STRACK (the sign form of the f16 filter for every
-# search that has or can make itself a seed; HTRACK where none exists) — csrc/nn1_brute.hip, table above launch_nn1_brute
-VARIANTS = [1, 2, 4, 6, 7, 8, 9]
+# search that has or can make itself a seed; HTRACK where none exists), 9 STRACK2 (the sign filter at two levels: chunk spheres, then records),
+# 10 STRACK3 (three levels: level-1 tiles' spheres, chunk spheres, records — the default from 32 768 target points) — csrc/nn1_brute.hip, table
+# above launch_nn1_brute; csrc/nn1_sphere.hpp
+VARIANTS = [1, 2, 4, 6, 7, 8, 9, 10]
 
 
 def set_variant(ctx, v):
@@ -746,7 +751,11 @@ def test_matrix_core_search_switches_change_no_bit(ctx, synth):
                 # (cold searches then take HTRACK, stale seeds are not merged with a cold one), one-slice launches too (variant 8)
                 dict(nn1_sign=2), dict(nn1_sign_flush=1), dict(nn1_sign_flush=100000), dict(nn1_cold_seed=2), dict(nn1_cold_seed=2, icp_seed_in_move=2),
                 dict(nn1_sign_flush=1, nn1_supers_per_slice=1), dict(nn1_supers_per_slice=100, nn1_btrack_qg=2),
-                dict(nn1_variant=8), dict(nn1_variant=8, nn1_xcd=-1, nn1_btrack_qg=2)]
+                dict(nn1_variant=8), dict(nn1_variant=8, nn1_xcd=-1, nn1_btrack_qg=2),
+                # the sphere forms on this small target: STRACK2 (its slices: super-tile ranges x phases), STRACK3 (groups per wave, evaluation cadence)
+                dict(nn1_variant=9), dict(nn1_variant=9, nn1_sphere_phases=1, nn1_sphere_l1_per_slice=1), dict(nn1_variant=9, nn1_sphere_phases=8, nn1_sphere_qg=2),
+                dict(nn1_variant=10), dict(nn1_variant=10, nn1_sphere_qg=2, nn1_sign_flush=1), dict(nn1_variant=10, nn1_sphere_qg=4, nn1_sphere_flush_end=128),
+                dict(nn1_variant=10, nn1_cold_seed=2, icp_seed_in_move=2)]
     for sw in switches:
         for k, v in sw.items():
             ctx.tune(k, v)

@@ -14,11 +14,11 @@ src, tgt = synth.kitti_like_pair(n)
 ctx = pcr.Context(0)
 ctx.tune("nn_method", 1)
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
-arms = [("STRACK2 (default)", {}), ("STRACK (nn1_sphere=2)", {"nn1_sphere": 2})]
+arms = [("STRACK3 (default)", {}), ("STRACK2 (nn1_sphere_levels=2)", {"nn1_sphere_levels": 2}), ("STRACK (nn1_sphere=2)", {"nn1_sphere": 2})]
 if extra:
     arms.append((f"STRACK2 + {extra}", {k: int(v) for k, v in extra.items()}))
 ref = None
-for name, tunes in arms + arms[:2]:
+for name, tunes in arms + arms[:3]:
     for k, v in tunes.items():
         ctx.tune(k, v)
     ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=3, eps=0.0)
@@ -35,12 +35,12 @@ for name, tunes in arms + arms[:2]:
     bits = "".join(f"{int(v):08x}" for v in T.view(np.uint32).ravel())
     ref = ref or bits
     ctx.tune("grid_stats", 1)
-    ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=3, eps=0.0)
+    ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=9, eps=0.0)
     w = ctx.nn1_stats()
     ctx.tune("grid_stats", 0)
     print(f"{name:28s} kernel {ctx.mfma_check()['last_nn1_kernel']}: search ms", " ".join(f"{v:.3f}" for v in each[:4]), "...", " ".join(f"{v:.3f}" for v in each[-3:]),
           f"| mean {each[1:].mean():.4f} | wall {best:.4f} ms/iteration = {n / best / 1e3:.0f} M corr/s | pose bits {'same' if bits == ref else 'DIFFERENT'}"
-          f" | evals/q {w[6] / n:.2f} l1 mfma {w[8]} l2 tiles flagged {w[9]} l2 mfma {w[10]}")
+          f" | evals/q {w[6] / n:.2f} l0 mfma {w[7]} l1 tiles flagged {w[3]} l1 mfma {w[8]} l2 tiles flagged {w[9]} l2 mfma {w[10]} | waves {w[13]} life us: mean {w[12] / max(w[13], 1) / 100:.1f} max {w[11] / 100:.1f}; most l2 mfma in a wave {w[14]}, waves over 200: {w[15]}")
     for k in tunes:
         ctx.tune(k, 0)
 ctx.close()

@@ -1,0 +1,26 @@
+import importlib, os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+pcr = importlib.import_module("hands-on-point-cloud-processing_amd")
+synth = importlib.import_module("hands-on-point-cloud-processing_amd.synth")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
+src, tgt = synth.kitti_like_pair(n)
+ctx = pcr.Context(0); ctx.tune("nn_method", 1)
+cs, ct = ctx.cloud(src), ctx.cloud(tgt)
+ref = None
+arms = [{}] + [dict(nn1_sphere_qg=q) for q in (4, 2, 1)] + [dict(nn1_sphere_levels=2)]
+if len(sys.argv) > 2:
+    arms = [dict(kv.split('=') for kv in a.split(',')) if a != '-' else {} for a in sys.argv[2:]]
+    arms = [{k: int(v) for k, v in a.items()} for a in arms]
+for tunes in arms:
+    for k, v in tunes.items(): ctx.tune(k, v)
+    ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=3, eps=0.0)
+    ctx.tune("prof", 1); ctx.prof_reset()
+    T, st = ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=20, eps=0.0)
+    each = ctx.prof_get_each("nn1_brute"); ctx.tune("prof", 0)
+    best = 1e9
+    for _ in range(3):
+        ctx.sync(); t0 = time.perf_counter(); ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=20, eps=0.0); best = min(best, (time.perf_counter() - t0) * 1e3 / 20)
+    bits = T.tobytes(); ref = ref or bits
+    print(tunes, f"search last3 {each[-3:].mean():.4f} mean {each[1:].mean():.4f} first {each[0]:.3f} wall {best:.4f} ms/it pose {'same' if bits == ref else 'DIFF'}", flush=True)
+    for k in tunes: ctx.tune(k, 0)
