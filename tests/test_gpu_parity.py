@@ -79,6 +79,44 @@ def test_sphere_form_never_misses_a_chunk_with_a_record_at_or_below_the_threshol
     assert flagged < 0.6 * pairs, (flagged, pairs)
 
 
+def test_sphere_forms_over_several_level0_supertiles_equal_the_exact_grid(ctx, synth):
+    """A target of 300 000 points spans three level-0 super-tiles of STRACK3 (131 072 records each) and 74 level-1 super-tiles of STRACK2: cold and
+    seeded searches of both, sliced every way (one level-0 super-tile per slice / all in one; every group size), return the keys of the exact grid
+    search bit for bit — on the scan pair, on queries far outside the target's box, and with non-finite queries among them."""
+    n, nq = 300_000, 24_000
+    src_all, tgt = synth.kitti_like_pair(n, seed_target=811, seed_pair=812)
+    src = np.ascontiguousarray(src_all[:, :: n // nq][:, :nq]).copy()
+    src[:, 17] = np.nan; src[1, 18] = np.inf
+    src[:, 100:140] += np.float32(500.0)                              # far outside: every level must still answer
+    src[:, 200:230] *= np.float32(1.0e-3)                             # a cluster at the sensor
+    ct = ctx.cloud(tgt)
+    clouds = [ctx.cloud(src), ctx.cloud(np.ascontiguousarray(src + np.array([[0.04], [0.02], [-0.01]], np.float32)))]
+    ctx.tune("nn_method", 2)
+    ref = [ctx.nn1(ct, c_) for c_ in clouds]
+    ctx.tune("nn_method", 1)
+    for sw in (dict(nn1_variant=10), dict(nn1_variant=10, nn1_sphere_l0_per_slice=1), dict(nn1_variant=10, nn1_sphere_l0_per_slice=2, nn1_sphere_qg=2),
+               dict(nn1_variant=10, nn1_sphere_l0_per_slice=3, nn1_sphere_qg=4, nn1_sign_flush=1), dict(nn1_variant=9), dict(nn1_variant=9, nn1_sphere_phases=2, nn1_sphere_qg=2), dict()):
+        for k, v in sw.items():
+            ctx.tune(k, v)
+        ctx.tune("nn1_async_in_loop", 1)
+        fresh = ctx.cloud(tgt)                                       # the first search is cold: it seeds itself; the later ones start from the previous keys
+        for k, c_ in enumerate(clouds + clouds):
+            ctx.nn1_async(fresh, c_)
+            if sw:
+                assert ctx.mfma_check()["last_nn1_kernel"] == {10: "strack3", 9: "strack2"}[sw["nn1_variant"]], (sw, k)
+            idx, d2 = ctx.nn1_fetch(nq)
+            ri, rd = ref[k % 2]
+            assert np.array_equal(idx, ri) and np.array_equal(bits32(d2), bits32(rd)), (sw, k, int((idx != ri).sum()))
+        ctx.tune("nn1_async_in_loop", 0)
+        fresh.free()
+        for k in sw:
+            ctx.tune(k, 0)
+    ctx.tune("nn_method", 0)
+    for c_ in clouds:
+        c_.free()
+    ct.free()
+
+
 def test_library_checks_the_matrix_core_arithmetic_itself_and_falls_back(ctx, orc, synth):
     """The dispatcher consults a once-per-context verdict before it first uses a matrix-core kernel; a failing verdict (forced here
     with the tune key) moves the search to the next form — f16 -> bf16 -> the f32 filters — with the same bits out."""
