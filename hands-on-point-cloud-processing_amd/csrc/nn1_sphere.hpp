@@ -519,6 +519,9 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_S2_WAVES) void nn1_strack3_kernel(
         if (stats) st_l1flag += n1;
         PCR_S2_TICK(pt_l0)
         if (!n1) continue;
+        // (Measured and dropped: the k-th eighth of the sorted query blocks on XCD k, so that an XCD's L2 holds one region of the target's rows instead
+        // of all of them — PMC: 31 MB fetched per launch for a 4 MB working set, every XCD its own copy: 0.036-0.037 ms against 0.034; the regions
+        // differ in work, and the launch is not bound by those fetches.)
         // (Measured and dropped: the whole of a SHORT list — up to eight level-1 tiles in up to four super-tiles, the settled pose's case — in one go:
         // all operands in one trip, four operand sets side by side, all level-2 tiles, one evaluation.  Three links in the wave's chain of trips to
         // memory instead of three per super-tile, and the same 0.034-0.035 ms: PMC counts 1 950 vector + 1 800 scalar instructions per wave of 32
