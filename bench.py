@@ -774,7 +774,7 @@ def main():
 def grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha):
     """steady state of the exact grid search: the searches of an ICP loop that STARTS at the final pose (HIP-event duration of every
     search of the loop: the cold first one and the first seeded one are skipped), and one more loop with the diagnostics counters for
-    the algorithmic bytes (SURVEY.md 8d "1-NN exact grid").  Large targets take the tile search (csrc/grid_tile.hpp), which needs the
+    the algorithmic bytes (SURVEY.md 8d "1-NN exact grid").  Large targets take the sign tile search (csrc/grid_stile.hpp), which needs the
     loop's sorted working cloud — a bare sequence of pcr_nn1_f32_async calls would measure the cell walk alone."""
     ctx.tune("nn_method", 2); ctx.tune("prof", 1); ctx.prof_reset()
     ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=8, eps=0.0)
@@ -806,9 +806,15 @@ def grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha):
         "compulsory_bytes": n_q * 24.0 + n_t * 16.0,
         "vs_hbm_stream_peak": alg_bytes / steady_s / 1e9 / HBM_PEAK_GBS,
         "compulsory_vs_hbm_peak": (n_q * 24.0 + n_t * 16.0) / steady_s / 1e9 / HBM_PEAK_GBS,
-        "kernel": ("pcr::nn1_tile_kernel (one wave per 32 consecutive queries of the sorted working cloud: shared rows, sphere tests and record loads; passes of "
-                   "more than four runs filtered on the f16 matrix pipe) + pcr::nn1_grid_kernel<16, false, 2, true> (the cell walk over the list of deferred "
-                   "queries), at the converged pose, seeded by the previous winners") if tile else
+        "kernel": (("pcr::nn1_stile_kernel<false> (csrc/grid_stile.hpp, the sign tile search: one wave per 64 consecutive queries of the sorted working cloud, a lane "
+                    "per query; quarter boxes -> coarse Morton cells -> tile spheres -> a wave-private list of tiles of 32 records; every listed tile through ONE "
+                    "v_mfma_f32_32x32x16_f16 per half-wave with the query's threshold folded into the free K-slots — the accumulator's sign says whether the record "
+                    "can matter (the exhaustive search's own exact-decision bound) — flagged (query, 16-record chunk) pairs evaluated exactly, four lanes per chunk) "
+                    "+ pcr::nn1_grid_kernel<16, false, 2, true> (the cell walk over the queue of deferred query segments), at the converged pose, seeded by the previous winners")
+                   if family == "grid-stile" else
+                   ("pcr::nn1_tile_kernel (one wave per 32 consecutive queries of the sorted working cloud: shared rows, sphere tests and record loads; passes of "
+                    "more than four runs filtered on the f16 matrix pipe) + pcr::nn1_grid_kernel<16, false, 2, true> (the cell walk over the list of deferred "
+                    "queries), at the converged pose, seeded by the previous winners")) if tile else
                   "pcr::nn1_grid_kernel (exact uniform-grid 1-NN, cell walk) at the converged pose, seeded by the previous correspondences as inside the loop",
         "kernel_family": family,
         "launches": gl, "avg_launch_ms": steady_s * 1e3, "kernel_M_corr_per_s": n_q / steady_s / 1e6,
@@ -819,7 +825,7 @@ def grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha):
                        f"sphere tested ({w[2] / max(n_q, 1):.1f}/query), 16 B per record loaded ({rec_loads / max(n_q, 1):.1f}/query; every loaded record is "
                        f"evaluated against up to 32 queries: {w[0] / max(n_q, 1):.0f} lower-bound / exact pair evaluations per query) and 256 B for the exact "
                        "evaluation of the winning run, counted by the kernels' diagnostics build.  Neighbouring groups need the same records: the bound is the "
-                       "L2 gather rate; the search is bound by dependent L2 round trips and vector issue, not by bandwidth (profiles/r03_grid_pmc.md)"}
+                       "L2 gather rate; the search is bound by vector issue and dependent L2 round trips, not by bandwidth (profiles/r04_grid_pmc.md)"}
 
 
 def bench_c4(ctx, pcr, synth, np, args):

@@ -1,5 +1,5 @@
 import importlib, sys, time
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 pcr = importlib.import_module("hands-on-point-cloud-processing_amd"); synth = importlib.import_module("hands-on-point-cloud-processing_amd.synth")
 scan = synth.kitti_like_scan(120000)
