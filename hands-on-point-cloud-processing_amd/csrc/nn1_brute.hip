@@ -1124,6 +1124,9 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
 //
 //   target                          search                                   kernel
 //   ------------------------------  ---------------------------------------  -----------------------------------------------------------
+//   >= 32 768 points, fits f16      any (a cold search seeds itself first)   STRACK3 nn1_strack3_kernel<1 | 2 | 4>  (nn1_sphere.hpp; variant 10: any size.  The sign
+//                                                                            filter at three levels — rows per 512-record tile, per 16-record chunk, per record)
+//   —                               only on request (nn1_sphere_levels = 2)  STRACK2 nn1_strack2_kernel<4 | 2>      (variant 9: the two-level form)
 //   >= 8 192 points, fits f16       any (a cold search seeds itself first)   STRACK  nn1_strack_kernel<4 | 2>       (variant 8: small targets too)
 //   —                               only on request (nn1_sign = 2)           HTRACK  nn1_btrack_kernel<4 | 2, true>   (variant 7: the minimum-tracking form of
 //                                                                            the f16 filter — round 4: no default path reaches it any more; measured cold,
@@ -1138,7 +1141,9 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
 // (Targets below 2 048 points inside loops, and one-shot searches with queries x targets > 2e9, never get here: api.cpp nn1_auto_grid
 // sends them to the exact grid.)  Tune keys read here — every one 0 = default:
 //   nn1_variant (above) · nn1_bf16 (1 force / 2 forbid the matrix-core forms) · nn1_f16 (1 / 2 the same for the f16 form) ·
-//   nn1_sign (STRACK: 2 = never) · nn1_sign_flush (list entries from which the end
+//   nn1_sign (the sign forms: 2 = never) · nn1_sphere (0 auto / 1 always / 2 never), nn1_sphere_levels (2 = STRACK2), nn1_sphere_qg (groups of 32 queries
+//   per wave), nn1_sphere_flush_end, nn1_sphere_l0_per_slice / nn1_sphere_l1_per_slice / nn1_sphere_blocks, nn1_sphere_phases (STRACK2) ·
+//   nn1_sign_flush (list entries from which the end
 //   of a super-tile evaluates them, default 64) · nn1_sign_dense (flagged half-lanes of one (group, tile) from which they evaluate in place, 12) ·
 //   nn1_btrack_qg (query groups of 32 per wave: 2 or 4; default 2 up to 49 152 queries) · nn1_supers_per_slice / nn1_btrack_blocks
 //   (slice length of the matrix-core launch directly / via the workgroup count, default 14 336) · nn1_xcd (XCD-aware launch: 1 / 2 / 4
