@@ -261,6 +261,7 @@ int pcr_ctx_destroy(pcr_ctx* ctx)
     if (ctx->wpos) hipFree(ctx->wpos);
     if (ctx->work_orig) hipFree(ctx->work_orig);
     if (ctx->grid_stats_dev) hipFree(ctx->grid_stats_dev);
+    if (ctx->pin_words) { hipHostFree(ctx->pin_words); for (int k = 0; k < 2; k++) if (ctx->pin_ev[k]) hipEventDestroy(ctx->pin_ev[k]); }
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->dev_out) hipFree(ctx->dev_out);
     if (ctx->host_out) hipHostFree(ctx->host_out);

@@ -30,6 +30,39 @@
 namespace pcr {
 
 constexpr int GR_BLOCK = 256;
+
+// ---- two host-read counters of the index builds, through pinned words behind an event each (pcr_internal.hpp pin_words)
+static hipError_t pin_word_begin(pcr_ctx* ctx, int slot, const uint32_t* dev_word)
+{
+    hipError_t e = hipSuccess;
+    if (!ctx->pin_words) {
+        e = hipHostMalloc((void**)&ctx->pin_words, 64, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ctx->pin_ev[k], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    e = hipMemcpyAsync(&ctx->pin_words[slot * 8], dev_word, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->pin_ev[slot], ctx->stream);
+    ctx->pin_pending[slot] = e == hipSuccess;
+    if (slot == 1) ctx->pin_gen++;
+    return e;
+}
+static uint32_t work_cells_now(pcr_ctx* ctx)
+{
+    if (ctx->pin_pending[0]) {
+        if (hipEventSynchronize(ctx->pin_ev[0]) == hipSuccess) ctx->work_cells = ctx->pin_words[0];
+        ctx->pin_pending[0] = false;
+    }
+    return ctx->work_cells;
+}
+static uint32_t grid_occupied_now(pcr_ctx* ctx, Grid* g)
+{
+    if (g->occupied == 0 && g->occupied_tag != 0 && g->occupied_tag == ctx->pin_gen && ctx->pin_words) {      // (a later build took the word: unknown, the walk serves)
+        if (ctx->pin_pending[1]) { (void)hipEventSynchronize(ctx->pin_ev[1]); ctx->pin_pending[1] = false; }
+        g->occupied = ctx->pin_words[8];
+    }
+    return g->occupied;
+}
 constexpr int SC_ITEMS = 8;                       // scan: items per thread
 constexpr int SC_TILE = SCAN_TILE;                // 2048 per block (pcr_internal.hpp)
 static_assert(SC_TILE == GR_BLOCK * SC_ITEMS, "scan tile");
@@ -1243,7 +1276,8 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, i
         e = hipMemsetAsync(nzf, 0, 4, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(count_nonzero_kernel, dim3(256), dim3(GR_BLOCK), 0, ctx->stream, count, (uint32_t)cells, nzf);
-            e = hipMemcpyAsync(&g->occupied, nzf, 4, hipMemcpyDeviceToHost, ctx->stream);
+            e = pin_word_begin(ctx, 1, nzf);
+            g->occupied = 0; g->occupied_tag = ctx->pin_gen;
         }
         if (e != hipSuccess) { grid_free(g); return fail(ctx, PCR_ERR_HIP, "grid occupancy", e); }
     }
@@ -1289,7 +1323,7 @@ int grid_build(pcr_ctx* ctx, const pcr_cloud* c, Grid** out, double cell_edge, i
 // 30.6 -> 26.0 ms per search with 2^22 instead of 2^17 bins, profiles/r01_c5_10M_single_gpu.txt).  perm[] goes to ctx->qperm.
 static int sort_queries(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
 {
-    ctx->work_cells = 0;                  // (coarse bins: the density of the order is unknown)
+    ctx->work_cells = 0; ctx->pin_pending[0] = false;     // (coarse bins: the density of the order is unknown)
     GridParams cp = g->p;
     int f = (int)tune_get(ctx, "grid_query_bin_min", 2);
     for (;;) {
@@ -1405,11 +1439,11 @@ static int sort_queries_fine(pcr_ctx* ctx, const Grid* g, const pcr_cloud* src)
     // how many cells of the target's grid the queries occupy (-> ctx->work_cells with the caller's next synchronisation; the sort's
     // input keys are dead by now: their first word is the counter)
     uint32_t* runs = (uint32_t*)k_in;
-    ctx->work_cells = 0;
+    ctx->work_cells = 0; ctx->pin_pending[0] = false;
     if (tile_possible) {
         PCR_HIP(ctx, hipMemsetAsync(runs, 0, 4, ctx->stream));
         hipLaunchKernelGGL(count_key_runs_kernel, dim3(256), dim3(GR_BLOCK), 0, ctx->stream, k_out, (uint32_t)n, QKEY_SUB_BITS, runs);
-        PCR_HIP(ctx, hipMemcpyAsync(&ctx->work_cells, runs, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP(ctx, pin_word_begin(ctx, 0, runs));
     }
     ctx->qperm_n = n;
     ctx->qperm_src = src;
@@ -1773,18 +1807,6 @@ int bt_ensure_l1(pcr_ctx* ctx, const pcr_cloud* tgt)
 }
 
 // ---- extras of the sign tile search (grid_stile.hpp)
-// the fine lattice cell of a coordinate exactly as bt_keys_kernel bins it (monotone non-decreasing in v: the box of a pass maps to a cell range)
-__device__ __forceinline__ uint32_t bt_fine_cell(float v, float lo, float inv) { return (uint32_t)fminf(fmaxf((v - lo) * inv, 0.0f), 1023.0f); }
-// 10 bits -> every third bit (bt_keys_kernel's key: bit 3 b + k = bit b of c[k])
-__device__ __forceinline__ uint32_t spread3_10(uint32_t x)
-{
-    x = (x | (x << 16)) & 0x030000FFu;
-    x = (x | (x << 8)) & 0x0300F00Fu;
-    x = (x | (x << 4)) & 0x030C30C3u;
-    x = (x | (x << 2)) & 0x09249249u;
-    return x;
-}
-__device__ __forceinline__ uint32_t bt_morton(uint32_t cx, uint32_t cy, uint32_t cz) { return spread3_10(cx) | (spread3_10(cy) << 1) | (spread3_10(cz) << 2); }
 // the Morton key a record was sorted by (non-finite records and padding: beyond every cell)
 __device__ __forceinline__ uint32_t bt_record_key(const float4 r, float lox, float loy, float loz, float inv)
 {
@@ -2112,7 +2134,10 @@ int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, 
     const unsigned blocks = (unsigned)((n + GR_BLOCK - 1) / GR_BLOCK);
     hipLaunchKernelGGL(bt_keys_kernel, dim3(blocks), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), (uint32_t)n, bt->key_lo[0], bt->key_lo[1],
                        bt->key_lo[2], bt->key_inv, bt->key_inv, bt->key_inv, k_in, v_in, 0);
-    hipError_t e = sort_pairs_u64_u32(temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, 31, ctx->stream);
+    // (tune bt_sort_begin_bit: the low bits of the Morton key the sort ignores — the order inside the cells they span stays the caller's; every
+    // eight bits less are one radix pass less)
+    const int begin_bit = (int)std::min<int64_t>(std::max<int64_t>(tune_get(ctx, "bt_sort_begin_bit", 0), 0), 24);
+    hipError_t e = sort_pairs_u64_u32(temp, temp_bytes, k_in, k_out, v_in, v_out, n, begin_bit, 31, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(permute_cloud_kernel, dim3(blocks), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), v_out, (uint32_t)n, sorted->x(), sorted->y(),
                            sorted->z());
@@ -2319,8 +2344,9 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     // cell walk (whose cost per query does not depend on the other queries) wins: 0.40 against 0.61 ms per converged search of a 1 / 8 shard of
     // the 10 M pair, 1.44 against 1.04 ms (tile ahead) at 1 / 2 — profiles/r03_c5_tile_search.txt.  Density = queries per occupied cell of
     // the target's grid against targets per occupied cell; a spatially compact shard keeps its local density and the tile search.
-    const bool dense = ctx->work_cells > 0 && g->occupied > 0 &&
-                       (double)ns / (double)ctx->work_cells >= 0.4 * (double)tgt->n / (double)g->occupied;
+    // (both counters come back through pinned words behind an event: the first search after a sort / a build waits for them here, once)
+    const uint32_t work_cells = (tile_tune != 2 && tgt->n >= 4000000) ? work_cells_now(ctx) : 0u, occupied = work_cells ? grid_occupied_now(ctx, tgt->grid) : 0u;
+    const bool dense = work_cells > 0 && occupied > 0 && (double)ns / (double)work_cells >= 0.4 * (double)tgt->n / (double)occupied;
     // (round 4: the FIRST search of a loop too — warm == 0: no correspondences yet — where the sign tile search can make itself a seed per query:
     // stile_seed_kernel, tune grid_stile_cold: 2 = the plain walk as before)
     const bool cold_tile = warm == 0 && reuse_perm && tune_get(ctx, "grid_stile_cold", 1) == 1 && tune_get(ctx, "grid_stile", 0) != 2;

@@ -19,7 +19,8 @@ struct Grid {
     GridParams p;
     size_t n_points = 0;
     size_t n_cells = 0;
-    uint32_t occupied = 0;            // non-empty cells (copied back asynchronously at build time: valid after the next stream synchronisation)
+    uint32_t occupied = 0;            // non-empty cells (0: not read back yet — grid_occupied_now() waits for the build's copy)
+    uint64_t occupied_tag = 0;        // which read-back of the context's pinned word is this grid's
     float4* records = nullptr;        // n_points, sorted by (cell, x): every x-row of cells is one x-sorted range
     uint32_t* cell_start = nullptr;   // n_cells + 2 (cell n_cells holds the non-finite points, never visited)
     // chunked, centred copy of the records for the expanded-form brute-force filter (nn1_brute.hip, ETRACK): per chunk of
@@ -371,6 +372,19 @@ __device__ __forceinline__ void st_setup_l1(float qx, float qy, float qz, const 
     Q[3] = st_theta_l1(thr, sc2, Rs);
     if (Q2) { Q2[0] = Q[0]; Q2[1] = z2; Q2[2] = 0x3C003C00u; Q2[3] = st_theta(thr, sc2, Rs); }
 }
+
+// the fine lattice cell of a coordinate exactly as bt_keys_kernel bins it (monotone non-decreasing in v: the box of a pass maps to a cell range)
+__device__ __forceinline__ uint32_t bt_fine_cell(float v, float lo, float inv) { return (uint32_t)fminf(fmaxf((v - lo) * inv, 0.0f), 1023.0f); }
+// 10 bits -> every third bit (bt_keys_kernel's key: bit 3 b + k = bit b of c[k])
+__device__ __forceinline__ uint32_t spread3_10(uint32_t x)
+{
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+__device__ __forceinline__ uint32_t bt_morton(uint32_t cx, uint32_t cy, uint32_t cz) { return spread3_10(cx) | (spread3_10(cy) << 1) | (spread3_10(cz) << 2); }
 
 void bt_free(BtIndex* b);
 // builds (and caches on tgt) the index if it is not there yet

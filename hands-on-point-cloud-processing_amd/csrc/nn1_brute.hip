@@ -1107,6 +1107,47 @@ __global__ __launch_bounds__(NN_BLOCK) void bt_seed_kernel(const float4* __restr
     keys[i] = key;
 }
 
+// Seeds for a cold search, second form (round 4): the records are in Morton order on a known lattice (BtIndex::key_lo / key_inv), so the record whose
+// key is nearest to the QUERY's key is found by a binary search over the records themselves (their 30-bit key recomputed from their coordinates — a
+// prefix of the key they were sorted by, so it is monotone along them) — 17 dependent 16-byte loads instead of a scan of every super-tile's centre —
+// and the 32 records around it are evaluated exactly.  A Morton neighbour is a spatial neighbour except across the curve's jumps; those queries get a
+// poorer seed, never a wrong answer (the search that follows is exhaustive).
+__global__ __launch_bounds__(NN_BLOCK) void bt_seed_morton_kernel(const float4* __restrict__ records, uint32_t n_rec, float lox, float loy, float loz, float inv,
+                                                                  const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
+                                                                  unsigned long long* __restrict__ keys, int merge)
+{
+    const uint32_t i = blockIdx.x * NN_BLOCK + threadIdx.x;
+    if (i >= ns) return;
+    const float qx = sx[i], qy = sy[i], qz = sz[i];
+    unsigned long long key = ~0ull;
+    if (fabsf(qx) < 1e30f && fabsf(qy) < 1e30f && fabsf(qz) < 1e30f) {
+        const uint32_t kq = bt_morton(bt_fine_cell(qx, lox, inv), bt_fine_cell(qy, loy, inv), bt_fine_cell(qz, loz, inv));
+        uint32_t lo = 0, hi = n_rec;                          // the first record whose key is >= kq
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            const float4 r = records[mid];
+            const bool fin = fabsf(r.x) < 1e30f && fabsf(r.y) < 1e30f && fabsf(r.z) < 1e30f;
+            const uint32_t kr = fin ? bt_morton(bt_fine_cell(r.x, lox, inv), bt_fine_cell(r.y, loy, inv), bt_fine_cell(r.z, loz, inv)) : (1u << 30);
+            if (kr < kq) lo = mid + 1; else hi = mid;
+        }
+        const uint32_t p0 = (uint32_t)max((int)min(lo, n_rec - 1u) - 16, 0), p1 = min(p0 + 32u, n_rec);
+#pragma unroll 1
+        for (uint32_t j0 = p0; j0 < p1; j0 += 8) {
+            float4 rec[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) rec[u] = records[min(j0 + (uint32_t)u, n_rec - 1u)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t e = d2_exact_bits(qx, qy, qz, rec[u].x, rec[u].y, rec[u].z);
+                const unsigned long long k = ((unsigned long long)e << 32) | __float_as_uint(rec[u].w);
+                if (e < 0x7F7FFFFFu && k < key) key = k;                               // FLT_MAX gate; padding records have x = +inf
+            }
+        }
+    }
+    if (merge) { const unsigned long long old = keys[i]; key = old < key ? old : key; }
+    keys[i] = key;
+}
+
 // keys -> (idx, d2) split for the host-facing API
 __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, uint32_t n,
                                   uint32_t* __restrict__ idx, float* __restrict__ d2)
@@ -1214,7 +1255,7 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     // targets (the parity tests' way to put the kernel in front of every input).
     const int64_t sign_tune = tune_get(ctx, "nn1_sign", 0);
     const bool sign = force_sign ? (warm || cold_seed) : f16 && sign_tune != 2 && (warm || cold_seed);
-    const bool reseed = sign && warm && !pre_seeded && tune_get(ctx, "nn1_cold_seed", 1) == 1;
+    bool reseed = sign && warm && !pre_seeded && tune_get(ctx, "nn1_cold_seed", 1) == 1;
     // STRACK2 (nn1_sphere.hpp): the sign filter at two levels — one MFMA row per chunk of 16 records first.  Tune nn1_sphere: 0 auto (targets from
     // 32 768 points on, where a level-1 super-tile of 4 096 records is a small part of the cloud), 1 = always, 2 = never; nn1_variant 9 forces it.
     const int64_t sph_tune = tune_get(ctx, "nn1_sphere", 0), variant_now = tune_get(ctx, "nn1_variant", 0);
@@ -1234,6 +1275,8 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
         }
         sphere = bt->l1_bad_host == 0;
     }
+    // (the sphere forms pay far less for a poor seed than STRACK does — tune nn1_sphere_reseed: 2 = a warm search keeps its stale seeds as they are)
+    if (sphere && tune_get(ctx, "nn1_sphere_reseed", 0) == 2) reseed = false;
     ctx->last_nn1_kernel = sphere ? (three ? "strack3" : "strack2") : sign ? "strack" : f16 ? "htrack" : "btrack";
     if (warm) seed_warm(ctx, tgt, src, pre_seeded);
     else if (merge_atomic && !cold_seed) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
@@ -1242,9 +1285,16 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     if (rc) return rc;
     {
         ProfScope p(ctx, "nn1_brute", 1);
-        if (cold_seed || reseed)                                                    // (inside the timed scope: it is part of the search)
+        // (tune nn1_seed_mode: 1 = the nearest super-tile's centre, 2 = the Morton neighbour by binary search, 3 = both, merged; 0 = both for a cold search —
+        // first search of a fresh pair, 120 k, three pairs: 0.147 / 0.295 / 0.290 -> 0.095 / 0.159 / 0.212 ms; a one-shot search of unsorted queries 0.366 ->
+        // 0.304 ms, 6.5 -> 2.4 chunks evaluated per query — and the centre alone where stale correspondences are merged in: 0.185 against 0.194 ms)
+        const int64_t seed_tune = tune_get(ctx, "nn1_seed_mode", 0), seed_mode = seed_tune ? seed_tune : (cold_seed ? 3 : 1);
+        if ((cold_seed || reseed) && seed_mode >= 2 && g->key_inv > 0.f)
+            hipLaunchKernelGGL(bt_seed_morton_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, g->records, n_super * BT_SUPER,
+                               g->key_lo[0], g->key_lo[1], g->key_lo[2], g->key_inv, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, reseed ? 1 : 0);
+        if ((cold_seed || reseed) && (seed_mode < 2 || seed_mode == 3 || !(g->key_inv > 0.f)))          // (inside the timed scope: it is part of the search)
             hipLaunchKernelGGL(bt_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->records, n_super,
-                               std::max<uint32_t>(1u, n_super / 1024u), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, reseed ? 1 : 0);
+                               std::max<uint32_t>(1u, n_super / 1024u), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, (reseed || seed_mode == 3) ? 1 : 0);
         // XCD-aware launch (tune nn1_xcd: 1 / 2 / 4 = query-block groups per 8 XCDs, -1 = the plain 2-D launch): see the kernel
         // STRACK: entries in a wave's list from which the end of a super-tile evaluates them (tune nn1_sign_flush; the end of the slice always does)
         const uint32_t st_flush_at = (uint32_t)std::min<int64_t>(std::max<int64_t>(tune_get(ctx, "nn1_sign_flush", 64), 1), 1 << 20);

@@ -128,7 +128,13 @@ struct pcr_ctx {
     // clone of the same size instead of two hipMalloc + two hipFree (each free a device synchronisation) per call
     float* spare_base[2] = { nullptr, nullptr };
     size_t spare_cap[2] = { 0, 0 };
-    uint32_t work_cells = 0;              // distinct target-grid cells the sorted working cloud occupies (0: unknown); valid after the sort's synchronisation
+    uint32_t work_cells = 0;              // distinct target-grid cells the sorted working cloud occupies (0: unknown); read through work_cells_now()
+    // two counters of the index builds come back through PINNED words behind an event each (a hipMemcpyAsync into pageable memory is ordered only
+    // by what the runtime happens to do): [0] work_cells, [1] the occupied cells of the grid built last (Grid::occupied_tag says whose)
+    uint32_t* pin_words = nullptr;
+    hipEvent_t pin_ev[2] = { nullptr, nullptr };
+    bool pin_pending[2] = { false, false };
+    uint64_t pin_gen = 0;
     double* partials = nullptr;           // block rows of the Kabsch pass (8192 x 58 doubles)
     size_t partials_cap = 0;
     double* dev_out = nullptr;            // 128 doubles: reduced sums / limbs + bookkeeping

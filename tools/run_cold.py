@@ -12,6 +12,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
 src, tgt = synth.kitti_like_pair(n)
 ctx = pcr.Context(0)
 ctx.tune("nn_method", 1)
+for kv in sys.argv[2:]:
+    k__, v__ = kv.split("="); ctx.tune(k__, int(v__))
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
 ctx.tune("nn1_variant", 2); ri, rd = ctx.nn1(ct, cs); ctx.tune("nn1_variant", 0)
 ctx.nn1(ct, cs)                                              # index, code objects
