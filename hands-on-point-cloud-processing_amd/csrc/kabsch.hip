@@ -526,6 +526,20 @@ __global__ __launch_bounds__(KF_BLOCK) void icp_update_move_kernel(const double*
     const bool mine = i < n4;
     float4 px = make_float4(0.f, 0.f, 0.f, 0.f), py = px, pz = px;
     if (mine) { px = reinterpret_cast<float4*>(x)[i]; py = reinterpret_cast<float4*>(y)[i]; pz = reinterpret_cast<float4*>(z)[i]; }
+    // the seeds of the next search (seed_next_search): the previous correspondences and their target points do not depend on the new pose — requested
+    // here, in front of the reduce and the solve, so that the two dependent trips to memory (key -> target point) are over when the move is done
+    unsigned long long sk[4] = { ~0ull, ~0ull, ~0ull, ~0ull };
+    float sq[4][3] = { { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f } };
+    if (sd.tx && mine) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (4 * i + u < n) sk[u] = sd.keys[4 * i + u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t j = (uint32_t)(sk[u] & 0xFFFFFFFFull);
+            if (j < sd.nt) { sq[u][0] = sd.tx[j]; sq[u][1] = sd.ty[j]; sq[u][2] = sd.tz[j]; }
+        }
+    }
     icp_state_stage(st_in, &s_st);
     const int phase = s_st.stop ? 0 : (s_st.stop_after_transform ? 1 : 2);       // (uniform over the workgroup)
     if (phase == 2) {
@@ -564,8 +578,19 @@ __global__ __launch_bounds__(KF_BLOCK) void icp_update_move_kernel(const double*
     reinterpret_cast<float4*>(y)[i] = oy;
     reinterpret_cast<float4*>(z)[i] = oz;
     if (sd.tx) {
-        seed_next_search(sd, base + 0, n, ox.x, oy.x, oz.x); seed_next_search(sd, base + 1, n, ox.y, oy.y, oz.y);
-        seed_next_search(sd, base + 2, n, ox.z, oy.z, oz.z); seed_next_search(sd, base + 3, n, ox.w, oy.w, oz.w);
+        const float mx[4] = { ox.x, ox.y, ox.z, ox.w }, my[4] = { oy.x, oy.y, oy.z, oy.w }, mz[4] = { oz.x, oz.y, oz.z, oz.w };
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (base + u >= n) continue;
+            const uint32_t j = (uint32_t)(sk[u] & 0xFFFFFFFFull);
+            unsigned long long key = ~0ull;
+            if (j < sd.nt) {
+                const float dx = mx[u] - sq[u][0], dy = my[u] - sq[u][1], dz = mz[u] - sq[u][2];
+                const uint32_t e2 = __float_as_uint((dx * dx + dy * dy) + dz * dz);       // A1, unfused (nanoflann.hpp:403-406): seed_next_search's arithmetic
+                if (e2 < 0x7F7FFFFFu) key = ((unsigned long long)e2 << 32) | j;            // FLT_MAX gate, nanoflann.hpp:163,1360
+            }
+            sd.keys[base + u] = key;
+        }
     }
 }
 
