@@ -197,7 +197,9 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     // (Measured and dropped, round 4: the Kabsch sums taken by the search kernel itself — STRACK3 ends with every query's final key in one wave, so each
     // wave added its 32 pairs' limbs (wave sums, a row per workgroup, f64 atomics into 64 rows; same bits) and the streaming pass + its launch gap
     // (7 + 4.5 us) went away: the search grew from 0.034 to 0.049 ms — 41 limbs x 6 f64 shuffle-adds per wave, four waves per SIMD ending together on
-    // the LDS crossbar and the half-rate f64 pipe — and an iteration from 0.0707 to 0.0755 ms.  Also measured: the 3 x 3 solve is 4.6 of the 17.5 us of the solve + move.)
+    // the LDS crossbar and the half-rate f64 pipe — and an iteration from 0.0707 to 0.0755 ms.  A second form without any cross-lane traffic (lane l takes
+    // moment l of the wave's 32 pairs from LDS) still cost the search 7.5 us — the block waits for its slowest wave, every wave ends 2 us later — for 0-1.3 us
+    // per iteration.  Also measured: the 3 x 3 solve is 4.6 of the 17.5 us of the solve + move.)
     uint64_t enq = 0, chunks = 0;
     bool stopped = false;
     while (rc == PCR_OK && !stopped && enq < prm->max_iter) {
