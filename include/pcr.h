@@ -421,7 +421,7 @@ int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
  *  ICP loop    icp_pipeline [0 = 1 device-resident] -1 synchronous · icp_chunk [4] · icp_bounded_search [on] 2 = off ·
  *              icp_fused_move [on] 2 = off, icp_fused_max [262 144] · icp_seed_in_move [on] 2 = off · icp_force_slots (tests) ·
  *              kabsch_bfly [on], kabsch_records [on], kabsch_one_pair_blocks [128], kabsch_max_blocks [1 024]
- *  other       iss_lanes [32] · radius_fused [on] 2 = off · grid_stats 1 = the next 1-NN launch fills pcr_nn1_stats · prof 0 / 1 / 2 */
+ *  other       plane_group [20: hypotheses per workgroup row of the plane count] · iss_lanes [32] · radius_fused [on] 2 = off · grid_stats 1 = the next 1-NN launch fills pcr_nn1_stats · prof 0 / 1 / 2 */
 int pcr_tune_set(pcr_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

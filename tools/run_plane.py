@@ -5,6 +5,8 @@ pcr = importlib.import_module("hands-on-point-cloud-processing_amd"); synth = im
 scan = synth.kitti_like_scan(120000)
 ctx = pcr.Context(0); c = ctx.cloud(scan)
 rng = np.random.default_rng(0)
+for kv in sys.argv[1:]:
+    k_, v_ = kv.split('='); ctx.tune(k_, int(v_)); print('tune', k_, v_)
 for nh in (1, 8, 40, 80, 96):
     planes = np.concatenate([rng.normal(size=(nh, 3)), rng.normal(size=(nh, 1))], axis=1)
     planes[:, :3] /= np.linalg.norm(planes[:, :3], axis=1, keepdims=True)
