@@ -427,7 +427,7 @@ def main():
         # ---- the shader clock the chip holds under the headline kernel's own load: s_memtime / s_memrealtime stamps of a diagnostics
         # launch (tune grid_stats) that follows 40 back-to-back launches of the same seeded search; median of 3
         clock_mhz = None
-        if extras and args.nn == "brute" and family in ("strack3", "strack2", "strack", "htrack", "btrack"):
+        if extras and args.nn == "brute" and family in ("strack3", "strack", "htrack", "btrack"):
             ca = cs.clone(); ctx.transform(ca, T)
             ctx.tune("nn_method", 1); ctx.tune("prof", 0); ctx.tune("nn1_async_in_loop", 1)
             clocks = []
@@ -442,16 +442,16 @@ def main():
             ca.free()
             clock_mhz = sorted(clocks)[len(clocks) // 2] if clocks else None
 
-        # ---- STRACK3 / STRACK2 (the sign filter at three / two levels): how many matrix instructions a search at the final pose executes — the last
+        # ---- STRACK3 (the sign filter over three levels of bounding spheres): how many matrix instructions a search at the final pose executes — the last
         # search of a 9-iteration loop from that pose (the loop sorts its working cloud along the target's order, as the timed loop does), diagnostics launch
         s2_counts = None
-        if args.nn == "brute" and family in ("strack3", "strack2"):
+        if args.nn == "brute" and family == "strack3":
             ctx.tune("nn_method", 1); ctx.tune("prof", 0)
             ctx.tune("grid_stats", 1)
             ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=9, eps=0.0)
             ctx.tune("grid_stats", 0)
             w = ctx.nn1_stats()
-            s2_counts = {"level0_mfma": int(w[7]) if family == "strack3" else 0, "level1_tiles_flagged": int(w[3]) if family == "strack3" else None,
+            s2_counts = {"level0_mfma": int(w[7]), "level1_tiles_flagged": int(w[3]),
                          "level1_mfma": int(w[8]), "level2_mfma": int(w[10]), "level2_tiles_flagged": int(w[9]), "chunks_evaluated_exactly": int(w[6])}
 
         # ---- the exact-only kernel (the 9-op convention's own kernel), the cold searches: a few launches each, HIP-event timed
@@ -554,11 +554,10 @@ def main():
         if rank == 0:
             gt_err = float(np.linalg.norm(T.astype(np.float64) - synth.gt_pose()))
             if args.nn == "brute":
-                two = family in ("strack2", "strack3")
-                three = family == "strack3"
-                sign = family in ("strack", "strack2", "strack3")
-                f16 = family in ("strack3", "strack2", "strack", "htrack")
-                bf16 = family in ("strack3", "strack2", "strack", "htrack", "btrack")
+                two = three = family == "strack3"
+                sign = family in ("strack", "strack3")
+                f16 = family in ("strack3", "strack", "htrack")
+                bf16 = family in ("strack3", "strack", "htrack", "btrack")
                 slots_pp = 32 if f16 else 64                 # flop per pair of ALL K-slots the matrix instruction(s) execute (16 / 2 x 16 multiply-adds)
                 flops_pp = STRACK_FLOPS_PER_PAIR if sign else HTRACK_FLOPS_PER_PAIR if f16 else BTRACK_FLOPS_PER_PAIR if bf16 else ETRACK_FLOPS_PER_PAIR
                 peak_tf = MFMA_BF16_PEAK_TFLOPS if bf16 else VALU_PEAK_TFLOPS
@@ -576,19 +575,14 @@ def main():
                     "traffic_note": (f"HBM-side bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) from separate rocprofv3 --pmc passes of this "
                                      f"kernel with this very libpcr_hip.so (sha {sha}), {pmc['source']}") if pmc else
                                     "null: PMC counters need a rocprofv3 wrapper (tools/gpu_check.sh); none was collected with the library loaded now",
-                    "kernel": ((("pcr::nn1_strack3_kernel<1> = STRACK3, the SIGN form of the f16 matrix-core filter at THREE LEVELS (csrc/nn1_sphere.hpp), one wave per 32 "
+                    "kernel": (("pcr::nn1_strack3_kernel<1> = STRACK3, the SIGN form of the f16 matrix-core filter at THREE LEVELS (csrc/nn1_sphere.hpp), one wave per 32 "
                                "queries: level 0 — one MFMA row per level-1 TILE of 512 records (its bounding sphere, in the scale of a level-0 super-tile of 131 072 "
                                "records: |r - c| <= sqrt(thr) + rho as a sum of 16 K-slot products whose sign answers), over EVERY row of the target; level 1 — the chunk "
                                "rows (16 records each) of the level-1 tiles level 0 flagged; level 2 — the per-record rows of the tiles of 32 records that hold a flagged "
                                "chunk; flagged (query, 16-record chunk) pairs evaluated with the exact unfused arithmetic, four lanes per chunk; thresholds = the exact "
                                "distance of the best candidate so far (the previous correspondence re-evaluated by the move, then whatever the scan finds).  Exhaustive "
-                               "in the brute-force contract's sense: no record is skipped without a computed sign that says it cannot matter") if three else
-                               ("pcr::nn1_strack2_kernel<4> = STRACK2, the SIGN form of the f16 matrix-core filter at TWO LEVELS (csrc/nn1_sphere.hpp): level 1 — one MFMA row "
-                               "per CHUNK of 16 records (its bounding sphere: |r - c| <= sqrt(thr) + rho as a sum of 16 K-slot products whose sign answers), over every "
-                               "chunk of the target: a sixteenth of the per-record filter's matrix and vector work; level 2 — the tiles of 32 records that hold a "
-                               "flagged chunk through the per-record sign filter (STRACK's operands), flagged (query, 16-record chunk) pairs evaluated with the exact "
-                               "unfused arithmetic, four lanes per chunk; thresholds = the exact distance of the best candidate so far (the previous correspondence "
-                               "re-evaluated by the move, then whatever the scan finds)")) if two else (("pcr::nn1_strack_kernel<4> = STRACK, the SIGN form of the f16 matrix-core filter, operands staged through LDS per workgroup "
+                               "in the brute-force contract's sense: no record is skipped without a computed sign that says it cannot matter")
+                               if two else (("pcr::nn1_strack_kernel<4> = STRACK, the SIGN form of the f16 matrix-core filter, operands staged through LDS per workgroup "
                                 "(exhaustive: the expanded-form lower bound of ALL (query, target) pairs from ONE v_mfma_f32_32x32x16_f16 per 32 queries "
                                 "x 32 targets — operands scaled per 256-target super-tile and cut into two f16 pieces, every piece product exact in f32 — "
                                 "with the query's threshold (the exact distance of its best candidate so far: the previous correspondence re-evaluated, "
@@ -786,7 +780,7 @@ def grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha):
     ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=3, eps=0.0)
     w = ctx.nn1_stats()
     ctx.tune("grid_stats", 0); ctx.tune("prof", 0)
-    tile = family in ("grid-tile", "grid-stile")
+    tile = family == "grid-stile"
     gpmc = load_pmc("latest_pmc_grid.json", sha)
     if gpmc and (gpmc.get("n") != n_t or n_q != n_t):
         gpmc = None
@@ -811,10 +805,7 @@ def grid_roofline(ctx, pcr, np, cs, ct, T, n_q, n_t, kern_s, sha):
                     "v_mfma_f32_32x32x16_f16 per half-wave with the query's threshold folded into the free K-slots — the accumulator's sign says whether the record "
                     "can matter (the exhaustive search's own exact-decision bound) — flagged (query, 16-record chunk) pairs evaluated exactly, four lanes per chunk) "
                     "+ pcr::nn1_grid_kernel<16, false, 2, true> (the cell walk over the queue of deferred query segments), at the converged pose, seeded by the previous winners")
-                   if family == "grid-stile" else
-                   ("pcr::nn1_tile_kernel (one wave per 32 consecutive queries of the sorted working cloud: shared rows, sphere tests and record loads; passes of "
-                    "more than four runs filtered on the f16 matrix pipe) + pcr::nn1_grid_kernel<16, false, 2, true> (the cell walk over the list of deferred "
-                    "queries), at the converged pose, seeded by the previous winners")) if tile else
+) if tile else
                   "pcr::nn1_grid_kernel (exact uniform-grid 1-NN, cell walk) at the converged pose, seeded by the previous correspondences as inside the loop",
         "kernel_family": family,
         "launches": gl, "avg_launch_ms": steady_s * 1e3, "kernel_M_corr_per_s": n_q / steady_s / 1e6,

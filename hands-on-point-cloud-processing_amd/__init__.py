@@ -444,7 +444,7 @@ class Context:
         return tuple(int(v) for v in out)
 
     def selftest_sphere_f16(self, trials: int = 64):
-        """(pairs that must be flagged, of those missed, pairs flagged, pairs) of the level-1 chunk-sphere form of the sign filter (STRACK2)"""
+        """(pairs that must be flagged, of those missed, pairs flagged, pairs) of the chunk-sphere rows of the sign filter (STRACK3)"""
         out = (C.c_uint64 * 4)()
         self._ck(lib().pcr_selftest_sphere_f16(self.h, int(trials), out))
         return tuple(int(v) for v in out)

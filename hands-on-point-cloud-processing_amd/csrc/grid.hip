@@ -757,7 +757,7 @@ __global__ __launch_bounds__(GR_BLOCK, (LIST && !STATS) ? PCR_LIST_WAVES : 1) vo
     constexpr bool CLIP = MODE == 1, SPH = MODE == 2;
     static_assert(!SPH || G == 16, "the sphere walk scans one 16-record run per sub-group");
     const uint32_t vb = xcd_run ? xcd_block(blockIdx.x, xcd_run) : blockIdx.x;
-    // LIST MODE (template LIST, G = 16): the queries the tile search deferred (grid_tile.hpp).  perm[] is a SEGMENTED list — segment s =
+    // LIST MODE (template LIST, G = 16): the queries the tile search deferred (grid_stile.hpp).  perm[] is a SEGMENTED list — segment s =
     // the deferred queries of the 32-query group s of the sorted working cloud, list_count[s] of them at perm[32 s ...] — so the list is
     // in the order of the working cloud however the tile kernel's waves were scheduled.  A fixed number of workgroups serves it: every
     // wave owns `list_segs` consecutive segments (16: at most 512 queries — small enough for the hardware's dispatch order to balance
@@ -1087,7 +1087,6 @@ __global__ __launch_bounds__(GR_BLOCK, (LIST && !STATS) ? PCR_LIST_WAVES : 1) vo
     }
 }
 
-#include "grid_tile.hpp"
 
 __global__ __launch_bounds__(GR_BLOCK) void count_nonzero_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ out)
 {
@@ -2325,19 +2324,14 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         launch_blocks = (nblocks + unit - 1) / unit * unit;
     }
     ctx->last_nn1_kernel = "grid";
-    // TILE SEARCH (grid_tile.hpp; tune grid_tile: 0 auto = targets of 4 000 000 points and more, 1 on, 2 off — the tile search is ahead of the
-    // sphere walk once the pose has settled, behind it while many queries are deferred; over a 20-iteration loop from the start pose the
-    // walk wins below ~4 M points: 500 k 195 against 310 us per iteration, 1 M 368 / 490, 2 M 753 / 858, 4 M 1 527 / 1 510, 10 M 4.7 / 3.7 ms;
-    // profiles/r03_grid_order.txt): the seeded searches of a loop
-    // whose working cloud is in the order of a Morton-ordered index — one wave per 32 consecutive queries shares rows, sphere tests and
-    // record loads, and passes of more than four runs are filtered on the f16 matrix pipe; queries whose ball exceeds
-    // grid_tile_bmax_pct % of a cell edge (default 400) and passes with more than grid_tile_keep surviving runs (default 512) go to a
-    // segmented list that the cell walk serves in a second launch (list mode).  Measured at 10 M x 10 M, same box, per search of a
-    // 20-iteration loop (profiles/r03_c5_tile_search.txt): converged 2.79 -> 1.66 ms, average over the first 20 searches 4.45 -> 3.65 ms.
-    // Other knobs (defaults measured in the same file): grid_tile_lim_pct (ball limit as a multiple of the group's mean ball, 1000 =
-    // off), grid_tile_reach_pct (cluster reach of a pass in ball limits, 200), grid_tile_total_mult (runs a pass may test, x keep, 16),
-    // grid_tile_min_members (8), grid_tile_list_segs (groups per wave of the list walk, 1), grid_tile_filter (2 = exact loop only).
-    // Same results as the walk alone, bit for bit (tests: test_config5.py, test_gpu_parity.py::test_icp_tile_search_...).
+    // TILE SEARCH (tune grid_tile: 0 auto = targets of 4 000 000 points and more, 1 on, 2 off): the searches of a loop whose working cloud is in the order
+    // of a Morton-ordered index, by coherent query tiles — one wave per 64 consecutive queries shares candidate tiles and record loads; queries it cannot
+    // serve go to a segmented list that the cell walk serves in a second launch (list mode).  The kernel is the SIGN tile search of round 4
+    // (grid_stile.hpp; the tile kernel of round 3 — operands built per visit, minimum tracking — was removed when it took over: over a 20-iteration loop
+    // at 10 M it ran 3.72 against 2.76 ms per iteration, profiles/r04_c5_stile.txt).  The tile search is ahead of the sphere walk once the pose has
+    // settled, behind it while many queries are deferred; over a whole loop from the start pose the walk wins below ~4 M points (profiles/r03_grid_order.txt).
+    // Shared knobs: grid_tile_reach_pct (cluster reach of a pass in ball limits, 200), grid_tile_min_members (8), grid_tile_list_segs (groups per wave of
+    // the static list walk, 1).  Same results as the walk alone, bit for bit (tests: test_config5.py, test_gpu_parity.py::test_icp_tile_search_...).
     const int64_t tile_tune = tune_get(ctx, "grid_tile", 0);
     // auto: large targets, and a working cloud about as dense as the target where it lies — 32 consecutive queries of a SPARSE subset (a
     // uniformly drawn 1 / 8 shard of a multi-GPU run) span eight times the region, their pass needs eight times the records per query, and the
@@ -2361,13 +2355,13 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
         }
         uint32_t* dlist = ctx->far_list;
         uint32_t* dcount = ctx->far_list + n_groups_sz * 32;
-        const float lim_k = (float)tune_get(ctx, "grid_tile_lim_pct", 1000) * 0.01f, reach_k = (float)tune_get(ctx, "grid_tile_reach_pct", 200) * 0.01f;
+        const float reach_k = (float)tune_get(ctx, "grid_tile_reach_pct", 200) * 0.01f;
         const uint32_t min_members = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, tune_get(ctx, "grid_tile_min_members", 8)));
         const uint32_t n_groups = (uint32_t)((ns + 31) / 32);
         const uint32_t list_segs = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, tune_get(ctx, "grid_tile_list_segs", 1)));
         const unsigned lblocks = (unsigned)(((n_groups_sz + (size_t)list_segs * 4 - 1) / ((size_t)list_segs * 4) + 255) / 256 * 256);      // (whole XCD runs)
         // SIGN TILE SEARCH (grid_stile.hpp, round 4; tune grid_stile: 0 auto = on where the f16 matrix pipe passed the device check and the
-        // target's Morton-ordered index fits f16, 2 = the round-3 tile kernel): one wave per 64 consecutive queries, the candidate tiles
+        // target's Morton-ordered index fits f16, 2 = off: the cell walk): one wave per 64 consecutive queries, the candidate tiles
         // of the target's matrix-core index found through coarse Morton cells and run spheres, one MFMA per tile and 32 queries whose
         // SIGN says whether a record can matter.  Knobs: grid_stile_bmax_cm (largest ball of a served query, default 100), grid_stile_lim_pct / grid_stile_lim_floor_mm (ball limit of a wave: a multiple of its mean ball, 400 %, never below 150 mm), grid_stile_keep (candidate
         // tiles a pass may keep, 768; grid_stile_keep_small: the same for passes whose largest ball is below grid_stile_split_mm, 192), grid_stile_cells (coarse cells a pass may open, 2 048), grid_stile_flush / grid_stile_dense (STRACK's list rules, 64 / 32).
@@ -2386,7 +2380,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
             stile = stile && bt->bad16_host == 0;
             if (stile && (rc = bt_ensure_tile(ctx, tgt))) return rc;
         }
-        if (!stile && warm != 3) break;                       // (a cold search without the sign tile search: the plain walk below)
+        if (!stile) break;                                    // (this device's f16 arithmetic failed the check, or the target leaves f16's range: the walk below)
         if (stile) {
             const BtIndex* bt = tgt->bt;
             const float sbmax = (float)tune_get(ctx, "grid_stile_bmax_cm", 100) * 0.01f;
@@ -2439,31 +2433,7 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
             PCR_HIP(ctx, hipGetLastError());
             return PCR_OK;
         }
-        const float bmax = (float)tune_get(ctx, "grid_tile_bmax_pct", 400) * 0.01f * g->p.h;
-        const uint32_t keep_max = (uint32_t)std::min<int64_t>(TL_KEEP, std::max<int64_t>(2, tune_get(ctx, "grid_tile_keep", 512)));
-        // (the filter of large passes runs on the f16 matrix pipe: only where this device's arithmetic passed the library's own check)
-        const int use_filter = (tune_get(ctx, "grid_tile_filter", 1) == 1 && mfma_verdict(ctx, true)) ? 1 : 0;
-        const uint32_t total_mult = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, tune_get(ctx, "grid_tile_total_mult", 16)));
-        size_t tblocks = (n_groups + (GR_BLOCK / 64) - 1) / (GR_BLOCK / 64);
-        int64_t trun = tune_get(ctx, "grid_xcd_run", 0);
-        if (trun == 0) trun = tblocks >= 4096 ? 32 : -1;
-        uint32_t txcd = 0;
-        if (trun > 0) { txcd = (uint32_t)trun; const size_t unit = 8 * (size_t)txcd; tblocks = (tblocks + unit - 1) / unit * unit; }
-        ctx->last_nn1_kernel = "grid-tile";
-        {
-            ProfScope p(ctx, "nn1_grid", 1);
-#define PCR_TILE(ST)                                                                                                                        \
-    hipLaunchKernelGGL((nn1_tile_kernel<ST>), dim3((unsigned)tblocks), dim3(GR_BLOCK), 0, ctx->stream, g->records, g->spheres, g->cell_start, g->p, \
-                       src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)tgt->n, cap2, wpos, dlist,  \
-                       dcount, txcd, bmax, n_groups, lim_k, reach_k, keep_max, use_filter, min_members, total_mult);                                                             \
-    hipLaunchKernelGGL((nn1_grid_kernel<16, ST, 2, true>), dim3(lblocks), dim3(GR_BLOCK), 0, ctx->stream, g->records, g->spheres, g->cell_start, g->p,   \
-                       src->x(), src->y(), src->z(), (const uint32_t*)dlist, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(),     \
-                       tgt->y(), tgt->z(), (uint32_t)tgt->n, 3, cap2, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, wpos, 0u, (const uint32_t*)dcount, list_segs)
-            if (stats_dev) { PCR_TILE(true); } else { PCR_TILE(false); }
-#undef PCR_TILE
-        }
-        PCR_HIP(ctx, hipGetLastError());
-        return PCR_OK;
+        break;                                                // (no sign tile search on this device / for this target: the cell walk below)
     } while (0);
     {
         ProfScope p(ctx, "nn1_grid", 1);

@@ -101,13 +101,13 @@ struct BtIndex {
     // cell c are [cell_start[c], cell_start[c + 1]), non-finite records and padding lie behind the last entry); tile_spheres = bounding
     // sphere of every tile of 32 records (radius < 0 = no finite member); g_of_b[p] = position of record p in the
     // records of the cell grid `g_of` (the winner positions of a loop — ctx->wpos — stay in that numbering for the walk and the Kabsch pass)
-    // ---- level 1 of the two-level sign filter (STRACK2, nn1_sphere.hpp; bt_ensure_l1): per level-1 super-tile of BT_L1_SUPER records a centre
+    // ---- level 1 of the two-level sign filter (the sphere forms, nn1_sphere.hpp; bt_ensure_l1): per level-1 super-tile of BT_L1_SUPER records a centre
     // + power-of-two scale, per chunk of 16 records ONE operand row (its bounding sphere): [level-1 tile of 32 chunks][64 lanes] x 16 bytes
     void* l1_block = nullptr;
     float4* l1_centres = nullptr;
     uint4* l1_ops = nullptr;
     uint4* l1_rec_ops = nullptr;      // the per-RECORD operands once more, in the scale of the record's level-1 super-tile ([tile][64 lanes] x 16 bytes): level 2 of
-                                      // STRACK2 then needs no operand setup of its own (one per query and 4 096 records instead of one per 256)
+                                      // the sphere form then needs no operand setup of its own (one per query and 4 096 records instead of one per 256)
     float4* l0_centres = nullptr;     // level 0 of STRACK3: one row per LEVEL-1 TILE (the bounding sphere of its 512 records), level-0 super-tiles of
     uint4* l0_ops = nullptr;          // BT_L0_SUPER records share a centre and a scale ([level-0 tile][64 lanes] x 16 bytes, 32 rows per tile)
     size_t n_l0_super = 0;
@@ -151,7 +151,7 @@ __device__ __forceinline__ uint4 ht_target_operand(float tx, float ty, float tz,
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// query side of the f16 filter (nn1_brute.hip HTRACK, grid_tile.hpp): error analysis in the header of nn1_btrack_kernel
+// query side of the f16 filter (nn1_brute.hip HTRACK): error analysis in the header of nn1_btrack_kernel
 #ifndef PCR_HT_ABS_SLACK
 #define PCR_HT_ABS_SLACK 2.384185791015625e-07f      // 2^-22 (A/B builds of the underflow test: -DPCR_HT_ABS_SLACK=0.0f)
 #endif
@@ -234,7 +234,7 @@ __device__ __forceinline__ void st_setup(float qx, float qy, float qz, const flo
     Q[3] = st_theta(thr, sc2, Rs);
 }
 
-// ---- LEVEL 1 of the two-level sign filter (STRACK2, nn1_sphere.hpp): one MFMA row per CHUNK of 16 records instead of one per record.  A chunk
+// ---- LEVEL 1 of the hierarchical sign filter (STRACK3, nn1_sphere.hpp): one MFMA row per CHUNK of 16 records instead of one per record.  A chunk
 // with bounding sphere (c, rho) cannot hold a record at or below a query's threshold thr unless |r - c| <= s + rho (s = sqrt(thr), scaled
 // units of the LEVEL-1 super-tile of 4 096 records: centre C1, power-of-two scale with |t - C1| scale <= 2^7), i.e. unless
 //     F = (|c|^2 - rho^2) - 2 r.c - 2 s rho - (s^2 - |r|^2) <= 0 :
@@ -352,7 +352,7 @@ __device__ __forceinline__ uint32_t st_theta_l1(float thr, float sc2, float Rs)
 // query side of the level-1 form for one (query, level-1 super-tile): P = the lower half-lane's words (x pieces, y pieces), Q = the upper
 // half-lane's (z: r1 r1 | r2, s | 1 1 | threshold pieces).  s = sqrt(thr) scale, rounded UP into an f16 (0 for "never": thr = -inf).
 // Q2 (optional): the upper half-lane's words of the RECORD form in the same scale (st_setup's: z: r1 r1 | r2 r2 | 1 1 | st_theta) — level 2 of
-// STRACK2 filters the records of a level-1 super-tile with operands in that super-tile's scale, so both forms come out of one setup.
+// STRACK3 filters the records of a level-1 super-tile with operands in that super-tile's scale, so both forms come out of one setup.
 __device__ __forceinline__ void st_setup_l1(float qx, float qy, float qz, const float4 C, float thr, float sc2, uint32_t P[4], uint32_t Q[4], uint32_t* Q2 = nullptr)
 {
     constexpr float KAPPA = 0.99999237060546875f;             // 1 - 2^-17

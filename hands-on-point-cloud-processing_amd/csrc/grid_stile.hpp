@@ -1,7 +1,7 @@
-// grid_stile.hpp — part of grid.hip (included there, inside namespace pcr, after grid_tile.hpp).
+// grid_stile.hpp — part of grid.hip (included there, inside namespace pcr, behind the cell walk's kernels).
 //
 // SIGN TILE SEARCH (round 4): the seeded searches of an ICP loop over a large target, rebuilt on the machinery of the exhaustive
-// search's default kernel (nn1_strack_kernel, nn1_brute.hip).  The tile search of round 3 (grid_tile.hpp) built the f16 operand of every
+// search's sign filter (nn1_strack_kernel, nn1_brute.hip).  The tile search of round 3 (removed since: DESIGN.md 5b-r3) built the f16 operand of every
 // record per visit, tracked first / second minima with v_min3 / v_med3 and spent the rest of its time on per-wave row scans: 138 vector
 // instructions per MFMA.  Here
 //   * the records are the target's Morton-ordered matrix-core index (BtIndex: 256-record super-tiles with a centre, a power-of-two scale
@@ -16,7 +16,7 @@
 //     with the exact A1 arithmetic, 16 lanes per chunk; tiles that touch the pass's box come first and the thresholds fall to what they
 //     held before the farther tiles are filtered;
 //   * far queries (ball beyond bmax, no previous winner, non-finite coordinates, passes with too many cells / tiles) are deferred to
-//     the segmented list the cell walk serves in its own launch, exactly as in grid_tile.hpp.
+//     the segmented list the cell walk serves in its own launch (list mode of nn1_grid_kernel).
 // Nothing is decided approximately: a record at or below a member's threshold (i) lies in a coarse cell the widened box reaches (the
 // cell of a coordinate is a monotone function of it: bt_fine_cell), (ii) in a tile one of whose run spheres is within the largest ball
 // of the box (margins of sphere_may_win), (iii) raises its sign (st_theta rounds the threshold up by more than the accumulation error
@@ -32,6 +32,19 @@
 constexpr int SL_KEEP = PCR_SL_KEEP;                 // candidate tiles a pass may keep (24 576 records); the launch passes the limit in force
 constexpr int SL_CAP = 128;                  // entries of a wave's list of flagged chunks
 constexpr uint32_t SL_BT = 0x80000000u;      // tag of a position in the Morton-ordered records (untagged: a position in the cell grid's records)
+
+// sum over the wave, the same value in every lane (a heuristic's input: the order of the additions is irrelevant)
+__device__ __forceinline__ float wave_sum_uniform(float v)
+{
+    v += __uint_as_float(dpp_mov<0xB1>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<0x4E>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<0x141>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<0x140>(__float_as_uint(v)));
+    const int b = (int)__float_as_uint(v);
+    return (__uint_as_float((uint32_t)__builtin_amdgcn_readlane(b, 0)) + __uint_as_float((uint32_t)__builtin_amdgcn_readlane(b, 16))) +
+           (__uint_as_float((uint32_t)__builtin_amdgcn_readlane(b, 32)) + __uint_as_float((uint32_t)__builtin_amdgcn_readlane(b, 48)));
+}
+
 
 struct StileWaveLds {
     float4 q[64];                            // the wave's queries (the lanes that evaluate a flagged chunk are not the owning ones)
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
     float qx = sx[ic], qy = sy[ic], qz = sz[ic];
     const uint32_t pp0 = wpos[ic];
     if (stopv) return;
-    // the caller's gate as the initial bound, then the previous winner (nn1_grid_kernel / nn1_tile_kernel: same rules, same "none")
+    // the caller's gate as the initial bound, then the previous winner (nn1_grid_kernel: same rules, same "none")
     const unsigned long long bound0 = (cap2 > 0.0f && cap2 < 1e30f) ? (((unsigned long long)__float_as_uint(cap2) << 32) | 0xFFFFFFFFull) : KEY_NONE;
     unsigned long long best = bound0;
     uint32_t bestp = 0;
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
     // radius of the ball that holds the answer (never reasoned about below the trusted range: grid.hip TRUST)
     float rho = __builtin_inff();
     if (fin && best != KEY_NONE) rho = sqrtf(fmaxf(__uint_as_float((uint32_t)(best >> 32)), TRUST2) * 1.0001f) * 1.00001f;
-    // ball limit of the wave: bmax, and lim_k x the mean ball of the queries within bmax (grid_tile.hpp: the box of a pass is widened by
+    // ball limit of the wave: bmax, and lim_k x the mean ball of the queries within bmax (the box of a pass is widened by
     // the LARGEST ball among its members)
     const bool near = valid && fin && rho <= bmax;
     const unsigned long long near_m = __ballot(near);

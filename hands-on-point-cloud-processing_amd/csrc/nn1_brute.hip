@@ -1167,7 +1167,6 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
 //   ------------------------------  ---------------------------------------  -----------------------------------------------------------
 //   >= 32 768 points, fits f16      any (a cold search seeds itself first)   STRACK3 nn1_strack3_kernel<1 | 2 | 4>  (nn1_sphere.hpp; variant 10: any size.  The sign
 //                                                                            filter at three levels — rows per 512-record tile, per 16-record chunk, per record)
-//   —                               only on request (nn1_sphere_levels = 2)  STRACK2 nn1_strack2_kernel<4 | 2>      (variant 9: the two-level form)
 //   >= 8 192 points, fits f16       any (a cold search seeds itself first)   STRACK  nn1_strack_kernel<4 | 2>       (variant 8: small targets too)
 //   —                               only on request (nn1_sign = 2)           HTRACK  nn1_btrack_kernel<4 | 2, true>   (variant 7: the minimum-tracking form of
 //                                                                            the f16 filter — round 4: no default path reaches it any more; measured cold,
@@ -1182,8 +1181,8 @@ __global__ void nn1_unpack_kernel(const unsigned long long* __restrict__ keys, u
 // (Targets below 2 048 points inside loops, and one-shot searches with queries x targets > 2e9, never get here: api.cpp nn1_auto_grid
 // sends them to the exact grid.)  Tune keys read here — every one 0 = default:
 //   nn1_variant (above) · nn1_bf16 (1 force / 2 forbid the matrix-core forms) · nn1_f16 (1 / 2 the same for the f16 form) ·
-//   nn1_sign (the sign forms: 2 = never) · nn1_sphere (0 auto / 1 always / 2 never), nn1_sphere_levels (2 = STRACK2), nn1_sphere_qg (groups of 32 queries
-//   per wave), nn1_sphere_flush_end, nn1_sphere_l0_per_slice / nn1_sphere_l1_per_slice / nn1_sphere_blocks, nn1_sphere_phases (STRACK2) ·
+//   nn1_sign (the sign forms: 2 = never) · nn1_sphere (0 auto / 1 always / 2 never), nn1_sphere_qg (groups of 32 queries per wave), nn1_sphere_flush_end,
+//   nn1_sphere_l0_per_slice / nn1_sphere_blocks, nn1_sphere_reseed, nn1_seed_mode ·
 //   nn1_sign_flush (list entries from which the end
 //   of a super-tile evaluates them, default 64) · nn1_sign_dense (flagged half-lanes of one (group, tile) from which they evaluate in place, 12) ·
 //   nn1_btrack_qg (query groups of 32 per wave: 2 or 4; default 2 up to 49 152 queries) · nn1_supers_per_slice / nn1_btrack_blocks
@@ -1235,7 +1234,7 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     // ms, 30 k 0.241 -> 0.218, 60 k 0.378 / 0.375, 120 k 0.664 -> 0.723
     int qg = tune_get(ctx, "nn1_btrack_qg", ns <= 49152 ? 2 : 4) == 2 ? 2 : 4;
     if (tune_get(ctx, "nn1_variant", 0) == 9 || tune_get(ctx, "nn1_variant", 0) == 10 || tune_get(ctx, "nn1_sphere", 0) == 1 || (tune_get(ctx, "nn1_sphere", 0) == 0 && tune_get(ctx, "nn1_variant", 0) == 0 && f16 &&
-        tgt->n >= 32768 && tune_get(ctx, "nn1_btrack_qg", 0) == 0)) qg = 4;                     // (STRACK2 holds four groups per wave)
+        tgt->n >= 32768 && tune_get(ctx, "nn1_btrack_qg", 0) == 0)) qg = 4;                     // (the launch geometry below is STRACK's; the sphere form has its own)
     const size_t qpb = (size_t)(NN_BLOCK / 64) * 32 * qg;                          // queries per workgroup
     const uint32_t qblocks = (uint32_t)((ns + qpb - 1) / qpb);
     const uint32_t n_super = (uint32_t)(g->n_tiles / (BT_SUPER / 32));
@@ -1256,13 +1255,10 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     const int64_t sign_tune = tune_get(ctx, "nn1_sign", 0);
     const bool sign = force_sign ? (warm || cold_seed) : f16 && sign_tune != 2 && (warm || cold_seed);
     bool reseed = sign && warm && !pre_seeded && tune_get(ctx, "nn1_cold_seed", 1) == 1;
-    // STRACK2 (nn1_sphere.hpp): the sign filter at two levels — one MFMA row per chunk of 16 records first.  Tune nn1_sphere: 0 auto (targets from
-    // 32 768 points on, where a level-1 super-tile of 4 096 records is a small part of the cloud), 1 = always, 2 = never; nn1_variant 9 forces it.
+    // STRACK3 (nn1_sphere.hpp): the sign filter over three levels of bounding spheres.  Tune nn1_sphere: 0 auto (targets from 32 768 points on, where a
+    // level-1 super-tile of 4 096 records is a small part of the cloud), 1 = always, 2 = never; nn1_variant 10 (9: its old number) forces it.
     const int64_t sph_tune = tune_get(ctx, "nn1_sphere", 0), variant_now = tune_get(ctx, "nn1_variant", 0);
     bool sphere = sign && f16 && qg == 4 && sph_tune != 2 && (variant_now == 9 || variant_now == 10 || sph_tune == 1 || (variant_now == 0 && tgt->n >= 32768));
-    // ... and STRACK3, the same with a level 0 in front (one row per level-1 tile of 512 records): the default wherever the sphere form runs
-    // (tune nn1_sphere_levels: 2 = STRACK2; nn1_variant 9 forces STRACK2, 10 STRACK3)
-    const bool three = variant_now == 10 || (variant_now != 9 && tune_get(ctx, "nn1_sphere_levels", 0) != 2);
     if (sphere) {
         int rc1 = bt_ensure_l1(ctx, tgt);
         if (rc1) return rc1;
@@ -1277,7 +1273,7 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
     }
     // (the sphere forms pay far less for a poor seed than STRACK does — tune nn1_sphere_reseed: 2 = a warm search keeps its stale seeds as they are)
     if (sphere && tune_get(ctx, "nn1_sphere_reseed", 0) == 2) reseed = false;
-    ctx->last_nn1_kernel = sphere ? (three ? "strack3" : "strack2") : sign ? "strack" : f16 ? "htrack" : "btrack";
+    ctx->last_nn1_kernel = sphere ? "strack3" : sign ? "strack" : f16 ? "htrack" : "btrack";
     if (warm) seed_warm(ctx, tgt, src, pre_seeded);
     else if (merge_atomic && !cold_seed) PCR_HIP(ctx, hipMemsetAsync(ctx->keys, 0xFF, ns * sizeof(unsigned long long), ctx->stream));
     unsigned long long* stats_dev = nullptr;
@@ -1309,7 +1305,7 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
 #define PCR_STRACK(Q)                                                                                                                      \
     hipLaunchKernelGGL((nn1_strack_kernel<Q>), grid, dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->ops16, g->records, n_super * BT_SUPER, n_super, sps,  \
                        src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)xq, qblocks, slices, st_flush_at, st_dense_at)
-        if (sphere && three) {
+        if (sphere) {
             // one wave per 128 (64: tune nn1_sphere_qg = 2) queries and slice of level-0 super-tiles (131 072 records each: one slice up to there)
             const uint32_t n_l0 = (uint32_t)g->n_l0_super;
             const int64_t qg3_t = tune_get(ctx, "nn1_sphere_qg", 0);
@@ -1325,27 +1321,6 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
                        n_super * BT_SUPER, n_l0, l0ps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, std::min<uint32_t>(st_flush_at, (uint32_t)S2_CAP), s3_flush_end)
             if (qg3 == 1) PCR_STRACK3(1); else if (qg3 == 2) PCR_STRACK3(2); else PCR_STRACK3(4);
 #undef PCR_STRACK3
-        }
-        else if (sphere) {
-            // slices = ranges of level-1 super-tiles x phases of their eight level-1 tiles (tune nn1_sphere_phases: 1 / 2 / 4 / 8); groups of 32
-            // queries per wave: tune nn1_sphere_qg (2 / 4)
-            const uint32_t n_l1 = (uint32_t)g->n_l1_super;
-            const int64_t ph_t = tune_get(ctx, "nn1_sphere_phases", 0), qg_t = tune_get(ctx, "nn1_sphere_qg", 0);
-            const uint32_t phases = (ph_t == 1 || ph_t == 2 || ph_t == 4 || ph_t == 8) ? (uint32_t)ph_t : 4u;
-            const uint32_t qg2 = qg_t == 2 ? 2u : 4u;
-            const uint32_t qblocks2 = (uint32_t)((ns + (size_t)(NN_BLOCK / 64) * 32 * qg2 - 1) / ((size_t)(NN_BLOCK / 64) * 32 * qg2));
-            uint32_t ranges = 1;
-            const uint32_t l1ps = slice_plan(n_l1, qblocks2, tune_get(ctx, "nn1_sphere_l1_per_slice", 0), tune_get(ctx, "nn1_sphere_blocks", 1024), &ranges);
-            const uint32_t s2_slices = ranges * phases;
-            int64_t xq2 = tune_get(ctx, "nn1_xcd", NN_XCD_DEFAULT);
-            if ((xq2 != 1 && xq2 != 2 && xq2 != 4) || s2_slices < 8 || (uint64_t)qblocks2 * s2_slices >= (1ull << 27)) xq2 = 0;
-            if (!xq2 && s2_slices > 65535u) return fail(ctx, PCR_ERR_ARG, "STRACK2: more slices than a launch has rows");
-            const dim3 grid2 = xq2 ? dim3(8u * ((qblocks2 + (uint32_t)xq2 - 1) / (uint32_t)xq2) * ((s2_slices + 8u / (uint32_t)xq2 - 1) / (8u / (uint32_t)xq2)), 1) : dim3(qblocks2, s2_slices);
-#define PCR_STRACK2(Q)                                                                                                                     \
-    hipLaunchKernelGGL((nn1_strack2_kernel<Q>), grid2, dim3(NN_BLOCK), 0, ctx->stream, g->l1_centres, g->l1_ops, g->l1_rec_ops, g->records, n_super * BT_SUPER,  \
-                       n_l1, l1ps, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, (uint32_t)xq2, qblocks2, s2_slices, st_flush_at, phases)
-            if (qg2 == 2) PCR_STRACK2(2); else PCR_STRACK2(4);
-#undef PCR_STRACK2
         }
         else if (sign) { if (qg == 2) PCR_STRACK(2); else PCR_STRACK(4); }
         else if (f16) { if (qg == 2) PCR_BTRACK(2, true, g->ops16); else PCR_BTRACK(4, true, g->ops16); }
@@ -1858,7 +1833,7 @@ int st_sign_selftest(pcr_ctx* ctx, int trials, unsigned long long res[4])
     return PCR_OK;
 }
 
-// ---- self-test of the LEVEL-1 statement of STRACK2 (pcr_selftest_sphere_f16; a short form is part of the f16 verdict below): random level-1
+// ---- self-test of the SPHERE statement of STRACK3 (pcr_selftest_sphere_f16; a short form is part of the f16 verdict below): random level-1
 // tiles — 32 chunks of 16 records in the scaled range of a level-1 super-tile: tight clusters, wide ones, chunks spread beyond 2^7 (the
 // whole-super-tile sphere), chunks without a finite record, records on the edge of the range — through the index build's own operand code
 // (l1_chunk_operand), the kernel's query code (st_setup_l1) and the MFMA, a power-of-two scale per tile; queries near a chunk, inside one, far
@@ -2004,7 +1979,7 @@ bool mfma_verdict(pcr_ctx* ctx, bool f16)
         // ... and the decision of the sign form (STRACK, the default search on this form): no pair at or below its threshold without the sign
         unsigned long long sg[4];
         ok = st_sign_selftest(ctx, 2, sg) == PCR_OK && sg[0] > 0 && sg[1] == 0;
-        // ... and the level-1 statement of the two-level form (STRACK2): no (query, chunk) pair with a record at or below the threshold without it
+        // ... and the sphere statement of the hierarchical form (STRACK3): no (query, chunk) pair with a record at or below the threshold without it
         if (ok) ok = st_sphere_selftest(ctx, 4, sg) == PCR_OK && sg[0] > 0 && sg[1] == 0;
     }
     v = ok ? 1 : 0;

@@ -1,32 +1,24 @@
 // nn1_sphere.hpp — part of nn1_brute.hip (included there, inside namespace pcr, behind nn1_strack_kernel).
 //
-// STRACK2: the exhaustive search with the sign filter applied at TWO LEVELS (round 4).  STRACK spends one matrix instruction and eight
-// half-rate v_or3_b32 per 32 queries x 32 RECORDS, for every record of the target — and at the settled pose of an ICP loop all but a
-// handful of them lie metres beyond the query's threshold.  The sign test is bilinear, so it works one level up as well: a chunk of 16
-// records with bounding sphere (c, rho) cannot matter to a query unless |r - c| <= sqrt(thr) + rho, which is again "a sum of K-slot
-// products is negative" (grid_common.hpp, LEVEL 1: the statement and what makes it a theorem).  So
-//   level 1: ONE MFMA row per CHUNK — one instruction per 32 queries x 32 chunks = 512 records: a sixteenth of STRACK's matrix and
-//            vector work — over EVERY chunk of the slice (still exhaustive: no chunk is skipped without its sign having been computed);
-//            level-1 super-tiles of 4 096 records share a centre and a scale (one operand setup per query and 8 level-1 tiles);
-//   level 2: the tiles of 32 records that hold a flagged chunk go through STRACK's per-record filter (one MFMA per tile and flagged group) with
-//            operands in the scale of their LEVEL-1 super-tile (BtIndex::l1_rec_ops: no operand setup of its own — with the 256-record
-//            super-tiles' operands a wave rebuilt its queries' side ~150 times per search, as much work as all of level 1), and the flagged
-//            (query, chunk) pairs of THAT are evaluated with the exact A1 arithmetic, four lanes per chunk — the canonical (d2 bits, index)
-//            minimum decides, thresholds fall after every level-1 super-tile.
-// Same keys bit for bit as every other kernel of this file (parity sweeps: nn1_variant 9; device check of the level-1 statement:
+// STRACK3: the exhaustive search with the sign filter applied to a HIERARCHY OF BOUNDING SPHERES (round 4).  STRACK spends one matrix instruction and
+// eight half-rate v_or3_b32 per 32 queries x 32 RECORDS, for every record of the target — and at the settled pose of an ICP loop all but a handful of
+// them lie metres beyond the query's threshold.  The sign test is bilinear, so it works on sets of records as well: a set inside the sphere (c, rho)
+// cannot matter to a query unless |r - c| <= sqrt(thr) + rho, which is again "a sum of K-slot products is negative" (grid_common.hpp, LEVEL 1: the
+// statement and what makes it a theorem).  Three levels of MFMA rows (BtIndex, built by bt_ensure_l1):
+//   level 0: one row per level-1 TILE of 512 records, in the scale of a level-0 super-tile of 131 072 records — EVERY row of the slice gets its sign for
+//            every query (still exhaustive: nothing is skipped without a computed sign that says it cannot matter);
+//   level 1: one row per CHUNK of 16 records of the level-1 tiles level 0 flagged, level-1 super-tiles of 4 096 records share a centre and a scale;
+//   level 2: the tiles of 32 records that hold a flagged chunk through STRACK's per-record rows, with operands in the scale of their LEVEL-1 super-tile
+//            (BtIndex::l1_rec_ops: no operand setup of its own); the flagged (query, chunk) pairs of THAT are evaluated with the exact A1 arithmetic,
+//            four lanes per chunk — the canonical (d2 bits, index) minimum decides, thresholds fall after every level-1 super-tile.
+// History: the two-level form without level 0 (STRACK2, every chunk row for every query) ran 0.085 ms per 120 k x 120 k search against
+// STRACK's 0.44 and was removed when this kernel (0.034 ms) took its place.
+// Same keys bit for bit as every other kernel of this file (parity sweeps: nn1_variant 10; device check of the sphere statement:
 // pcr_selftest_sphere_f16, part of the once-per-context verdict).  Matches: registration.cpp:925-941.
 #pragma once
 
 constexpr int S2_TILES = 512;                 // level-2 tiles a wave may collect per level-1 super-tile (of its 128: the list is flushed when full)
 constexpr int S2_CAP = 128;                   // flagged (query, chunk) pairs a wave lists before it evaluates them
-
-template <int QG>
-struct S2WaveLds {
-    float4 q[QG * 32];                        // the wave's queries
-    unsigned long long best[QG * 32];         // (d2 bits << 32 | index) found so far, ~0 = nothing
-    uint32_t tiles[S2_TILES];                 // level-2 tile | groups that flagged it << 28
-    uint32_t list[S2_CAP];                    // (chunk << 7) | query slot
-};
 
 // the listed chunks against their queries: four lanes per chunk, four records each, sixteen chunks per round
 template <int QG, class LDS>
@@ -85,241 +77,9 @@ __device__ __forceinline__ uint32_t s2_or16(const f32x16 acc)
 #ifndef PCR_S2_WAVES
 #define PCR_S2_WAVES 4
 #endif
-template <int QG>
-__global__ __launch_bounds__(NN_BLOCK, PCR_S2_WAVES) void nn1_strack2_kernel(
-    const float4* __restrict__ l1_centres, const uint4* __restrict__ l1_ops, const uint4* __restrict__ ops,
-    const float4* __restrict__ records, uint32_t n_rec, uint32_t n_l1, uint32_t l1_per_slice,
-    const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
-    unsigned long long* __restrict__ keys, const int* __restrict__ stop, unsigned long long* __restrict__ stats,
-    uint32_t xq, uint32_t qblocks, uint32_t slices, uint32_t flush_at, uint32_t phases)
-{
-    static_assert(QG == 4 || QG == 2, "query groups per wave come in pairs: a lane owns query n of the groups 2 p + h");
-    const int stopv = stop ? (stop[0] | stop[1]) : 0;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t n = lane & 31;
-    const bool h = lane >= 32;
-    uint32_t qb = blockIdx.x, sl = blockIdx.y;                // (query block, slice): as nn1_strack_kernel
-    if (xq) {
-        const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, xs = 8u / xq, qb_per = (qblocks + xq - 1) / xq;
-        qb = (j % qb_per) * xq + k % xq;
-        sl = (j / qb_per) * xs + k / xq;
-        if (qb >= qblocks || sl >= slices) return;
-    }
-    __shared__ S2WaveLds<QG> lds_all[NN_BLOCK / 64];
-    S2WaveLds<QG>& L = lds_all[wave];
-    const uint32_t qbase = (qb * (NN_BLOCK / 64) + wave) * (32 * QG);
-    if (qbase >= ns) return;                                  // (a surplus wave: no workgroup barrier below)
-    float qx[QG / 2], qy[QG / 2], qz[QG / 2], thr[QG / 2];
-    bool ok[QG / 2];
-    bool okg[QG];
-#pragma unroll
-    for (int p = 0; p < QG / 2; p++) {
-        const uint32_t slot = (2 * p + (h ? 1 : 0)) * 32 + n, i = min(qbase + slot, ns - 1);
-        qx[p] = sx[i]; qy[p] = sy[i]; qz[p] = sz[i];
-        const uint32_t cb = (uint32_t)(__atomic_load_n(&keys[i], __ATOMIC_RELAXED) >> 32);      // the candidate's d2 (or what other slices published)
-        ok[p] = fabsf(qx[p]) < 1e18f && fabsf(qy[p]) < 1e18f && fabsf(qz[p]) < 1e18f && cb < 0x7F7FFFFFu;
-        thr[p] = ok[p] ? __uint_as_float(cb) : -INFINITY;
-        L.q[slot] = make_float4(qx[p], qy[p], qz[p], 0.0f);
-        L.best[slot] = ~0ull;
-        if (!ok[p]) { qx[p] = 0.0f; qy[p] = 0.0f; qz[p] = 0.0f; }                                // (finite operands; thr = -inf: no flag, ever)
-        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok[p]);
-        okg[2 * p] = (uint32_t)okm == 0xFFFFFFFFu; okg[2 * p + 1] = (uint32_t)(okm >> 32) == 0xFFFFFFFFu;
-    }
-    if (stopv) return;
-#ifdef PCR_S2_PROF
-    unsigned long long* const stats_p = stats;
-    stats = nullptr;                                           // (profile build: the kernel as it runs without diagnostics, stamps only)
-#endif
-    unsigned long long st_l1 = 0, st_l1flag = 0, st_l2 = 0, st_eval = 0, st_flushes = 0;       // diagnostics (stats != nullptr)
-    unsigned long long clk0 = 0, rt0 = 0;
-    if (stats) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    // a slice = a range of level-1 super-tiles x a PHASE of their eight level-1 tiles (tiles ph, ph + phases, ...: the level-2 work of a group of
-    // queries sits in the few super-tiles around it — whole super-tiles per wave left it to one wave in five, alone on its SIMD for 80 us)
-    const uint32_t ph = sl % phases, sb = (sl / phases) * l1_per_slice, se = min(sb + l1_per_slice, n_l1);
-    f32x16 zero;
-#pragma unroll
-    for (int j = 0; j < 16; j++) zero[j] = 0.0f;
-    uint32_t cnt = 0;                                         // entries in the wave's list of flagged (query, chunk) pairs (wave-uniform)
-    auto refresh = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int p = 0; p < QG / 2; p++) {
-            const uint32_t fb = (uint32_t)(L.best[(2 * p + (h ? 1 : 0)) * 32 + n] >> 32);       // (~0 >> 32 is a NaN pattern: fminf keeps thr)
-            thr[p] = ok[p] ? fminf(thr[p], __uint_as_float(fb)) : thr[p];
-        }
-    };
-    // the B operands of the wave's four groups for one level-1 super-tile, both forms (chunk rows: bq1, record rows: bq2): lane (n, h) builds the
-    // whole operand of query n of group 2 p + h, the halves change places by v_permlane32_swap (nn1_strack_kernel)
-    uint4 bq1[QG], bq2[QG];
-    auto setup = [&](const float4 C) {
-        const float sc2 = C.w * C.w;
-#pragma unroll
-        for (int p = 0; p < QG / 2; p++) {
-            uint32_t P[4], Q[4], Q2[4], P2[4];
-            st_setup_l1(qx[p], qy[p], qz[p], C, thr[p], sc2, P, Q, Q2);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                P2[j] = P[j];
-                const auto r = __builtin_amdgcn_permlane32_swap(P[j], Q[j], false, false);
-                P[j] = r[0]; Q[j] = r[1];
-                const auto r2 = __builtin_amdgcn_permlane32_swap(P2[j], Q2[j], false, false);
-                P2[j] = r2[0]; Q2[j] = r2[1];
-            }
-            bq1[2 * p] = make_uint4(P[0], P[1], P[2], P[3]);
-            bq1[2 * p + 1] = make_uint4(Q[0], Q[1], Q[2], Q[3]);
-            bq2[2 * p] = make_uint4(P2[0], P2[1], P2[2], P2[3]);
-            bq2[2 * p + 1] = make_uint4(Q2[0], Q2[1], Q2[2], Q2[3]);
-        }
-    };
-    // LEVEL 2 over the collected tiles: the per-record filter (operands in the level-1 super-tile's scale) for the groups that flagged the tile;
-    // flagged (query, chunk) pairs are listed and evaluated exactly
-    auto level2 = [&](uint32_t n_tiles) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (lane 0 wrote the list)
-        uint32_t En = n_tiles ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tiles[0]) : 0u;
-        uint4 An = ops[(size_t)(En & 0x0FFFFFFFu) * 64 + lane];
-        for (uint32_t k = 0; k < n_tiles; k++) {
-            const uint32_t E = En, T = E & 0x0FFFFFFFu, gm = E >> 28;
-            const uint4 A = An;
-            En = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tiles[min(k + 1, n_tiles - 1)]);
-            An = ops[(size_t)(En & 0x0FFFFFFFu) * 64 + lane];            // the next tile's operand, one ahead
-            const uint32_t chunk = 2u * T + (h ? 1u : 0u);
-#pragma unroll
-            for (int g = 0; g < QG; g++) {
-                if (!((gm >> g) & 1u)) continue;              // (wave-uniform)
-                const uint32_t og = s2_or16(__builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, bq2[g]), zero, 0, 0, 0));
-                if (stats) st_l2++;
-#ifdef PCR_S2_T_NOEVAL
-                if (og != 0x12345u) continue;                 // timing build: levels 1 and 2 without the exact evaluation
-#endif
-                const unsigned long long m = __builtin_amdgcn_ballot_w64((int)og < 0);
-                if (!m) continue;
-                const uint32_t kf = (uint32_t)__popcll(m);
-                if (cnt + kf > (uint32_t)S2_CAP) { s2_flush<QG>(L, cnt, records, lane); st_flushes++; st_eval += cnt; cnt = 0; }
-                if ((int)og < 0) L.list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (chunk << 7) | (uint32_t)(g * 32) | n;
-                cnt += kf;
-            }
-            if (cnt >= flush_at) { s2_flush<QG>(L, cnt, records, lane); st_flushes++; st_eval += cnt; cnt = 0; }
-        }
-        if (cnt) { s2_flush<QG>(L, cnt, records, lane); st_flushes++; st_eval += cnt; cnt = 0; }
-        refresh();
-    };
-    uint32_t n_tiles = 0;                                     // level-2 tiles collected (wave-uniform)
-#ifdef PCR_S2_PROF
-    unsigned long long pt_setup = 0, pt_l1 = 0, pt_l2 = 0, pt_a = 0, pt_b = 0;
-    pt_a = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long pt_begin = pt_a;
-#endif
-    for (uint32_t S1 = sb; S1 < se; S1++) {
-        setup(l1_centres[S1]);
-        PCR_S2_TICK(pt_setup)
-        uint4 A = l1_ops[((size_t)S1 * 8 + ph) * 64 + lane];
-#pragma unroll 1
-        for (uint32_t t = ph; t < 8; t += phases) {
-            const uint32_t T1 = S1 * 8 + t;
-            const uint4 An = l1_ops[(size_t)min(t + phases < 8 ? T1 + phases : (S1 + 1) * 8 + ph, n_l1 * 8 - 1) * 64 + lane];   // the next level-1 tile of the phase, one ahead
-            uint32_t anyg[QG];
-#pragma unroll
-            for (int g = 0; g < QG; g++)
-                anyg[g] = s2_or16(__builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, bq1[g]), zero, 0, 0, 0));
-            if (stats) st_l1 += QG;
-            uint32_t anyall = anyg[0];
-#pragma unroll
-            for (int g = 1; g < QG; g++) anyall |= anyg[g];
-            if (__builtin_amdgcn_ballot_w64((int)anyall < 0)) {
-                // rare: some group may need some chunk of this level-1 tile.  Which chunks: the accumulators once more, one ballot per chunk pair
-                // (lanes < 32 hold chunks 0..15 of the tile, lanes >= 32 chunks 16..31: accumulator i <-> chunk 16 h + i)
-                uint32_t tmask[QG];                           // bit k: level-2 tile k of this level-1 tile (chunks 2 k, 2 k + 1) flagged by the group
-#pragma unroll
-                for (int g = 0; g < QG; g++) {
-                    tmask[g] = 0u;
-                    if (!__builtin_amdgcn_ballot_w64((int)anyg[g] < 0)) continue;
-                    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, bq1[g]), zero, 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 16; i += 2) {
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64((int)(__float_as_uint(acc[i]) | __float_as_uint(acc[i + 1])) < 0);
-                        tmask[g] |= ((uint32_t)m != 0u ? 1u : 0u) << (i / 2);                  // chunks i, i + 1 of the lower half: tile i / 2
-                        tmask[g] |= ((uint32_t)(m >> 32) != 0u ? 1u : 0u) << (8 + i / 2);      // chunks 16 + i, 17 + i: tile 8 + i / 2
-                    }
-                }
-                uint32_t un = tmask[0];
-#pragma unroll
-                for (int g = 1; g < QG; g++) un |= tmask[g];
-                if (stats) st_l1flag += (unsigned long long)__popc(un);
-                if (n_tiles + (uint32_t)__popc(un) > (uint32_t)S2_TILES) { level2(n_tiles); n_tiles = 0; setup(l1_centres[S1]); }   // (list full: thresholds fell — rebuilt)
-                while (un) {                                  // wave-uniform
-                    const uint32_t k = (uint32_t)__builtin_ctz(un);
-                    un &= un - 1u;
-                    uint32_t gm = 0u;
-#pragma unroll
-                    for (int g = 0; g < QG; g++) gm |= ((tmask[g] >> k) & 1u) << g;
-                    const uint32_t T2 = T1 * 16u + k;
-                    if ((size_t)T2 * 32 < n_rec) { if (lane == 0) L.tiles[n_tiles] = T2 | (gm << 28); n_tiles++; }      // (tiles of the index's padding hold nothing)
-                }
-            }
-            A = An;
-        }
-        // the tiles this level-1 super-tile flagged: filtered and evaluated before the next one's operands are built (thresholds fall)
-#ifdef PCR_S2_T_NOL2
-        n_tiles = 0;                                          // timing build: level 1 alone
-#endif
-        PCR_S2_TICK(pt_l1)
-        if (n_tiles) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); level2(n_tiles); n_tiles = 0; }
-        PCR_S2_TICK(pt_l2)
-    }
-#ifdef PCR_S2_PROF
-    if (stats_p && lane == 0 && ((blockIdx.x * 7u + blockIdx.y * 3u + wave) & 15u) == 0u) {        // (one wave in 16 reports: the same-line atomics of all of them would be the longest part of the launch) profile build: the diagnostics words mean [0] setup [1] level 1 [2] level 2 + evaluation ticks (10 ns), [3] waves, [4..11] lives by 20 us bins
-        const unsigned long long life = pt_a - pt_begin;
-        atomicAdd(&stats_p[0], pt_setup); atomicAdd(&stats_p[1], pt_l1); atomicAdd(&stats_p[2], pt_l2); atomicAdd(&stats_p[3], 1ull);
-        atomicAdd(&stats_p[4 + min((int)(life / 1000), 7)], 1ull);
-        atomicMax(&stats_p[12], life); atomicAdd(&stats_p[13], life);
-        atomicMax(&stats_p[14], pt_l2); atomicMax(&stats_p[15], pt_l1);
-    }
-#endif
-#pragma unroll
-    for (int g = 0; g < QG; g++) {
-        unsigned long long kbest = L.best[g * 32 + n];
-        if (!okg[g] && sb < se && ph == 0) {
-            // a query without finite coordinates or without a candidate: the wave scans the slice exactly for this group, each half-lane one half
-            // of it (rare: NaN / inf queries, a seed kernel that found nothing acceptable)
-            const float4 q = L.q[g * 32 + n];
-            const uint32_t r0 = min(sb * (uint32_t)BT_L1_SUPER, n_rec), r1 = (uint32_t)min((unsigned long long)se * BT_L1_SUPER, (unsigned long long)n_rec), mid = r0 + (r1 - r0) / 2;
-            for (uint32_t j = h ? mid : r0; j < (h ? r1 : mid); j++) {
-                const float4 rec = records[j];
-                const uint32_t e = d2_exact_bits(q.x, q.y, q.z, rec.x, rec.y, rec.z);
-                const unsigned long long key = ((unsigned long long)e << 32) | __float_as_uint(rec.w);
-                if (e < 0x7F7FFFFFu && key < kbest) kbest = key;
-            }
-            const unsigned long long ko = ((unsigned long long)(uint32_t)__shfl_xor((int)(kbest >> 32), 32, 64) << 32) |
-                                          (uint32_t)__shfl_xor((int)(uint32_t)kbest, 32, 64);
-            kbest = ko < kbest ? ko : kbest;
-            if (kbest == ~0ull) kbest = 0x7F800000FFFFFFFFull;           // "no neighbour" is the key (+inf, no index), as every other kernel writes it
-        }
-        const uint32_t i = qbase + g * 32 + n;
-        if (!h && i < ns && kbest != ~0ull) merge_key(&keys[i], kbest);
-    }
-    if (stats && threadIdx.x == 0) {                                      // shader clock under this kernel's load: cycles / 100 MHz ticks (bench.py)
-        atomicAdd(&stats[4], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0);
-        atomicAdd(&stats[5], (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt0);
-    }
-    if (stats && lane == 0) {
-        const unsigned long long dur = (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt0;      // this wave's life in 10 ns ticks
-        atomicMax(&stats[11], dur); atomicAdd(&stats[12], dur); atomicAdd(&stats[13], 1ull);
-        atomicMax(&stats[14], st_l2); if (st_l2 > 200) atomicAdd(&stats[15], 1ull);
-        if (st_flushes) atomicAdd(&stats[2], st_flushes);                 // joint evaluations (wave level)
-        if (st_eval) atomicAdd(&stats[6], st_eval);                       // (query, chunk) pairs evaluated exactly
-        if (st_l1) atomicAdd(&stats[8], st_l1);                           // level-1 MFMAs
-        if (st_l1flag) atomicAdd(&stats[9], st_l1flag);                   // level-2 tiles flagged by level 1 (per wave and level-1 tile: union of its groups)
-        if (st_l2) atomicAdd(&stats[10], st_l2);                          // level-2 MFMAs
-    }
-}
-
-
-// ---- STRACK3: the same with a LEVEL 0 in front — one MFMA row per level-1 TILE (the bounding sphere of its 512 records, in the scale of a
-// level-0 super-tile of 131 072 records: the whole cloud of the headline configuration).  Measured on STRACK2 (sorted queries, 120 000 x
-// 120 000, profile build): 86 % of a wave's life went into level 1 — every chunk row of the target for every group of queries, 300 SIMD
-// cycles per level-1 tile — and 10 % into level 2 and the exact evaluation.  With level 0 a wave looks at 8 level-0 tiles, then only at the
-// level-1 tiles whose sphere some query's ball reaches (a few dozen of 240), for the groups that reach them; level 2 as before.  Still
-// exhaustive in the sense of the brute-force contract: no record is skipped without a computed sign that says it cannot matter.
+// ---- the kernel.  (Measured on the two-level predecessor, sorted queries, 120 000 x 120 000, profile build: 86 % of a wave's life went into level 1 —
+// every chunk row of the target for every group of queries, 300 SIMD cycles per level-1 tile — and 10 % into level 2 and the exact evaluation.  With
+// level 0 a wave looks at 8 level-0 tiles, then only at the level-1 tiles whose sphere some query's ball reaches: a few of 240.)
 constexpr int S3_L1LIST = 256;                // level-1 tiles of one level-0 super-tile
 
 template <int QG>

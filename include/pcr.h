@@ -330,16 +330,12 @@ int pcr_prof_get_each(pcr_ctx* ctx, const char* kernel, double* ms, size_t cap, 
  * out = { candidates evaluated, fine x-rows opened, coarse rows tested, far stages run } summed over the queries */
 int pcr_grid_stats(pcr_ctx* ctx, uint64_t out[4]);
 /* the sixteen diagnostics words of the last 1-NN launch made with tune "grid_stats" = 1.  Cell walk: [0..3] as pcr_grid_stats.
- * Tile search (csrc/grid_tile.hpp) + the walk of its deferred queries: [0] record evaluations summed over the queries, [1] rows
- * opened, [2] spheres tested, [3] far stages of the walk, [4] / [5] largest box edge / largest ball of the served passes (um, summed),
- * [6] queries deferred to the walk, [7] passes, [8] passes that took the matrix-pipe filter, [9] of those, passes it could not settle, [10] records the passes loaded
- * (each once for all queries of its pass).
  * Matrix-core exhaustive search (HTRACK / BTRACK): [2] = (wave, query group) pairs that were filtered a second time, [4] = shader
  * cycles (s_memtime) and [5] = 100 MHz real-time ticks (s_memrealtime) summed over the workgroups: [4] / [5] x 100 MHz is the shader
  * clock the chip held under that launch (bench.py: the clock-corrected roofline).  STRACK (the sign form of the f16 filter): [2] =
  * joint evaluations of a wave's list of flagged chunks, [6] = (query, 16-record chunk) pairs evaluated exactly, [4] / [5] as above.
- * STRACK2 / STRACK3 (csrc/nn1_sphere.hpp) in addition: [8] level-1 MFMAs, [9] level-2 tiles flagged by level 1, [10] level-2 MFMAs, and for
- * STRACK3 [7] level-0 MFMAs, [3] level-1 tiles flagged by level 0.  Sign tile search (csrc/grid_stile.hpp) + the walk of its deferred
+ * STRACK3 (csrc/nn1_sphere.hpp) in addition: [7] level-0 MFMAs, [3] level-1 tiles flagged by level 0, [8] level-1 MFMAs, [9] level-2 tiles flagged
+ * by level 1, [10] level-2 MFMAs.  Sign tile search (csrc/grid_stile.hpp) + the walk of its deferred
  * queries: [0] pairs through the sign filter, [1] coarse cells read, [2] tile spheres tested, [3] operand setups, [4] / [5] box / ball (um,
  * summed), [6] queries deferred, [7] passes, [8] exact evaluations, [9] joint evaluations, [10] records under listed tiles, [11] MFMAs,
  * [12] most tiles in a pass, [13] / [14] / [15] deferred because: beyond the ball limit / more clusters than passes / list overflow. */
@@ -364,7 +360,7 @@ int pcr_selftest_mfma_f16(pcr_ctx* ctx, int trials, double worst[2]);
  * out = { pairs whose exact f32 distance lies at or below their query's threshold, of those WITHOUT the sign — must be 0 —,
  * pairs with the sign set, pairs in all }.  A short form is part of the once-per-context check below. */
 int pcr_selftest_sign_f16(pcr_ctx* ctx, int trials, uint64_t out[4]);
-/* The LEVEL-1 statement of the two-level form of that filter (STRACK2, csrc/nn1_sphere.hpp: one MFMA row per CHUNK of 16 records — its bounding
+/* The SPHERE statement of the hierarchical form of that filter (STRACK3, csrc/nn1_sphere.hpp: one MFMA row per set of records — its bounding
  * sphere — before any per-record row): `trials` random level-1 tiles of 32 chunks (tight and wide clusters, chunks spread beyond the scaled
  * range, empty chunks, non-finite records) against 32 queries each (near, inside, far, beyond the clamp) with thresholds on / one ulp off / a
  * factor off exact distances and zero, through the index build's operand code, the kernel's query code and the MFMA.
@@ -373,8 +369,8 @@ int pcr_selftest_sphere_f16(pcr_ctx* ctx, int trials, uint64_t out[4]);
 /* The library runs a short form of the two self-tests ITSELF, once per context, before it first picks a matrix-core kernel, and only
  * uses a form whose four figures stay within HALF of what its bound assumes (f16 -> bf16 -> the f32 filters, whose bounds need IEEE
  * arithmetic only).  This reports the verdicts (-1 = not run yet; run_now != 0 runs them), the figures, the host time the checks
- * took, and which 1-NN kernel family served the last search ("strack3", "strack2", "strack", "htrack", "btrack", "etrack", "ftrack",
- * "track", "grid", "grid-stile", "grid-tile"). */
+ * took, and which 1-NN kernel family served the last search ("strack3", "strack", "htrack", "btrack", "etrack", "ftrack",
+ * "track", "grid", "grid-stile"). */
 typedef struct {
     int32_t f16_ok, bf16_ok;
     double f16_worst[4], bf16_worst[4];
@@ -386,19 +382,18 @@ int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
  * (the parity tests run the switches against each other), only speed and which kernel serves a call.  Defaults in brackets.
  *  dispatch    nn_method [0 auto: api.cpp nn1_auto_grid] 1 exhaustive / 2 exact grid · nn1_variant [0: table above launch_nn1_brute,
  *              csrc/nn1_brute.hip] 1 FTRACK, 2 TRACK (exact arithmetic only), 4 ETRACK, 6 BTRACK, 7 HTRACK, 8 STRACK for every search
- *              that has or can make itself a seed (HTRACK otherwise), 9 STRACK2, 10 STRACK3 (the sphere forms on targets of any size) ·
+ *              that has or can make itself a seed (HTRACK otherwise), 10 STRACK3 (the sphere form on targets of any size; 9 = its old number) ·
  *              nn1_bf16, nn1_f16 [on] 1 force / 2 forbid the matrix-core forms ·
  *              nn1_sign [on: the sign forms for every search on a target that fits f16 — a cold one seeds itself] 2 = never (HTRACK) ·
- *              nn1_sphere [0: the sphere forms from 32 768 target points] 1 always / 2 never (STRACK) · nn1_sphere_levels [3: STRACK3] 2 = STRACK2 ·
+ *              nn1_sphere [0: STRACK3 from 32 768 target points] 1 always / 2 never (STRACK) ·
  *              mfma_force_fail 1 f16 / 2 bf16 / 3 both (tests: a failing device check) ·
  *              knn_method, radius_method [auto] 1 exhaustive / 2 grid · nn1_async_in_loop [off] 1 = pcr_nn1_f32_async calls of one
  *              caller-side loop seed each other as the searches inside pcr_icp_p2p_f32 do
  *  exhaustive  nn1_btrack_qg [2 up to 49 152 queries, else 4] · nn1_supers_per_slice [from nn1_btrack_blocks = 14 336] ·
  *              nn1_sign_flush [64: entries of a wave's list of flagged chunks from which the end of a super-tile evaluates them] ·
  *              nn1_sign_dense [12: flagged half-lanes of one (group, tile) from which they evaluate their chunk in place] ·
- *              nn1_sphere_qg [1: groups of 32 queries per STRACK3 wave; STRACK2 4] 2 / 4 · nn1_sphere_flush_end [1: entries from which the end of
- *              a level-1 super-tile evaluates them] · nn1_sphere_l0_per_slice [from nn1_sphere_blocks = 1 024] · STRACK2: nn1_sphere_l1_per_slice,
- *              nn1_sphere_phases [4: a slice = a range of level-1 super-tiles x every 4th of their level-1 tiles] 1 / 2 / 8 ·
+ *              nn1_sphere_qg [1: groups of 32 queries per STRACK3 wave] 2 / 4 · nn1_sphere_flush_end [1: entries from which the end of
+ *              a level-1 super-tile evaluates them] · nn1_sphere_l0_per_slice [from nn1_sphere_blocks = 1 024] ·
  *              nn1_xcd [4] 1 / 2 / 4, -1 plain launch · nn1_cold_seed [on] 2 = off, 3 = round 3's rule (sliced launches only) ·
  *              nn1_seed_mode [0: centre of the nearest super-tile + Morton neighbour for a cold search, the centre alone beside stale correspondences]
  *              1 centre / 2 Morton neighbour / 3 both · nn1_sphere_reseed [on] 2 = a warm search of the sphere forms keeps stale seeds as they are ·
@@ -409,10 +404,9 @@ int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
  *              grid_lanes [16] · grid_cell_um, grid_cell_scale_x100 [150 for Morton], grid_occupancy_x10 [20], grid_max_cells ·
  *              grid_sort_queries, grid_sort_work, grid_warm_start, grid_wpos, grid_seed_run, grid_far_brute [on] 2 = off ·
  *              grid_sort_fine [auto] 1 / 2 · grid_query_bins_log2 [22], grid_query_bin_min [2] · grid_xcd_run [32 from 4 096 blocks]
- *              -1 = identity · grid_tile [0: targets from 4 000 000 points, working cloud about as dense as the target] 1 on / 2 off, grid_tile_bmax_pct [400], grid_tile_keep [512],
- *              grid_tile_lim_pct [1000], grid_tile_reach_pct [200], grid_tile_total_mult [16], grid_tile_min_members [8],
- *              grid_tile_list_segs [1], grid_tile_filter [on] 2 = off (csrc/grid.hip launch_nn1_grid) · knn_cell_scale_x100, knn_slices ·
- *              the sign tile search (csrc/grid_stile.hpp, what grid_tile selects since round 4): grid_stile [on] 2 = round 3's tile kernel ·
+ *              -1 = identity · grid_tile [0: the tile search for targets from 4 000 000 points whose working cloud is about as dense as the target] 1 on / 2 off,
+ *              grid_tile_reach_pct [200], grid_tile_min_members [8], grid_tile_list_segs [1] (csrc/grid.hip launch_nn1_grid) · knn_cell_scale_x100, knn_slices ·
+ *              the sign tile search (csrc/grid_stile.hpp, what grid_tile selects): grid_stile [on] 2 = off, the cell walk ·
  *              grid_stile_cbits [9: bits per axis of the coarse Morton cells] · bt_fine_bits [6 from 2^20 points] · grid_stile_bmax_cm [100],
  *              grid_stile_lim_pct [400], grid_stile_lim_floor_mm [150], grid_stile_split_mm [40] (ball limits of a pass) · grid_stile_keep [768],
  *              grid_stile_keep_small [192], grid_stile_cells [2 048] (tiles / cells a pass may hold) · grid_stile_flush [64], grid_stile_dense [32] ·

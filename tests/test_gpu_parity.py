@@ -70,7 +70,7 @@ def test_sign_form_never_misses_a_pair_at_or_below_its_threshold(ctx):
 
 
 def test_sphere_form_never_misses_a_chunk_with_a_record_at_or_below_the_threshold(ctx):
-    """STRACK2's level 1 (csrc/nn1_sphere.hpp, grid_common.hpp l1_chunk_operand / st_setup_l1): the chunk-sphere form of the sign filter through
+    """The sphere rows of STRACK3 (csrc/nn1_sphere.hpp, grid_common.hpp l1_chunk_operand / st_setup_l1): the chunk-sphere form of the sign filter through
     the index build's operand code, the kernel's query code and the MFMA, on the device under test — no (query, chunk) pair with a record at or
     below the query's threshold comes out without its sign; the form prunes (most pairs are not flagged)."""
     must, missed, flagged, pairs = ctx.selftest_sphere_f16(512)
@@ -80,9 +80,8 @@ def test_sphere_form_never_misses_a_chunk_with_a_record_at_or_below_the_threshol
 
 
 def test_sphere_forms_over_several_level0_supertiles_equal_the_exact_grid(ctx, synth):
-    """A target of 300 000 points spans three level-0 super-tiles of STRACK3 (131 072 records each) and 74 level-1 super-tiles of STRACK2: cold and
-    seeded searches of both, sliced every way (one level-0 super-tile per slice / all in one; every group size), return the keys of the exact grid
-    search bit for bit — on the scan pair, on queries far outside the target's box, and with non-finite queries among them."""
+    """A target of 300 000 points spans three level-0 super-tiles of STRACK3 (131 072 records each) and 74 level-1 super-tiles: cold and seeded
+    searches, sliced every way (one level-0 super-tile per slice / all in one; every group size), return the keys of the exact grid search bit for bit — on the scan pair, on queries far outside the target's box, and with non-finite queries among them."""
     n, nq = 300_000, 24_000
     src_all, tgt = synth.kitti_like_pair(n, seed_target=811, seed_pair=812)
     src = np.ascontiguousarray(src_all[:, :: n // nq][:, :nq]).copy()
@@ -95,7 +94,7 @@ def test_sphere_forms_over_several_level0_supertiles_equal_the_exact_grid(ctx, s
     ref = [ctx.nn1(ct, c_) for c_ in clouds]
     ctx.tune("nn_method", 1)
     for sw in (dict(nn1_variant=10), dict(nn1_variant=10, nn1_sphere_l0_per_slice=1), dict(nn1_variant=10, nn1_sphere_l0_per_slice=2, nn1_sphere_qg=2),
-               dict(nn1_variant=10, nn1_sphere_l0_per_slice=3, nn1_sphere_qg=4, nn1_sign_flush=1), dict(nn1_variant=9), dict(nn1_variant=9, nn1_sphere_phases=2, nn1_sphere_qg=2), dict()):
+               dict(nn1_variant=10, nn1_sphere_l0_per_slice=3, nn1_sphere_qg=4, nn1_sign_flush=1), dict()):
         for k, v in sw.items():
             ctx.tune(k, v)
         ctx.tune("nn1_async_in_loop", 1)
@@ -103,7 +102,7 @@ def test_sphere_forms_over_several_level0_supertiles_equal_the_exact_grid(ctx, s
         for k, c_ in enumerate(clouds + clouds):
             ctx.nn1_async(fresh, c_)
             if sw:
-                assert ctx.mfma_check()["last_nn1_kernel"] == {10: "strack3", 9: "strack2"}[sw["nn1_variant"]], (sw, k)
+                assert ctx.mfma_check()["last_nn1_kernel"] == "strack3", (sw, k)
             idx, d2 = ctx.nn1_fetch(nq)
             ri, rd = ref[k % 2]
             assert np.array_equal(idx, ri) and np.array_equal(bits32(d2), bits32(rd)), (sw, k, int((idx != ri).sum()))
@@ -223,26 +222,24 @@ def test_sign_filter_bad_seeds_nonfinite_queries_and_full_lists(ctx, orc, synth)
     ref = [ctx.nn1(ct, c_) for c_ in clouds]
     oi, od = orc.nn1_f32(tgt, poses[0])
     assert np.array_equal(ref[0][0], oi) and np.array_equal(bits32(ref[0][1]), bits32(od))
-    # (variant 8: STRACK; 9: STRACK2, the two-level form — sps then is its slice length in level-1 super-tiles; 10: STRACK3, the three-level form —
-    # qg then is its number of query groups per wave, sps the entries from which the end of a level-1 super-tile evaluates them)
+    # (variant 8: STRACK; 10: STRACK3, the sign filter over three levels of bounding spheres — qg then is its number of query groups per wave, sps the
+    # entries from which the end of a level-1 super-tile evaluates them)
     for qg, flush, sps, variant in ((4, 0, 0, 8), (2, 1, 0, 8), (4, 100000, 1, 8), (2, 0, 3, 8), (4, 1, 200, 8), (4, 3, 0, 8),
-                                    (4, 0, 0, 9), (4, 1, 1, 9), (4, 100000, 2, 9), (4, 3, 200, 9),
                                     (1, 0, 0, 10), (1, 1, 0, 10), (1, 100000, 64, 10), (2, 0, 0, 10), (2, 3, 16, 10), (4, 0, 0, 10), (4, 100000, 128, 10), (4, 1, 1, 10)):
         ctx.tune("nn1_btrack_qg", qg if variant != 10 else 0); ctx.tune("nn1_sign_flush", flush); ctx.tune("nn1_supers_per_slice", sps if variant == 8 else 0)
-        ctx.tune("nn1_sphere_l1_per_slice", sps if variant == 9 else 0)
         ctx.tune("nn1_sphere_qg", qg if variant == 10 else 0); ctx.tune("nn1_sphere_flush_end", sps if variant == 10 else 0)
         ctx.tune("nn1_variant", variant)
         ctx.tune("nn1_async_in_loop", 1)
         fresh = ctx.cloud(tgt)                                       # the first search is cold: it seeds itself
         for k, c_ in enumerate(clouds + clouds[:2]):
             ctx.nn1_async(fresh, c_)
-            assert ctx.mfma_check()["last_nn1_kernel"] == {8: "strack", 9: "strack2", 10: "strack3"}[variant], (qg, flush, sps, variant, k)
+            assert ctx.mfma_check()["last_nn1_kernel"] == {8: "strack", 10: "strack3"}[variant], (qg, flush, sps, variant, k)
             idx, d2 = ctx.nn1_fetch(n)
             ri, rd = ref[k % len(clouds)]
             assert np.array_equal(idx, ri) and np.array_equal(bits32(d2), bits32(rd)), (qg, flush, sps, k, int((idx != ri).sum()))
         ctx.tune("nn1_async_in_loop", 0)
         fresh.free()
-    for k_ in ("nn1_btrack_qg", "nn1_sign_flush", "nn1_supers_per_slice", "nn1_sphere_l1_per_slice", "nn1_sphere_qg", "nn1_sphere_flush_end", "nn1_variant", "nn_method"):
+    for k_ in ("nn1_btrack_qg", "nn1_sign_flush", "nn1_supers_per_slice", "nn1_sphere_qg", "nn1_sphere_flush_end", "nn1_variant", "nn_method"):
         ctx.tune(k_, 0)
     for c_ in clouds:
         c_.free()
@@ -302,10 +299,9 @@ def test_nn1_vs_nanoflann_golden(ctx, orc, golden, case, method):
 # nn1_variant: 1 FTRACK (fused-filter tracking, exact decision; no index), 2 TRACK (the exact arithmetic for every pair: the on-device
 # reference), 4 ETRACK (expanded-form f32 filter on the grid's chunked target copy), 6 BTRACK (the filter on the bf16 matrix cores,
 # three-piece operands), 7 HTRACK (one f16 MFMA per tile, two-piece scaled operands), 8 STRACK (the sign form of the f16 filter for every
-# search that has or can make itself a seed; HTRACK where none exists), 9 STRACK2 (the sign filter at two levels: chunk spheres, then records),
-# 10 STRACK3 (three levels: level-1 tiles' spheres, chunk spheres, records — the default from 32 768 target points) — csrc/nn1_brute.hip, table
-# above launch_nn1_brute; csrc/nn1_sphere.hpp
-VARIANTS = [1, 2, 4, 6, 7, 8, 9, 10]
+# search that has or can make itself a seed; HTRACK where none exists), 10 STRACK3 (the sign filter over three levels of bounding spheres: 512-record
+# tiles, 16-record chunks, records — the default from 32 768 target points) — csrc/nn1_brute.hip, table above launch_nn1_brute; csrc/nn1_sphere.hpp
+VARIANTS = [1, 2, 4, 6, 7, 8, 10]
 
 
 def set_variant(ctx, v):
@@ -544,13 +540,12 @@ def test_icp_sphere_walk_gate_as_bound_and_any_working_order(ctx, synth, n):
     cs.free(); ct.free(); cm.free()
 
 
-@pytest.mark.parametrize("flavour", ["stile", "tile"])
+@pytest.mark.parametrize("flavour", ["stile", "walk"])
 @pytest.mark.parametrize("n", [30000, 200000])
 def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n, flavour):
     """flavour "stile": the SIGN tile search (csrc/grid_stile.hpp, round 4: 64 queries per wave over the target's Morton-ordered matrix-core
-    index, the sign form of the f16 filter); "tile": round 3's tile kernel (tune grid_stile = 2).
-    The tile search of the large-target loops (csrc/grid_tile.hpp: one wave per 32 consecutive queries of the sorted working cloud,
-    far queries deferred to the cell walk in list mode), forced onto small pairs: pose bits, pair count and loss of every iteration
+    index, the sign form of the f16 filter; far queries deferred to the cell walk in list mode); "walk": the same loops with it switched off
+    (tune grid_stile = 2: the cell walk alone, what a device whose f16 arithmetic fails the check gets).  Forced onto small pairs: pose bits, pair count and loss of every iteration
     count, gate and ball limit equal the exhaustive search's — with non-finite, far-away, gated-out and duplicated points in the
     clouds, and with the limits so tight that whole groups overflow a wave and take the deferral path."""
     src, tgt = synth.kitti_like_pair(n, seed_target=247, seed_pair=248)
@@ -567,19 +562,19 @@ def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n, flavour
         for it in its:
             ref[gate, it] = ctx.icp_point2point(cs, ct, max_corr=gate, max_iter=it, eps=0.0)
     ctx.tune("nn_method", 2); ctx.tune("grid_order", 2); ctx.tune("grid_mode", 3); ctx.tune("grid_tile", 1)
-    ctx.tune("grid_stile", 2 if flavour == "tile" else 0)
+    ctx.tune("grid_stile", 2 if flavour == "walk" else 0)
     cm = ctx.cloud(tgt)                                    # a fresh cloud: its index is built Morton-ordered
     used = set()
     # (ball limit, loop, extra knobs): for the sign tile search also lists flushed after every entry / chunks always evaluated in place /
     # never in place, passes limited to 2 tiles or 1 coarse cell (whole waves overflow and take the deferral path), coarser / finer cells
-    arms = ((0, 0, {}), (5, 0, {}), (150, 0, {}), (400, -1, {}), (50, 1, {}))
+    arms = ((0, 0, {}), (400, -1, {}))
     if flavour == "stile":
         arms = ((0, 0, {}), (1, 0, {}), (30, 0, {"grid_stile_flush": 1}), (200, -1, {"grid_stile_dense": 1}), (10, 1, {"grid_stile_dense": 65}),
                 (100, 0, {"grid_stile_keep": 2}), (100, 0, {"grid_stile_cells": 1}), (300, 0, {"grid_stile_cells": 4096, "grid_tile_min_members": 1}),
                 (20, 0, {"grid_stile_queue": 2}), (20, 0, {"grid_stile_list_wgs": 1}), (60, 0, {"grid_stile_split_mm": 1}),
                 (60, 0, {"grid_stile_cold": 2}), (100, 0, {"grid_stile_cold_own": 1, "grid_stile_cold_per": 0}), (100, 0, {"grid_stile_cold_per": 64}))
     for bmax, pipe, extra in arms:
-        ctx.tune("grid_stile_bmax_cm" if flavour == "stile" else "grid_tile_bmax_pct", bmax); ctx.tune("icp_pipeline", pipe)
+        ctx.tune("grid_stile_bmax_cm", bmax); ctx.tune("icp_pipeline", pipe)
         for k in ("grid_stile_flush", "grid_stile_dense", "grid_stile_keep", "grid_stile_cells", "grid_tile_min_members", "grid_stile_queue", "grid_stile_list_wgs",
                   "grid_stile_split_mm", "grid_stile_cold", "grid_stile_cold_own", "grid_stile_cold_per"):
             ctx.tune(k, extra.get(k, 0))
@@ -593,10 +588,10 @@ def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n, flavour
                 for k in ("iters_run", "last_pairs", "empty_pairs"):
                     assert st[k] == r[1][k], (k, bmax, pipe, gate, it)
                 assert np.float32(st["last_loss"]).view(np.uint32) == np.float32(r[1]["last_loss"]).view(np.uint32)
-    assert used == {"grid-stile" if flavour == "stile" else "grid-tile"}, used
+    assert used == {"grid-stile" if flavour == "stile" else "grid"}, used
     # the exits of the state machine with the tile search's two launches in the enqueued tail: convergence at the 16th iteration
     # (registration.cpp:948-958 with eps large), no pair at all (the loop stops at once), max_iter 0
-    for k in ("grid_tile_bmax_pct", "grid_stile_bmax_cm", "grid_stile_flush", "grid_stile_dense", "grid_stile_keep", "grid_stile_cells", "grid_tile_min_members",
+    for k in ("grid_stile_bmax_cm", "grid_stile_flush", "grid_stile_dense", "grid_stile_keep", "grid_stile_cells", "grid_tile_min_members",
               "grid_stile_queue", "grid_stile_list_wgs", "grid_stile_split_mm", "grid_stile_cold", "grid_stile_cold_own", "grid_stile_cold_per"):
         ctx.tune(k, 0)
     for pipe in (0, -1):
@@ -611,15 +606,15 @@ def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n, flavour
                 assert stt[k] == sb[k], (k, pipe, kw)
     assert sb["iters_run"] == 0
     # the diagnostics: a loop at the converged pose serves nearly every query from the tiles
-    ctx.tune("grid_tile_bmax_pct", 0); ctx.tune("icp_pipeline", 0)
+    ctx.tune("icp_pipeline", 0)
     T, _ = ctx.icp_point2point(cs, cm, max_corr=1.0, max_iter=25, eps=0.0)
     ca = cs.clone(); ctx.transform(ca, T)
     ctx.tune("grid_stats", 1)
     ctx.icp_point2point(ca, cm, max_corr=1.0, max_iter=3, eps=0.0)
     w = ctx.nn1_stats()
     ctx.tune("grid_stats", 0)
-    assert w[0] > 0 and w[6] < n, w                       # (sparse clouds: balls of the size of a cell — most queries take the walk at 30 000 points)
-    for k in ("nn_method", "grid_order", "grid_mode", "grid_tile", "grid_tile_bmax_pct", "icp_pipeline", "grid_stile"):
+    assert w[0] > 0 and (flavour == "walk" or w[6] < n), w      # (sparse clouds: balls of the size of a cell — most queries take the walk at 30 000 points)
+    for k in ("nn_method", "grid_order", "grid_mode", "grid_tile", "icp_pipeline", "grid_stile"):
         ctx.tune(k, 0)
     cs.free(); ct.free(); cm.free(); ca.free()
 
@@ -790,8 +785,7 @@ def test_matrix_core_search_switches_change_no_bit(ctx, synth):
                 dict(nn1_sign=2), dict(nn1_sign_flush=1), dict(nn1_sign_flush=100000), dict(nn1_cold_seed=2), dict(nn1_cold_seed=2, icp_seed_in_move=2),
                 dict(nn1_sign_flush=1, nn1_supers_per_slice=1), dict(nn1_supers_per_slice=100, nn1_btrack_qg=2),
                 dict(nn1_variant=8), dict(nn1_variant=8, nn1_xcd=-1, nn1_btrack_qg=2),
-                # the sphere forms on this small target: STRACK2 (its slices: super-tile ranges x phases), STRACK3 (groups per wave, evaluation cadence)
-                dict(nn1_variant=9), dict(nn1_variant=9, nn1_sphere_phases=1, nn1_sphere_l1_per_slice=1), dict(nn1_variant=9, nn1_sphere_phases=8, nn1_sphere_qg=2),
+                # the sphere form on this small target (groups per wave, evaluation cadence)
                 dict(nn1_variant=10), dict(nn1_variant=10, nn1_sphere_qg=2, nn1_sign_flush=1), dict(nn1_variant=10, nn1_sphere_qg=4, nn1_sphere_flush_end=128),
                 dict(nn1_variant=10, nn1_cold_seed=2, icp_seed_in_move=2),
                 # where cold seeds come from (centre of the nearest super-tile / Morton neighbour / both), stale seeds kept as they are, a coarser working-cloud sort

@@ -2,7 +2,7 @@
 """Per-iteration picture of the 10 M ICP (BASELINE configs[4], one GPU): the HIP-event duration of every search of a loop (median of
 three runs of the same loop) — and, with STATS=1, the diagnostics of a search at the converged pose.  A/B over tunes given as KEY=VALUE arguments, e.g.
     run_c5_iters.py 10000000 20 grid_tile=2      (the cell walk alone)
-    run_c5_iters.py 10000000 20 grid_tile_bmax_pct=100
+    run_c5_iters.py 10000000 20 grid_stile_bmax_cm=50
 Prints: nn1 ms per iteration (1 .. iters), the average over the first 10 / 20, wall per iteration of the 20-iteration run, pose bits."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

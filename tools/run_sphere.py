@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""STRACK2 (two-level sign filter, default from 32 768 target points) against STRACK (tune nn1_sphere = 2): HIP-event duration of every search of
+"""STRACK3 (the sign filter over three levels of bounding spheres, default from 32 768 target points) against STRACK (tune nn1_sphere = 2): HIP-event duration of every search of
 a 20-iteration brute-force ICP loop, wall time per iteration without event pairs, flagged statistics at the final pose, pose bits.
 usage: python tools/run_sphere.py [n] [key=value ...]   (arms: default, nn1_sphere=2, plus the given tunes on top of the default)"""
 import importlib, os, sys, time
@@ -14,11 +14,11 @@ src, tgt = synth.kitti_like_pair(n)
 ctx = pcr.Context(0)
 ctx.tune("nn_method", 1)
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
-arms = [("STRACK3 (default)", {}), ("STRACK2 (nn1_sphere_levels=2)", {"nn1_sphere_levels": 2}), ("STRACK (nn1_sphere=2)", {"nn1_sphere": 2})]
+arms = [("STRACK3 (default)", {}), ("STRACK (nn1_sphere=2)", {"nn1_sphere": 2})]
 if extra:
-    arms.append((f"STRACK2 + {extra}", {k: int(v) for k, v in extra.items()}))
+    arms.append((f"STRACK3 + {extra}", {k: int(v) for k, v in extra.items()}))
 ref = None
-for name, tunes in arms + arms[:3]:
+for name, tunes in arms + arms[:2]:
     for k, v in tunes.items():
         ctx.tune(k, v)
     ctx.icp_point2point(cs, ct, max_corr=1.0, max_iter=3, eps=0.0)

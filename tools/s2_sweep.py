@@ -8,7 +8,7 @@ src, tgt = synth.kitti_like_pair(n)
 ctx = pcr.Context(0); ctx.tune("nn_method", 1)
 cs, ct = ctx.cloud(src), ctx.cloud(tgt)
 ref = None
-arms = [{}] + [dict(nn1_sphere_qg=q) for q in (4, 2, 1)] + [dict(nn1_sphere_levels=2)]
+arms = [{}] + [dict(nn1_sphere_qg=q) for q in (4, 2, 1)] + [dict(nn1_sphere=2)]
 if len(sys.argv) > 2:
     arms = [dict(kv.split('=') for kv in a.split(',')) if a != '-' else {} for a in sys.argv[2:]]
     arms = [{k: int(v) for k, v in a.items()} for a in arms]

@@ -53,13 +53,10 @@ for case in range(cases):
     res = {}
     for name, tunes in (("exact", {"nn1_variant": 2}), ("default", {}), ("etrack_cold", {"nn1_variant": 4}), ("btrack_cold", {"nn1_variant": 6}), ("htrack_cold", {"nn1_variant": 7}),
                         ("strack", {"nn1_variant": 8}), ("strack_flush1", {"nn1_variant": 8, "nn1_sign_flush": 1, "nn1_supers_per_slice": 2}),
-                        ("strack2", {"nn1_variant": 9}), ("strack2_sliced_flush1", {"nn1_variant": 9, "nn1_sign_flush": 1, "nn1_sphere_l1_per_slice": 1}),
                         ("strack3", {"nn1_variant": 10}), ("strack3_qg4_flush1", {"nn1_variant": 10, "nn1_sign_flush": 1, "nn1_sphere_qg": 4}),
                         ("strack3_qg2_late", {"nn1_variant": 10, "nn1_sphere_flush_end": 128, "nn1_sphere_qg": 2}), ("grid", {"nn_method": 2}),
                         ("grid_stile_tight", {"nn_method": 2, "grid_order": 2, "grid_mode": 3, "grid_tile": 1, "grid_stile_bmax_cm": 100000, "grid_stile_keep": 6, "grid_stile_flush": 1, "grid_stile_split_mm": 1, "grid_stile_cells": 3}),
-                        ("grid_tile_r3", {"nn_method": 2, "grid_order": 2, "grid_mode": 3, "grid_tile": 1, "grid_stile": 2}),
-                        ("grid_tile", {"nn_method": 2, "grid_order": 2, "grid_mode": 3, "grid_tile": 1}),
-                        ("grid_tile_tight", {"nn_method": 2, "grid_order": 2, "grid_mode": 3, "grid_tile": 1, "grid_tile_bmax_pct": 30, "grid_tile_keep": 6, "grid_tile_filter": 2})):
+                        ("grid_tile", {"nn_method": 2, "grid_order": 2, "grid_mode": 3, "grid_tile": 1})):
         ctx = pcr.Context(0)
         ctx.tune("nn_method", 1)
         for k, v in tunes.items():
@@ -72,8 +69,7 @@ for case in range(cases):
             out.append(T.view(np.uint32).copy()); out.append(np.array([st["iters_run"], st["last_pairs"]]))
         res[name] = out
         ctx.close()
-    for name in ("default", "etrack_cold", "btrack_cold", "htrack_cold", "strack", "strack_flush1", "strack2", "strack2_sliced_flush1", "strack3", "strack3_qg4_flush1", "strack3_qg2_late", "grid", "grid_tile", "grid_stile_tight", "grid_tile_r3",
-                 "grid_tile_tight"):
+    for name in ("default", "etrack_cold", "btrack_cold", "htrack_cold", "strack", "strack_flush1", "strack3", "strack3_qg4_flush1", "strack3_qg2_late", "grid", "grid_tile", "grid_stile_tight"):
         ok = all(np.array_equal(a, b) for a, b in zip(res["exact"], res[name]))
         if not ok:
             bad += 1

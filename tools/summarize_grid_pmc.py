@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense the --pmc passes of tools/gpu_pmc_grid.sh into profiles/<tag>_grid_pmc.md + profiles/latest_pmc_grid.json
 (read by bench.py --nn grid / --workload c5 for roofline.traffic).  A SEARCH is one launch of the cell walk, or one launch of the tile
-search plus the launch of the list walk that serves its deferred queries (csrc/grid_tile.hpp); counters and durations are summed per
+search plus the launch of the list walk that serves its deferred queries (csrc/grid_stile.hpp); counters and durations are summed per
 search and averaged over the warm searches.  usage: python tools/summarize_grid_pmc.py r03 10000000 [suffix of the second set, e.g. _walk]"""
 import collections, csv, glob, hashlib, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
@@ -71,7 +71,7 @@ def collect(suffix):
 
 vals, durs, split = collect("")
 lines = [f"# {tag}: PMC passes of the exact grid search inside an ICP loop at the converged pose, {n} x {n} (tools/gpu_pmc_grid.sh), library {LIB_SHA16}\n",
-         "One search = pcr::nn1_tile_kernel + pcr::nn1_grid_kernel<16, false, 2, true> (the list walk of its deferred queries); figures are sums over the "
+         "One search = the tile kernel (pcr::nn1_stile_kernel; rounds 2-3: nn1_tile_kernel) + pcr::nn1_grid_kernel<16, false, 2, true> (the list walk of its deferred queries); figures are sums over the "
          "two launches, mean over the warm searches of the loop.\n",
          "| counter | per search | of which tile kernel | list walk |", "|---|---|---|---|"]
 for c, v in vals.items():
@@ -87,7 +87,7 @@ if "FETCH_SIZE" in vals:
     lines.append(f"\nHBM-side traffic per search: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB x 2 (gfx950 correction, MI355X_MICROARCH.md §HBM) = {fetch/1e6:.1f} MB"
                  f" + WRITE_SIZE {write/1e6:.1f} MB = {(fetch+write)/1e6:.0f} MB -> {(fetch+write)/ (ms*1e-3)/1e9:.0f} GB/s over the {ms:.2f} ms search; compulsory: "
                  f"{compulsory/1e6:.0f} MB (queries 12 B, records 16 B once, winner position 4 B, key 8 B): x {(fetch+write)/compulsory:.2f}")
-    json.dump({"lib_sha16": LIB_SHA16, "kernel": "pcr::nn1_tile_kernel + list walk", "n": n, "source": f"profiles/{tag}_grid_pmc.md", "fetch_bytes_per_launch_corrected_x2": fetch,
+    json.dump({"lib_sha16": LIB_SHA16, "kernel": "pcr::nn1_stile_kernel + list walk", "n": n, "source": f"profiles/{tag}_grid_pmc.md", "fetch_bytes_per_launch_corrected_x2": fetch,
                "write_bytes_per_launch": write, "launch_ms_in_pass": ms, "valu_insts_per_launch": vals.get("SQ_INSTS_VALU")}, open(os.path.join(out, "latest_pmc_grid.json"), "w"), indent=1)
 if other:
     v2, d2, _ = collect(other)

@@ -7,7 +7,7 @@ last = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 seq = []
 for r in rows:
     n = r["Kernel_Name"]
-    if "nn1_tile_kernel" in n or "nn1_grid_kernel" in n:
+    if "nn1_stile_kernel" in n or "nn1_grid_kernel" in n:
         kind = "tile" if "tile" in n else ("list" if ", true>" in n.split("(")[0] else "walk")
         seq.append((int(r["Start_Timestamp"]), kind, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
 seq.sort()
