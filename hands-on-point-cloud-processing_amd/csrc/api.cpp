@@ -145,7 +145,7 @@ static void spare_trim(pcr_ctx* ctx)
         if (ctx->spare_base[k]) { hipFree(ctx->spare_base[k]); ctx->spare_base[k] = nullptr; ctx->spare_cap[k] = 0; }
 }
 
-static int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out)
+int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out)
 {
     pcr_cloud* c = new (std::nothrow) pcr_cloud();
     if (!c) return fail(ctx, PCR_ERR_NOMEM, "cloud alloc");

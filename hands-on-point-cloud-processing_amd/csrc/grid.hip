@@ -2051,10 +2051,13 @@ int grid_prepare_queries(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
 // dst[t] = src[perm[t]] (cell-sorted working copy of the grid ICP); the padding of dst is left alone
 __global__ __launch_bounds__(GR_BLOCK) void permute_cloud_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
                                                                  const uint32_t* __restrict__ perm, uint32_t n, float* __restrict__ dx, float* __restrict__ dy,
-                                                                 float* __restrict__ dz)
+                                                                 float* __restrict__ dz, uint32_t cap)
 {
+    // (the destination is a fresh allocation: positions [n, cap) get every cloud's padding here — x = +inf, y = z = 0 — instead of a whole-cloud
+    // copy in front of this launch)
     const uint32_t t = blockIdx.x * GR_BLOCK + threadIdx.x;
-    if (t >= n) return;
+    if (t >= cap) return;
+    if (t >= n) { dx[t] = __builtin_inff(); dy[t] = 0.0f; dz[t] = 0.0f; return; }
     const uint32_t i = perm[t];
     dx[t] = sx[i]; dy[t] = sy[i]; dz[t] = sz[i];
 }
@@ -2078,10 +2081,10 @@ int grid_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work
         ctx->work_orig_cap = padded(n);
     }
     pcr_cloud* sorted = nullptr;
-    rc = pcr_cloud_clone(ctx, w, &sorted);                        // same size, padding included
+    rc = cloud_alloc(ctx, n, &sorted);                            // same size; the permute writes all of it, padding included
     if (rc) return rc;
-    hipLaunchKernelGGL(permute_cloud_kernel, dim3((unsigned)((n + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), ctx->qperm,
-                       (uint32_t)n, sorted->x(), sorted->y(), sorted->z());
+    hipLaunchKernelGGL(permute_cloud_kernel, dim3((unsigned)((sorted->cap + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), ctx->qperm,
+                       (uint32_t)n, sorted->x(), sorted->y(), sorted->z(), (uint32_t)sorted->cap);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->work_orig, ctx->qperm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
     if (e != hipSuccess) { pcr_cloud_destroy(ctx, sorted); return fail(ctx, PCR_ERR_HIP, "grid_sort_working_cloud", e); }
@@ -2128,9 +2131,10 @@ int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, 
         ctx->work_orig_cap = padded(n);
     }
     pcr_cloud* sorted = nullptr;
-    rc = pcr_cloud_clone(ctx, w, &sorted);                        // same size, padding included
+    rc = cloud_alloc(ctx, n, &sorted);                            // same size; the permute writes all of it, padding included
     if (rc) return rc;
     const unsigned blocks = (unsigned)((n + GR_BLOCK - 1) / GR_BLOCK);
+    v_out = ctx->work_orig;                                       // (the sorted values ARE the original indices: no copy behind the sort)
     hipLaunchKernelGGL(bt_keys_kernel, dim3(blocks), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), (uint32_t)n, bt->key_lo[0], bt->key_lo[1],
                        bt->key_lo[2], bt->key_inv, bt->key_inv, bt->key_inv, k_in, v_in, 0);
     // (tune bt_sort_begin_bit: the low bits of the Morton key the sort ignores — the order inside the cells they span stays the caller's; every
@@ -2138,11 +2142,10 @@ int bt_sort_working_cloud(pcr_ctx* ctx, const pcr_cloud* tgt, pcr_cloud** work, 
     const int begin_bit = (int)std::min<int64_t>(std::max<int64_t>(tune_get(ctx, "bt_sort_begin_bit", 0), 0), 24);
     hipError_t e = sort_pairs_u64_u32(temp, temp_bytes, k_in, k_out, v_in, v_out, n, begin_bit, 31, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(permute_cloud_kernel, dim3(blocks), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), v_out, (uint32_t)n, sorted->x(), sorted->y(),
-                           sorted->z());
+        hipLaunchKernelGGL(permute_cloud_kernel, dim3((unsigned)((sorted->cap + GR_BLOCK - 1) / GR_BLOCK)), dim3(GR_BLOCK), 0, ctx->stream, w->x(), w->y(), w->z(), v_out,
+                           (uint32_t)n, sorted->x(), sorted->y(), sorted->z(), (uint32_t)sorted->cap);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->work_orig, v_out, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
     if (e != hipSuccess) { pcr_cloud_destroy(ctx, sorted); return fail(ctx, PCR_ERR_HIP, "bt_sort_working_cloud", e); }
     if (in_place) { std::swap(w->base, sorted->base); std::swap(w, sorted); cloud_modified(sorted); }
     cloud_release(ctx, w);                                         // (no synchronisation: the permute above still reads it — the buffer stays allocated)

@@ -48,11 +48,11 @@ static int icp_sync(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tgt, co
     // pairs are kept only if d2 < max_corr (:936), so the grid search need not look farther (tune icp_bounded_search: 2 = off)
     const float gate = tune_get(ctx, "icp_bounded_search", 1) == 1 ? prm->max_corr : __builtin_inff();
     pcr_cloud* work = nullptr;
-    int rc = pcr_cloud_clone(ctx, src, &work);                                   // :872
+    int rc = cloud_alloc(ctx, src->n, &work);                                    // :872 (the copy and the initial transform are one launch)
     if (rc) return rc;
     const float R0[9] = { init_T[0], init_T[1], init_T[2], init_T[4], init_T[5], init_T[6], init_T[8], init_T[9], init_T[10] };
     const float t0[3] = { init_T[3], init_T[7], init_T[11] };
-    rc = launch_transform(ctx, work, R0, t0);                                    // :874
+    rc = launch_transform_into(ctx, src, work, R0, t0);                          // :874
     if (rc == PCR_OK) rc = icp_uses_grid(ctx, tgt) ? grid_sort_working_cloud(ctx, tgt, &work) : icp_sort_for_brute(ctx, tgt, &work, prm->max_iter);
     float T_total[16] = { R0[0], R0[1], R0[2], t0[0], R0[3], R0[4], R0[5], t0[1],
                           R0[6], R0[7], R0[8], t0[2], 0, 0, 0, 1 };              // :910-913
@@ -162,11 +162,11 @@ static int icp_pipelined(pcr_ctx* ctx, const pcr_cloud* src, const pcr_cloud* tg
     // pairs are kept only if d2 < max_corr (:936), so the grid search need not look farther (tune icp_bounded_search: 2 = off)
     const float gate = tune_get(ctx, "icp_bounded_search", 1) == 1 ? prm->max_corr : __builtin_inff();
     pcr_cloud* work = nullptr;
-    int rc = pcr_cloud_clone(ctx, src, &work);                                   // :872
+    int rc = cloud_alloc(ctx, src->n, &work);                                    // :872 (the copy and the initial transform are one launch)
     if (rc) return rc;
     const float R0[9] = { init_T[0], init_T[1], init_T[2], init_T[4], init_T[5], init_T[6], init_T[8], init_T[9], init_T[10] };
     const float t0[3] = { init_T[3], init_T[7], init_T[11] };
-    rc = launch_transform(ctx, work, R0, t0);                                    // :874
+    rc = launch_transform_into(ctx, src, work, R0, t0);                          // :874
     if (rc == PCR_OK) rc = icp_uses_grid(ctx, tgt) ? grid_sort_working_cloud(ctx, tgt, &work) : icp_sort_for_brute(ctx, tgt, &work, prm->max_iter);
     IcpState& h0 = host[RING];
     memset(&h0, 0, sizeof h0);

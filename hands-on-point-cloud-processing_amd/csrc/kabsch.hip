@@ -792,6 +792,56 @@ __global__ void repad_kernel(float* __restrict__ x, float* __restrict__ y, float
     if (i < n_end) { x[i] = __builtin_inff(); y[i] = 0.0f; z[i] = 0.0f; }
 }
 
+// out of place, the destination's padding written too: group i < n4 = the transformed points (the tail group's lanes beyond n get the padding),
+// groups behind it = padding
+__global__ __launch_bounds__(256) void transform_into_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                                                             float* __restrict__ x, float* __restrict__ y, float* __restrict__ z, uint32_t n, uint32_t n4,
+                                                             uint32_t cap4, Rt m)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap4) return;
+    const float inf = __builtin_inff();
+    float4 ox = make_float4(inf, inf, inf, inf), oy = make_float4(0.f, 0.f, 0.f, 0.f), oz = oy;
+    if (i < n4) {
+        const float4 px = reinterpret_cast<const float4*>(sx)[i], py = reinterpret_cast<const float4*>(sy)[i], pz = reinterpret_cast<const float4*>(sz)[i];
+#define PCR_ROW(o, r0, r1, r2, tt)                                   \
+    o.x = ((m.r[r0] * px.x + m.r[r1] * py.x) + m.r[r2] * pz.x) + m.t[tt]; \
+    o.y = ((m.r[r0] * px.y + m.r[r1] * py.y) + m.r[r2] * pz.y) + m.t[tt]; \
+    o.z = ((m.r[r0] * px.z + m.r[r1] * py.z) + m.r[r2] * pz.z) + m.t[tt]; \
+    o.w = ((m.r[r0] * px.w + m.r[r1] * py.w) + m.r[r2] * pz.w) + m.t[tt];
+        PCR_ROW(ox, 0, 1, 2, 0)
+        PCR_ROW(oy, 3, 4, 5, 1)
+        PCR_ROW(oz, 6, 7, 8, 2)
+#undef PCR_ROW
+        const uint32_t base = 4 * i;
+        if (base + 3 >= n) {
+            if (base + 0 >= n) { ox.x = inf; oy.x = 0.f; oz.x = 0.f; }
+            if (base + 1 >= n) { ox.y = inf; oy.y = 0.f; oz.y = 0.f; }
+            if (base + 2 >= n) { ox.z = inf; oy.z = 0.f; oz.z = 0.f; }
+            if (base + 3 >= n) { ox.w = inf; oy.w = 0.f; oz.w = 0.f; }
+        }
+    }
+    reinterpret_cast<float4*>(x)[i] = ox;
+    reinterpret_cast<float4*>(y)[i] = oy;
+    reinterpret_cast<float4*>(z)[i] = oz;
+}
+
+int launch_transform_into(pcr_ctx* ctx, const pcr_cloud* src, pcr_cloud* dst, const float R[9], const float t[3])
+{
+    if (dst->cap != src->cap || dst->n != src->n || dst->cap % 4) return fail(ctx, PCR_ERR_ARG, "launch_transform_into");
+    Rt m;
+    memcpy(m.r, R, sizeof m.r);
+    memcpy(m.t, t, sizeof m.t);
+    const uint32_t n4 = (uint32_t)((src->n + 3) / 4), cap4 = (uint32_t)(src->cap / 4);
+    {
+        ProfScope p(ctx, "transform");
+        hipLaunchKernelGGL(transform_into_kernel, dim3((cap4 + 255) / 256), dim3(256), 0, ctx->stream, src->x(), src->y(), src->z(), dst->x(), dst->y(), dst->z(),
+                           (uint32_t)src->n, n4, cap4, m);
+    }
+    PCR_HIP(ctx, hipGetLastError());
+    return PCR_OK;
+}
+
 int launch_transform(pcr_ctx* ctx, pcr_cloud* c, const float R[9], const float t[3])
 {
     if (c->n == 0) return PCR_OK;

@@ -246,6 +246,9 @@ int nn1_unpack(pcr_ctx* ctx, size_t n, uint32_t* idx_dev, float* d2_dev);
 int cloud_shard_spatial(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* full, int nranks, int rank, int chunks_per_rank, pcr_cloud** out,
                         int (*alloc)(pcr_ctx*, size_t, pcr_cloud**));
 int launch_transform(pcr_ctx* ctx, pcr_cloud* c, const float R[9], const float t[3]);
+// dst (a fresh allocation of src's size: cloud_alloc) = R src + t, padding included — the clone and the transform of a loop's working copy in one launch
+int launch_transform_into(pcr_ctx* ctx, const pcr_cloud* src, pcr_cloud* dst, const float R[9], const float t[3]);
+int cloud_alloc(pcr_ctx* ctx, size_t n, pcr_cloud** out);     // api.cpp: an uninitialised cloud of n points (from the parked buffers when one fits)
 int cloud_absmax(pcr_ctx* ctx, const pcr_cloud* c, float* out);       // largest finite |coordinate|, cached on the cloud (grid.hip)
 int kabsch_grid_exponent(float target_absmax, float max_corr);
 int kabsch_plan(pcr_ctx* ctx, const pcr_cloud* tgt, float max_corr, KabschPlan* plan);
