@@ -413,7 +413,11 @@ def main():
         cs, src = shard_of(full_src, ct)
         ctx.tune("nn_method", 0)
         main_method = 1 if args.nn == "brute" else 2
-        T, st, dt = timed_icp(cs, ct, main_method, src)
+        # the K timed steps run WITHOUT event pairs (a pair around every search costs ~10 us of stream time per step — 15 % of a 70 us iteration);
+        # the same K steps are then repeated with the pairs for the kernel's duration (roofline): same pose bits, `ms_per_step_with_event_pairs` beside it
+        T, st, dt = timed_icp(cs, ct, main_method, src, prof=0)
+        Tp, stp, dt_pairs = timed_icp(cs, ct, main_method, src, prof=1)
+        assert np.array_equal(T.view(np.uint32), Tp.view(np.uint32)) and stp["iters_run"] == st["iters_run"]
         nn_name = "nn1_brute" if args.nn == "brute" else "nn1_grid"
         nn_launches, nn_ms = ctx.prof_get(nn_name)
         family = ctx.mfma_check()["last_nn1_kernel"]        # which kernel family the library's dispatcher took for the timed searches
@@ -688,6 +692,7 @@ def main():
                            "collective": collective,
                            "pose_err_vs_gt_fro": gt_err, "kept_pairs_last_iter": int(st["last_pairs"]), "lib_sha16": sha,
                            "first_timed_iteration": "seeded by the warm-up run's correspondences (as every iteration after the first of an ICP is)",
+                           "timing": "the K timed steps carry no HIP-event pairs; an identical repetition with a pair around every search gives the kernel durations (roofline)",
                            "M_corr_per_s_three_readings": ({"warm_icp_iteration (= value)": n * args.steps / dt / 1e6,
                                                             "one_shot_indexed_target (kernel, cold)": one_shot["indexed_target"]["M_corr_per_s"],
                                                             "one_shot_fresh_target (wall, index build included)": one_shot["fresh_target"]["M_corr_per_s"]}
@@ -698,6 +703,7 @@ def main():
             }
             # the fixed tail of an iteration (sums + solve + move + the bench's own event pairs): what caps strong scaling on a small pair
             out["tail_us_per_iteration"] = (dt * 1e3 / args.steps - kern_s * 1e3) * 1e3
+            out["ms_per_step_with_event_pairs"] = dt_pairs * 1e3 / args.steps        # (the repetition the kernel durations of `roofline` come from)
             if pred_c2 is not None:
                 out["predicted_scaling"] = pred_c2
             if one_shot:
