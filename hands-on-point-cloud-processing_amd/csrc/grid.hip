@@ -2383,6 +2383,21 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
             stile = stile && bt->bad16_host == 0;
             if (stile && (rc = bt_ensure_tile(ctx, tgt))) return rc;
         }
+        // operands: the per-record rows in the scale of the LEVEL-1 super-tiles (4 096 records share a centre: BtIndex::l1_rec_ops, what STRACK3's level 2
+        // reads) instead of the 256-record super-tiles' — a wave at the settled pose of the 10 M pair rebuilt its queries' side 11 times per search, 30 % of
+        // its vector instructions (tune grid_stile_l1: 2 = the super-tiles' operands)
+        bool stile_l1 = stile && tune_get(ctx, "grid_stile_l1", 1) == 1;
+        if (stile_l1) {
+            if ((rc = bt_ensure_l1(ctx, tgt))) return rc;
+            BtIndex* bt = tgt->bt;
+            if (bt->l1_bad_host < 0) {
+                int flag = 1;
+                PCR_HIP(ctx, hipMemcpyAsync(&flag, bt->l1_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                PCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                bt->l1_bad_host = flag;
+            }
+            stile_l1 = bt->l1_bad_host == 0;
+        }
         if (!stile) break;                                    // (this device's f16 arithmetic failed the check, or the target leaves f16's range: the walk below)
         if (stile) {
             const BtIndex* bt = tgt->bt;
@@ -2424,10 +2439,10 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
             }
 
 #define PCR_STILE(ST)                                                                                                                       \
-    hipLaunchKernelGGL((nn1_stile_kernel<ST>), dim3((unsigned)sblocks), dim3(GR_BLOCK), 0, ctx->stream, bt->records, bt->ops16, bt->centres,           \
+    hipLaunchKernelGGL((nn1_stile_kernel<ST>), dim3((unsigned)sblocks), dim3(GR_BLOCK), 0, ctx->stream, bt->records, stile_l1 ? bt->l1_rec_ops : bt->ops16, stile_l1 ? bt->l1_centres : bt->centres, \
                        bt->tile_spheres, bt->cell_start, bt->g_of_b, bt->b_of_g, g->records, (uint32_t)(g->n_chunks * GRID_CHUNK), bt->key_lo[0], bt->key_lo[1], \
                        bt->key_lo[2], bt->key_inv, 3 * (10 - bt->cbits), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, ctx->stop_flag_dev,    \
-                       stats_dev, cap2, wpos, dlist, dcount, lqueue, sxcd, sbmax, n_waves, n_groups, slim_k, reach_k, skeep, scells, min_members, sflush, sdense, ssplit, (uint32_t)(bt->n_tiles / 8), spasses, skeep_small, slim_floor); \
+                       stats_dev, cap2, wpos, dlist, dcount, lqueue, sxcd, sbmax, n_waves, n_groups, slim_k, reach_k, skeep, scells, min_members, sflush, sdense, ssplit, stile_l1 ? (uint32_t)bt->n_l1_super : (uint32_t)(bt->n_tiles / 8), spasses, skeep_small, slim_floor, stile_l1 ? 7u : 3u); \
     hipLaunchKernelGGL((nn1_grid_kernel<16, ST, 2, true>), dim3(lblocks_s), dim3(GR_BLOCK), 0, ctx->stream, g->records, g->spheres, g->cell_start, g->p,   \
                        src->x(), src->y(), src->z(), (const uint32_t*)dlist, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(),     \
                        tgt->y(), tgt->z(), (uint32_t)tgt->n, 3, cap2, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, wpos, 0u, (const uint32_t*)dcount, list_segs_s, lqueue)

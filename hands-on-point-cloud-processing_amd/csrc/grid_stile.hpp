@@ -176,7 +176,7 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
     unsigned long long* __restrict__ keys, const int* __restrict__ stop, unsigned long long* __restrict__ stats, float cap2,
     uint32_t* __restrict__ wpos, uint32_t* __restrict__ defer_list, uint32_t* __restrict__ defer_count, uint32_t* __restrict__ defer_queue, uint32_t xcd_run,
     float bmax, uint32_t n_waves, uint32_t n_groups32, float lim_k, float reach_k, uint32_t keep_max, uint32_t cell_max, uint32_t min_members,
-    uint32_t flush_at, uint32_t dense_at, float split_at, uint32_t n_super, uint32_t max_pass, uint32_t keep_small, float lim_floor)
+    uint32_t flush_at, uint32_t dense_at, float split_at, uint32_t n_super, uint32_t max_pass, uint32_t keep_small, float lim_floor, uint32_t sshift)
 {
     const int stopv = stop ? (stop[0] | stop[1]) : 0;         // requested here, tested after the query loads are on their way
     __shared__ StileWaveLds lds_all[GR_BLOCK / 64];
@@ -382,13 +382,15 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
         uint4 bq[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
         uint32_t E0 = nt > 0 ? entry_at(0) : 0u, E1 = nt > 1 ? entry_at(1) : 0u, E2 = nt > 2 ? entry_at(2) : 0u;
         uint4 A0 = make_uint4(0, 0, 0, 0), A1 = A0;
-        float4 Cc = centres[min((E0 & 0x3FFFFFFFu) >> 3, n_super - 1u)];
+        float4 Cc = centres[min((E0 & 0x3FFFFFFFu) >> sshift, n_super - 1u)];    // (sshift: 3 = the 256-record super-tiles' operands, 7 = the level-1 super-tiles')
         if (nt > 0) A0 = ops16[(size_t)(E0 & 0x3FFFFFFFu) * 64 + lane];
         if (nt > 1) A1 = ops16[(size_t)(E1 & 0x3FFFFFFFu) * 64 + lane];
         auto refresh = [&]() {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (in) thr = fminf(thr, __uint_as_float((uint32_t)(L.best[lane] >> 32)));
             curS = 0xFFFFFFFFu;                                // the operands carry the old thresholds: rebuilt before the next tile
+            // (measured and dropped: rebuilt only where some threshold fell below 90 / 70 / 40 % of what the operands carry — 1.399 -> 1.403 / 1.400 /
+            // 1.404 ms per converged 10 M search, the first searches of a loop slower: the setups are not what the loop is made of)
         };
         // (Measured and dropped: three tiles per trip with their operands in three fixed register sets — no copy of a register a load is
         // still writing, loads two tiles ahead of their use — and one copy of the rare path behind the trip: 1.55 -> 1.62 ms per converged
@@ -404,9 +406,9 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
             const uint32_t Tn = (uint32_t)__builtin_amdgcn_readfirstlane((int)E0) & 0x3FFFFFFFu, Tnn = (uint32_t)__builtin_amdgcn_readfirstlane((int)E1) & 0x3FFFFFFFu;
             if (k + 2 < nt) A1 = ops16[(size_t)Tnn * 64 + lane];                     // two tiles ahead
             E2 = entry_at(k + 3);
-            const float4 Cn = centres[min(Tn >> 3, n_super - 1u)];                    // the next tile's super-tile (scalar load, one tile ahead)
+            const float4 Cn = centres[min(Tn >> sshift, n_super - 1u)];                    // the next tile's super-tile (scalar load, one tile ahead)
             if (split && k == nn && cnt) { sl_flush(L, cnt, records, lane); if (STATS) { st_flushes++; st_eval += cnt; } cnt = 0; refresh(); }   // the boxes' own tiles are done: thresholds fall before the farther ones
-            const uint32_t S = T >> 3;
+            const uint32_t S = T >> sshift;
 #ifdef PCR_SL_T_NOSETUP                                       // (timing builds only: what the operand setups cost — wrong answers)
             if (curS == 0xFFFFFFFFu && k == 0) {
 #else

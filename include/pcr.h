@@ -411,6 +411,7 @@ int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
  *              grid_stile_lim_pct [400], grid_stile_lim_floor_mm [150], grid_stile_split_mm [40] (ball limits of a pass) · grid_stile_keep [768],
  *              grid_stile_keep_small [192], grid_stile_cells [2 048] (tiles / cells a pass may hold) · grid_stile_flush [64], grid_stile_dense [32] ·
  *              grid_stile_passes [3] · grid_stile_queue [on] 2 = static list walk, grid_stile_list_wgs [8 per CU] ·
+ *              grid_stile_l1 [on: per-record operands in the scale of the level-1 super-tiles] 2 = the 256-record super-tiles' ·
  *              grid_stile_cold [on] 2 = off, grid_stile_cold_own [32], grid_stile_cold_per [4] (cold seeds from the coarse cells)
  *  ICP loop    icp_pipeline [0 = 1 device-resident] -1 synchronous · icp_chunk [4] · icp_bounded_search [on] 2 = off ·
  *              icp_fused_move [on] 2 = off, icp_fused_max [262 144] · icp_seed_in_move [on] 2 = off · icp_force_slots (tests) ·

@@ -572,11 +572,11 @@ def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n, flavour
         arms = ((0, 0, {}), (1, 0, {}), (30, 0, {"grid_stile_flush": 1}), (200, -1, {"grid_stile_dense": 1}), (10, 1, {"grid_stile_dense": 65}),
                 (100, 0, {"grid_stile_keep": 2}), (100, 0, {"grid_stile_cells": 1}), (300, 0, {"grid_stile_cells": 4096, "grid_tile_min_members": 1}),
                 (20, 0, {"grid_stile_queue": 2}), (20, 0, {"grid_stile_list_wgs": 1}), (60, 0, {"grid_stile_split_mm": 1}),
-                (60, 0, {"grid_stile_cold": 2}), (100, 0, {"grid_stile_cold_own": 1, "grid_stile_cold_per": 0}), (100, 0, {"grid_stile_cold_per": 64}))
+                (60, 0, {"grid_stile_cold": 2}), (60, 0, {"grid_stile_l1": 2}), (100, 0, {"grid_stile_cold_own": 1, "grid_stile_cold_per": 0}), (100, 0, {"grid_stile_cold_per": 64}))
     for bmax, pipe, extra in arms:
         ctx.tune("grid_stile_bmax_cm", bmax); ctx.tune("icp_pipeline", pipe)
         for k in ("grid_stile_flush", "grid_stile_dense", "grid_stile_keep", "grid_stile_cells", "grid_tile_min_members", "grid_stile_queue", "grid_stile_list_wgs",
-                  "grid_stile_split_mm", "grid_stile_cold", "grid_stile_cold_own", "grid_stile_cold_per"):
+                  "grid_stile_split_mm", "grid_stile_cold", "grid_stile_cold_own", "grid_stile_cold_per", "grid_stile_l1"):
             ctx.tune(k, extra.get(k, 0))
         for gate in gates:
             for it in its:
@@ -592,7 +592,7 @@ def test_icp_tile_search_equals_cell_walk_and_brute_force(ctx, synth, n, flavour
     # the exits of the state machine with the tile search's two launches in the enqueued tail: convergence at the 16th iteration
     # (registration.cpp:948-958 with eps large), no pair at all (the loop stops at once), max_iter 0
     for k in ("grid_stile_bmax_cm", "grid_stile_flush", "grid_stile_dense", "grid_stile_keep", "grid_stile_cells", "grid_tile_min_members",
-              "grid_stile_queue", "grid_stile_list_wgs", "grid_stile_split_mm", "grid_stile_cold", "grid_stile_cold_own", "grid_stile_cold_per"):
+              "grid_stile_queue", "grid_stile_list_wgs", "grid_stile_split_mm", "grid_stile_cold", "grid_stile_cold_own", "grid_stile_cold_per", "grid_stile_l1"):
         ctx.tune(k, 0)
     for pipe in (0, -1):
         ctx.tune("icp_pipeline", pipe)
