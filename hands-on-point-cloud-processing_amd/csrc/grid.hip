@@ -2446,7 +2446,11 @@ int launch_nn1_grid(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* src, bo
     hipLaunchKernelGGL((nn1_grid_kernel<16, ST, 2, true>), dim3(lblocks_s), dim3(GR_BLOCK), 0, ctx->stream, g->records, g->spheres, g->cell_start, g->p,   \
                        src->x(), src->y(), src->z(), (const uint32_t*)dlist, (uint32_t)ns, ctx->keys, ctx->stop_flag_dev, stats_dev, tgt->x(),     \
                        tgt->y(), tgt->z(), (uint32_t)tgt->n, 3, cap2, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, wpos, 0u, (const uint32_t*)dcount, list_segs_s, lqueue)
+#ifdef PCR_SL_PROF
+            PCR_STILE(false);                                 // (profile build: the production instantiation, stamps into the diagnostics words)
+#else
             if (stats_dev) { PCR_STILE(true); } else { PCR_STILE(false); }
+#endif
 #undef PCR_STILE
             PCR_HIP(ctx, hipGetLastError());
             return PCR_OK;

@@ -164,6 +164,12 @@ __global__ __launch_bounds__(GR_BLOCK) void stile_seed_kernel(const float4* __re
     wpos[i] = out;
 }
 
+// profile build (-DPCR_SL_PROF, tools/stile_prof.py): one wave in 16 stamps its phases with s_memrealtime and adds them to the diagnostics words
+#ifdef PCR_SL_PROF
+#define PCR_SL_TICK(acc) { pt_b = __builtin_amdgcn_s_memrealtime(); acc += pt_b - pt_a; pt_a = pt_b; }
+#else
+#define PCR_SL_TICK(acc)
+#endif
 #ifndef PCR_STILE_WAVES
 #define PCR_STILE_WAVES 5
 #endif
@@ -192,6 +198,10 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
     float qx = sx[ic], qy = sy[ic], qz = sz[ic];
     const uint32_t pp0 = wpos[ic];
     if (stopv) return;
+#ifdef PCR_SL_PROF
+    unsigned long long pt_pro = 0, pt_list = 0, pt_tiles = 0, pt_epi = 0, pt_a = __builtin_amdgcn_s_memrealtime(), pt_b = 0;
+    const unsigned long long pt_begin = pt_a;
+#endif
     // the caller's gate as the initial bound, then the previous winner (nn1_grid_kernel: same rules, same "none")
     const unsigned long long bound0 = (cap2 > 0.0f && cap2 < 1e30f) ? (((unsigned long long)__float_as_uint(cap2) << 32) | 0xFFFFFFFFull) : KEY_NONE;
     unsigned long long best = bound0;
@@ -243,6 +253,7 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
 #pragma unroll
     for (int j = 0; j < 16; j++) zero[j] = 0.0f;
     const int fs = cshift / 3;                                // fine cell -> coarse cell
+    PCR_SL_TICK(pt_pro)
     for (uint32_t pass = 0; pass < max_pass && remaining; pass++) {
         const int lead = (int)__builtin_ctzll(remaining);
         const float lqx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qx), lead)),
@@ -372,6 +383,7 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
         // ---- the tiles against the pass's queries: STRACK's tile loop (nn1_brute.hip) over a LIST of tiles.  Lane l owns query l: it builds
         // the whole operand of its query per super-tile (st_setup) and the halves change places by v_permlane32_swap — afterwards bq[0] is the
         // B operand of queries 0..31, bq[1] that of queries 32..63.
+        PCR_SL_TICK(pt_list)
         float thr = in ? __uint_as_float((uint32_t)(L.best[lane] >> 32)) : -__builtin_inff();
         auto entry_at = [&](uint32_t k) -> uint32_t {
             const uint32_t kk = min(k, max(nt, 1u) - 1u);     // (beyond the list: its last entry once more — never used)
@@ -488,6 +500,7 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
             }
         }
         if (cnt) { sl_flush(L, cnt, records, lane); if (STATS) { st_flushes++; st_eval += cnt; } cnt = 0; }
+        PCR_SL_TICK(pt_tiles)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (in) {
             const unsigned long long kb = L.best[lane];
@@ -519,6 +532,14 @@ __global__ __launch_bounds__(GR_BLOCK, STATS ? 1 : PCR_STILE_WAVES) void nn1_sti
         }
         if (STATS && lane == 0 && dm) atomicAdd(&stats[6], (unsigned long long)__popcll(dm));     // [6]: queries handed to the cell walk
     }
+#ifdef PCR_SL_PROF
+    PCR_SL_TICK(pt_epi)
+    if (stats && lane == 0 && (wv & 15u) == 0u) {             // [0] prologue [1] boxes + cells + spheres + list [2] tile loops + evaluations [3] write-back + deferral (10 ns ticks), [4] waves, [5] sum of lives, [6] longest
+        atomicAdd(&stats[0], pt_pro); atomicAdd(&stats[1], pt_list); atomicAdd(&stats[2], pt_tiles); atomicAdd(&stats[3], pt_epi);
+        atomicAdd(&stats[4], 1ull); atomicAdd(&stats[5], pt_a - pt_begin); atomicMax(&stats[6], pt_a - pt_begin);
+    }
+    return;
+#endif
     if (STATS && lane == 0) {
         if (st_cand) atomicAdd(&stats[0], st_cand);                                   // [0]: (query, record) pairs that went through the filter
         if (st_cells) atomicAdd(&stats[1], st_cells);                                 // [1]: coarse cells looked up
