@@ -1057,13 +1057,36 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_seed_kernel(const float* __restr
 // iteration (0.95 -> ? ms per unseeded 120 k x 120 k search); without it every slice evaluates a chunk exactly and proves it.
 __global__ __launch_bounds__(NN_BLOCK) void bt_seed_kernel(const float4* __restrict__ centres, const float4* __restrict__ records, uint32_t n_super, uint32_t centre_step,
                                                            const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, uint32_t ns,
-                                                           unsigned long long* __restrict__ keys, int merge)
+                                                           unsigned long long* __restrict__ keys, int merge, const float4* __restrict__ l1_centres, uint32_t n_l1)
 {
     const uint32_t i = blockIdx.x * NN_BLOCK + threadIdx.x;
     if (i >= ns) return;
     const float qx = sx[i], qy = sy[i], qz = sz[i];
     float bc = INFINITY;
     uint32_t sc = 0;
+    if (l1_centres) {
+        // two levels (round 4, where the level-1 super-tiles exist): the two nearest level-1 centres (means of 4 096 records) of all of them, then the 16
+        // super-tile centres under each — 30 + 32 centres at 120 000 points instead of 469
+        float b1 = INFINITY, b2 = INFINITY;
+        uint32_t s1 = 0, s2 = 0;
+        for (uint32_t c = 0; c < n_l1; c++) {
+            const float4 C = l1_centres[c];
+            const float dx = qx - C.x, dy = qy - C.y, dz = qz - C.z;
+            const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (d < b1) { b2 = b1; s2 = s1; b1 = d; s1 = c; } else if (d < b2) { b2 = d; s2 = c; }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const uint32_t c0 = (pass ? s2 : s1) * (BT_L1_SUPER / BT_SUPER);
+            if (pass && !(b2 < INFINITY)) break;
+            for (uint32_t u = 0; u < (uint32_t)(BT_L1_SUPER / BT_SUPER) && c0 + u < n_super; u++) {
+                const float4 C = centres[c0 + u];
+                const float dx = qx - C.x, dy = qy - C.y, dz = qz - C.z;
+                const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                if (d < bc) { bc = d; sc = c0 + u; }
+            }
+        }
+    } else {
     // (eight wave-uniform centre loads in flight: one scalar-cache round trip per centre made this scan 64 us at 120 k queries)
     const uint32_t n_c = (n_super + centre_step - 1) / centre_step;
     uint32_t c0 = 0;
@@ -1085,6 +1108,7 @@ __global__ __launch_bounds__(NN_BLOCK) void bt_seed_kernel(const float4* __restr
         const float dx = qx - C.x, dy = qy - C.y, dz = qz - C.z;
         const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
         if (d < bc) { bc = d; sc = c0 * centre_step; }
+    }
     }
     unsigned long long key = ~0ull;
     // (64 / 128 / 256 samples: 6.1 / 5.5 / 5.1 instead of 6.9 flagged chunks per query, no faster.)  Eight gathers in flight per lane: the
@@ -1290,7 +1314,8 @@ static int launch_matrix(pcr_ctx* ctx, const pcr_cloud* tgt, const pcr_cloud* sr
                                g->key_lo[0], g->key_lo[1], g->key_lo[2], g->key_inv, src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, reseed ? 1 : 0);
         if ((cold_seed || reseed) && (seed_mode < 2 || seed_mode == 3 || !(g->key_inv > 0.f)))          // (inside the timed scope: it is part of the search)
             hipLaunchKernelGGL(bt_seed_kernel, dim3((unsigned)((ns + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, ctx->stream, g->centres, g->records, n_super,
-                               std::max<uint32_t>(1u, n_super / 1024u), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, (reseed || seed_mode == 3) ? 1 : 0);
+                               std::max<uint32_t>(1u, n_super / 1024u), src->x(), src->y(), src->z(), (uint32_t)ns, ctx->keys, (reseed || seed_mode == 3) ? 1 : 0,
+                               (sphere && tune_get(ctx, "nn1_seed_levels", 0) != 1) ? g->l1_centres : (const float4*)nullptr, (uint32_t)g->n_l1_super);
         // XCD-aware launch (tune nn1_xcd: 1 / 2 / 4 = query-block groups per 8 XCDs, -1 = the plain 2-D launch): see the kernel
         // STRACK: entries in a wave's list from which the end of a super-tile evaluates them (tune nn1_sign_flush; the end of the slice always does)
         const uint32_t st_flush_at = (uint32_t)std::min<int64_t>(std::max<int64_t>(tune_get(ctx, "nn1_sign_flush", 64), 1), 1 << 20);

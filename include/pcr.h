@@ -396,7 +396,7 @@ int pcr_ctx_mfma_check(pcr_ctx* ctx, int run_now, pcr_mfma_check* out);
  *              a level-1 super-tile evaluates them] · nn1_sphere_l0_per_slice [from nn1_sphere_blocks = 1 024] ·
  *              nn1_xcd [4] 1 / 2 / 4, -1 plain launch · nn1_cold_seed [on] 2 = off, 3 = round 3's rule (sliced launches only) ·
  *              nn1_seed_mode [0: centre of the nearest super-tile + Morton neighbour for a cold search, the centre alone beside stale correspondences]
- *              1 centre / 2 Morton neighbour / 3 both · nn1_sphere_reseed [on] 2 = a warm search of the sphere forms keeps stale seeds as they are ·
+ *              1 centre / 2 Morton neighbour / 3 both · nn1_seed_levels [2: the centre scan goes through the level-1 super-tiles' centres first] 1 = all centres · nn1_sphere_reseed [on] 2 = a warm search of the sphere forms keeps stale seeds as they are ·
  *              bt_sort_begin_bit [0: low bits of the Morton key the working-cloud sort ignores] ·
  *              nn1_warm_start [on] 2 = off · nn1_chunks_per_slice [from
  *              nn1_etrack_blocks = 32 768] · nn1_tiles_per_slice [from nn1_target_blocks = 16 384] · bt_sort_work [on] 2 = off

@@ -789,7 +789,7 @@ def test_matrix_core_search_switches_change_no_bit(ctx, synth):
                 dict(nn1_variant=10), dict(nn1_variant=10, nn1_sphere_qg=2, nn1_sign_flush=1), dict(nn1_variant=10, nn1_sphere_qg=4, nn1_sphere_flush_end=128),
                 dict(nn1_variant=10, nn1_cold_seed=2, icp_seed_in_move=2),
                 # where cold seeds come from (centre of the nearest super-tile / Morton neighbour / both), stale seeds kept as they are, a coarser working-cloud sort
-                dict(nn1_seed_mode=1), dict(nn1_seed_mode=2), dict(nn1_seed_mode=3, nn1_variant=8), dict(nn1_seed_mode=2, nn1_variant=10, nn1_sphere_reseed=2),
+                dict(nn1_seed_mode=1), dict(nn1_seed_mode=1, nn1_seed_levels=1, nn1_variant=10), dict(nn1_seed_mode=2), dict(nn1_seed_mode=3, nn1_variant=8), dict(nn1_seed_mode=2, nn1_variant=10, nn1_sphere_reseed=2),
                 dict(nn1_variant=10, nn1_sphere_reseed=2, icp_seed_in_move=2), dict(bt_sort_begin_bit=12), dict(bt_sort_begin_bit=24, nn1_variant=10)]
     for sw in switches:
         for k, v in sw.items():
