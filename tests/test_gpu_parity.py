@@ -921,6 +921,11 @@ def test_plane_count_120k_80_hypotheses_vs_oracle(ctx, orc, synth):
     many = np.tile(planes, (3, 1))[:200]
     assert np.array_equal(ctx.plane_count(c, many, 0.15), orc.plane_count(scan, many, 0.15))
     assert ctx.plane_count(c, np.zeros((0, 4)), 0.15).size == 0
+    # the hypotheses in groups of any size across the rows of the launch (default 20): groups that straddle lane 64, one per row, all in one
+    for group in (1, 7, 33, 64, 96):
+        ctx.tune("plane_group", group)
+        assert np.array_equal(ctx.plane_count(c, many, 0.15), orc.plane_count(scan, many, 0.15)), group
+    ctx.tune("plane_group", 0)
     c.free()
 
 
