@@ -279,6 +279,8 @@ __global__ __launch_bounds__(NN_BLOCK, PCR_S2_WAVES) void nn1_strack3_kernel(
         if (stats) st_l1flag += n1;
         PCR_S2_TICK(pt_l0)
         if (!n1) continue;
+        // (Measured and dropped: the level-0 tiles of a super-tile dealt to 2 / 4 waves per group of queries — twice / four times the waves, each with a
+        // share of the level-0 rows and what hangs under them: 0.036 / 0.034 ms, the same.)
         // (Measured and dropped: the k-th eighth of the sorted query blocks on XCD k, so that an XCD's L2 holds one region of the target's rows instead
         // of all of them — PMC: 31 MB fetched per launch for a 4 MB working set, every XCD its own copy: 0.036-0.037 ms against 0.034; the regions
         // differ in work, and the launch is not bound by those fetches.)
