@@ -345,7 +345,10 @@ static uint32_t kabsch_blocks(pcr_ctx* ctx, size_t ns)
     const uint32_t one_pair = (uint32_t)std::min<int64_t>(KB_MAX_BLOCKS, std::max<int64_t>(1, tune_get(ctx, "kabsch_one_pair_blocks", 128)));
     if (blocks > one_pair) blocks = std::max<uint32_t>(one_pair, (uint32_t)((ns + 4 * KB_BLOCK - 1) / (4 * KB_BLOCK)));
     if (blocks < 1) blocks = 1;
-    const uint32_t cap = (uint32_t)std::min<int64_t>(KB_MAX_BLOCKS, std::max<int64_t>(1, tune_get(ctx, "kabsch_max_blocks", 1024)));
+    // (round 4: at most one workgroup per 2 048 pairs as well — a 1 / 8 shard of the 10 M pair ran 1 024 workgroups of 1 220 pairs and its solve reduced
+    // 1 024 rows: 0.370 -> 0.352 ms per iteration with 610; the 10 M pair itself stays at the cap)
+    const int64_t cap_t = tune_get(ctx, "kabsch_max_blocks", 0);
+    const uint32_t cap = (uint32_t)std::min<int64_t>(KB_MAX_BLOCKS, std::max<int64_t>(1, cap_t > 0 ? cap_t : std::min<int64_t>(1024, std::max<int64_t>(128, (int64_t)(ns / 2048)))));
     if (blocks > cap) blocks = cap;
     // exactness before tuning: a thread's limb accumulators are normalised only after its whole chunk, every term adds < 2^40 to
     // each, so a thread may hold < 2^13 terms: never fewer workgroups than 4 096 pairs per thread need (10 M points: 10)

@@ -30,6 +30,11 @@ for init, name in ((None, "from the start pose"), (T, "from the final pose")):
     ctx.icp_point2point(cs, ct, init_T=init, max_corr=1.0, max_iter=12, eps=0.0)
     each = ctx.prof_get_each("nn1_grid")
     print(f"{how} shard {r}/{N} ({len(cs)} queries) {name}: kernel {ctx.mfma_check()['last_nn1_kernel']}; nn1 ms", " ".join(f"{v:.3f}" for v in each))
+ctx.tune("prof", 0)
+best = 1e9
+for _ in range(3):
+    ctx.sync(); t0 = time.perf_counter(); ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=40, eps=0.0); best = min(best, (time.perf_counter() - t0) * 1e3 / 40)
+print(f"whole iteration from the final pose (wall of a 40-iteration call / 40, no event pairs): {best:.4f} ms")
 ctx.tune("grid_stats", 1)
 ctx.icp_point2point(cs, ct, init_T=T, max_corr=1.0, max_iter=3, eps=0.0)
 w = ctx.nn1_stats(); nq = len(cs)
