@@ -644,6 +644,10 @@ def main():
                                    "note": "equivalent_strack_frac = what roofline.frac would read if every (query, target) pair had gone through the per-record "
                                            "filter (28 flop) in this launch's time — an equivalent for comparison with earlier rounds (0.33-0.38), not a bound"}
                                   if (two and s2_counts) else None),
+                    "issue_view": ({k: pmc.get(k) for k in ("valu_insts_per_launch", "salu_insts_per_launch", "mfma_insts_per_launch", "waves_per_launch", "valu_busy_frac",
+                                                              "mfma_busy_frac", "wave_life_us")} | {
+                                       "note": "from the same --pmc passes as `traffic` (mean over the launches of a 9-iteration loop, its cold first search included): what the launch is "
+                                               "made of — instructions issued, the share of the launch the vector / matrix pipes were busy, a wave's mean life"}) if pmc else None,
                     "hbm_view": {"algorithmic_bytes": compulsory_bytes, "achieved": compulsory_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": compulsory_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
                                  "note": "targets + sources + keys once per launch against the 8 TB/s roof: the search is nowhere near it either"},

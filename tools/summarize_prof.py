@@ -93,7 +93,14 @@ if pm and "FETCH_SIZE" in pm:
           "fetch_bytes_per_launch_corrected_x2": pm["FETCH_SIZE"][0] * 2 * 1024,
           "write_bytes_per_launch": pm.get("WRITE_SIZE", (0,))[0] * 1024,
           "clock_ghz_profiled": (pm["GRBM_GUI_ACTIVE"][0] / 8 / (ms * 1e-3) / 1e9) if "GRBM_GUI_ACTIVE" in pm else None,
-          "valu_insts_per_launch": pm.get("SQ_INSTS_VALU", (None,))[0]}
+          "valu_insts_per_launch": pm.get("SQ_INSTS_VALU", (None,))[0],
+          "salu_insts_per_launch": pm.get("SQ_INSTS_SALU", (None,))[0], "mfma_insts_per_launch": pm.get("SQ_INSTS_MFMA", (None,))[0],
+          "waves_per_launch": pm.get("SQ_WAVES", (None,))[0],
+          # SQ_ACTIVE_INST_VALU counts quad-cycles of vector issue summed over the SIMDs; the launch offers 1024 SIMDs x its cycles
+          "valu_busy_frac": (pm["SQ_ACTIVE_INST_VALU"][0] * 4 / (1024 * pm["GRBM_GUI_ACTIVE"][0] / 8)) if ("SQ_ACTIVE_INST_VALU" in pm and "GRBM_GUI_ACTIVE" in pm) else None,
+          "mfma_busy_frac": (pm["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (1024 * pm["GRBM_GUI_ACTIVE"][0] / 8)) if ("SQ_VALU_MFMA_BUSY_CYCLES" in pm and "GRBM_GUI_ACTIVE" in pm) else None,
+          "wave_life_us": (pm["SQ_WAVE_CYCLES"][0] * 4 / pm["SQ_WAVES"][0] / (pm["GRBM_GUI_ACTIVE"][0] / 8 / (ms * 1e-3)) * 1e6)
+                          if all(k in pm for k in ("SQ_WAVE_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE")) and ms else None}
     json.dump(js, open(os.path.join(out, "latest_pmc.json"), "w"), indent=1)
 open(os.path.join(out, f"{tag}_bench_rocprof_summary.md"), "w").write(
     f"# {tag}: rocprofv3 summary (generated by tools/summarize_prof.py from gpurun_out/)\n\n" + "\n".join(lines) + "\n")
